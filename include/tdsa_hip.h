@@ -1,0 +1,179 @@
+/*
+ * tdsa_hip.h - C-ABI of libtdsa_hip.so, the MI355X (gfx950) IQ -> spectrum engine.
+ *
+ * This is the drop-in boundary for the reference's "sample method" hot path
+ * (CWNE88/topdogspectrumanalyser).  The reference is pure Python and reaches native code only
+ * through numpy.fft / scipy.fft; a maintainer binds this library with ctypes.
+ * Every entry point names the reference code it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every function returns int: 0 = TDSA_OK, negative = error; tdsa_last_error_string() gives text
+ *   - no C++ exception and no torch/numpy type crosses this ABI: plain pointers and sizes only
+ *   - the caller owns every host buffer; a plan owns its device buffers, HIP stream and events
+ *   - one plan is used by one host thread at a time (the reference serialises the path under
+ *     HackrfSamplesDataSource._lock, datasources/hackrf_samples.py:50,341)
+ *   - "samples" always counts complex samples (one I,Q pair)
+ *   - spectra are returned fftshift-ed (DC at index N/2) exactly as
+ *     np.fft.fftshift(np.fft.fft(x)) orders them (datasources/hackrf_samples.py:370)
+ */
+#ifndef TDSA_HIP_H
+#define TDSA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TDSA_OK 0
+#define TDSA_ERR_ARG (-1)      /* bad argument (size, mode, null pointer) */
+#define TDSA_ERR_HIP (-2)      /* a HIP runtime call failed               */
+#define TDSA_ERR_STATE (-3)    /* call sequence error (no window set ...) */
+#define TDSA_ERR_NOMEM (-4)
+
+#define TDSA_VERSION 100
+
+typedef struct tdsa_plan_s* tdsa_plan;
+
+/* input sample formats (the unpack pyhackrf / pyrtlsdr do on the host) */
+#define TDSA_IN_I8 0   /* interleaved int8  I,Q ; x = (I + jQ)/128          (HackRF / build contract) */
+#define TDSA_IN_U8 1   /* interleaved uint8 I,Q ; x = (u/127.5 - 1) pairs   (pyrtlsdr convention)     */
+#define TDSA_IN_C64 2  /* interleaved float32 re,im (numpy complex64)                               */
+
+/* dB conversion (utils/constants.py:152-155 floors are passed in tdsa_mode.log_floor) */
+#define TDSA_DB_MAG 0  /* 20*log10(|X| + floor)            datasources/hackrf_samples.py:382-383 */
+#define TDSA_DB_POW 1  /* 10*log10(|X|^2 * scale + floor)  hackrf_samples.py:374-381, rtl_samples.py:175-184 */
+
+/* trace averaging (utils/signal_processing.py:5-73) */
+#define TDSA_AVG_OFF 0
+#define TDSA_AVG_EXP 1
+#define TDSA_AVG_LIN 2
+
+/* hold_flags / reset bits */
+#define TDSA_HOLD_MAX 1u
+#define TDSA_HOLD_MIN 2u
+#define TDSA_RESET_AVG 1u
+#define TDSA_RESET_HOLD_MAX 2u
+#define TDSA_RESET_HOLD_MIN 4u
+#define TDSA_RESET_DC 8u
+#define TDSA_RESET_TARE 16u
+#define TDSA_RESET_ALL 31u
+
+typedef struct tdsa_mode {
+  int32_t db_mode;       /* TDSA_DB_MAG | TDSA_DB_POW                                                */
+  float power_scale;     /* POW only: 1 or 1/(fs*N) for PSD (hackrf_samples.py:375, rtl_samples.py:177) */
+  float log_floor;       /* 1e-12 (LOG_FLOOR) or 1e-10 (POWER_LOG_FLOOR)                               */
+  int32_t avg_mode;      /* TDSA_AVG_*  ; set_mode semantics of TraceAverager.set_mode (:19-28)        */
+  int32_t avg_n;         /* clamped to >= 1; n <= 1 means pass-through                                 */
+  float dc_alpha;        /* < 0: no DC removal (RTL branch); 1: per-frame mean removal; (0,1): tracker
+                            dc <- (1-a)*dc + a*mean(x)  (hackrf_samples.py:360-365, :32, :654-657)     */
+  float cal_offset_db;   /* added to every dB value (core/display_data_processor.py:317-327)           */
+  uint32_t hold_flags;   /* TDSA_HOLD_MAX | TDSA_HOLD_MIN (display_data_processor.py:371-395)          */
+} tdsa_mode;
+
+typedef struct tdsa_info {
+  int32_t nfft, max_frames, device_id;
+  int32_t grid, block, frames_per_block, lds_bytes; /* launch geometry of the frame kernel          */
+  int32_t num_cu;
+  int64_t frames_held_max, frames_held_min;          /* frames folded into the hold traces           */
+  int32_t avg_count;                                 /* TraceAverager._count                          */
+  int32_t version;
+} tdsa_info;
+
+/* ---- library / device --------------------------------------------------------------------- */
+const char* tdsa_last_error_string(void);
+int tdsa_version(void);
+int tdsa_device_count(int* count);
+
+/* ---- plan lifetime ------------------------------------------------------------------------ */
+/* One plan = (device, FFT size, batch capacity).  Replaces _allocate_fft_resources
+ * (datasources/hackrf_samples.py:311-324) + the per-source TraceAverager (datasources/base.py:59)
+ * + the hold buffers mw.max_power_levels / mw.min_power_levels (main.py:70-105).
+ * nfft: power of two, 64 .. 16384 (single-pass-in-LDS kernel) or 2^20 (four-step kernel). */
+int tdsa_create(int device_id, int nfft, int max_frames, tdsa_plan* out);
+int tdsa_destroy(tdsa_plan p);
+int tdsa_get_info(tdsa_plan p, tdsa_info* out);
+
+/* Window table, n == nfft float32 values built by the host exactly as the reference builds them
+ * (np.hanning(N).astype(f32) / sqrt(mean(w^2)) for HackRF, raw np.hanning/np.hamming/np.ones for RTL;
+ * hackrf_samples.py:314-316, rtl_samples.py:199-206).  Applied as x*w before the FFT (:368 / :169). */
+int tdsa_set_window(tdsa_plan p, const float* w_host, int n);
+
+/* Replaces set_psd_mode / set_averaging / set_dc_alpha / CalibrationManager.get_offset / hold toggles
+ * (datasources/base.py:148-165, hackrf_samples.py:654-657, core/calibration_manager.py:29-31).
+ * Changing avg_mode/avg_n resets the averager (TraceAverager.set_mode :19-28). */
+int tdsa_set_mode(tdsa_plan p, const tdsa_mode* m);
+
+/* reset_averaging (base.py:167), hold clears (core/display_manager.py:139-185), _flush_buffers DC
+ * reset (hackrf_samples.py:444-445), _clear_tare. */
+int tdsa_reset_state(tdsa_plan p, uint32_t what);
+
+/* Tare baseline in dB (core/display_data_processor.py:329-369): NULL disables.  While set, every
+ * dB value has baseline[k] subtracted after the calibration offset and before the hold update. */
+int tdsa_set_tare_baseline(tdsa_plan p, const float* baseline_db_host, int n);
+
+/* ---- the hot path -------------------------------------------------------------------------- */
+/* Batched get_power_levels(): frame k = iq[k*hop : k*hop + nfft],
+ * n_frames frames, each: unpack -> DC removal -> window -> FFT -> fftshift -> |X| / |X|^2 ->
+ * (PSD scale) -> (TraceAverager) -> dB(+floor) -> +cal offset -> -tare -> max/min hold.
+ * Replaces hackrf_samples.py:357-386 / rtl_samples.py:167-188 per frame and
+ * display_data_processor.py:177-181 per frame.
+ * Host-pointer variants copy in/out synchronously (out_db_host may be NULL: hold/avg only).
+ * n_samples >= (n_frames-1)*hop + nfft. */
+int tdsa_process_i8(tdsa_plan p, const int8_t* iq_host, size_t n_samples, int hop, int n_frames,
+                    float* out_db_host);
+int tdsa_process_u8(tdsa_plan p, const uint8_t* iq_host, size_t n_samples, int hop, int n_frames,
+                    float* out_db_host);
+int tdsa_process_c64(tdsa_plan p, const float* iq_host, size_t n_samples, int hop, int n_frames,
+                     float* out_db_host);
+
+/* Device-resident variant: iq_dev / out_db_dev are device pointers on the plan's device; the work
+ * is enqueued on the plan's stream and the call returns immediately (tdsa_synchronize to wait).
+ * This is what bench.py times (inputs resident in HBM).  out_db_dev may be NULL. */
+int tdsa_process_dev(tdsa_plan p, int in_format, const void* iq_dev, size_t n_samples, int hop,
+                     int n_frames, float* out_db_dev);
+
+/* Hold traces (mw.max_power_levels / mw.min_power_levels); either pointer may be NULL.
+ * *frames_held = number of frames folded in (0: trace is empty, buffer left untouched). */
+int tdsa_get_hold(tdsa_plan p, float* max_host, float* min_host, int64_t* frames_held);
+
+/* TraceAverager._buffer (float64 linear power, fftshift-ed) and ._count; used by the host to
+ * combine per-GPU Welch partials. */
+int tdsa_get_avg(tdsa_plan p, double* avg_linear_host, int* count);
+
+/* HackrfSamplesDataSource._dc_estimate (complex, units of x). */
+int tdsa_get_dc(tdsa_plan p, float* re, float* im);
+
+int tdsa_synchronize(tdsa_plan p);
+
+/* ---- DataProcessor trace operations on host arrays (core/display_data_processor.py) -------- */
+/* One displayed frame: db_in (n float32 dB values from ANY SampleDataSource) -> +cal offset ->
+ * tare (collect / subtract) -> live; max/min hold updated.  Replaces _apply_cal_offset (:317-327),
+ * _apply_tare (:329-369), _update_max_hold (:371-382), _update_min_hold (:384-395) in one launch.
+ * tare_collect != 0: this frame is accumulated into the tare buffer (10^(dB/10)); when
+ * tare_total frames have been collected the baseline becomes active (returned in *tare_done).
+ * live_out/max_out/min_out may be NULL. */
+int tdsa_trace_update(tdsa_plan p, const float* db_in_host, int n, float cal_offset_db,
+                      int tare_collect, int tare_total, uint32_t hold_flags,
+                      float* live_out, float* max_out, float* min_out, int* tare_done);
+int tdsa_get_tare_baseline(tdsa_plan p, float* baseline_db_host, int* active);
+
+/* TraceAverager.process on a host array of linear power (utils/signal_processing.py:35-61);
+ * used for the sweep-source averager DataProcessor owns (display_data_processor.py:41,217-221). */
+int tdsa_avg_process(tdsa_plan p, const float* linear_in_host, int n, double* avg_out_host);
+
+/* ---- helpers for callers without their own device allocator -------------------------------- */
+int tdsa_dev_alloc(int device_id, size_t bytes, void** out_dev);
+int tdsa_dev_free(int device_id, void* dev);
+int tdsa_memcpy_h2d(int device_id, void* dst_dev, const void* src_host, size_t bytes);
+int tdsa_memcpy_d2h(int device_id, void* dst_host, const void* src_dev, size_t bytes);
+
+/* HIP-event timer on the plan's stream (bench.py: kernel time on the stream the kernels run on). */
+int tdsa_timer_begin(tdsa_plan p);
+int tdsa_timer_end(tdsa_plan p, float* elapsed_ms); /* records, synchronises, returns elapsed */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TDSA_HIP_H */

@@ -1,0 +1,60 @@
+"""GPU parity: HIP path (through the C-ABI) vs the float64 gold oracle on identical IQ.
+
+Tolerances (BASELINE.json north_star: 1e-4 relative float32):
+  * linear power error <= 1e-4 * frame maximum on every bin  (REL_TOL)
+  * |dB error| <= 2e-3 dB on every bin within 80 dB of the frame maximum (DB_TOL)
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import spectrum_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-4
+DB_TOL = 2e-3
+
+
+@pytest.fixture(scope="module")
+def eng_mod():
+    import topdogspectrumanalyser_amd as pkg
+    return pkg
+
+
+def _check(db_gpu, db_gold, what=""):
+    rel, ddb = so.parity_metrics(db_gpu, db_gold)
+    assert rel <= REL_TOL and ddb <= DB_TOL, f"{what}: rel={rel:.3e} ddb={ddb:.3e}"
+    return rel, ddb
+
+
+@pytest.mark.parametrize("nfft", [64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384])
+def test_hackrf_plain_int8_all_sizes(eng_mod, nfft):
+    nf = 5
+    hop = nfft // 2
+    iq = so.synth_iq_int8(hop * (nf - 1) + nfft, nfft, seed=nfft)
+    gold, gmax, gmin = so.hackrf_batch(iq, nfft, hop, 20e6, precision="gold")
+    with eng_mod.SpectrumEngine(nfft, max_frames=nf) as e:
+        e.set_window(so.hackrf_window(nfft))
+        e.configure(db_mode="mag", log_floor=so.LOG_FLOOR, dc_alpha=1.0, hold_max=True, hold_min=True)
+        out = e.process(iq, hop=hop)
+        mx, mn = e.hold()
+    assert out.shape == gold.shape
+    _check(out, gold, f"N={nfft}")
+    _check(mx, gmax, "max hold")
+    _check(mn, gmin, "min hold")
+    assert np.array_equal(mx, out.max(axis=0)) and np.array_equal(mn, out.min(axis=0))
+
+
+@pytest.mark.parametrize("nfft", [64, 1024, 4096, 16384])
+def test_hackrf_plain_c64(eng_mod, nfft):
+    nf = 3
+    iq = so.synth_iq_int8(nfft * nf, nfft, seed=7 + nfft)
+    x = so.unpack_iq_int8(iq)
+    gold, _, _ = so.hackrf_batch(iq, nfft, nfft, 20e6, precision="gold", hold=False)
+    with eng_mod.SpectrumEngine(nfft, max_frames=nf) as e:
+        e.set_window(so.hackrf_window(nfft))
+        e.configure(db_mode="mag", log_floor=so.LOG_FLOOR, dc_alpha=1.0)
+        out = e.process(x, hop=nfft)
+    _check(out, gold, f"c64 N={nfft}")

@@ -1,0 +1,570 @@
+// tdsa_capi.cpp - the extern "C" boundary of libtdsa_hip.so (declared in include/tdsa_hip.h).
+// Plain C types only; every entry point returns a status and never throws.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/tdsa_hip.h"
+#include "tdsa_kernels.hpp"
+
+using namespace tdsa;
+
+namespace {
+
+thread_local char g_err[512] = "ok";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIPCHK(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fail(TDSA_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+int ilog2i(int x) {
+  int l = 0;
+  while ((1 << l) < x) ++l;
+  return l;
+}
+
+}  // namespace
+
+struct tdsa_plan_s {
+  int device = 0, nfft = 0, log2n = 0, max_frames = 0, num_cu = 256;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  tdsa_mode mode{};
+  bool window_set = false;
+  float* d_window[3] = {nullptr, nullptr, nullptr};   // window * input scale, per input format
+  float2* d_tw = nullptr;
+  float* d_hold_max = nullptr;
+  float* d_hold_min = nullptr;
+  long long held_max = 0, held_min = 0;
+  float* d_part_max = nullptr;
+  float* d_part_min = nullptr;
+  int part_rows = 0;
+  double* d_avg = nullptr;
+  int avg_count = 0;
+  float* d_lin = nullptr;                // [max_frames][N] linear power scratch (averaging modes)
+  float2* d_dc_state = nullptr;
+  float2* d_sums = nullptr;
+  float2* d_dc_sub = nullptr;
+  float* d_tare_base = nullptr;
+  float* d_tare_acc = nullptr;
+  bool tare_active = false;
+  int tare_count = 0;
+  void* d_in_stage = nullptr;
+  size_t in_stage_bytes = 0;
+  float* d_out_stage = nullptr;
+  float* d_trace_in = nullptr;
+  float* d_trace_live = nullptr;
+  long long frames_seen = 0;             // frames processed since the last hold reset (nan_safe rule)
+};
+
+namespace {
+
+int bytes_per_sample(int fmt) { return fmt == TDSA_IN_C64 ? 8 : 2; }
+
+bool avg_active(const tdsa_mode& m) { return m.avg_mode != TDSA_AVG_OFF && m.avg_n > 1; }
+
+int reset_hold(tdsa_plan p, bool mx, bool mn) {
+  if (mx) {
+    HIPCHK(launch_fill(p->d_hold_max, p->nfft, -INFINITY, p->stream));
+    p->held_max = 0;
+  }
+  if (mn) {
+    HIPCHK(launch_fill(p->d_hold_min, p->nfft, INFINITY, p->stream));
+    p->held_min = 0;
+  }
+  return TDSA_OK;
+}
+
+int ensure_partials(tdsa_plan p) {
+  if (p->d_part_max) return TDSA_OK;
+  LaunchGeom g = spectrum_geometry(p->log2n, p->max_frames, p->num_cu);
+  p->part_rows = g.grid * g.fpw;
+  const size_t bytes = size_t(p->part_rows) * p->nfft * sizeof(float);
+  HIPCHK(hipMalloc(&p->d_part_max, bytes));
+  HIPCHK(hipMalloc(&p->d_part_min, bytes));
+  return TDSA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* tdsa_last_error_string(void) { return g_err; }
+int tdsa_version(void) { return TDSA_VERSION; }
+
+int tdsa_device_count(int* count) {
+  if (!count) return fail(TDSA_ERR_ARG, "count is null");
+  HIPCHK(hipGetDeviceCount(count));
+  return TDSA_OK;
+}
+
+int tdsa_create(int device_id, int nfft, int max_frames, tdsa_plan* out) {
+  if (!out) return fail(TDSA_ERR_ARG, "out is null");
+  *out = nullptr;
+  if (nfft < (1 << kMinLog2N) || nfft > (1 << kMaxLog2N) || (nfft & (nfft - 1)))
+    return fail(TDSA_ERR_ARG, "nfft=%d: need a power of two in [%d, %d]", nfft, 1 << kMinLog2N, 1 << kMaxLog2N);
+  if (max_frames < 1) return fail(TDSA_ERR_ARG, "max_frames=%d must be >= 1", max_frames);
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (device_id < 0 || device_id >= ndev) return fail(TDSA_ERR_ARG, "device %d of %d", device_id, ndev);
+  HIPCHK(hipSetDevice(device_id));
+  tdsa_plan p = new (std::nothrow) tdsa_plan_s();
+  if (!p) return fail(TDSA_ERR_NOMEM, "host allocation failed");
+  p->device = device_id;
+  p->nfft = nfft;
+  p->log2n = ilog2i(nfft);
+  p->max_frames = max_frames;
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device_id));
+  p->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  HIPCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreate(&p->ev0));
+  HIPCHK(hipEventCreate(&p->ev1));
+  const size_t nb = size_t(nfft) * sizeof(float);
+  for (int f = 0; f < 3; ++f) HIPCHK(hipMalloc(&p->d_window[f], nb));
+  HIPCHK(hipMalloc(&p->d_tw, size_t(nfft) * sizeof(float2)));
+  HIPCHK(hipMalloc(&p->d_hold_max, nb));
+  HIPCHK(hipMalloc(&p->d_hold_min, nb));
+  HIPCHK(hipMalloc(&p->d_avg, size_t(nfft) * sizeof(double)));
+  HIPCHK(hipMalloc(&p->d_dc_state, sizeof(float2)));
+  HIPCHK(hipMalloc(&p->d_sums, size_t(max_frames) * sizeof(float2)));
+  HIPCHK(hipMalloc(&p->d_dc_sub, size_t(max_frames) * sizeof(float2)));
+  HIPCHK(hipMalloc(&p->d_tare_base, nb));
+  HIPCHK(hipMalloc(&p->d_tare_acc, nb));
+  HIPCHK(hipMalloc(&p->d_trace_in, nb));
+  HIPCHK(hipMalloc(&p->d_trace_live, nb));
+  HIPCHK(hipMemsetAsync(p->d_dc_state, 0, sizeof(float2), p->stream));
+  HIPCHK(hipMemsetAsync(p->d_avg, 0, size_t(nfft) * sizeof(double), p->stream));
+  // twiddle table exp(-2 pi i m / N), evaluated in double, rounded once
+  std::vector<float2> tw(nfft);
+  for (int m = 0; m < nfft; ++m) {
+    const double ang = -2.0 * M_PI * double(m) / double(nfft);
+    tw[m] = float2{float(std::cos(ang)), float(std::sin(ang))};
+  }
+  HIPCHK(hipMemcpy(p->d_tw, tw.data(), size_t(nfft) * sizeof(float2), hipMemcpyHostToDevice));
+  int rc = reset_hold(p, true, true);
+  if (rc != TDSA_OK) return rc;
+  // defaults = HackRF plain branch (hackrf_samples.py:382-383)
+  p->mode.db_mode = TDSA_DB_MAG;
+  p->mode.power_scale = 1.0f;
+  p->mode.log_floor = 1e-12f;
+  p->mode.avg_mode = TDSA_AVG_OFF;
+  p->mode.avg_n = 1;
+  p->mode.dc_alpha = 1.0f;
+  p->mode.cal_offset_db = 0.0f;
+  p->mode.hold_flags = 0;
+  HIPCHK(hipStreamSynchronize(p->stream));
+  *out = p;
+  return TDSA_OK;
+}
+
+int tdsa_destroy(tdsa_plan p) {
+  if (!p) return TDSA_OK;
+  (void)hipSetDevice(p->device);
+  if (p->stream) (void)hipStreamSynchronize(p->stream);
+  void* bufs[] = {p->d_window[0], p->d_window[1], p->d_window[2], p->d_tw, p->d_hold_max, p->d_hold_min,
+                  p->d_part_max, p->d_part_min, p->d_avg, p->d_lin, p->d_dc_state, p->d_sums, p->d_dc_sub,
+                  p->d_tare_base, p->d_tare_acc, p->d_in_stage, p->d_out_stage, p->d_trace_in,
+                  p->d_trace_live};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  if (p->ev0) (void)hipEventDestroy(p->ev0);
+  if (p->ev1) (void)hipEventDestroy(p->ev1);
+  if (p->stream) (void)hipStreamDestroy(p->stream);
+  delete p;
+  return TDSA_OK;
+}
+
+int tdsa_get_info(tdsa_plan p, tdsa_info* out) {
+  if (!p || !out) return fail(TDSA_ERR_ARG, "null argument");
+  LaunchGeom g = spectrum_geometry(p->log2n, p->max_frames, p->num_cu);
+  out->nfft = p->nfft;
+  out->max_frames = p->max_frames;
+  out->device_id = p->device;
+  out->grid = g.grid;
+  out->block = g.block;
+  out->frames_per_block = g.fpw;
+  out->lds_bytes = int(g.lds_bytes);
+  out->num_cu = p->num_cu;
+  out->frames_held_max = p->held_max;
+  out->frames_held_min = p->held_min;
+  out->avg_count = p->avg_count;
+  out->version = TDSA_VERSION;
+  return TDSA_OK;
+}
+
+int tdsa_set_window(tdsa_plan p, const float* w_host, int n) {
+  if (!p || !w_host) return fail(TDSA_ERR_ARG, "null argument");
+  if (n != p->nfft) return fail(TDSA_ERR_ARG, "window length %d != nfft %d", n, p->nfft);
+  HIPCHK(hipSetDevice(p->device));
+  const float scale[3] = {1.0f / 128.0f, 1.0f / 127.5f, 1.0f};
+  std::vector<float> tmp(n);
+  HIPCHK(hipStreamSynchronize(p->stream));
+  for (int f = 0; f < 3; ++f) {
+    for (int i = 0; i < n; ++i) tmp[i] = w_host[i] * scale[f];
+    HIPCHK(hipMemcpy(p->d_window[f], tmp.data(), size_t(n) * sizeof(float), hipMemcpyHostToDevice));
+  }
+  p->window_set = true;
+  return TDSA_OK;
+}
+
+int tdsa_set_mode(tdsa_plan p, const tdsa_mode* m) {
+  if (!p || !m) return fail(TDSA_ERR_ARG, "null argument");
+  if (m->db_mode != TDSA_DB_MAG && m->db_mode != TDSA_DB_POW) return fail(TDSA_ERR_ARG, "db_mode %d", m->db_mode);
+  if (m->avg_mode < TDSA_AVG_OFF || m->avg_mode > TDSA_AVG_LIN) return fail(TDSA_ERR_ARG, "avg_mode %d", m->avg_mode);
+  if (m->dc_alpha > 1.0f) return fail(TDSA_ERR_ARG, "dc_alpha %g > 1", double(m->dc_alpha));
+  if (!(m->log_floor >= 0.0f)) return fail(TDSA_ERR_ARG, "log_floor must be >= 0");
+  tdsa_mode nm = *m;
+  if (nm.avg_n < 1) nm.avg_n = 1;   // TraceAverager.set_mode: n = max(1, n)
+  const bool avg_changed = nm.avg_mode != p->mode.avg_mode || nm.avg_n != p->mode.avg_n;
+  p->mode = nm;
+  if (avg_changed) p->avg_count = 0;   // set_mode() resets the buffer (signal_processing.py:26-28)
+  return TDSA_OK;
+}
+
+int tdsa_reset_state(tdsa_plan p, uint32_t what) {
+  if (!p) return fail(TDSA_ERR_ARG, "null plan");
+  HIPCHK(hipSetDevice(p->device));
+  if (what & TDSA_RESET_AVG) p->avg_count = 0;
+  int rc = reset_hold(p, (what & TDSA_RESET_HOLD_MAX) != 0, (what & TDSA_RESET_HOLD_MIN) != 0);
+  if (rc != TDSA_OK) return rc;
+  if ((what & TDSA_RESET_HOLD_MAX) && (what & TDSA_RESET_HOLD_MIN)) p->frames_seen = 0;
+  if (what & TDSA_RESET_DC) HIPCHK(hipMemsetAsync(p->d_dc_state, 0, sizeof(float2), p->stream));
+  if (what & TDSA_RESET_TARE) {
+    p->tare_active = false;
+    p->tare_count = 0;
+  }
+  return TDSA_OK;
+}
+
+int tdsa_set_tare_baseline(tdsa_plan p, const float* baseline_db_host, int n) {
+  if (!p) return fail(TDSA_ERR_ARG, "null plan");
+  if (!baseline_db_host) {
+    p->tare_active = false;
+    return TDSA_OK;
+  }
+  if (n != p->nfft) return fail(TDSA_ERR_ARG, "baseline length %d != nfft %d", n, p->nfft);
+  HIPCHK(hipSetDevice(p->device));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  HIPCHK(hipMemcpy(p->d_tare_base, baseline_db_host, size_t(n) * sizeof(float), hipMemcpyHostToDevice));
+  p->tare_active = true;
+  return TDSA_OK;
+}
+
+int tdsa_process_dev(tdsa_plan p, int in_format, const void* iq_dev, size_t n_samples, int hop, int n_frames,
+                     float* out_db_dev) {
+  if (!p) return fail(TDSA_ERR_ARG, "null plan");
+  if (in_format < TDSA_IN_I8 || in_format > TDSA_IN_C64) return fail(TDSA_ERR_ARG, "in_format %d", in_format);
+  if (n_frames == 0) return TDSA_OK;
+  if (!iq_dev) return fail(TDSA_ERR_ARG, "iq pointer is null");
+  if (n_frames < 0 || n_frames > p->max_frames)
+    return fail(TDSA_ERR_ARG, "n_frames=%d outside [0, max_frames=%d]", n_frames, p->max_frames);
+  if (hop < 1) return fail(TDSA_ERR_ARG, "hop=%d must be >= 1", hop);
+  if (n_samples < size_t(n_frames - 1) * size_t(hop) + size_t(p->nfft))
+    return fail(TDSA_ERR_ARG, "n_samples=%zu too small for %d frames of %d at hop %d", n_samples, n_frames,
+                p->nfft, hop);
+  if (!p->window_set) return fail(TDSA_ERR_STATE, "tdsa_set_window has not been called");
+  const int bps = bytes_per_sample(in_format);
+  if ((reinterpret_cast<uintptr_t>(iq_dev) % (bps == 8 ? 8 : 2)) != 0)
+    return fail(TDSA_ERR_ARG, "iq pointer must be aligned to one sample (%d bytes)", bps);
+  HIPCHK(hipSetDevice(p->device));
+
+  const tdsa_mode& m = p->mode;
+  const bool averaging = avg_active(m);
+  const bool hold = (m.hold_flags & 3u) != 0;
+  const int in_c64 = in_format == TDSA_IN_C64;
+
+  SpecParams sp{};
+  sp.in = iq_dev;
+  sp.frame_stride = (long long)hop * bps;
+  sp.n_frames = n_frames;
+  sp.first_frame_index = p->frames_seen > 0 ? 1 : 0;
+  sp.window = p->d_window[in_format];
+  sp.tw = p->d_tw;
+  sp.xor_mask = in_format == TDSA_IN_I8 ? 0x80808080u : 0u;
+  sp.in_off = in_format == TDSA_IN_I8 ? 128.0f : (in_format == TDSA_IN_U8 ? 127.5f : 0.0f);
+  sp.in_scale = in_format == TDSA_IN_I8 ? 1.0f / 128.0f : (in_format == TDSA_IN_U8 ? 1.0f / 127.5f : 1.0f);
+  sp.db_mode = m.db_mode;
+  sp.pscale = m.db_mode == TDSA_DB_POW ? m.power_scale : 1.0f;
+  sp.log_floor = m.log_floor;
+  sp.cal_db = m.cal_offset_db;
+  sp.tare = p->tare_active ? p->d_tare_base : nullptr;
+
+  if (m.dc_alpha < 0.0f) {
+    sp.dc_mode = DC_NONE;
+  } else if (m.dc_alpha >= 1.0f) {
+    sp.dc_mode = DC_FRAME_MEAN;
+    sp.dc_state = p->d_dc_state;
+  } else {
+    sp.dc_mode = DC_TRACKED;
+    HIPCHK(launch_frame_sums(iq_dev, in_c64, sp.xor_mask, sp.frame_stride, p->nfft, n_frames, p->d_sums,
+                             p->stream));
+    HIPCHK(launch_dc_track(p->d_sums, p->nfft, n_frames, m.dc_alpha, sp.in_off, sp.in_scale, p->d_dc_state,
+                           p->d_dc_sub, p->stream));
+    sp.dc_sub = p->d_dc_sub;
+  }
+
+  const LaunchGeom g = spectrum_geometry(p->log2n, n_frames, p->num_cu);
+  if (averaging) {
+    if (!p->d_lin) HIPCHK(hipMalloc(&p->d_lin, size_t(p->max_frames) * p->nfft * sizeof(float)));
+    sp.out_lin = p->d_lin;
+    sp.hold_flags = 0;
+    HIPCHK(launch_spectrum(p->log2n, in_c64, sp, g, p->stream));
+    AvgParams ap{};
+    ap.lin = p->d_lin;
+    ap.n_frames = n_frames;
+    ap.n = p->nfft;
+    ap.state = p->d_avg;
+    ap.count_in = p->avg_count;
+    ap.mode = m.avg_mode;
+    ap.avg_n = m.avg_n;
+    ap.log_floor = m.log_floor;
+    ap.cal_db = m.cal_offset_db;
+    ap.tare = sp.tare;
+    ap.out_db = out_db_dev;
+    ap.state_max = (m.hold_flags & TDSA_HOLD_MAX) ? p->d_hold_max : nullptr;
+    ap.state_min = (m.hold_flags & TDSA_HOLD_MIN) ? p->d_hold_min : nullptr;
+    HIPCHK(launch_avg_scan(ap, p->stream));
+    if (m.avg_mode == TDSA_AVG_LIN) {
+      long long c = (long long)p->avg_count + n_frames;
+      p->avg_count = int(c < m.avg_n ? c : m.avg_n);
+    } else {
+      p->avg_count = 1;
+    }
+  } else {
+    sp.out_db = out_db_dev;
+    sp.hold_flags = int(m.hold_flags & 3u);
+    if (hold) {
+      int rc = ensure_partials(p);
+      if (rc != TDSA_OK) return rc;
+      sp.part_max = p->d_part_max;
+      sp.part_min = p->d_part_min;
+    }
+    HIPCHK(launch_spectrum(p->log2n, in_c64, sp, g, p->stream));
+    if (hold)
+      HIPCHK(launch_hold_reduce((m.hold_flags & TDSA_HOLD_MAX) ? p->d_part_max : nullptr,
+                                (m.hold_flags & TDSA_HOLD_MIN) ? p->d_part_min : nullptr, g.grid * g.fpw,
+                                p->nfft, p->d_hold_max, p->d_hold_min, p->stream));
+  }
+  if (m.hold_flags & TDSA_HOLD_MAX) p->held_max += n_frames;
+  if (m.hold_flags & TDSA_HOLD_MIN) p->held_min += n_frames;
+  p->frames_seen += n_frames;
+  return TDSA_OK;
+}
+
+static int process_host(tdsa_plan p, int fmt, const void* iq_host, size_t n_samples, int hop, int n_frames,
+                        float* out_db_host) {
+  if (!p) return fail(TDSA_ERR_ARG, "null plan");
+  if (n_frames == 0) return TDSA_OK;
+  if (!iq_host) return fail(TDSA_ERR_ARG, "iq pointer is null");
+  if (n_frames < 0 || n_frames > p->max_frames)
+    return fail(TDSA_ERR_ARG, "n_frames=%d outside [0, max_frames=%d]", n_frames, p->max_frames);
+  if (hop < 1) return fail(TDSA_ERR_ARG, "hop=%d must be >= 1", hop);
+  const size_t need = size_t(n_frames - 1) * size_t(hop) + size_t(p->nfft);
+  if (n_samples < need)
+    return fail(TDSA_ERR_ARG, "n_samples=%zu too small for %d frames of %d at hop %d", n_samples, n_frames,
+                p->nfft, hop);
+  HIPCHK(hipSetDevice(p->device));
+  const size_t in_bytes = need * bytes_per_sample(fmt);
+  if (in_bytes > p->in_stage_bytes) {
+    HIPCHK(hipStreamSynchronize(p->stream));
+    if (p->d_in_stage) HIPCHK(hipFree(p->d_in_stage));
+    p->d_in_stage = nullptr;
+    p->in_stage_bytes = 0;
+    HIPCHK(hipMalloc(&p->d_in_stage, in_bytes));
+    p->in_stage_bytes = in_bytes;
+  }
+  if (out_db_host && !p->d_out_stage)
+    HIPCHK(hipMalloc(&p->d_out_stage, size_t(p->max_frames) * p->nfft * sizeof(float)));
+  HIPCHK(hipMemcpyAsync(p->d_in_stage, iq_host, in_bytes, hipMemcpyHostToDevice, p->stream));
+  int rc = tdsa_process_dev(p, fmt, p->d_in_stage, need, hop, n_frames, out_db_host ? p->d_out_stage : nullptr);
+  if (rc != TDSA_OK) return rc;
+  if (out_db_host)
+    HIPCHK(hipMemcpyAsync(out_db_host, p->d_out_stage, size_t(n_frames) * p->nfft * sizeof(float),
+                          hipMemcpyDeviceToHost, p->stream));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  return TDSA_OK;
+}
+
+int tdsa_process_i8(tdsa_plan p, const int8_t* iq_host, size_t n_samples, int hop, int n_frames,
+                    float* out_db_host) {
+  return process_host(p, TDSA_IN_I8, iq_host, n_samples, hop, n_frames, out_db_host);
+}
+int tdsa_process_u8(tdsa_plan p, const uint8_t* iq_host, size_t n_samples, int hop, int n_frames,
+                    float* out_db_host) {
+  return process_host(p, TDSA_IN_U8, iq_host, n_samples, hop, n_frames, out_db_host);
+}
+int tdsa_process_c64(tdsa_plan p, const float* iq_host, size_t n_samples, int hop, int n_frames,
+                     float* out_db_host) {
+  return process_host(p, TDSA_IN_C64, iq_host, n_samples, hop, n_frames, out_db_host);
+}
+
+int tdsa_get_hold(tdsa_plan p, float* max_host, float* min_host, int64_t* frames_held) {
+  if (!p) return fail(TDSA_ERR_ARG, "null plan");
+  HIPCHK(hipSetDevice(p->device));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  const size_t nb = size_t(p->nfft) * sizeof(float);
+  if (max_host && p->held_max > 0) HIPCHK(hipMemcpy(max_host, p->d_hold_max, nb, hipMemcpyDeviceToHost));
+  if (min_host && p->held_min > 0) HIPCHK(hipMemcpy(min_host, p->d_hold_min, nb, hipMemcpyDeviceToHost));
+  if (frames_held) *frames_held = p->held_max > p->held_min ? p->held_max : p->held_min;
+  return TDSA_OK;
+}
+
+int tdsa_get_avg(tdsa_plan p, double* avg_linear_host, int* count) {
+  if (!p) return fail(TDSA_ERR_ARG, "null plan");
+  HIPCHK(hipSetDevice(p->device));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  if (avg_linear_host && p->avg_count > 0)
+    HIPCHK(hipMemcpy(avg_linear_host, p->d_avg, size_t(p->nfft) * sizeof(double), hipMemcpyDeviceToHost));
+  if (count) *count = p->avg_count;
+  return TDSA_OK;
+}
+
+int tdsa_get_dc(tdsa_plan p, float* re, float* im) {
+  if (!p) return fail(TDSA_ERR_ARG, "null plan");
+  HIPCHK(hipSetDevice(p->device));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  float2 dc;
+  HIPCHK(hipMemcpy(&dc, p->d_dc_state, sizeof(dc), hipMemcpyDeviceToHost));
+  if (re) *re = dc.x;
+  if (im) *im = dc.y;
+  return TDSA_OK;
+}
+
+int tdsa_synchronize(tdsa_plan p) {
+  if (!p) return fail(TDSA_ERR_ARG, "null plan");
+  HIPCHK(hipSetDevice(p->device));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  return TDSA_OK;
+}
+
+int tdsa_trace_update(tdsa_plan p, const float* db_in_host, int n, float cal_offset_db, int tare_collect,
+                      int tare_total, uint32_t hold_flags, float* live_out, float* max_out, float* min_out,
+                      int* tare_done) {
+  if (!p || !db_in_host) return fail(TDSA_ERR_ARG, "null argument");
+  if (n != p->nfft) return fail(TDSA_ERR_ARG, "trace length %d != nfft %d", n, p->nfft);
+  if (tare_collect && tare_total < 1) return fail(TDSA_ERR_ARG, "tare_total=%d", tare_total);
+  HIPCHK(hipSetDevice(p->device));
+  const size_t nb = size_t(n) * sizeof(float);
+  HIPCHK(hipMemcpyAsync(p->d_trace_in, db_in_host, nb, hipMemcpyHostToDevice, p->stream));
+  TraceParams tp{};
+  tp.db_in = p->d_trace_in;
+  tp.n = n;
+  tp.cal_db = cal_offset_db;
+  tp.tare_acc = p->d_tare_acc;
+  tp.tare_base = p->d_tare_base;
+  bool finish = false;
+  if (tare_collect) {
+    tp.tare_collect = 1;
+    tp.tare_first = p->tare_count == 0;
+    p->tare_count += 1;
+    tp.tare_count = p->tare_count;
+    finish = p->tare_count >= tare_total;
+    tp.tare_finish = finish;
+  }
+  tp.tare_active = (p->tare_active || finish) ? 1 : 0;
+  tp.live = p->d_trace_live;
+  tp.state_max = (hold_flags & TDSA_HOLD_MAX) ? p->d_hold_max : nullptr;
+  tp.state_min = (hold_flags & TDSA_HOLD_MIN) ? p->d_hold_min : nullptr;
+  tp.max_first = p->held_max == 0;
+  tp.min_first = p->held_min == 0;
+  HIPCHK(launch_trace_update(tp, p->stream));
+  if (finish) {
+    p->tare_active = true;
+    p->tare_count = 0;
+  }
+  if (tare_done) *tare_done = finish ? 1 : 0;
+  if (hold_flags & TDSA_HOLD_MAX) p->held_max += 1;
+  if (hold_flags & TDSA_HOLD_MIN) p->held_min += 1;
+  if (live_out) HIPCHK(hipMemcpyAsync(live_out, p->d_trace_live, nb, hipMemcpyDeviceToHost, p->stream));
+  if (max_out && (hold_flags & TDSA_HOLD_MAX))
+    HIPCHK(hipMemcpyAsync(max_out, p->d_hold_max, nb, hipMemcpyDeviceToHost, p->stream));
+  if (min_out && (hold_flags & TDSA_HOLD_MIN))
+    HIPCHK(hipMemcpyAsync(min_out, p->d_hold_min, nb, hipMemcpyDeviceToHost, p->stream));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  return TDSA_OK;
+}
+
+int tdsa_get_tare_baseline(tdsa_plan p, float* baseline_db_host, int* active) {
+  if (!p) return fail(TDSA_ERR_ARG, "null plan");
+  HIPCHK(hipSetDevice(p->device));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  if (baseline_db_host && p->tare_active)
+    HIPCHK(hipMemcpy(baseline_db_host, p->d_tare_base, size_t(p->nfft) * sizeof(float), hipMemcpyDeviceToHost));
+  if (active) *active = p->tare_active ? 1 : 0;
+  return TDSA_OK;
+}
+
+int tdsa_avg_process(tdsa_plan p, const float* linear_in_host, int n, double* avg_out_host) {
+  if (!p || !linear_in_host) return fail(TDSA_ERR_ARG, "null argument");
+  if (n != p->nfft) return fail(TDSA_ERR_ARG, "trace length %d != nfft %d", n, p->nfft);
+  if (!avg_active(p->mode)) return fail(TDSA_ERR_STATE, "averaging is off (pass-through is the caller's job)");
+  HIPCHK(hipSetDevice(p->device));
+  HIPCHK(hipMemcpyAsync(p->d_trace_in, linear_in_host, size_t(n) * sizeof(float), hipMemcpyHostToDevice,
+                        p->stream));
+  HIPCHK(launch_avg_host_frame(p->d_trace_in, n, p->d_avg, p->avg_count, p->mode.avg_mode, p->mode.avg_n,
+                               p->stream));
+  if (p->avg_count == 0) p->avg_count = 1;
+  else if (p->mode.avg_mode == TDSA_AVG_LIN && p->avg_count < p->mode.avg_n) p->avg_count += 1;
+  if (avg_out_host)
+    HIPCHK(hipMemcpyAsync(avg_out_host, p->d_avg, size_t(n) * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  return TDSA_OK;
+}
+
+int tdsa_dev_alloc(int device_id, size_t bytes, void** out_dev) {
+  if (!out_dev) return fail(TDSA_ERR_ARG, "out is null");
+  HIPCHK(hipSetDevice(device_id));
+  HIPCHK(hipMalloc(out_dev, bytes));
+  return TDSA_OK;
+}
+int tdsa_dev_free(int device_id, void* dev) {
+  HIPCHK(hipSetDevice(device_id));
+  if (dev) HIPCHK(hipFree(dev));
+  return TDSA_OK;
+}
+int tdsa_memcpy_h2d(int device_id, void* dst_dev, const void* src_host, size_t bytes) {
+  HIPCHK(hipSetDevice(device_id));
+  HIPCHK(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+  return TDSA_OK;
+}
+int tdsa_memcpy_d2h(int device_id, void* dst_host, const void* src_dev, size_t bytes) {
+  HIPCHK(hipSetDevice(device_id));
+  HIPCHK(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+  return TDSA_OK;
+}
+
+int tdsa_timer_begin(tdsa_plan p) {
+  if (!p) return fail(TDSA_ERR_ARG, "null plan");
+  HIPCHK(hipSetDevice(p->device));
+  HIPCHK(hipEventRecord(p->ev0, p->stream));
+  return TDSA_OK;
+}
+int tdsa_timer_end(tdsa_plan p, float* elapsed_ms) {
+  if (!p) return fail(TDSA_ERR_ARG, "null plan");
+  HIPCHK(hipSetDevice(p->device));
+  HIPCHK(hipEventRecord(p->ev1, p->stream));
+  HIPCHK(hipEventSynchronize(p->ev1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+  if (elapsed_ms) *elapsed_ms = ms;
+  return TDSA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,100 @@
+// tdsa_kernels.hpp - kernel parameter blocks and launcher prototypes shared by the kernel TUs
+// and the C-ABI layer (tdsa_capi.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace tdsa {
+
+constexpr int kMinLog2N = 6;    // 64
+constexpr int kMaxLog2N = 14;   // 16384 : largest frame whose c64 working set fits the 160 KiB LDS
+
+// dc_mode
+constexpr int DC_NONE = 0, DC_FRAME_MEAN = 1, DC_TRACKED = 2;
+
+struct SpecParams {
+  const void* in;            // device: interleaved int8/uint8 I,Q or float2 samples
+  long long frame_stride;    // bytes between consecutive frame starts (hop * bytes per sample)
+  int n_frames;
+  int first_frame_index;     // global index of frame 0 of this launch (nan_safe semantics of frame 0)
+  const float* window;       // [N] window * input scale
+  const float2* tw;          // [N] exp(-2 pi i m / N)
+  float* out_db;             // [F][N] fftshift-ed dB, or null
+  float* out_lin;            // [F][N] fftshift-ed linear power * pscale (averaging modes), or null
+  const float2* dc_sub;      // [F] per-frame subtract value in raw-sample units (DC_TRACKED), or null
+  float2* dc_state;          // last frame's mean in units of x is stored here (DC_FRAME_MEAN), or null
+  float* part_max;           // [grid*FPW][N] per-workgroup-slot partial max hold, or null
+  float* part_min;           // [grid*FPW][N]
+  const float* tare;         // [N] dB baseline to subtract, or null
+  unsigned xor_mask;         // 0x80808080 for int8 (-> offset binary), 0 for uint8
+  float in_off;              // 128 (int8), 127.5 (uint8), 0 (c64): value of "zero" in raw units
+  float in_scale;            // 1/128, 1/127.5, 1 : raw unit -> x
+  int dc_mode;
+  int db_mode;               // TDSA_DB_MAG / TDSA_DB_POW
+  float pscale;              // linear power scale (PSD) for DB_POW / out_lin
+  float log_floor;
+  float cal_db;              // calibration offset added to dB
+  int hold_flags;            // bit0 max, bit1 min
+};
+
+struct LaunchGeom {
+  int grid, block, fpw;
+  size_t lds_bytes;
+};
+
+// format: 0 = bytes (int8/uint8), 1 = complex64
+LaunchGeom spectrum_geometry(int log2n, int n_frames, int num_cu);
+hipError_t launch_spectrum(int log2n, int in_c64, const SpecParams& p, const LaunchGeom& g,
+                           hipStream_t s);
+
+// fold [rows][n] partial hold traces into the persistent state
+hipError_t launch_hold_reduce(const float* part_max, const float* part_min, int rows, int n,
+                              float* state_max, float* state_min, hipStream_t s);
+
+struct AvgParams {
+  const float* lin;       // [F][N] linear power (already PSD-scaled)
+  int n_frames, n;
+  double* state;          // [N] TraceAverager._buffer
+  int count_in;           // TraceAverager._count before this batch (0: buffer is None)
+  int mode, avg_n;        // TDSA_AVG_EXP / TDSA_AVG_LIN, n >= 2
+  float log_floor, cal_db;
+  const float* tare;      // or null
+  float* out_db;          // [F][N] or null
+  float* state_max;       // hold state (updated in place) or null
+  float* state_min;
+  int first_frame_index;
+};
+hipError_t launch_avg_scan(const AvgParams& p, hipStream_t s);
+
+// per-frame sums for the DC tracker (dc_alpha in (0,1)): sums[f] = sum of raw I, raw Q (float2)
+hipError_t launch_frame_sums(const void* in, int in_c64, unsigned xor_mask, long long frame_stride,
+                             int n, int n_frames, float2* sums, hipStream_t s);
+// sequential tracker: dc <- (1-a) dc + a mean ; writes dc_sub[f] (raw units) and the final state
+hipError_t launch_dc_track(const float2* sums, int n, int n_frames, float alpha, float in_off,
+                           float in_scale, float2* dc_state, float2* dc_sub, hipStream_t s);
+
+struct TraceParams {
+  const float* db_in;   // [n]
+  int n;
+  float cal_db;
+  float* tare_acc;      // [n] linear accumulator (collecting) or null
+  int tare_collect;     // accumulate this frame
+  int tare_first;       // first collected frame: acc = linear (not +=)
+  int tare_finish;      // this frame completes the baseline: baseline = 10log10(max(acc/cnt,1e-30))
+  int tare_count;       // frames collected including this one
+  float* tare_base;     // [n] baseline (written when finishing; read when active)
+  int tare_active;      // subtract baseline (after a finish in the same call too)
+  float* live;          // [n] out
+  float* state_max;     // or null
+  float* state_min;
+  int max_first, min_first;  // adopt (nan_safe) instead of fmax/fmin
+};
+hipError_t launch_trace_update(const TraceParams& p, hipStream_t s);
+
+hipError_t launch_avg_host_frame(const float* lin, int n, double* state, int count_in, int mode,
+                                 int avg_n, hipStream_t s);
+
+hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s);
+
+}  // namespace tdsa

@@ -1,0 +1,230 @@
+// tdsa_trace.hip - trace-domain kernels around the frame kernel:
+//   hold_reduce   : fold per-workgroup partial max/min hold rows into the persistent hold traces
+//                   (core/display_data_processor.py:371-395: np.fmax / np.fmin in the dB domain)
+//   avg_scan      : TraceAverager recurrence over the frames of a batch, one bin per thread, float64
+//                   state (utils/signal_processing.py:35-61) + dB + cal offset + tare + hold
+//   frame_sums / dc_track : the HackRF DC tracker for dc_alpha < 1 (hackrf_samples.py:360-365)
+//   trace_update  : DataProcessor's per-frame cal offset / tare / hold on a dB row handed in from the
+//                   host (display_data_processor.py:317-395)
+#include "tdsa_kernels.hpp"
+
+namespace tdsa {
+
+constexpr float k10Log10_2f = 3.01029995663981195214f;
+
+__global__ void __launch_bounds__(256) hold_reduce_kernel(const float* __restrict__ part_max,
+                                                          const float* __restrict__ part_min, int rows,
+                                                          int n, float* state_max, float* state_min) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  if (part_max != nullptr) {
+    float m = state_max[k];
+    float m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
+    int r = 0;
+    for (; r + 3 < rows; r += 4) {
+      m = fmaxf(m, part_max[(size_t)r * n + k]);
+      m1 = fmaxf(m1, part_max[(size_t)(r + 1) * n + k]);
+      m2 = fmaxf(m2, part_max[(size_t)(r + 2) * n + k]);
+      m3 = fmaxf(m3, part_max[(size_t)(r + 3) * n + k]);
+    }
+    for (; r < rows; ++r) m = fmaxf(m, part_max[(size_t)r * n + k]);
+    state_max[k] = fmaxf(fmaxf(m, m1), fmaxf(m2, m3));
+  }
+  if (part_min != nullptr) {
+    float m = state_min[k];
+    float m1 = INFINITY, m2 = INFINITY, m3 = INFINITY;
+    int r = 0;
+    for (; r + 3 < rows; r += 4) {
+      m = fminf(m, part_min[(size_t)r * n + k]);
+      m1 = fminf(m1, part_min[(size_t)(r + 1) * n + k]);
+      m2 = fminf(m2, part_min[(size_t)(r + 2) * n + k]);
+      m3 = fminf(m3, part_min[(size_t)(r + 3) * n + k]);
+    }
+    for (; r < rows; ++r) m = fminf(m, part_min[(size_t)r * n + k]);
+    state_min[k] = fminf(fminf(m, m1), fminf(m2, m3));
+  }
+}
+
+hipError_t launch_hold_reduce(const float* part_max, const float* part_min, int rows, int n,
+                              float* state_max, float* state_min, hipStream_t s) {
+  hipLaunchKernelGGL(hold_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, part_max, part_min, rows,
+                     n, state_max, state_min);
+  return hipGetLastError();
+}
+
+// One thread per bin walks the batch in frame order (the recurrence is order dependent: SURVEY.md 7).
+__global__ void __launch_bounds__(64) avg_scan_kernel(const AvgParams p) {
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  if (k >= p.n) return;
+  double buf = p.count_in > 0 ? p.state[k] : 0.0;
+  int count = p.count_in;
+  const double one_minus_alpha = 1.0 - 1.0 / double(p.avg_n);
+  const float alpha_f = float(1.0 / double(p.avg_n));   // numpy: python float * float32 array -> float32
+  const float tare = p.tare != nullptr ? p.tare[k] : 0.f;
+  float hmax = p.state_max != nullptr ? p.state_max[k] : 0.f;
+  float hmin = p.state_min != nullptr ? p.state_min[k] : 0.f;
+  constexpr int U = 8;
+  for (int f0 = 0; f0 < p.n_frames; f0 += U) {
+    float lin[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) lin[u] = (f0 + u < p.n_frames) ? p.lin[(size_t)(f0 + u) * p.n + k] : 0.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (f0 + u >= p.n_frames) break;
+      if (count == 0) {            // buffer is None: adopt the frame (signal_processing.py:47-50)
+        buf = double(lin[u]);
+        count = 1;
+      } else if (p.mode == 1) {    // exp (:52-55)
+        buf = buf * one_minus_alpha;
+        buf += double(alpha_f * lin[u]);
+      } else {                     // lin (:56-59)
+        if (count < p.avg_n) ++count;
+        buf += (double(lin[u]) - buf) / double(count);
+      }
+      float db = fmaf(k10Log10_2f, __builtin_amdgcn_logf(float(buf + double(p.log_floor))), p.cal_db) - tare;
+      if (p.out_db != nullptr) p.out_db[(size_t)(f0 + u) * p.n + k] = db;
+      hmax = fmaxf(hmax, db);
+      hmin = fminf(hmin, db);
+    }
+  }
+  p.state[k] = buf;
+  if (p.state_max != nullptr) p.state_max[k] = hmax;
+  if (p.state_min != nullptr) p.state_min[k] = hmin;
+}
+
+hipError_t launch_avg_scan(const AvgParams& p, hipStream_t s) {
+  hipLaunchKernelGGL(avg_scan_kernel, dim3((p.n + 63) / 64), dim3(64), 0, s, p);
+  return hipGetLastError();
+}
+
+// TraceAverager.process on one host-provided frame (sweep averager DataProcessor owns)
+__global__ void __launch_bounds__(256) avg_frame_kernel(const float* lin, int n, double* state, int count_in,
+                                                        int mode, int avg_n) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  double buf;
+  if (count_in == 0) {
+    buf = double(lin[k]);
+  } else if (mode == 1) {
+    buf = state[k] * (1.0 - 1.0 / double(avg_n));
+    buf += double(float(1.0 / double(avg_n)) * lin[k]);
+  } else {
+    int count = count_in < avg_n ? count_in + 1 : count_in;
+    buf = state[k];
+    buf += (double(lin[k]) - buf) / double(count);
+  }
+  state[k] = buf;
+}
+
+hipError_t launch_avg_host_frame(const float* lin, int n, double* state, int count_in, int mode, int avg_n,
+                                 hipStream_t s) {
+  hipLaunchKernelGGL(avg_frame_kernel, dim3((n + 255) / 256), dim3(256), 0, s, lin, n, state, count_in, mode,
+                     avg_n);
+  return hipGetLastError();
+}
+
+// ---- DC tracker (dc_alpha < 1) ----------------------------------------------------------------------
+template <bool IN_C64>
+__global__ void __launch_bounds__(256) frame_sums_kernel(const void* in, unsigned xor_mask,
+                                                         long long frame_stride, int n, float2* sums) {
+  __shared__ float red[8];
+  const int f = blockIdx.x;
+  const unsigned char* fb = static_cast<const unsigned char*>(in) + (long long)f * frame_stride;
+  float sr = 0.f, si = 0.f;
+  if constexpr (IN_C64) {
+    const float2* x = reinterpret_cast<const float2*>(fb);
+    for (int i = threadIdx.x; i < n; i += 256) { sr += x[i].x; si += x[i].y; }
+  } else {
+    const uint16_t* x = reinterpret_cast<const uint16_t*>(fb);
+    unsigned ui = 0, uq = 0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const unsigned u = (unsigned(x[i]) ^ xor_mask) & 0xffffu;
+      ui += u & 0xffu; uq += u >> 8;
+    }
+    sr = float(ui); si = float(uq);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { sr += __shfl_xor(sr, off); si += __shfl_xor(si, off); }
+  if ((threadIdx.x & 63) == 0) { red[(threadIdx.x >> 6) * 2] = sr; red[(threadIdx.x >> 6) * 2 + 1] = si; }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    sums[f] = float2{red[0] + red[2] + red[4] + red[6], red[1] + red[3] + red[5] + red[7]};
+}
+
+hipError_t launch_frame_sums(const void* in, int in_c64, unsigned xor_mask, long long frame_stride, int n,
+                             int n_frames, float2* sums, hipStream_t s) {
+  if (in_c64)
+    hipLaunchKernelGGL(frame_sums_kernel<true>, dim3(n_frames), dim3(256), 0, s, in, xor_mask, frame_stride, n,
+                       sums);
+  else
+    hipLaunchKernelGGL(frame_sums_kernel<false>, dim3(n_frames), dim3(256), 0, s, in, xor_mask, frame_stride, n,
+                       sums);
+  return hipGetLastError();
+}
+
+__global__ void dc_track_kernel(const float2* sums, int n, int n_frames, float alpha, float in_off,
+                                float in_scale, float2* dc_state, float2* dc_sub) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float2 dc = *dc_state;                       // units of x
+  const float inv_n = 1.0f / float(n);
+  for (int f = 0; f < n_frames; ++f) {
+    const float mr = (sums[f].x * inv_n - in_off) * in_scale;
+    const float mi = (sums[f].y * inv_n - in_off) * in_scale;
+    dc.x = (1.0f - alpha) * dc.x + alpha * mr;   // hackrf_samples.py:361-364
+    dc.y = (1.0f - alpha) * dc.y + alpha * mi;
+    dc_sub[f] = float2{in_off + dc.x / in_scale, in_off + dc.y / in_scale};
+  }
+  *dc_state = dc;
+}
+
+hipError_t launch_dc_track(const float2* sums, int n, int n_frames, float alpha, float in_off, float in_scale,
+                           float2* dc_state, float2* dc_sub, hipStream_t s) {
+  hipLaunchKernelGGL(dc_track_kernel, dim3(1), dim3(64), 0, s, sums, n, n_frames, alpha, in_off, in_scale,
+                     dc_state, dc_sub);
+  return hipGetLastError();
+}
+
+// ---- DataProcessor per-frame trace update -----------------------------------------------------------
+__global__ void __launch_bounds__(256) trace_update_kernel(const TraceParams p) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= p.n) return;
+  float db = p.db_in[k] + p.cal_db;                         // _apply_cal_offset (:317-327)
+  if (p.tare_collect) {                                     // _apply_tare collecting (:335-343)
+    const float lin = exp2f(db * (3.32192809488736234787f / 10.0f));   // 10^(dB/10)
+    const float acc = p.tare_first ? lin : p.tare_acc[k] + lin;
+    p.tare_acc[k] = acc;
+    if (p.tare_finish)                                      // (:351-356)
+      p.tare_base[k] = k10Log10_2f * __builtin_amdgcn_logf(fmaxf(acc / float(p.tare_count), 1e-30f));
+  }
+  if (p.tare_active) db -= p.tare_base[k];                  // (:361-367)
+  if (p.live != nullptr) p.live[k] = db;
+  if (p.state_max != nullptr) {                             // _update_max_hold (:371-382)
+    float m = p.max_first ? ((db != db) ? -500.f : db) : fmaxf(p.state_max[k], db);
+    p.state_max[k] = m;
+  }
+  if (p.state_min != nullptr) {                             // _update_min_hold (:384-395)
+    float m = p.min_first ? ((db != db) ? 500.f : db) : fminf(p.state_min[k], db);
+    p.state_min[k] = m;
+  }
+}
+
+hipError_t launch_trace_update(const TraceParams& p, hipStream_t s) {
+  hipLaunchKernelGGL(trace_update_kernel, dim3((p.n + 255) / 256), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) fill_kernel(float* p, size_t n, float v) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (; i < n; i += stride) p[i] = v;
+}
+
+hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s) {
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, n, v);
+  return hipGetLastError();
+}
+
+}  // namespace tdsa

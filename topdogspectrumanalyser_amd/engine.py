@@ -1,0 +1,180 @@
+"""SpectrumEngine - thin Python owner of one libtdsa_hip plan (device, FFT size, batch capacity).
+
+All arithmetic happens in the HIP kernels behind the C-ABI (include/tdsa_hip.h); this class only
+marshals numpy buffers / raw device pointers and mirrors the knobs the reference exposes on its
+sources (set_psd_mode, set_averaging, set_dc_alpha, window, cal offset, hold toggles).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _native as nat
+
+_AVG = {"off": nat.AVG_OFF, "exp": nat.AVG_EXP, "lin": nat.AVG_LIN}
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class SpectrumEngine:
+    def __init__(self, nfft: int, max_frames: int = 1, device: int = 0):
+        self.nfft = int(nfft)
+        self.max_frames = int(max_frames)
+        self.device = int(device)
+        self._h = C.c_void_p()
+        nat.check(nat.lib.tdsa_create(self.device, self.nfft, self.max_frames, C.byref(self._h)))
+        self._mode = nat.Mode(nat.DB_MAG, 1.0, 1e-12, nat.AVG_OFF, 1, 1.0, 0.0, 0)
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            nat.lib.tdsa_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ------------------------------------------------------------------ configuration
+    def set_window(self, window: np.ndarray) -> None:
+        w = np.ascontiguousarray(window, dtype=np.float32)
+        nat.check(nat.lib.tdsa_set_window(self._h, _ptr(w), int(w.size)))
+
+    def configure(self, *, db_mode: Optional[str] = None, power_scale: Optional[float] = None,
+                  log_floor: Optional[float] = None, avg: Optional[Tuple[str, int]] = None,
+                  dc_alpha: Optional[float] = None, cal_offset_db: Optional[float] = None,
+                  hold_max: Optional[bool] = None, hold_min: Optional[bool] = None) -> None:
+        m = self._mode
+        if db_mode is not None:
+            m.db_mode = {"mag": nat.DB_MAG, "pow": nat.DB_POW}[db_mode]
+        if power_scale is not None:
+            m.power_scale = float(power_scale)
+        if log_floor is not None:
+            m.log_floor = float(log_floor)
+        if avg is not None:
+            m.avg_mode, m.avg_n = _AVG[avg[0]], int(avg[1])
+        if dc_alpha is not None:
+            m.dc_alpha = float(dc_alpha)
+        if cal_offset_db is not None:
+            m.cal_offset_db = float(cal_offset_db)
+        flags = m.hold_flags
+        if hold_max is not None:
+            flags = (flags | nat.HOLD_MAX) if hold_max else (flags & ~nat.HOLD_MAX)
+        if hold_min is not None:
+            flags = (flags | nat.HOLD_MIN) if hold_min else (flags & ~nat.HOLD_MIN)
+        m.hold_flags = flags
+        nat.check(nat.lib.tdsa_set_mode(self._h, C.byref(m)))
+
+    def reset(self, what: int = nat.RESET_ALL) -> None:
+        nat.check(nat.lib.tdsa_reset_state(self._h, what))
+
+    def set_tare_baseline(self, baseline_db: Optional[np.ndarray]) -> None:
+        if baseline_db is None:
+            nat.check(nat.lib.tdsa_set_tare_baseline(self._h, None, 0))
+        else:
+            b = np.ascontiguousarray(baseline_db, dtype=np.float32)
+            nat.check(nat.lib.tdsa_set_tare_baseline(self._h, _ptr(b), int(b.size)))
+
+    # ------------------------------------------------------------------ hot path
+    def process(self, iq: np.ndarray, hop: Optional[int] = None, n_frames: Optional[int] = None,
+                want_db: bool = True) -> Optional[np.ndarray]:
+        """Host arrays in, [frames, nfft] float32 dB out.
+
+        iq: int8/uint8 interleaved I,Q (length 2*samples) or complex64 (length samples)."""
+        iq = np.ascontiguousarray(iq)
+        hop = self.nfft if hop is None else int(hop)
+        if iq.dtype == np.complex64:
+            n_samples, fn = iq.size, nat.lib.tdsa_process_c64
+        elif iq.dtype == np.int8:
+            n_samples, fn = iq.size // 2, nat.lib.tdsa_process_i8
+        elif iq.dtype == np.uint8:
+            n_samples, fn = iq.size // 2, nat.lib.tdsa_process_u8
+        else:
+            raise TypeError(f"unsupported IQ dtype {iq.dtype}; need int8, uint8 or complex64")
+        if n_frames is None:
+            n_frames = 0 if n_samples < self.nfft else (n_samples - self.nfft) // hop + 1
+        out = np.empty((n_frames, self.nfft), dtype=np.float32) if want_db else None
+        nat.check(fn(self._h, _ptr(iq), n_samples, hop, n_frames, _ptr(out)))
+        return out
+
+    def process_device(self, in_format: int, iq_dev: int, n_samples: int, hop: int, n_frames: int,
+                       out_db_dev: Optional[int]) -> None:
+        """Raw device pointers, asynchronous on the plan's stream (bench path)."""
+        nat.check(nat.lib.tdsa_process_dev(self._h, in_format, C.c_void_p(iq_dev), n_samples, hop,
+                                           n_frames, C.c_void_p(out_db_dev) if out_db_dev else None))
+
+    def synchronize(self) -> None:
+        nat.check(nat.lib.tdsa_synchronize(self._h))
+
+    # ------------------------------------------------------------------ state read-back
+    def hold(self) -> Tuple[Optional[np.ndarray], Optional[np.ndarray]]:
+        info = self.info()
+        mx = np.empty(self.nfft, dtype=np.float32) if info.frames_held_max > 0 else None
+        mn = np.empty(self.nfft, dtype=np.float32) if info.frames_held_min > 0 else None
+        held = C.c_int64()
+        nat.check(nat.lib.tdsa_get_hold(self._h, _ptr(mx), _ptr(mn), C.byref(held)))
+        return mx, mn
+
+    def averaged(self) -> Tuple[Optional[np.ndarray], int]:
+        cnt = C.c_int()
+        buf = np.empty(self.nfft, dtype=np.float64)
+        nat.check(nat.lib.tdsa_get_avg(self._h, _ptr(buf), C.byref(cnt)))
+        return (buf if cnt.value > 0 else None), cnt.value
+
+    @property
+    def dc_estimate(self) -> complex:
+        re, im = C.c_float(), C.c_float()
+        nat.check(nat.lib.tdsa_get_dc(self._h, C.byref(re), C.byref(im)))
+        return complex(re.value, im.value)
+
+    def info(self) -> nat.Info:
+        inf = nat.Info()
+        nat.check(nat.lib.tdsa_get_info(self._h, C.byref(inf)))
+        return inf
+
+    # ------------------------------------------------------------------ DataProcessor trace ops
+    def trace_update(self, db_in: np.ndarray, cal_offset_db: float = 0.0, tare_collect: bool = False,
+                     tare_total: int = 32, hold_max: bool = False, hold_min: bool = False):
+        x = np.ascontiguousarray(db_in, dtype=np.float32)
+        live = np.empty(self.nfft, dtype=np.float32)
+        mx = np.empty(self.nfft, dtype=np.float32) if hold_max else None
+        mn = np.empty(self.nfft, dtype=np.float32) if hold_min else None
+        done = C.c_int()
+        flags = (nat.HOLD_MAX if hold_max else 0) | (nat.HOLD_MIN if hold_min else 0)
+        nat.check(nat.lib.tdsa_trace_update(self._h, _ptr(x), int(x.size), float(cal_offset_db),
+                                            int(bool(tare_collect)), int(tare_total), flags,
+                                            _ptr(live), _ptr(mx), _ptr(mn), C.byref(done)))
+        return live, mx, mn, bool(done.value)
+
+    def tare_baseline(self) -> Optional[np.ndarray]:
+        act = C.c_int()
+        b = np.empty(self.nfft, dtype=np.float32)
+        nat.check(nat.lib.tdsa_get_tare_baseline(self._h, _ptr(b), C.byref(act)))
+        return b if act.value else None
+
+    def avg_process(self, linear_power: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(linear_power, dtype=np.float32)
+        out = np.empty(self.nfft, dtype=np.float64)
+        nat.check(nat.lib.tdsa_avg_process(self._h, _ptr(x), int(x.size), _ptr(out)))
+        return out
+
+    # ------------------------------------------------------------------ timing (HIP events, plan stream)
+    def timer_begin(self) -> None:
+        nat.check(nat.lib.tdsa_timer_begin(self._h))
+
+    def timer_end(self) -> float:
+        ms = C.c_float()
+        nat.check(nat.lib.tdsa_timer_end(self._h, C.byref(ms)))
+        return float(ms.value)
