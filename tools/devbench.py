@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Developer micro-benchmark for the frame kernel (not the contract bench: see bench.py).
+
+python tools/devbench.py [--nfft 16384] [--hop 8192] [--frames 2440] [--steps 20] [--hold 1] [--fmt i8]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from topdogspectrumanalyser_amd import SpectrumEngine, _native as nat  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nfft", type=int, default=16384)
+    ap.add_argument("--hop", type=int, default=0)
+    ap.add_argument("--frames", type=int, default=2440)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--hold", type=int, default=1)
+    ap.add_argument("--nodb", type=int, default=0)
+    ap.add_argument("--mode", default="mag")
+    a = ap.parse_args()
+    n, hop, F = a.nfft, (a.hop or a.nfft // 2), a.frames
+    ns = hop * (F - 1) + n
+    rng = np.random.default_rng(0)
+    iq = rng.integers(-100, 100, size=2 * ns, dtype=np.int8)
+    dev_in, dev_out = C.c_void_p(), C.c_void_p()
+    nat.check(nat.lib.tdsa_dev_alloc(0, iq.nbytes, C.byref(dev_in)))
+    nat.check(nat.lib.tdsa_dev_alloc(0, F * n * 4, C.byref(dev_out)))
+    nat.check(nat.lib.tdsa_memcpy_h2d(0, dev_in, iq.ctypes.data_as(C.c_void_p), iq.nbytes))
+    e = SpectrumEngine(n, max_frames=F)
+    w = np.hanning(n).astype(np.float32)
+    e.set_window(w)
+    e.configure(db_mode=a.mode, log_floor=1e-12, dc_alpha=1.0, hold_max=bool(a.hold & 1), hold_min=bool(a.hold & 2))
+    out_ptr = None if a.nodb else dev_out.value
+    for _ in range(a.warmup):
+        e.process_device(nat.IN_I8, dev_in.value, ns, hop, F, out_ptr)
+    e.synchronize()
+    e.timer_begin()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        e.process_device(nat.IN_I8, dev_in.value, ns, hop, F, out_ptr)
+    ms = e.timer_end()
+    t1 = time.perf_counter()
+    per = ms / a.steps
+    fps = F / (per * 1e-3)
+    bytes_per_frame = 2 * hop + 4 * n
+    inf = e.info()
+    print(f"lib={os.path.basename(nat.LIB_PATH)} N={n} hop={hop} F={F} hold={a.hold} grid={inf.grid}x{inf.block} lds={inf.lds_bytes} "
+          f"step={per*1e3:.1f} us  {fps/1e6:.3f} Mframes/s  {fps*bytes_per_frame/1e12:.3f} TB/s algorithmic "
+          f"({fps*bytes_per_frame/8e12*100:.1f}% of 8 TB/s)  host wall {((t1-t0)/a.steps)*1e6:.1f} us/step")
+
+
+if __name__ == "__main__":
+    main()

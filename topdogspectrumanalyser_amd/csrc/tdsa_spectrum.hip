@@ -1,397 +1,32 @@
-// tdsa_spectrum.hip - the fused frame kernel: one LDS-resident FFT frame per workgroup slot.
-//
-//   raw int8/uint8/complex64 IQ  ->  (x - dc) * window  ->  N-point FFT (A x 32 x 32 Stockham, data
-//   exchanged through LDS between register-resident radix passes)  ->  fftshift  ->  |X| / |X|^2  ->
-//   dB (+floor, +cal offset, -tare)  ->  per-frame dB row + register-resident max/min hold.
-//
-// Replaces, per frame, datasources/hackrf_samples.py:357-383 and datasources/rtl_samples.py:167-184
-// of the reference (numpy mean / window multiply / np.fft.fft / fftshift / abs / log10) and
-// core/display_data_processor.py:177-181 (cal offset, hold).  HBM traffic per frame is the
-// algorithmic minimum: the raw samples are read once, the dB row is written once.
-//
-// Work decomposition (N = A * 32 * 32 for N >= 2048, N = A * 32 below):
-//   * SG = N/32 threads own one frame; each thread holds 32 complex points in VGPRs in every pass.
-//   * pass 1: M = 32/A adjacent radix-A butterflies per thread, inputs straight from global memory
-//             (thread t reads samples a*(N/A) + t*M .. +M-1 : 2M contiguous bytes per load), no twiddles.
-//   * pass 2 / pass 3: one radix-32 butterfly per thread, operands gathered from LDS with unit lane
-//             stride (conflict free), twiddles rebuilt from 10 exact table values per pass.
-//   * the thread -> bin mapping of the last pass is frame invariant, so the window, the twiddle seeds
-//     and the max/min hold traces live in registers across the persistent frame loop.
-//   * a workgroup processes a CONTIGUOUS range of frames (overlapping frames re-read their shared
-//     half from the same XCD's L2, not from HBM).
-#include "tdsa_fft.hpp"
+// tdsa_spectrum.hip - size dispatch for the fused frame kernel (kernels live in
+// tdsa_spectrum_kernel.hpp, one instantiation TU per size).
 #include "tdsa_kernels.hpp"
 
 namespace tdsa {
+template <int LOG2N> hipError_t launch_size(int in_c64, const SpecParams& p, const LaunchGeom& g, hipStream_t s);
+template <int LOG2N> LaunchGeom geom_size(int n_frames, int num_cu);
 
-template <int LOG2N>
-struct Cfg {
-  static constexpr int N = 1 << LOG2N;
-  static constexpr int SG = N / 32;                       // threads per frame
-  static constexpr int NPASS = (N >= 2048) ? 3 : 2;
-  static constexpr int A = (NPASS == 3) ? N / 1024 : N / 32;  // radix of the first pass
-  static constexpr int M = 32 / A;                        // adjacent first-pass butterflies per thread
-  static constexpr int WGT = SG > 256 ? SG : 256;         // threads per workgroup
-  static constexpr int FPW = WGT / SG;                    // frames in flight per workgroup
-  static constexpr int NPAD = N + (N / 32) * 2;           // LDS slot, complex elements (16 B pad / 256 B)
-  static constexpr int WPF = SG >= 64 ? SG / 64 : 1;      // waves per frame
-  static constexpr int NWAVE = WGT / 64;
-  static constexpr size_t LDS_BYTES = size_t(FPW) * NPAD * sizeof(c32) + NWAVE * 2 * sizeof(float);
-};
-
-// unaligned-tolerant wide loads (frame starts are only guaranteed to be sample (2 byte) aligned)
-struct __attribute__((packed, aligned(2))) PU1 { uint32_t x; };
-struct __attribute__((packed, aligned(2))) PU2 { uint32_t x, y; };
-struct __attribute__((packed, aligned(2))) PU4 { uint32_t x, y, z, w; };
-
-template <int DW>
-__device__ __forceinline__ void load_raw(const unsigned char* q, uint32_t* dst) {
-  if constexpr (DW == 1) {
-    dst[0] = reinterpret_cast<const PU1*>(q)->x;
-  } else if constexpr (DW == 2) {
-    const PU2 r = *reinterpret_cast<const PU2*>(q);
-    dst[0] = r.x; dst[1] = r.y;
-  } else {
-    static_for<0, DW / 4>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      const PU4 r = *reinterpret_cast<const PU4*>(q + 16 * i);
-      dst[4 * i] = r.x; dst[4 * i + 1] = r.y; dst[4 * i + 2] = r.z; dst[4 * i + 3] = r.w;
-    });
-  }
-}
-
-template <int W>
-__device__ __forceinline__ float seg_sum(float x) {
-#pragma unroll
-  for (int off = W / 2; off >= 1; off >>= 1) x += __shfl_xor(x, off);
-  return x;
-}
-
-constexpr float k20Log10_2 = 6.02059991327962390427f;   // 20*log10(2)
-constexpr float k10Log10_2 = 3.01029995663981195214f;   // 10*log10(2)
-
-template <int LOG2N, bool IN_C64, bool HOLD>
-__global__ void __launch_bounds__(Cfg<LOG2N>::WGT) spectrum_kernel(const SpecParams p) {
-  using C = Cfg<LOG2N>;
-  constexpr int N = C::N, SG = C::SG, A = C::A, M = C::M, FPW = C::FPW, NPAD = C::NPAD;
-  constexpr int LA = ilog2(A);
-  constexpr int DW = (M >= 2) ? M / 2 : 1;   // raw dwords per first-pass row
-
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  c32* lds = reinterpret_cast<c32*>(smem);
-  float* red = reinterpret_cast<float*>(smem + size_t(FPW) * NPAD * sizeof(c32));
-
-  const int tid = threadIdx.x;
-  const int slot = tid / SG;
-  const int t = tid - slot * SG;
-  const int wave = tid >> 6;
-  c32* buf = lds + slot * NPAD;
-
-  const int n_units = (p.n_frames + FPW - 1) / FPW;
-  const int u0 = int((long long)blockIdx.x * n_units / gridDim.x);
-  const int u1 = int((long long)(blockIdx.x + 1) * n_units / gridDim.x);
-
-  // ---- frame-invariant per-thread state ---------------------------------------------------------
-  float win[32];
-  static_for<0, 32>([&](auto ic) {
-    constexpr int i = decltype(ic)::value;
-    constexpr int jj = i / A, a = i % A;
-    win[i] = p.window[a * (N / A) + t * M + jj];
-  });
-  c32 twf_lo[3], twf_hi[7];   // final pass: W_N^(t*c)
-  static_for<0, 3>([&](auto ic) { constexpr int i = decltype(ic)::value; twf_lo[i] = p.tw[t * (i + 1)]; });
-  static_for<0, 7>([&](auto ic) { constexpr int i = decltype(ic)::value; twf_hi[i] = p.tw[t * 4 * (i + 1)]; });
-  c32 twm_lo[3], twm_hi[7];   // middle pass (3-pass sizes): W_(32A)^((t mod A)*b)
-  if constexpr (C::NPASS == 3) {
-    const int ka = t % A;
-    constexpr int step = N / (32 * A);
-    static_for<0, 3>([&](auto ic) { constexpr int i = decltype(ic)::value; twm_lo[i] = p.tw[ka * (i + 1) * step]; });
-    static_for<0, 7>([&](auto ic) { constexpr int i = decltype(ic)::value; twm_hi[i] = p.tw[ka * 4 * (i + 1) * step]; });
-  }
-  float hmax[HOLD ? 32 : 1], hmin[HOLD ? 32 : 1];
-  if constexpr (HOLD) {
-    static_for<0, 32>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      hmax[i] = -INFINITY; hmin[i] = INFINITY;
-    });
-  }
-
-  // LDS addressing (complex-element units); pad(i) = i + 2*(i >> 5)
-  const int wr1_base = 34 * t;                                  // pass-1 write: rows of 32 + 2 pad
-  int rd_base, rd_stride;                                       // gather read: pad(t + b*SG)
-  if constexpr (SG % 32 == 0) { rd_base = t + 2 * (t >> 5); rd_stride = SG + 2 * (SG >> 5); }
-  const int wr2_base = (t / A) * (34 * A) + (t % A);            // middle-pass scatter
-
-  for (int unit = u0; unit < u1; ++unit) {
-    const int frame = unit * FPW + slot;
-    const bool active = frame < p.n_frames;
-    const unsigned char* fbase = static_cast<const unsigned char*>(p.in) + (long long)frame * p.frame_stride;
-
-    c32 v[32];
-    float sum_re = 0.f, sum_im = 0.f;
-    uint32_t raw[IN_C64 ? 1 : A * DW];
-
-    // ---- global -> registers --------------------------------------------------------------------
-    if constexpr (IN_C64) {
-      const c32* fp = reinterpret_cast<const c32*>(fbase);
-      static_for<0, 32>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        constexpr int jj = i / A, a = i % A;
-        v[i] = active ? fp[a * (N / A) + t * M + jj] : c32{0.f, 0.f};
-      });
-      if (p.dc_mode == DC_FRAME_MEAN) {
-        static_for<0, 32>([&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          sum_re += v[i].x; sum_im += v[i].y;
-        });
-      }
-    } else {
-      unsigned si = 0, sq = 0;
-      static_for<0, A>([&](auto ic) {
-        constexpr int a = decltype(ic)::value;
-        if (active) {
-          if constexpr (M == 1) {
-            raw[a] = *reinterpret_cast<const uint16_t*>(fbase + (a * (N / A) + t) * 2);
-            raw[a] = (raw[a] ^ p.xor_mask) & 0xffffu;
-          } else {
-            load_raw<DW>(fbase + (a * (N / A) + t * M) * 2, &raw[a * DW]);
-            static_for<0, DW>([&](auto jc) { raw[a * DW + decltype(jc)::value] ^= p.xor_mask; });
-          }
-        } else {
-          static_for<0, DW>([&](auto jc) { raw[a * DW + decltype(jc)::value] = 0u; });
-        }
-      });
-      if (p.dc_mode == DC_FRAME_MEAN) {
-        static_for<0, A * DW>([&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          si = __builtin_amdgcn_udot4(raw[i], 0x00010001u, si, false);
-          sq = __builtin_amdgcn_udot4(raw[i], 0x01000100u, sq, false);
-        });
-        sum_re = float(si); sum_im = float(sq);   // exact: <= 255 * 16384 < 2^24
-      }
-    }
-
-    // ---- frame mean (DC) : segmented wave reduce, then across the frame's waves via LDS ---------
-    float sub_re = p.in_off, sub_im = p.in_off;
-    if (p.dc_mode == DC_FRAME_MEAN) {
-      constexpr int W = SG < 64 ? SG : 64;
-      sum_re = seg_sum<W>(sum_re);
-      sum_im = seg_sum<W>(sum_im);
-      if constexpr (SG > 64) {
-        if ((tid & 63) == 0) { red[wave * 2] = sum_re; red[wave * 2 + 1] = sum_im; }
-      }
-    }
-    __syncthreads();   // also the WAR fence between the previous frame's LDS reads and our writes
-    if (p.dc_mode == DC_FRAME_MEAN) {
-      if constexpr (SG > 64) {
-        const int w0 = (slot * SG) >> 6;
-        sum_re = 0.f; sum_im = 0.f;
-#pragma unroll
-        for (int i = 0; i < C::WPF; ++i) { sum_re += red[(w0 + i) * 2]; sum_im += red[(w0 + i) * 2 + 1]; }
-      }
-      sub_re = sum_re * (1.0f / N);
-      sub_im = sum_im * (1.0f / N);
-      if (p.dc_state != nullptr && frame == p.n_frames - 1 && t == 0)
-        *p.dc_state = c32{(sub_re - p.in_off) * p.in_scale, (sub_im - p.in_off) * p.in_scale};
-    } else if (p.dc_mode == DC_TRACKED) {
-      if (active) { const c32 s = p.dc_sub[frame]; sub_re = s.x; sub_im = s.y; }
-    }
-
-    // ---- unpack + DC removal + window ------------------------------------------------------------
-    if constexpr (IN_C64) {
-      static_for<0, 32>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        v[i] = c32{(v[i].x - sub_re) * win[i], (v[i].y - sub_im) * win[i]};
-      });
-    } else if constexpr (M == 1) {
-      static_for<0, 32>([&](auto ic) {
-        constexpr int a = decltype(ic)::value;
-        const uint32_t u = raw[a];
-        v[a] = c32{(float(u & 0xffu) - sub_re) * win[a], (float((u >> 8) & 0xffu) - sub_im) * win[a]};
-      });
-    } else {
-      static_for<0, A>([&](auto ac) {
-        constexpr int a = decltype(ac)::value;
-        static_for<0, DW>([&](auto dc) {
-          constexpr int d = decltype(dc)::value;
-          const uint32_t u = raw[a * DW + d];
-          constexpr int i0 = (2 * d) * A + a, i1 = (2 * d + 1) * A + a;
-          v[i0] = c32{(float(u & 0xffu) - sub_re) * win[i0], (float((u >> 8) & 0xffu) - sub_im) * win[i0]};
-          v[i1] = c32{(float((u >> 16) & 0xffu) - sub_re) * win[i1], (float(u >> 24) - sub_im) * win[i1]};
-        });
-      });
-    }
-
-    // ---- pass 1: M radix-A butterflies, rows written contiguously (16 B stores) ------------------
-    static_for<0, M>([&](auto jc) { dif<A, decltype(jc)::value * A, 32>(v); });
-    static_for<0, 16>([&](auto ic) {
-      constexpr int li = 2 * decltype(ic)::value;           // local index jj*A + ka, even
-      constexpr int jj = li / A, ka = li % A;
-      constexpr int r0 = jj * A + bitrev(ka, LA), r1 = jj * A + bitrev(ka + 1, LA);
-      *reinterpret_cast<float4*>(&buf[wr1_base + li]) = float4{v[r0].x, v[r0].y, v[r1].x, v[r1].y};
-    });
-    __syncthreads();
-
-    // ---- gather for the next radix-32 pass -------------------------------------------------------
-    auto gather = [&]() {
-      static_for<0, 32>([&](auto ic) {
-        constexpr int b = decltype(ic)::value;
-        if constexpr (SG % 32 == 0) v[b] = buf[rd_base + b * rd_stride];
-        else { const int i = t + b * SG; v[b] = buf[i + ((i >> 5) << 1)]; }
-      });
-    };
-    gather();
-
-    if constexpr (C::NPASS == 3) {
-      twiddle32(v, twm_lo, twm_hi);
-      dif<32, 0, 32>(v);
-      __syncthreads();                                      // everyone finished reading pass-1 data
-      static_for<0, 32>([&](auto ic) {
-        constexpr int kb = decltype(ic)::value;
-        buf[wr2_base + kb * A + 2 * ((kb * A) >> 5)] = v[bitrev(kb, 5)];
-      });
-      __syncthreads();
-      gather();
-    }
-    twiddle32(v, twf_lo, twf_hi);
-    dif<32, 0, 32>(v);
-
-    // ---- epilogue: |X|^2 -> dB -> hold ; bin k = t + kc*SG lands at k ^ N/2 (fftshift) -----------
-    if (active) {
-      const long long row = (long long)frame * N + t;
-      if (p.out_lin != nullptr) {
-        static_for<0, 32>([&](auto ic) {
-          constexpr int kc = decltype(ic)::value;
-          const c32 X = v[bitrev(kc, 5)];
-          p.out_lin[row + (kc ^ 16) * SG] = (X.x * X.x + X.y * X.y) * p.pscale;
-        });
-      } else {
-        float db[32];
-        if (p.db_mode == 0) {
-          static_for<0, 32>([&](auto ic) {
-            constexpr int kc = decltype(ic)::value;
-            const c32 X = v[bitrev(kc, 5)];
-            const float mag = __builtin_amdgcn_sqrtf(X.x * X.x + X.y * X.y);
-            db[kc] = fmaf(k20Log10_2, __builtin_amdgcn_logf(mag + p.log_floor), p.cal_db);
-          });
-        } else {
-          static_for<0, 32>([&](auto ic) {
-            constexpr int kc = decltype(ic)::value;
-            const c32 X = v[bitrev(kc, 5)];
-            const float pw = X.x * X.x + X.y * X.y;
-            db[kc] = fmaf(k10Log10_2, __builtin_amdgcn_logf(fmaf(pw, p.pscale, p.log_floor)), p.cal_db);
-          });
-        }
-        if (p.tare != nullptr) {
-          static_for<0, 32>([&](auto ic) {
-            constexpr int kc = decltype(ic)::value;
-            db[kc] -= p.tare[t + (kc ^ 16) * SG];
-          });
-        }
-        if (p.out_db != nullptr) {
-          static_for<0, 32>([&](auto ic) {
-            constexpr int kc = decltype(ic)::value;
-            p.out_db[row + (kc ^ 16) * SG] = db[kc];
-          });
-        }
-        if constexpr (HOLD) {
-          const bool nanfix = IN_C64 && (p.first_frame_index + frame == 0);
-          static_for<0, 32>([&](auto ic) {
-            constexpr int kc = decltype(ic)::value;
-            float dmx = db[kc], dmn = db[kc];
-            if (nanfix && dmx != dmx) { dmx = -500.f; dmn = 500.f; }   // _nan_safe on the first frame
-            hmax[kc] = fmaxf(hmax[kc], dmx);                           // np.fmax: NaN ignored
-            hmin[kc] = fminf(hmin[kc], dmn);
-          });
-        }
-      }
-    }
-  }
-
-  if constexpr (HOLD) {
-    const long long prow = ((long long)blockIdx.x * FPW + slot) * N + t;
-    if (p.hold_flags & 1) {
-      static_for<0, 32>([&](auto ic) {
-        constexpr int kc = decltype(ic)::value;
-        p.part_max[prow + (kc ^ 16) * SG] = hmax[kc];
-      });
-    }
-    if (p.hold_flags & 2) {
-      static_for<0, 32>([&](auto ic) {
-        constexpr int kc = decltype(ic)::value;
-        p.part_min[prow + (kc ^ 16) * SG] = hmin[kc];
-      });
-    }
-  }
-}
-
-// ---- host-side dispatch ----------------------------------------------------------------------------
-template <int LOG2N>
-static LaunchGeom geom_for(int n_frames, int num_cu) {
-  using C = Cfg<LOG2N>;
-  LaunchGeom g;
-  g.block = C::WGT;
-  g.fpw = C::FPW;
-  g.lds_bytes = C::LDS_BYTES;
-  const int per_cu = int((160 * 1024) / C::LDS_BYTES) < 1 ? 1 : int((160 * 1024) / C::LDS_BYTES);
-  const int by_waves = 2048 / C::WGT;                         // <= 32 waves per CU
-  const int wg_per_cu = per_cu < by_waves ? per_cu : by_waves;
-  const int units = (n_frames + C::FPW - 1) / C::FPW;
-  int grid = num_cu * wg_per_cu;
-  if (grid > units) grid = units;
-  if (grid < 1) grid = 1;
-  g.grid = grid;
-  return g;
-}
+#define TDSA_FOR_SIZES(X) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14)
+#define TDSA_DECL(k)                                                                                  \
+  template <> hipError_t launch_size<k>(int, const SpecParams&, const LaunchGeom&, hipStream_t);      \
+  template <> LaunchGeom geom_size<k>(int, int);
+TDSA_FOR_SIZES(TDSA_DECL)
 
 LaunchGeom spectrum_geometry(int log2n, int n_frames, int num_cu) {
   switch (log2n) {
-    case 6: return geom_for<6>(n_frames, num_cu);
-    case 7: return geom_for<7>(n_frames, num_cu);
-    case 8: return geom_for<8>(n_frames, num_cu);
-    case 9: return geom_for<9>(n_frames, num_cu);
-    case 10: return geom_for<10>(n_frames, num_cu);
-    case 11: return geom_for<11>(n_frames, num_cu);
-    case 12: return geom_for<12>(n_frames, num_cu);
-    case 13: return geom_for<13>(n_frames, num_cu);
-    default: return geom_for<14>(n_frames, num_cu);
+#define TDSA_CASE(k) case k: return geom_size<k>(n_frames, num_cu);
+    TDSA_FOR_SIZES(TDSA_CASE)
+#undef TDSA_CASE
+    default: return LaunchGeom{1, 256, 1, 0};
   }
-}
-
-template <int LOG2N, bool IN_C64, bool HOLD>
-static hipError_t launch_one(const SpecParams& p, const LaunchGeom& g, hipStream_t s) {
-  auto k = spectrum_kernel<LOG2N, IN_C64, HOLD>;
-  static bool attr_set = false;   // one plan thread at a time per process-wide kernel symbol is fine
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(g.lds_bytes));
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(k, dim3(g.grid), dim3(g.block), g.lds_bytes, s, p);
-  return hipGetLastError();
-}
-
-template <int LOG2N>
-static hipError_t launch_n(int in_c64, const SpecParams& p, const LaunchGeom& g, hipStream_t s) {
-  const bool hold = (p.hold_flags & 3) != 0 && p.out_lin == nullptr;
-  if (in_c64) return hold ? launch_one<LOG2N, true, true>(p, g, s) : launch_one<LOG2N, true, false>(p, g, s);
-  return hold ? launch_one<LOG2N, false, true>(p, g, s) : launch_one<LOG2N, false, false>(p, g, s);
 }
 
 hipError_t launch_spectrum(int log2n, int in_c64, const SpecParams& p, const LaunchGeom& g, hipStream_t s) {
   switch (log2n) {
-    case 6: return launch_n<6>(in_c64, p, g, s);
-    case 7: return launch_n<7>(in_c64, p, g, s);
-    case 8: return launch_n<8>(in_c64, p, g, s);
-    case 9: return launch_n<9>(in_c64, p, g, s);
-    case 10: return launch_n<10>(in_c64, p, g, s);
-    case 11: return launch_n<11>(in_c64, p, g, s);
-    case 12: return launch_n<12>(in_c64, p, g, s);
-    case 13: return launch_n<13>(in_c64, p, g, s);
-    case 14: return launch_n<14>(in_c64, p, g, s);
+#define TDSA_CASE(k) case k: return launch_size<k>(in_c64, p, g, s);
+    TDSA_FOR_SIZES(TDSA_CASE)
+#undef TDSA_CASE
     default: return hipErrorInvalidValue;
   }
 }
-
 }  // namespace tdsa
