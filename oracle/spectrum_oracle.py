@@ -380,7 +380,7 @@ def synth_iq_int8(n_samples: int, nfft: int, seed: int) -> np.ndarray:
     return out
 
 
-def parity_metrics(db_gpu: np.ndarray, db_gold: np.ndarray, floor_rel_db: float = 80.0):
+def parity_metrics(db_gpu: np.ndarray, db_gold: np.ndarray, floor_rel_db: float = 60.0):
     """SURVEY.md 8(d) parity definition: per frame, linear power error relative to the frame
     maximum, and |dB| error on bins within ``floor_rel_db`` of the frame maximum."""
     db_gpu = np.asarray(db_gpu, dtype=np.float64)
