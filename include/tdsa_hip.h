@@ -173,6 +173,12 @@ int tdsa_memcpy_d2h(int device_id, void* dst_host, const void* src_dev, size_t b
 int tdsa_timer_begin(tdsa_plan p);
 int tdsa_timer_end(tdsa_plan p, float* elapsed_ms); /* records, synchronises, returns elapsed */
 
+/* Per-launch HIP-event bracketing of the frame kernel alone (the dominant kernel bench.py prices
+ * against the HBM roofline).  enable != 0 starts collecting; read synchronises the stream and returns
+ * the number of frame-kernel launches and the sum of their durations since the last read. */
+int tdsa_profile_enable(tdsa_plan p, int enable);
+int tdsa_profile_read(tdsa_plan p, int* launches, float* total_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,8 @@ _SIGNATURES = {
     "tdsa_dev_free": (C.c_int, [C.c_int, _P]),
     "tdsa_memcpy_h2d": (C.c_int, [C.c_int, _P, _P, C.c_size_t]),
     "tdsa_memcpy_d2h": (C.c_int, [C.c_int, _P, _P, C.c_size_t]),
+    "tdsa_profile_enable": (C.c_int, [_P, C.c_int]),
+    "tdsa_profile_read": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "tdsa_timer_begin": (C.c_int, [_P]),
     "tdsa_timer_end": (C.c_int, [_P, C.POINTER(C.c_float)]),
 }

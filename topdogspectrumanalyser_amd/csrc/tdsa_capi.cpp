@@ -71,6 +71,9 @@ struct tdsa_plan_s {
   float* d_trace_in = nullptr;
   float* d_trace_live = nullptr;
   long long frames_seen = 0;             // frames processed since the last hold reset (nan_safe rule)
+  bool profiling = false;
+  std::vector<hipEvent_t> prof_events;   // pairs (begin, end) around frame-kernel launches
+  size_t prof_used = 0;
 };
 
 namespace {
@@ -98,6 +101,25 @@ int ensure_partials(tdsa_plan p) {
   const size_t bytes = size_t(p->part_rows) * p->nfft * sizeof(float);
   HIPCHK(hipMalloc(&p->d_part_max, bytes));
   HIPCHK(hipMalloc(&p->d_part_min, bytes));
+  return TDSA_OK;
+}
+
+int launch_spectrum_profiled(tdsa_plan p, int in_c64, const SpecParams& sp, const LaunchGeom& g) {
+  if (!p->profiling) {
+    HIPCHK(launch_spectrum(p->log2n, in_c64, sp, g, p->stream));
+    return TDSA_OK;
+  }
+  if (p->prof_used + 2 > p->prof_events.size()) {
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    p->prof_events.push_back(a);
+    p->prof_events.push_back(b);
+  }
+  HIPCHK(hipEventRecord(p->prof_events[p->prof_used], p->stream));
+  HIPCHK(launch_spectrum(p->log2n, in_c64, sp, g, p->stream));
+  HIPCHK(hipEventRecord(p->prof_events[p->prof_used + 1], p->stream));
+  p->prof_used += 2;
   return TDSA_OK;
 }
 
@@ -184,6 +206,7 @@ int tdsa_destroy(tdsa_plan p) {
                   p->d_trace_live};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
+  for (hipEvent_t e : p->prof_events) (void)hipEventDestroy(e);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
   if (p->ev1) (void)hipEventDestroy(p->ev1);
   if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -325,7 +348,8 @@ int tdsa_process_dev(tdsa_plan p, int in_format, const void* iq_dev, size_t n_sa
     if (!p->d_lin) HIPCHK(hipMalloc(&p->d_lin, size_t(p->max_frames) * p->nfft * sizeof(float)));
     sp.out_lin = p->d_lin;
     sp.hold_flags = 0;
-    HIPCHK(launch_spectrum(p->log2n, in_c64, sp, g, p->stream));
+    int rc_p = launch_spectrum_profiled(p, in_c64, sp, g);
+    if (rc_p != TDSA_OK) return rc_p;
     AvgParams ap{};
     ap.lin = p->d_lin;
     ap.n_frames = n_frames;
@@ -356,7 +380,8 @@ int tdsa_process_dev(tdsa_plan p, int in_format, const void* iq_dev, size_t n_sa
       sp.part_max = p->d_part_max;
       sp.part_min = p->d_part_min;
     }
-    HIPCHK(launch_spectrum(p->log2n, in_c64, sp, g, p->stream));
+    int rc_p = launch_spectrum_profiled(p, in_c64, sp, g);
+    if (rc_p != TDSA_OK) return rc_p;
     if (hold)
       HIPCHK(launch_hold_reduce((m.hold_flags & TDSA_HOLD_MAX) ? p->d_part_max : nullptr,
                                 (m.hold_flags & TDSA_HOLD_MIN) ? p->d_part_min : nullptr, g.grid * g.fpw,
@@ -547,6 +572,28 @@ int tdsa_memcpy_h2d(int device_id, void* dst_dev, const void* src_host, size_t b
 int tdsa_memcpy_d2h(int device_id, void* dst_host, const void* src_dev, size_t bytes) {
   HIPCHK(hipSetDevice(device_id));
   HIPCHK(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+  return TDSA_OK;
+}
+
+int tdsa_profile_enable(tdsa_plan p, int enable) {
+  if (!p) return fail(TDSA_ERR_ARG, "null plan");
+  p->profiling = enable != 0;
+  return TDSA_OK;
+}
+
+int tdsa_profile_read(tdsa_plan p, int* launches, float* total_ms) {
+  if (!p) return fail(TDSA_ERR_ARG, "null plan");
+  HIPCHK(hipSetDevice(p->device));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  float total = 0.f;
+  for (size_t i = 0; i + 1 < p->prof_used; i += 2) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, p->prof_events[i], p->prof_events[i + 1]));
+    total += ms;
+  }
+  if (launches) *launches = int(p->prof_used / 2);
+  if (total_ms) *total_ms = total;
+  p->prof_used = 0;
   return TDSA_OK;
 }
 

@@ -108,6 +108,26 @@ __device__ __forceinline__ void dif(c32 (&v)[TOT]) {
   }
 }
 
+// Same butterfly network, depth first, calling emit(integral_constant<register index>) as soon as a
+// register holds a final output: the LDS stores of the first outputs then issue while the rest of the
+// butterfly is still being computed (X[k] sits in register BASE + bitrev(k)).
+template <int R, int BASE, int TOT, class F>
+__device__ __forceinline__ void dif_emit(c32 (&v)[TOT], F&& emit) {
+  if constexpr (R == 1) {
+    emit(std::integral_constant<int, BASE>{});
+  } else {
+    constexpr int h = R / 2;
+    static_for<0, h>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const c32 a = v[BASE + i], b = v[BASE + i + h];
+      v[BASE + i] = cadd(a, b);
+      v[BASE + i + h] = mul_w<i, R>(csub(a, b));
+    });
+    dif_emit<h, BASE, TOT>(v, emit);
+    dif_emit<h, BASE + h, TOT>(v, emit);
+  }
+}
+
 // Multiply v[c] by w^c for c = 1..31 where w^1..w^3 (lo) and w^4, w^8 .. w^28 (hi) come exact from
 // the twiddle table: every factor is at most ONE rounded product away from the table value.
 __device__ __forceinline__ void twiddle32(c32 (&v)[32], const c32 (&lo)[3], const c32 (&hi)[7]) {

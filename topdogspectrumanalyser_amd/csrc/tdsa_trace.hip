@@ -12,43 +12,53 @@ namespace tdsa {
 
 constexpr float k10Log10_2f = 3.01029995663981195214f;
 
-__global__ void __launch_bounds__(256) hold_reduce_kernel(const float* __restrict__ part_max,
-                                                          const float* __restrict__ part_min, int rows,
-                                                          int n, float* state_max, float* state_min) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
+// float max/min through integer atomics (IEEE-754 order trick); the state is initialised to -inf / +inf
+__device__ __forceinline__ void atomic_fmax(float* addr, float v) {
+  if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else atomicMin(reinterpret_cast<unsigned*>(addr), __float_as_uint(v));
+}
+__device__ __forceinline__ void atomic_fmin(float* addr, float v) {
+  if (v >= 0.f) atomicMin(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else atomicMax(reinterpret_cast<unsigned*>(addr), __float_as_uint(v));
+}
+
+// grid = (n/256 column groups of 4 bins x 64 lanes, row slices): every thread folds kRowsPerSlice rows of
+// four adjacent bins with independent 16-byte loads, then merges into the state with one atomic per bin.
+constexpr int kRowsPerSlice = 16;
+__global__ void __launch_bounds__(64) hold_reduce_kernel(const float* __restrict__ part_max,
+                                                         const float* __restrict__ part_min, int rows,
+                                                         int n, float* state_max, float* state_min) {
+  const int k = (blockIdx.x * 64 + threadIdx.x) * 4;
   if (k >= n) return;
+  const int r0 = blockIdx.y * kRowsPerSlice;
+  const int r1 = r0 + kRowsPerSlice < rows ? r0 + kRowsPerSlice : rows;
   if (part_max != nullptr) {
-    float m = state_max[k];
-    float m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
-    int r = 0;
-    for (; r + 3 < rows; r += 4) {
-      m = fmaxf(m, part_max[(size_t)r * n + k]);
-      m1 = fmaxf(m1, part_max[(size_t)(r + 1) * n + k]);
-      m2 = fmaxf(m2, part_max[(size_t)(r + 2) * n + k]);
-      m3 = fmaxf(m3, part_max[(size_t)(r + 3) * n + k]);
+    float4 m = float4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll 8
+    for (int r = r0; r < r1; ++r) {
+      const float4 v = *reinterpret_cast<const float4*>(part_max + (size_t)r * n + k);
+      m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
     }
-    for (; r < rows; ++r) m = fmaxf(m, part_max[(size_t)r * n + k]);
-    state_max[k] = fmaxf(fmaxf(m, m1), fmaxf(m2, m3));
+    atomic_fmax(state_max + k, m.x); atomic_fmax(state_max + k + 1, m.y);
+    atomic_fmax(state_max + k + 2, m.z); atomic_fmax(state_max + k + 3, m.w);
   }
   if (part_min != nullptr) {
-    float m = state_min[k];
-    float m1 = INFINITY, m2 = INFINITY, m3 = INFINITY;
-    int r = 0;
-    for (; r + 3 < rows; r += 4) {
-      m = fminf(m, part_min[(size_t)r * n + k]);
-      m1 = fminf(m1, part_min[(size_t)(r + 1) * n + k]);
-      m2 = fminf(m2, part_min[(size_t)(r + 2) * n + k]);
-      m3 = fminf(m3, part_min[(size_t)(r + 3) * n + k]);
+    float4 m = float4{INFINITY, INFINITY, INFINITY, INFINITY};
+#pragma unroll 8
+    for (int r = r0; r < r1; ++r) {
+      const float4 v = *reinterpret_cast<const float4*>(part_min + (size_t)r * n + k);
+      m.x = fminf(m.x, v.x); m.y = fminf(m.y, v.y); m.z = fminf(m.z, v.z); m.w = fminf(m.w, v.w);
     }
-    for (; r < rows; ++r) m = fminf(m, part_min[(size_t)r * n + k]);
-    state_min[k] = fminf(fminf(m, m1), fminf(m2, m3));
+    atomic_fmin(state_min + k, m.x); atomic_fmin(state_min + k + 1, m.y);
+    atomic_fmin(state_min + k + 2, m.z); atomic_fmin(state_min + k + 3, m.w);
   }
 }
 
 hipError_t launch_hold_reduce(const float* part_max, const float* part_min, int rows, int n,
                               float* state_max, float* state_min, hipStream_t s) {
-  hipLaunchKernelGGL(hold_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, part_max, part_min, rows,
-                     n, state_max, state_min);
+  const dim3 grid((n / 4 + 63) / 64, (rows + kRowsPerSlice - 1) / kRowsPerSlice);
+  hipLaunchKernelGGL(hold_reduce_kernel, grid, dim3(64), 0, s, part_max, part_min, rows, n, state_max,
+                     state_min);
   return hipGetLastError();
 }
 

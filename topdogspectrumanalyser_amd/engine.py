@@ -170,6 +170,15 @@ class SpectrumEngine:
         nat.check(nat.lib.tdsa_avg_process(self._h, _ptr(x), int(x.size), _ptr(out)))
         return out
 
+    def profile_enable(self, on: bool = True) -> None:
+        nat.check(nat.lib.tdsa_profile_enable(self._h, int(bool(on))))
+
+    def profile_read(self):
+        """(launches, total_ms) of the frame kernel alone since the last read (HIP events)."""
+        n, ms = C.c_int(), C.c_float()
+        nat.check(nat.lib.tdsa_profile_read(self._h, C.byref(n), C.byref(ms)))
+        return n.value, float(ms.value)
+
     # ------------------------------------------------------------------ timing (HIP events, plan stream)
     def timer_begin(self) -> None:
         nat.check(nat.lib.tdsa_timer_begin(self._h))
