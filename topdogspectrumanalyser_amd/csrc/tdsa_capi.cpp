@@ -71,6 +71,7 @@ struct tdsa_plan_s {
   float* d_trace_in = nullptr;
   float* d_trace_live = nullptr;
   long long frames_seen = 0;             // frames processed since the last hold reset (nan_safe rule)
+  unsigned long long* d_dbg = nullptr;   // TDSA_TIMELINE developer builds
   bool profiling = false;
   std::vector<hipEvent_t> prof_events;   // pairs (begin, end) around frame-kernel launches
   size_t prof_used = 0;
@@ -328,6 +329,7 @@ int tdsa_process_dev(tdsa_plan p, int in_format, const void* iq_dev, size_t n_sa
   sp.log_floor = m.log_floor;
   sp.cal_db = m.cal_offset_db;
   sp.tare = p->tare_active ? p->d_tare_base : nullptr;
+  sp.dbg = p->d_dbg;
 
   if (m.dc_alpha < 0.0f) {
     sp.dc_mode = DC_NONE;
@@ -572,6 +574,21 @@ int tdsa_memcpy_h2d(int device_id, void* dst_dev, const void* src_host, size_t b
 int tdsa_memcpy_d2h(int device_id, void* dst_host, const void* src_dev, size_t bytes) {
   HIPCHK(hipSetDevice(device_id));
   HIPCHK(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+  return TDSA_OK;
+}
+
+// developer hook (not part of include/tdsa_hip.h): phase timeline of workgroup 0, TDSA_TIMELINE builds
+int tdsa_debug_timeline(tdsa_plan p, unsigned long long* host_out_1024) {
+  if (!p) return fail(TDSA_ERR_ARG, "null plan");
+  HIPCHK(hipSetDevice(p->device));
+  if (!p->d_dbg) {
+    HIPCHK(hipMalloc(&p->d_dbg, 1024 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(p->d_dbg, 0, 1024 * sizeof(unsigned long long)));
+  }
+  if (host_out_1024) {
+    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(hipMemcpy(host_out_1024, p->d_dbg, 1024 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  }
   return TDSA_OK;
 }
 

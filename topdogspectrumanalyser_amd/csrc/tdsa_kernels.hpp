@@ -36,6 +36,7 @@ struct SpecParams {
   float log_floor;
   float cal_db;              // calibration offset added to dB
   int hold_flags;            // bit0 max, bit1 min
+  unsigned long long* dbg;   // developer timeline buffer (TDSA_TIMELINE builds only), else null
 };
 
 struct LaunchGeom {

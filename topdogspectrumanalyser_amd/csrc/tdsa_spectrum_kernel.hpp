@@ -46,6 +46,11 @@ struct Cfg {
   static constexpr int TWM = (NPASS == 3) ? 32 * A : 0;   // middle-pass twiddle table entries [b][ka]
   static constexpr size_t DATA_BYTES = size_t(FPW) * NPAD * sizeof(c32);
   static constexpr size_t LDS_BYTES = DATA_BYTES + size_t(TWM) * sizeof(c32) + NWAVE * 2 * sizeof(double);
+  static constexpr size_t LDS_ALLOC = LDS_BYTES
+#ifdef TDSA_TIMELINE
+      + 8 * 8 * 16 * 8
+#endif
+      ;
 };
 
 // unaligned-tolerant wide loads (frame starts are only guaranteed to be sample (2 byte) aligned)
@@ -124,6 +129,27 @@ __device__ __forceinline__ void buf_load(rsrc_t r, unsigned voff, unsigned soff,
 constexpr float k10Log10_2 = 3.01029995663981195214f;   // 10*log10(2)
 constexpr float kMagExactBelow = 1e-8f;                  // |X|^2 below this: the 1e-12 floor is visible
 
+// developer ablation builds (-DTDSA_ABLATE=mask): 1 no barriers, 2 no LDS exchange, 4 no dB stores,
+// 8 no raw/window loads.  Results are wrong by construction; timing only.
+#ifndef TDSA_ABLATE
+#define TDSA_ABLATE 0
+#endif
+#define TDSA_SYNC()                                  \
+  do {                                               \
+    if constexpr ((TDSA_ABLATE & 1) == 0) __syncthreads(); \
+  } while (0)
+
+#ifdef TDSA_TIMELINE
+// developer build: wave 0..7 of workgroup 0 stamp s_memtime into LDS at phase boundaries (first 8 frames)
+#define TDSA_STAMP(i)                                                                              \
+  do {                                                                                             \
+    if (p.dbg != nullptr && blockIdx.x == 0 && (tid & 63) == 0 && unit - u0 < 8)                   \
+      tl[((unit - u0) * 8 + wave) * 16 + (i)] = __builtin_amdgcn_s_memtime();                      \
+  } while (0)
+#else
+#define TDSA_STAMP(i)
+#endif
+
 template <int LOG2N, bool IN_C64, int HOLD>   // HOLD: bit0 = max trace, bit1 = min trace
 __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 2) spectrum_kernel(const SpecParams p) {
   using C = Cfg<LOG2N>;
@@ -136,6 +162,9 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 2) spectrum_kernel(const Spec
   c32* lds = reinterpret_cast<c32*>(smem);
   c32* twm = reinterpret_cast<c32*>(smem + C::DATA_BYTES);
   double* red = reinterpret_cast<double*>(smem + C::DATA_BYTES + size_t(C::TWM) * sizeof(c32));
+#ifdef TDSA_TIMELINE
+  unsigned long long* tl = reinterpret_cast<unsigned long long*>(smem + C::LDS_BYTES);   // 8 KiB extra
+#endif
 
   const int tid = threadIdx.x;
   const int slot = (FPW == 1) ? 0 : tid / SG;
@@ -191,7 +220,9 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 2) spectrum_kernel(const Spec
     if constexpr (!IN_C64) {
       const bool act = frame < p.n_frames;
       const unsigned char* fb = static_cast<const unsigned char*>(p.in) + (long long)frame * p.frame_stride;
-      if constexpr (FPW == 1 && M >= 2) {   // frame is workgroup-uniform: SGPR descriptor + lane offset
+      if constexpr ((TDSA_ABLATE & 8) != 0) {
+        static_for<0, NRAW>([&](auto ic) { raw[decltype(ic)::value] = 0x01020304u * (t + 1); });
+      } else if constexpr (FPW == 1 && M >= 2) {   // frame is workgroup-uniform: SGPR descriptor + lane offset
         const rsrc_t r = make_rsrc(fb, N * 2u);
         static_for<0, A>([&](auto ic) {
           constexpr int a = decltype(ic)::value;
@@ -217,13 +248,15 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 2) spectrum_kernel(const Spec
     const int frame = unit * FPW + slot;
     const bool active = frame < p.n_frames;
 
+    TDSA_STAMP(0);
     c32 v[32];
     float sub_re = p.in_off, sub_im = p.in_off;
     float win[32];                                          // win[jj*A + a] = w[a*(N/A) + t*M + jj]
     static_for<0, A>([&](auto ic) {
       constexpr int a = decltype(ic)::value;
       uint32_t wq[M];
-      buf_load<M>(win_rsrc, win_voff, a * (N / A) * 4u, wq);
+      if constexpr ((TDSA_ABLATE & 8) != 0) { static_for<0, M>([&](auto jc) { wq[decltype(jc)::value] = 0x3f800000u; }); }
+      else buf_load<M>(win_rsrc, win_voff, a * (N / A) * 4u, wq);
       static_for<0, M>([&](auto jc) { constexpr int jj = decltype(jc)::value; win[jj * A + a] = __uint_as_float(wq[jj]); });
     });
 
@@ -252,7 +285,9 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 2) spectrum_kernel(const Spec
         const int wi = dpp_wave_sum(int(si)), wq = dpp_wave_sum(int(sq));
         if ((tid & 63) == 63) *reinterpret_cast<int2*>(&redi[wave * 2]) = int2{wi, wq};
       }
-      __syncthreads();   // also the WAR fence between the previous frame's LDS reads and our writes
+      TDSA_STAMP(1);
+      TDSA_SYNC();       // also the WAR fence between the previous frame's LDS reads and our writes
+      TDSA_STAMP(2);
       if (p.dc_mode == DC_FRAME_MEAN) {
         const int w0 = (slot * SG) >> 6;
         int part[2 * C::WPF];
@@ -339,6 +374,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 2) spectrum_kernel(const Spec
         });
       });
     }
+    TDSA_STAMP(3);
     // raw registers are free again: start the next frame's HBM read now, it lands during the FFT
     if (unit + 1 < u1) load_frame_raw((unit + 1) * FPW + slot);
 
@@ -348,17 +384,20 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 2) spectrum_kernel(const Spec
       dif_emit<A, jj * A, 32>(v, [&](auto rc) {
         constexpr int r = decltype(rc)::value;                 // register jj*A + bitrev(ka)
         constexpr int ka = bitrev(r - jj * A, LA);
-        buf[wr1_base + jj * A + ka] = v[r];
+        if constexpr ((TDSA_ABLATE & 2) == 0) buf[wr1_base + jj * A + ka] = v[r];
       });
     });
-    __syncthreads();
+    TDSA_STAMP(4);
+    TDSA_SYNC();
+    TDSA_STAMP(5);
 
     // ---- middle radix-32 pass (3-pass sizes), IN PLACE: thread t owns the 32 slots it gathers -----
     if constexpr (C::NPASS == 3) {
       static_for<0, 32>([&](auto ic) {
         constexpr int b = decltype(ic)::value;
-        v[b] = buf[rd_base + b * rd_stride];
+        if constexpr ((TDSA_ABLATE & 2) == 0) v[b] = buf[rd_base + b * rd_stride];
       });
+      TDSA_STAMP(6);
       int ka_o = ka_mid;
       asm volatile("" : "+v"(ka_o));                        // keep the table reads inside the loop
       static_for<1, 32>([&](auto ic) {
@@ -368,12 +407,14 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 2) spectrum_kernel(const Spec
       dif_emit<32, 0, 32>(v, [&](auto rc) {
         constexpr int r = decltype(rc)::value;
         constexpr int kb = bitrev(r, 5);
-        buf[rd_base + kb * rd_stride] = v[r];                  // same slot element b = kb came from
+        if constexpr ((TDSA_ABLATE & 2) == 0) buf[rd_base + kb * rd_stride] = v[r];   // slot of element b = kb
       });
-      __syncthreads();
+      TDSA_STAMP(7);
+      TDSA_SYNC();
+      TDSA_STAMP(8);
       static_for<0, 32>([&](auto ic) {                         // element (c, kb, ka) for this (kb, ka)
         constexpr int c = decltype(ic)::value;
-        v[c] = buf[rd3_base + c * A + ((c * A) >> 5)];
+        if constexpr ((TDSA_ABLATE & 2) == 0) v[c] = buf[rd3_base + c * A + ((c * A) >> 5)];
       });
     } else {
       static_for<0, 32>([&](auto ic) {
@@ -382,10 +423,12 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 2) spectrum_kernel(const Spec
         else { const int i = t + b * SG; v[b] = buf[i + (i >> 5)]; }
       });
     }
+    TDSA_STAMP(9);
     static_for<0, 3>([&](auto ic) { opaque(twf_lo[decltype(ic)::value]); });
     static_for<0, 7>([&](auto ic) { opaque(twf_hi[decltype(ic)::value]); });
     twiddle32(v, twf_lo, twf_hi);
     dif<32, 0, 32>(v);
+    TDSA_STAMP(10);
 
     // ---- epilogue: |X|^2 -> dB -> hold ; bin k = t + kc*SG lands at k ^ N/2 (fftshift) -----------
     if (active) {
@@ -420,7 +463,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 2) spectrum_kernel(const Spec
             db[kc] -= (p.tare + (kc ^ 16) * SG)[t];
           });
         }
-        if (p.out_db != nullptr) {
+        if ((TDSA_ABLATE & 4) == 0 && p.out_db != nullptr) {
           float* orow = p.out_db + (long long)frame * N;
           if constexpr (FPW == 1) {
             const rsrc_t r = make_rsrc(orow, N * 4u);
@@ -448,8 +491,14 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 2) spectrum_kernel(const Spec
         }
       }
     }
+    TDSA_STAMP(11);
   }
 
+#ifdef TDSA_TIMELINE
+  __syncthreads();
+  if (p.dbg != nullptr && blockIdx.x == 0)
+    for (int i = tid; i < 8 * 8 * 16; i += C::WGT) p.dbg[i] = tl[i];
+#endif
   if constexpr (HOLD != 0) {
     const long long prow = ((long long)blockIdx.x * FPW + slot) * N;
     static_for<0, 32>([&](auto ic) {
@@ -466,7 +515,7 @@ inline LaunchGeom geom_for(int n_frames, int num_cu) {
   LaunchGeom g;
   g.block = C::WGT;
   g.fpw = C::FPW;
-  g.lds_bytes = C::LDS_BYTES;
+  g.lds_bytes = C::LDS_ALLOC;
   int per_cu = int((160 * 1024) / C::LDS_BYTES);
   if (per_cu < 1) per_cu = 1;
   const int by_waves = 2 * 4 * 64 / C::WGT;                   // kernel is built for 2 waves per SIMD
