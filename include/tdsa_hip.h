@@ -147,21 +147,36 @@ int tdsa_get_dc(tdsa_plan p, float* re, float* im);
 
 int tdsa_synchronize(tdsa_plan p);
 
-/* ---- DataProcessor trace operations on host arrays (core/display_data_processor.py) -------- */
+/* ---- trace objects: DataProcessor / TraceAverager arithmetic on host-provided rows ------------- */
+/* A trace object owns the per-bin state the reference keeps in numpy arrays on MainWindow /
+ * DisplayManager / TraceAverager for ONE displayed trace of n bins (any n >= 1, not tied to an FFT
+ * plan): hold traces (mw.max_power_levels / mw.min_power_levels, main.py:70-105), the tare
+ * accumulator + baseline (core/tare_state.py:9-13, mw.baseline_power_levels) and a TraceAverager
+ * buffer (utils/signal_processing.py:16-17). */
+typedef struct tdsa_trace_s* tdsa_trace;
+int tdsa_trace_create(int device_id, int n, tdsa_trace* out);
+int tdsa_trace_destroy(tdsa_trace t);
+int tdsa_trace_reset(tdsa_trace t, uint32_t what); /* TDSA_RESET_* bits */
+
 /* One displayed frame: db_in (n float32 dB values from ANY SampleDataSource) -> +cal offset ->
  * tare (collect / subtract) -> live; max/min hold updated.  Replaces _apply_cal_offset (:317-327),
- * _apply_tare (:329-369), _update_max_hold (:371-382), _update_min_hold (:384-395) in one launch.
+ * _apply_tare (:329-369), _update_max_hold (:371-382), _update_min_hold (:384-395) of
+ * core/display_data_processor.py in one launch.
  * tare_collect != 0: this frame is accumulated into the tare buffer (10^(dB/10)); when
- * tare_total frames have been collected the baseline becomes active (returned in *tare_done).
- * live_out/max_out/min_out may be NULL. */
-int tdsa_trace_update(tdsa_plan p, const float* db_in_host, int n, float cal_offset_db,
-                      int tare_collect, int tare_total, uint32_t hold_flags,
+ * tare_total frames have been collected the baseline becomes active (reported in *tare_done) and
+ * is subtracted from this very frame, as the reference does.  tare_subtract != 0: subtract the
+ * active baseline.  live_out/max_out/min_out may be NULL. */
+int tdsa_trace_update(tdsa_trace t, const float* db_in_host, int n, float cal_offset_db,
+                      int tare_collect, int tare_total, int tare_subtract, uint32_t hold_flags,
                       float* live_out, float* max_out, float* min_out, int* tare_done);
-int tdsa_get_tare_baseline(tdsa_plan p, float* baseline_db_host, int* active);
+int tdsa_trace_get_tare_baseline(tdsa_trace t, float* baseline_db_host, int* active);
+int tdsa_trace_set_tare_baseline(tdsa_trace t, const float* baseline_db_host, int n);
 
-/* TraceAverager.process on a host array of linear power (utils/signal_processing.py:35-61);
- * used for the sweep-source averager DataProcessor owns (display_data_processor.py:41,217-221). */
-int tdsa_avg_process(tdsa_plan p, const float* linear_in_host, int n, double* avg_out_host);
+/* TraceAverager on host rows of linear power (utils/signal_processing.py:19-61); also used for the
+ * sweep averager DataProcessor owns (display_data_processor.py:41,217-221).  set_mode resets. */
+int tdsa_trace_avg_set_mode(tdsa_trace t, int avg_mode, int avg_n);
+int tdsa_trace_avg_process(tdsa_trace t, const double* linear_in_host, int n, double* avg_out_host,
+                           int* count_out);
 
 /* ---- helpers for callers without their own device allocator -------------------------------- */
 int tdsa_dev_alloc(int device_id, size_t bytes, void** out_dev);

@@ -1,0 +1,61 @@
+"""The C-ABI shared library loads without a GPU and exports every symbol include/tdsa_hip.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+HEADER = os.path.join(ROOT, "include", "tdsa_hip.h")
+
+
+def _declared_functions():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = re.findall(r"\b(?:int|const char\s*\*)\s+(tdsa_\w+)\s*\(", txt)
+    assert len(names) >= 30, names
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol():
+    from topdogspectrumanalyser_amd import _native as nat
+    lib = ctypes.CDLL(nat.LIB_PATH)
+    missing = [n for n in _declared_functions() if not hasattr(lib, n)]
+    assert not missing, f"declared in tdsa_hip.h but not exported: {missing}"
+
+
+def test_ctypes_binding_covers_header():
+    from topdogspectrumanalyser_amd import _native as nat
+    declared = set(_declared_functions())
+    bound = set(nat._SIGNATURES)
+    assert declared == bound, (sorted(declared - bound), sorted(bound - declared))
+
+
+def test_struct_layouts_match_header():
+    from topdogspectrumanalyser_amd import _native as nat
+    assert ctypes.sizeof(nat.Mode) == 32          # 8 x 4-byte fields, tdsa_mode
+    assert ctypes.sizeof(nat.Info) == 56          # 8 x i32, 2 x i64, 2 x i32
+    assert nat.lib.tdsa_version() >= 100
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="checks the no-GPU error path")
+def test_no_gpu_fails_loudly_not_silently():
+    """Without a device every entry point reports an error; nothing falls back to the CPU."""
+    from topdogspectrumanalyser_amd import SpectrumEngine, _native as nat
+    with pytest.raises(nat.TdsaError):
+        SpectrumEngine(1024)
+    assert b"failed" in nat.lib.tdsa_last_error_string() or b"device" in nat.lib.tdsa_last_error_string()
+
+
+def test_missing_library_is_an_import_error(tmp_path, monkeypatch):
+    import importlib
+    import sys
+    monkeypatch.setenv("TDSA_HIP_LIB", str(tmp_path / "nope.so"))
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k.startswith("topdogspectrumanalyser_amd")}
+    try:
+        with pytest.raises(ImportError):
+            importlib.import_module("topdogspectrumanalyser_amd")
+    finally:
+        for k in [k for k in sys.modules if k.startswith("topdogspectrumanalyser_amd")]:
+            sys.modules.pop(k)
+        sys.modules.update(saved)

@@ -54,10 +54,15 @@ _SIGNATURES = {
     "tdsa_get_avg": (C.c_int, [_P, _P, C.POINTER(C.c_int)]),
     "tdsa_get_dc": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "tdsa_synchronize": (C.c_int, [_P]),
-    "tdsa_trace_update": (C.c_int, [_P, _P, C.c_int, C.c_float, C.c_int, C.c_int, C.c_uint32,
+    "tdsa_trace_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(_P)]),
+    "tdsa_trace_destroy": (C.c_int, [_P]),
+    "tdsa_trace_reset": (C.c_int, [_P, C.c_uint32]),
+    "tdsa_trace_update": (C.c_int, [_P, _P, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_uint32,
                                     _P, _P, _P, C.POINTER(C.c_int)]),
-    "tdsa_get_tare_baseline": (C.c_int, [_P, _P, C.POINTER(C.c_int)]),
-    "tdsa_avg_process": (C.c_int, [_P, _P, C.c_int, _P]),
+    "tdsa_trace_get_tare_baseline": (C.c_int, [_P, _P, C.POINTER(C.c_int)]),
+    "tdsa_trace_set_tare_baseline": (C.c_int, [_P, _P, C.c_int]),
+    "tdsa_trace_avg_set_mode": (C.c_int, [_P, C.c_int, C.c_int]),
+    "tdsa_trace_avg_process": (C.c_int, [_P, _P, C.c_int, _P, C.POINTER(C.c_int)]),
     "tdsa_dev_alloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(_P)]),
     "tdsa_dev_free": (C.c_int, [C.c_int, _P]),
     "tdsa_memcpy_h2d": (C.c_int, [C.c_int, _P, _P, C.c_size_t]),

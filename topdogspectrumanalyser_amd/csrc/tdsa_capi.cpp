@@ -481,77 +481,170 @@ int tdsa_synchronize(tdsa_plan p) {
   return TDSA_OK;
 }
 
-int tdsa_trace_update(tdsa_plan p, const float* db_in_host, int n, float cal_offset_db, int tare_collect,
-                      int tare_total, uint32_t hold_flags, float* live_out, float* max_out, float* min_out,
-                      int* tare_done) {
-  if (!p || !db_in_host) return fail(TDSA_ERR_ARG, "null argument");
-  if (n != p->nfft) return fail(TDSA_ERR_ARG, "trace length %d != nfft %d", n, p->nfft);
-  if (tare_collect && tare_total < 1) return fail(TDSA_ERR_ARG, "tare_total=%d", tare_total);
-  HIPCHK(hipSetDevice(p->device));
+// ---- trace objects ---------------------------------------------------------------------------------
+struct tdsa_trace_s {
+  int device = 0, n = 0;
+  hipStream_t stream = nullptr;
+  float* d_in = nullptr;
+  float* d_live = nullptr;
+  float* d_hold_max = nullptr;
+  float* d_hold_min = nullptr;
+  float* d_tare_base = nullptr;
+  float* d_tare_acc = nullptr;
+  double* d_avg = nullptr;
+  double* d_avg_in = nullptr;
+  long long held_max = 0, held_min = 0;
+  bool tare_active = false;
+  int tare_count = 0;
+  int avg_mode = TDSA_AVG_OFF, avg_n = 1, avg_count = 0;
+};
+
+int tdsa_trace_create(int device_id, int n, tdsa_trace* out) {
+  if (!out) return fail(TDSA_ERR_ARG, "out is null");
+  *out = nullptr;
+  if (n < 1) return fail(TDSA_ERR_ARG, "n=%d must be >= 1", n);
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (device_id < 0 || device_id >= ndev) return fail(TDSA_ERR_ARG, "device %d of %d", device_id, ndev);
+  HIPCHK(hipSetDevice(device_id));
+  tdsa_trace t = new (std::nothrow) tdsa_trace_s();
+  if (!t) return fail(TDSA_ERR_NOMEM, "host allocation failed");
+  t->device = device_id;
+  t->n = n;
+  HIPCHK(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
   const size_t nb = size_t(n) * sizeof(float);
-  HIPCHK(hipMemcpyAsync(p->d_trace_in, db_in_host, nb, hipMemcpyHostToDevice, p->stream));
+  HIPCHK(hipMalloc(&t->d_in, nb));
+  HIPCHK(hipMalloc(&t->d_live, nb));
+  HIPCHK(hipMalloc(&t->d_hold_max, nb));
+  HIPCHK(hipMalloc(&t->d_hold_min, nb));
+  HIPCHK(hipMalloc(&t->d_tare_base, nb));
+  HIPCHK(hipMalloc(&t->d_tare_acc, nb));
+  HIPCHK(hipMalloc(&t->d_avg, size_t(n) * sizeof(double)));
+  HIPCHK(hipMalloc(&t->d_avg_in, size_t(n) * sizeof(double)));
+  *out = t;
+  return TDSA_OK;
+}
+
+int tdsa_trace_destroy(tdsa_trace t) {
+  if (!t) return TDSA_OK;
+  (void)hipSetDevice(t->device);
+  if (t->stream) (void)hipStreamSynchronize(t->stream);
+  void* bufs[] = {t->d_in, t->d_live, t->d_hold_max, t->d_hold_min, t->d_tare_base, t->d_tare_acc, t->d_avg,
+                  t->d_avg_in};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  if (t->stream) (void)hipStreamDestroy(t->stream);
+  delete t;
+  return TDSA_OK;
+}
+
+int tdsa_trace_reset(tdsa_trace t, uint32_t what) {
+  if (!t) return fail(TDSA_ERR_ARG, "null trace");
+  if (what & TDSA_RESET_AVG) t->avg_count = 0;
+  if (what & TDSA_RESET_HOLD_MAX) t->held_max = 0;
+  if (what & TDSA_RESET_HOLD_MIN) t->held_min = 0;
+  if (what & TDSA_RESET_TARE) {
+    t->tare_active = false;
+    t->tare_count = 0;
+  }
+  return TDSA_OK;
+}
+
+int tdsa_trace_update(tdsa_trace t, const float* db_in_host, int n, float cal_offset_db, int tare_collect,
+                      int tare_total, int tare_subtract, uint32_t hold_flags, float* live_out, float* max_out,
+                      float* min_out, int* tare_done) {
+  if (!t || !db_in_host) return fail(TDSA_ERR_ARG, "null argument");
+  if (n != t->n) return fail(TDSA_ERR_ARG, "row length %d != trace length %d", n, t->n);
+  if (tare_collect && tare_total < 1) return fail(TDSA_ERR_ARG, "tare_total=%d", tare_total);
+  HIPCHK(hipSetDevice(t->device));
+  const size_t nb = size_t(n) * sizeof(float);
+  HIPCHK(hipMemcpyAsync(t->d_in, db_in_host, nb, hipMemcpyHostToDevice, t->stream));
   TraceParams tp{};
-  tp.db_in = p->d_trace_in;
+  tp.db_in = t->d_in;
   tp.n = n;
   tp.cal_db = cal_offset_db;
-  tp.tare_acc = p->d_tare_acc;
-  tp.tare_base = p->d_tare_base;
+  tp.tare_acc = t->d_tare_acc;
+  tp.tare_base = t->d_tare_base;
   bool finish = false;
   if (tare_collect) {
     tp.tare_collect = 1;
-    tp.tare_first = p->tare_count == 0;
-    p->tare_count += 1;
-    tp.tare_count = p->tare_count;
-    finish = p->tare_count >= tare_total;
+    tp.tare_first = t->tare_count == 0;
+    t->tare_count += 1;
+    tp.tare_count = t->tare_count;
+    finish = t->tare_count >= tare_total;
     tp.tare_finish = finish;
   }
-  tp.tare_active = (p->tare_active || finish) ? 1 : 0;
-  tp.live = p->d_trace_live;
-  tp.state_max = (hold_flags & TDSA_HOLD_MAX) ? p->d_hold_max : nullptr;
-  tp.state_min = (hold_flags & TDSA_HOLD_MIN) ? p->d_hold_min : nullptr;
-  tp.max_first = p->held_max == 0;
-  tp.min_first = p->held_min == 0;
-  HIPCHK(launch_trace_update(tp, p->stream));
+  tp.tare_active = ((tare_subtract && t->tare_active) || finish) ? 1 : 0;
+  tp.live = t->d_live;
+  tp.state_max = (hold_flags & TDSA_HOLD_MAX) ? t->d_hold_max : nullptr;
+  tp.state_min = (hold_flags & TDSA_HOLD_MIN) ? t->d_hold_min : nullptr;
+  tp.max_first = t->held_max == 0;
+  tp.min_first = t->held_min == 0;
+  HIPCHK(launch_trace_update(tp, t->stream));
   if (finish) {
-    p->tare_active = true;
-    p->tare_count = 0;
+    t->tare_active = true;
+    t->tare_count = 0;
   }
   if (tare_done) *tare_done = finish ? 1 : 0;
-  if (hold_flags & TDSA_HOLD_MAX) p->held_max += 1;
-  if (hold_flags & TDSA_HOLD_MIN) p->held_min += 1;
-  if (live_out) HIPCHK(hipMemcpyAsync(live_out, p->d_trace_live, nb, hipMemcpyDeviceToHost, p->stream));
+  if (hold_flags & TDSA_HOLD_MAX) t->held_max += 1;
+  if (hold_flags & TDSA_HOLD_MIN) t->held_min += 1;
+  if (live_out) HIPCHK(hipMemcpyAsync(live_out, t->d_live, nb, hipMemcpyDeviceToHost, t->stream));
   if (max_out && (hold_flags & TDSA_HOLD_MAX))
-    HIPCHK(hipMemcpyAsync(max_out, p->d_hold_max, nb, hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipMemcpyAsync(max_out, t->d_hold_max, nb, hipMemcpyDeviceToHost, t->stream));
   if (min_out && (hold_flags & TDSA_HOLD_MIN))
-    HIPCHK(hipMemcpyAsync(min_out, p->d_hold_min, nb, hipMemcpyDeviceToHost, p->stream));
-  HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(hipMemcpyAsync(min_out, t->d_hold_min, nb, hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(hipStreamSynchronize(t->stream));
   return TDSA_OK;
 }
 
-int tdsa_get_tare_baseline(tdsa_plan p, float* baseline_db_host, int* active) {
-  if (!p) return fail(TDSA_ERR_ARG, "null plan");
-  HIPCHK(hipSetDevice(p->device));
-  HIPCHK(hipStreamSynchronize(p->stream));
-  if (baseline_db_host && p->tare_active)
-    HIPCHK(hipMemcpy(baseline_db_host, p->d_tare_base, size_t(p->nfft) * sizeof(float), hipMemcpyDeviceToHost));
-  if (active) *active = p->tare_active ? 1 : 0;
+int tdsa_trace_get_tare_baseline(tdsa_trace t, float* baseline_db_host, int* active) {
+  if (!t) return fail(TDSA_ERR_ARG, "null trace");
+  HIPCHK(hipSetDevice(t->device));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  if (baseline_db_host && t->tare_active)
+    HIPCHK(hipMemcpy(baseline_db_host, t->d_tare_base, size_t(t->n) * sizeof(float), hipMemcpyDeviceToHost));
+  if (active) *active = t->tare_active ? 1 : 0;
   return TDSA_OK;
 }
 
-int tdsa_avg_process(tdsa_plan p, const float* linear_in_host, int n, double* avg_out_host) {
-  if (!p || !linear_in_host) return fail(TDSA_ERR_ARG, "null argument");
-  if (n != p->nfft) return fail(TDSA_ERR_ARG, "trace length %d != nfft %d", n, p->nfft);
-  if (!avg_active(p->mode)) return fail(TDSA_ERR_STATE, "averaging is off (pass-through is the caller's job)");
-  HIPCHK(hipSetDevice(p->device));
-  HIPCHK(hipMemcpyAsync(p->d_trace_in, linear_in_host, size_t(n) * sizeof(float), hipMemcpyHostToDevice,
-                        p->stream));
-  HIPCHK(launch_avg_host_frame(p->d_trace_in, n, p->d_avg, p->avg_count, p->mode.avg_mode, p->mode.avg_n,
-                               p->stream));
-  if (p->avg_count == 0) p->avg_count = 1;
-  else if (p->mode.avg_mode == TDSA_AVG_LIN && p->avg_count < p->mode.avg_n) p->avg_count += 1;
-  if (avg_out_host)
-    HIPCHK(hipMemcpyAsync(avg_out_host, p->d_avg, size_t(n) * sizeof(double), hipMemcpyDeviceToHost, p->stream));
-  HIPCHK(hipStreamSynchronize(p->stream));
+int tdsa_trace_set_tare_baseline(tdsa_trace t, const float* baseline_db_host, int n) {
+  if (!t) return fail(TDSA_ERR_ARG, "null trace");
+  if (!baseline_db_host) {
+    t->tare_active = false;
+    return TDSA_OK;
+  }
+  if (n != t->n) return fail(TDSA_ERR_ARG, "baseline length %d != trace length %d", n, t->n);
+  HIPCHK(hipSetDevice(t->device));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  HIPCHK(hipMemcpy(t->d_tare_base, baseline_db_host, size_t(n) * sizeof(float), hipMemcpyHostToDevice));
+  t->tare_active = true;
+  return TDSA_OK;
+}
+
+int tdsa_trace_avg_set_mode(tdsa_trace t, int avg_mode, int avg_n) {
+  if (!t) return fail(TDSA_ERR_ARG, "null trace");
+  if (avg_mode < TDSA_AVG_OFF || avg_mode > TDSA_AVG_LIN) return fail(TDSA_ERR_ARG, "avg_mode %d", avg_mode);
+  t->avg_mode = avg_mode;
+  t->avg_n = avg_n < 1 ? 1 : avg_n;   // TraceAverager.set_mode: n = max(1, n), then reset()
+  t->avg_count = 0;
+  return TDSA_OK;
+}
+
+int tdsa_trace_avg_process(tdsa_trace t, const double* linear_in_host, int n, double* avg_out_host,
+                           int* count_out) {
+  if (!t || !linear_in_host) return fail(TDSA_ERR_ARG, "null argument");
+  if (n != t->n) return fail(TDSA_ERR_ARG, "row length %d != trace length %d", n, t->n);
+  if (t->avg_mode == TDSA_AVG_OFF || t->avg_n <= 1)
+    return fail(TDSA_ERR_STATE, "averaging is off (pass-through is the caller's job)");
+  HIPCHK(hipSetDevice(t->device));
+  const size_t nb = size_t(n) * sizeof(double);
+  HIPCHK(hipMemcpyAsync(t->d_avg_in, linear_in_host, nb, hipMemcpyHostToDevice, t->stream));
+  HIPCHK(launch_avg_host_frame(t->d_avg_in, n, t->d_avg, t->avg_count, t->avg_mode, t->avg_n, t->stream));
+  if (t->avg_count == 0) t->avg_count = 1;
+  else if (t->avg_mode == TDSA_AVG_LIN && t->avg_count < t->avg_n) t->avg_count += 1;
+  if (avg_out_host) HIPCHK(hipMemcpyAsync(avg_out_host, t->d_avg, nb, hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  if (count_out) *count_out = t->avg_count;
   return TDSA_OK;
 }
 

@@ -93,7 +93,7 @@ struct TraceParams {
 };
 hipError_t launch_trace_update(const TraceParams& p, hipStream_t s);
 
-hipError_t launch_avg_host_frame(const float* lin, int n, double* state, int count_in, int mode,
+hipError_t launch_avg_host_frame(const double* lin, int n, double* state, int count_in, int mode,
                                  int avg_n, hipStream_t s);
 
 hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s);

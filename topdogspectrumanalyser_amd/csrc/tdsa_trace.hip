@@ -108,25 +108,25 @@ hipError_t launch_avg_scan(const AvgParams& p, hipStream_t s) {
 }
 
 // TraceAverager.process on one host-provided frame (sweep averager DataProcessor owns)
-__global__ void __launch_bounds__(256) avg_frame_kernel(const float* lin, int n, double* state, int count_in,
+__global__ void __launch_bounds__(256) avg_frame_kernel(const double* lin, int n, double* state, int count_in,
                                                         int mode, int avg_n) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= n) return;
   double buf;
   if (count_in == 0) {
-    buf = double(lin[k]);
+    buf = lin[k];
   } else if (mode == 1) {
     buf = state[k] * (1.0 - 1.0 / double(avg_n));
-    buf += double(float(1.0 / double(avg_n)) * lin[k]);
+    buf += (1.0 / double(avg_n)) * lin[k];
   } else {
     int count = count_in < avg_n ? count_in + 1 : count_in;
     buf = state[k];
-    buf += (double(lin[k]) - buf) / double(count);
+    buf += (lin[k] - buf) / double(count);
   }
   state[k] = buf;
 }
 
-hipError_t launch_avg_host_frame(const float* lin, int n, double* state, int count_in, int mode, int avg_n,
+hipError_t launch_avg_host_frame(const double* lin, int n, double* state, int count_in, int mode, int avg_n,
                                  hipStream_t s) {
   hipLaunchKernelGGL(avg_frame_kernel, dim3((n + 255) / 256), dim3(256), 0, s, lin, n, state, count_in, mode,
                      avg_n);

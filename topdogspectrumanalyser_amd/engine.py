@@ -144,32 +144,6 @@ class SpectrumEngine:
         nat.check(nat.lib.tdsa_get_info(self._h, C.byref(inf)))
         return inf
 
-    # ------------------------------------------------------------------ DataProcessor trace ops
-    def trace_update(self, db_in: np.ndarray, cal_offset_db: float = 0.0, tare_collect: bool = False,
-                     tare_total: int = 32, hold_max: bool = False, hold_min: bool = False):
-        x = np.ascontiguousarray(db_in, dtype=np.float32)
-        live = np.empty(self.nfft, dtype=np.float32)
-        mx = np.empty(self.nfft, dtype=np.float32) if hold_max else None
-        mn = np.empty(self.nfft, dtype=np.float32) if hold_min else None
-        done = C.c_int()
-        flags = (nat.HOLD_MAX if hold_max else 0) | (nat.HOLD_MIN if hold_min else 0)
-        nat.check(nat.lib.tdsa_trace_update(self._h, _ptr(x), int(x.size), float(cal_offset_db),
-                                            int(bool(tare_collect)), int(tare_total), flags,
-                                            _ptr(live), _ptr(mx), _ptr(mn), C.byref(done)))
-        return live, mx, mn, bool(done.value)
-
-    def tare_baseline(self) -> Optional[np.ndarray]:
-        act = C.c_int()
-        b = np.empty(self.nfft, dtype=np.float32)
-        nat.check(nat.lib.tdsa_get_tare_baseline(self._h, _ptr(b), C.byref(act)))
-        return b if act.value else None
-
-    def avg_process(self, linear_power: np.ndarray) -> np.ndarray:
-        x = np.ascontiguousarray(linear_power, dtype=np.float32)
-        out = np.empty(self.nfft, dtype=np.float64)
-        nat.check(nat.lib.tdsa_avg_process(self._h, _ptr(x), int(x.size), _ptr(out)))
-        return out
-
     def profile_enable(self, on: bool = True) -> None:
         nat.check(nat.lib.tdsa_profile_enable(self._h, int(bool(on))))
 
@@ -187,3 +161,72 @@ class SpectrumEngine:
         ms = C.c_float()
         nat.check(nat.lib.tdsa_timer_end(self._h, C.byref(ms)))
         return float(ms.value)
+
+
+class TraceState:
+    """Device-side state of ONE displayed trace of n bins (any n): hold traces, tare accumulator and
+    baseline, TraceAverager buffer.  The arithmetic of DataProcessor._apply_cal_offset / _apply_tare /
+    _update_max_hold / _update_min_hold and TraceAverager.process runs in HIP kernels."""
+
+    def __init__(self, n: int, device: int = 0):
+        self.n = int(n)
+        self.device = int(device)
+        self._h = C.c_void_p()
+        nat.check(nat.lib.tdsa_trace_create(self.device, self.n, C.byref(self._h)))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            nat.lib.tdsa_trace_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, what: int = nat.RESET_ALL) -> None:
+        nat.check(nat.lib.tdsa_trace_reset(self._h, what))
+
+    def update(self, db_in: np.ndarray, cal_offset_db: float = 0.0, tare_collect: bool = False,
+               tare_total: int = 32, tare_subtract: bool = False, hold_max: bool = False,
+               hold_min: bool = False):
+        """-> (live, max or None, min or None, tare_done)"""
+        x = np.ascontiguousarray(db_in, dtype=np.float32)
+        live = np.empty(self.n, dtype=np.float32)
+        mx = np.empty(self.n, dtype=np.float32) if hold_max else None
+        mn = np.empty(self.n, dtype=np.float32) if hold_min else None
+        done = C.c_int()
+        flags = (nat.HOLD_MAX if hold_max else 0) | (nat.HOLD_MIN if hold_min else 0)
+        nat.check(nat.lib.tdsa_trace_update(self._h, _ptr(x), int(x.size), float(cal_offset_db),
+                                            int(bool(tare_collect)), int(tare_total), int(bool(tare_subtract)),
+                                            flags, _ptr(live), _ptr(mx), _ptr(mn), C.byref(done)))
+        return live, mx, mn, bool(done.value)
+
+    def tare_baseline(self) -> Optional[np.ndarray]:
+        act = C.c_int()
+        b = np.empty(self.n, dtype=np.float32)
+        nat.check(nat.lib.tdsa_trace_get_tare_baseline(self._h, _ptr(b), C.byref(act)))
+        return b if act.value else None
+
+    def tare_is_active(self) -> bool:
+        act = C.c_int()
+        nat.check(nat.lib.tdsa_trace_get_tare_baseline(self._h, None, C.byref(act)))
+        return bool(act.value)
+
+    def set_tare_baseline(self, baseline_db: Optional[np.ndarray]) -> None:
+        if baseline_db is None:
+            nat.check(nat.lib.tdsa_trace_set_tare_baseline(self._h, None, 0))
+        else:
+            b = np.ascontiguousarray(baseline_db, dtype=np.float32)
+            nat.check(nat.lib.tdsa_trace_set_tare_baseline(self._h, _ptr(b), int(b.size)))
+
+    def avg_set_mode(self, mode: str, n: int) -> None:
+        nat.check(nat.lib.tdsa_trace_avg_set_mode(self._h, _AVG[mode], int(n)))
+
+    def avg_process(self, linear_power: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(linear_power, dtype=np.float64)
+        out = np.empty(self.n, dtype=np.float64)
+        cnt = C.c_int()
+        nat.check(nat.lib.tdsa_trace_avg_process(self._h, _ptr(x), int(x.size), _ptr(out), C.byref(cnt)))
+        return out

@@ -1,0 +1,84 @@
+"""The numeric constants and enums the sample-method hot path reads.
+
+Mirrors the names of the reference's utils/constants.py (DSPConstants :152-155, FFTSize :20-41,
+WindowType :68-73, SourceLimits :103-118, UIConstants.TARE_NUM_SAMPLES :141, DisplayMode :6-17) so code
+written against the reference keeps working; the 228 menu-button ids are GUI-only and not carried.
+"""
+from enum import Enum, IntEnum
+
+
+class DisplayMode(IntEnum):
+    TWO_D = 0
+    THREE_D = 1
+    WATERFALL = 2
+    SURFACE = 3
+    LOGO = 4
+    CONSTELLATION_2D = 5
+    CONSTELLATION_3D = 6
+    ZERO_SPAN = 7
+    RIBBON = 8
+    DENSITY = 9
+
+
+class FFTSize(IntEnum):
+    """FFT sizes the reference enumerates (512..8192); the GPU path additionally takes any power of two
+    from 64 to 16384 (see GPU_MIN / GPU_MAX)."""
+    SIZE_512 = 512
+    SIZE_1024 = 1024
+    SIZE_2048 = 2048
+    SIZE_4096 = 4096
+    SIZE_8192 = 8192
+
+    @classmethod
+    def is_valid(cls, size: int) -> bool:
+        return size in [s.value for s in cls]
+
+    @classmethod
+    def get_min(cls) -> int:
+        return min(s.value for s in cls)
+
+    @classmethod
+    def get_max(cls) -> int:
+        return max(s.value for s in cls)
+
+
+GPU_MIN_FFT = 64
+GPU_MAX_FFT = 16384
+
+
+class WindowType(str, Enum):
+    HAMMING = "hamming"
+    HANNING = "hanning"
+    BLACKMAN = "blackman"
+    RECTANGLE = "rectangle"
+
+
+class SourceLimits:
+    RTL_MIN_FREQ = 24e6
+    RTL_MAX_FREQ = 1.766e9
+    RTL_MAX_SAMPLE_RATE = 2.4e6
+    HACKRF_MIN_FREQ = 1e6
+    HACKRF_MAX_FREQ = 6e9
+    HACKRF_MAX_SAMPLE_RATE = 20e6
+    MICROPHONE_MIN_FREQ = 20
+    MICROPHONE_MAX_FREQ = 20e3
+    MICROPHONE_SAMPLE_RATE = 44100
+
+
+class UIConstants:
+    DEFAULT_FFT_SIZE = FFTSize.SIZE_1024.value
+    SWEEP_RATE_UPDATE_INTERVAL = 50
+    TARE_NUM_SAMPLES = 32          # frames averaged to build the tare baseline
+
+
+class DSPConstants:
+    LOG_FLOOR = 1e-12              # floor inside 20*log10(|X| + .) and the PSD 10*log10
+    POWER_LOG_FLOOR = 1e-10        # floor inside 10*log10(|X|^2 + .)
+
+
+class SourceType(str, Enum):
+    RTL_SWEEP = "rtl_sweep"
+    HACKRF_SWEEP = "hackrf_sweep"
+    RTL_SAMPLES = "rtl_samples"
+    MICROPHONE_SAMPLES = "microphone_samples"
+    HACKRF_SAMPLES = "hackrf_samples"
