@@ -37,15 +37,15 @@ def main():
     e.synchronize()
     nat.check(dbg(e._h, None))
     e.process_device(nat.IN_I8, dev_in.value, ns, hop, F, dev_out.value)
-    out = np.zeros(1024, dtype=np.uint64)
+    out = np.zeros(2048, dtype=np.uint64)
     nat.check(dbg(e._h, out.ctypes.data_as(C.c_void_p)))
-    t = out.reshape(8, 8, 16)[:, :, :12].astype(np.int64)   # [frame][wave][stamp]
+    t = out.reshape(8, 16, 16)[:, :, :12].astype(np.int64)   # [frame][wave][stamp]
     t0 = t[0, :, 0].min()
     print("frame-to-frame period (wave 0, cycles):", np.diff(t[:, 0, 0]))
     for f in (2, 3):
-        print(f"-- frame {f}: cycles since frame top (rows: waves 0..7)")
+        print(f"-- frame {f}: cycles since frame top (rows: waves 0..15)")
         print("   " + " ".join(f"{s:>9.9s}" for s in NAMES))
-        for w in range(8):
+        for w in range(16):
             print(f"w{w} " + " ".join(f"{int(x - t[f, w, 0]):9d}" for x in t[f, w]))
     d = np.diff(t[2:7], axis=2).mean(axis=(0, 1))
     print("mean phase durations (frames 2..6, all waves):")

@@ -675,12 +675,12 @@ int tdsa_debug_timeline(tdsa_plan p, unsigned long long* host_out_1024) {
   if (!p) return fail(TDSA_ERR_ARG, "null plan");
   HIPCHK(hipSetDevice(p->device));
   if (!p->d_dbg) {
-    HIPCHK(hipMalloc(&p->d_dbg, 1024 * sizeof(unsigned long long)));
-    HIPCHK(hipMemset(p->d_dbg, 0, 1024 * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&p->d_dbg, 2048 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(p->d_dbg, 0, 2048 * sizeof(unsigned long long)));
   }
   if (host_out_1024) {
     HIPCHK(hipStreamSynchronize(p->stream));
-    HIPCHK(hipMemcpy(host_out_1024, p->d_dbg, 1024 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(host_out_1024, p->d_dbg, 2048 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   }
   return TDSA_OK;
 }

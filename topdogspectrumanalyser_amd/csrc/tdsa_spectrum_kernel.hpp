@@ -34,21 +34,23 @@ namespace tdsa {
 template <int LOG2N>
 struct Cfg {
   static constexpr int N = 1 << LOG2N;
-  static constexpr int SG = N / 32;                       // threads per frame
+  static constexpr int SG = N / 32;                       // butterfly rows per frame
+  static constexpr int TPF = 2 * SG;                      // threads per frame: two half-threads per row
   static constexpr int NPASS = (N >= 2048) ? 3 : 2;
   static constexpr int A = (NPASS == 3) ? N / 1024 : N / 32;  // radix of the first pass
-  static constexpr int M = 32 / A;                        // adjacent first-pass butterflies per thread
-  static constexpr int WGT = SG > 256 ? SG : 256;         // threads per workgroup
-  static constexpr int FPW = WGT / SG;                    // frames in flight per workgroup
+  static constexpr int M = 32 / A;                        // adjacent first-pass butterflies per row
+  static constexpr int H = A / 2;                         // first-pass radix done inside one lane
+  static constexpr int WGT = TPF > 256 ? TPF : 256;       // threads per workgroup
+  static constexpr int FPW = WGT / TPF;                   // frames in flight per workgroup
   static constexpr int NPAD = N + N / 32;                 // LDS slot: rows of 32 complex + 1 pad element
-  static constexpr int WPF = SG >= 64 ? SG / 64 : 1;      // waves per frame
+  static constexpr int WPF = SG >= 32 ? SG / 32 : 1;      // waves per frame
   static constexpr int NWAVE = WGT / 64;
   static constexpr int TWM = (NPASS == 3) ? 32 * A : 0;   // middle-pass twiddle table entries [b][ka]
   static constexpr size_t DATA_BYTES = size_t(FPW) * NPAD * sizeof(c32);
   static constexpr size_t LDS_BYTES = DATA_BYTES + size_t(TWM) * sizeof(c32) + NWAVE * 2 * sizeof(double);
   static constexpr size_t LDS_ALLOC = LDS_BYTES
 #ifdef TDSA_TIMELINE
-      + 8 * 8 * 16 * 8
+      + 16 * 8 * 16 * 8
 #endif
       ;
 };
@@ -144,32 +146,75 @@ constexpr float kMagExactBelow = 1e-8f;                  // |X|^2 below this: th
 #define TDSA_STAMP(i)                                                                              \
   do {                                                                                             \
     if (p.dbg != nullptr && blockIdx.x == 0 && (tid & 63) == 0 && unit - u0 < 8)                   \
-      tl[((unit - u0) * 8 + wave) * 16 + (i)] = __builtin_amdgcn_s_memtime();                      \
+      tl[((unit - u0) * 16 + wave) * 16 + (i)] = __builtin_amdgcn_s_memtime();                      \
   } while (0)
 #else
 #define TDSA_STAMP(i)
 #endif
 
+// exchange the upper half-wave of `a` with the lower half-wave of `b` (one v_permlane32_swap per dword):
+// afterwards a = [a.lo | b.lo], b = [a.hi | b.hi]
+__device__ __forceinline__ void swap_halves(c32& a, c32& b) {
+  auto rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+  auto ry = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+  a.x = __uint_as_float(rx[0]); b.x = __uint_as_float(rx[1]);
+  a.y = __uint_as_float(ry[0]); b.y = __uint_as_float(ry[1]);
+}
+
+// radix-2 combine  (E, O) -> (E + w O, E - w O)  in six FMAs (second output as 2E - first)
+__device__ __forceinline__ void combine(c32& e, c32& o, c32 w) {
+  const float x1 = fmaf(w.x, o.x, fmaf(-w.y, o.y, e.x));
+  const float y1 = fmaf(w.x, o.y, fmaf(w.y, o.x, e.y));
+  o = c32{fmaf(2.0f, e.x, -x1), fmaf(2.0f, e.y, -y1)};
+  e = c32{x1, y1};
+}
+// radix-32 combine for unit u + 8h: the lower half-wave uses W_32^u, the upper W_32^(u+8) = -i W_32^u.
+// The -i is applied to O with two selects (-i (x + iy) = y - ix), the rest is compile-time constants.
+template <int U>
+__device__ __forceinline__ void combine32(c32& e, c32& o, bool odd_half) {
+  const c32 orot = c32{odd_half ? o.y : o.x, odd_half ? -o.x : o.y};
+  const c32 t = mul_w<U, 32>(orot);
+  o = csub(e, t);
+  e = cadd(e, t);
+}
+template <int K, int R>   // compile-time twiddle W_R^K
+__device__ __forceinline__ void combine_const(c32& e, c32& o) {
+  const c32 t = mul_w<K, R>(o);
+  o = csub(e, t);
+  e = cadd(e, t);
+}
+
+// Thread layout: a wave owns 32 consecutive butterfly rows; lane l < 32 is the EVEN half-thread of row
+// (l & 31), lane l + 32 the ODD half-thread of the same row.  Every radix-R pass is done as two
+// radix-R/2 DFTs (one per half-thread, on the even / odd indexed inputs) followed by one radix-2
+// combine stage whose operands are brought together with v_permlane32_swap: after the swap the lower
+// half-wave holds (E_u, O_u) for units u = 0..7 and the upper half-wave (E_(u+8), O_(u+8)), so both
+// halves do full butterflies and no lane idles.  16 points per thread keeps the kernel under 128 VGPRs:
+// 4 waves per SIMD, which is what it takes to keep the VALU fed (one wave issues at most one VALU op
+// every 4 clocks; the SIMD retires one every 2).
 template <int LOG2N, bool IN_C64, int HOLD>   // HOLD: bit0 = max trace, bit1 = min trace
-__global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 2) spectrum_kernel(const SpecParams p) {
+__global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const SpecParams p) {
   using C = Cfg<LOG2N>;
-  constexpr int N = C::N, SG = C::SG, A = C::A, M = C::M, FPW = C::FPW, NPAD = C::NPAD;
-  constexpr int LA = ilog2(A);
-  constexpr int DW = (M >= 2) ? M / 2 : 1;   // raw dwords per first-pass row
-  constexpr int NRAW = IN_C64 ? 1 : A * DW;
+  constexpr int N = C::N, SG = C::SG, A = C::A, M = C::M, H = C::H, FPW = C::FPW, NPAD = C::NPAD;
+  constexpr int LH = ilog2(H);
+  constexpr int DW = (M >= 2) ? M / 2 : 1;        // raw dwords per first-pass row
+  constexpr int NRAW = IN_C64 ? 1 : H * DW;       // rows a = 2i + h, i < H
+  constexpr int ROWB = (N / A) * 2;               // bytes per first-pass row (byte formats)
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   c32* lds = reinterpret_cast<c32*>(smem);
   c32* twm = reinterpret_cast<c32*>(smem + C::DATA_BYTES);
   double* red = reinterpret_cast<double*>(smem + C::DATA_BYTES + size_t(C::TWM) * sizeof(c32));
 #ifdef TDSA_TIMELINE
-  unsigned long long* tl = reinterpret_cast<unsigned long long*>(smem + C::LDS_BYTES);   // 8 KiB extra
+  unsigned long long* tl = reinterpret_cast<unsigned long long*>(smem + C::LDS_BYTES);
 #endif
 
   const int tid = threadIdx.x;
-  const int slot = (FPW == 1) ? 0 : tid / SG;
-  const int t = (FPW == 1) ? tid : tid - slot * SG;
   const int wave = tid >> 6;
+  const int h = (tid >> 5) & 1;                              // 0: even half-thread, 1: odd half-thread
+  const int g = wave * 32 + (tid & 31);                      // row inside the workgroup
+  const int slot = (FPW == 1) ? 0 : g / SG;
+  const int t = (FPW == 1) ? g : g - slot * SG;              // butterfly row inside the frame
   c32* buf = lds + slot * NPAD;
 
   const int n_units = (p.n_frames + FPW - 1) / FPW;
@@ -177,66 +222,66 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 2) spectrum_kernel(const Spec
   const int u1 = int((long long)(blockIdx.x + 1) * n_units / gridDim.x);
 
   // ---- frame-invariant per-thread state ---------------------------------------------------------
-  // the window is re-read from L2 every frame (64 KiB table shared by all workgroups): keeping its
-  // 32 values per thread in VGPRs pushed the hold variants into scratch spills
   const rsrc_t win_rsrc = make_rsrc(p.window, N * 4u);
-  const unsigned win_voff = unsigned(t) * (M * 4u);
-  c32 twf_lo[3], twf_hi[7];   // last pass seeds: W_N^(t*c), c = 1,2,3 and 4,8,..,28
-  static_for<0, 3>([&](auto ic) { constexpr int i = decltype(ic)::value; twf_lo[i] = p.tw[t * (i + 1)]; });
-  static_for<0, 7>([&](auto ic) { constexpr int i = decltype(ic)::value; twf_hi[i] = p.tw[t * 4 * (i + 1)]; });
+  const unsigned win_voff = unsigned(h) * (N / A) * 4u + unsigned(t) * (M * 4u);
+  const bool odd_half = h != 0;   // upper half-wave: its radix-32 combine twiddle is W_32^(u+8) = -i * W_32^u
+  c32 twf_lo[3], twf_hi[4];   // last pass: W_N^(t*(2i+h)), i = 4a + j  ->  hi[a] = W^(t(8a+h)), lo[j-1] = W^(2tj)
+  static_for<0, 3>([&](auto ic) { constexpr int j = decltype(ic)::value; twf_lo[j] = p.tw[t * 2 * (j + 1)]; });
+  static_for<0, 4>([&](auto ic) { constexpr int a = decltype(ic)::value; twf_hi[a] = p.tw[t * (8 * a + h)]; });
   if constexpr (C::NPASS == 3) {   // middle pass table twm[b*A + ka] = W_(32A)^(ka*b)
     if (tid < C::TWM) {
       const int b = tid / A, ka = tid % A;
       twm[tid] = p.tw[ka * b * (N / (32 * A))];
     }
   }
-  float hmax[(HOLD & 1) ? 32 : 1], hmin[(HOLD & 2) ? 32 : 1];
-  static_for<0, 32>([&](auto ic) {
+  float hmax[(HOLD & 1) ? 16 : 1], hmin[(HOLD & 2) ? 16 : 1];
+  static_for<0, 16>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
     if constexpr ((HOLD & 1) != 0) hmax[i] = -INFINITY;
     if constexpr ((HOLD & 2) != 0) hmin[i] = INFINITY;
   });
+  const unsigned xm_v = [&] { unsigned x = (M == 1) ? (p.xor_mask & 0xffffu) : p.xor_mask; asm volatile("" : "+v"(x)); return x; }();
   // epilogue constants in VGPRs.  DB_MAG is evaluated as 10*log10(|X|^2): identical to
   // 20*log10(|X| + 1e-12) in float32 whenever |X|^2 >= 1e-8 (the floor is below half an ulp of |X|);
   // frames with a smaller bin take the exact path below.
-  const unsigned xm_v = [&] { unsigned x = (M == 1) ? (p.xor_mask & 0xffffu) : p.xor_mask; asm volatile("" : "+v"(x)); return x; }();
   const bool mag_mode = p.db_mode == 0;
   const float ps_v = in_vgpr(mag_mode ? 1.0f : p.pscale);
   const float fl_v = in_vgpr(mag_mode ? 0.0f : p.log_floor);
   const float cal_v = in_vgpr(p.cal_db);
 
   // LDS addressing in complex elements: element i of a pass lives at i + (i >> 5)
-  const int wr1_base = 33 * t;                                   // pass 1 writes row t
-  int rd_base = 0;                                               // gather of y[t + b*SG]
+  const int wr1_base = 33 * t + (A == 32 ? 8 : 16) * h;          // pass 1 writes row t
   constexpr int rd_stride = SG + SG / 32;
-  if constexpr (SG % 32 == 0) rd_base = t + (t >> 5);
+  const int rd_base = (SG % 32 == 0) ? t + (t >> 5) : 0;         // gather of y[t + b*SG]
+  const int rdA = rd_base + h * rd_stride;                       // element b = 2i + h
+  const int wrM = rd_base + 8 * h * rd_stride;                   // in-place output kb = u + 8h
   const int ka_mid = t % A;
-  const int rd3_base = (t / A) * rd_stride + ka_mid;             // last gather after the in-place pass
+  const int rd3A = (t / A) * rd_stride + ka_mid + h * A;         // last gather, element c = 2i + h
 
-  const unsigned lane_in_off = unsigned(t) * (IN_C64 ? M * 8u : M * 2u);   // byte offset inside a row
+  const unsigned lane_in_off = unsigned(t) * (IN_C64 ? M * 8u : M * 2u) +
+                               unsigned(h) * (IN_C64 ? (N / A) * 8u : unsigned(ROWB));
+  const unsigned out_voff = unsigned(t) * 4u + unsigned(h) * (8u * SG * 4u);
 
   uint32_t raw[NRAW];
   auto load_frame_raw = [&](int frame) {
     if constexpr (!IN_C64) {
       const bool act = frame < p.n_frames;
       const unsigned char* fb = static_cast<const unsigned char*>(p.in) + (long long)frame * p.frame_stride;
-      if constexpr ((TDSA_ABLATE & 8) != 0) {
-        static_for<0, NRAW>([&](auto ic) { raw[decltype(ic)::value] = 0x01020304u * (t + 1); });
-      } else if constexpr (FPW == 1 && M >= 2) {   // frame is workgroup-uniform: SGPR descriptor + lane offset
+      if constexpr (FPW == 1 && M >= 2) {   // frame is workgroup-uniform: SGPR descriptor + lane offset
         const rsrc_t r = make_rsrc(fb, N * 2u);
-        static_for<0, A>([&](auto ic) {
-          constexpr int a = decltype(ic)::value;
-          buf_load<DW>(r, lane_in_off, a * (N / A) * 2u, &raw[a * DW]);
+        static_for<0, H>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          buf_load<DW>(r, lane_in_off, 2 * i * ROWB, &raw[i * DW]);
         });
       } else {
-        static_for<0, A>([&](auto ic) {
-          constexpr int a = decltype(ic)::value;
-          const unsigned char* row = fb + a * (N / A) * 2;
+        static_for<0, H>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          const unsigned char* row = fb + 2 * i * ROWB + lane_in_off;
           if (act) {
-            if constexpr (M == 1) raw[a] = *reinterpret_cast<const uint16_t*>(row + lane_in_off);
-            else load_raw<DW>(row + lane_in_off, &raw[a * DW]);
+            if constexpr (M == 1) raw[i] = *reinterpret_cast<const uint16_t*>(row);
+            else load_raw<DW>(row, &raw[i * DW]);
           } else {
-            static_for<0, DW>([&](auto jc) { raw[a * DW + decltype(jc)::value] = 0u; });
+            static_for<0, DW>([&](auto jc) { raw[i * DW + decltype(jc)::value] = 0u; });
           }
         });
       }
@@ -247,32 +292,23 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 2) spectrum_kernel(const Spec
   for (int unit = u0; unit < u1; ++unit) {
     const int frame = unit * FPW + slot;
     const bool active = frame < p.n_frames;
-
     TDSA_STAMP(0);
-    c32 v[32];
-    float sub_re = p.in_off, sub_im = p.in_off;
-    float win[32];                                          // win[jj*A + a] = w[a*(N/A) + t*M + jj]
-    static_for<0, A>([&](auto ic) {
-      constexpr int a = decltype(ic)::value;
-      uint32_t wq[M];
-      if constexpr ((TDSA_ABLATE & 8) != 0) { static_for<0, M>([&](auto jc) { wq[decltype(jc)::value] = 0x3f800000u; }); }
-      else buf_load<M>(win_rsrc, win_voff, a * (N / A) * 4u, wq);
-      static_for<0, M>([&](auto jc) { constexpr int jj = decltype(jc)::value; win[jj * A + a] = __uint_as_float(wq[jj]); });
-    });
 
+    c32 v[16];                                              // pass 1: v[jj*H + i] = sample a = 2i + h of butterfly jj
+    float sub_re = p.in_off, sub_im = p.in_off;
     // ---- frame sums for DC removal ---------------------------------------------------------------
     if constexpr (IN_C64) {
       const unsigned char* fb = static_cast<const unsigned char*>(p.in) + (long long)frame * p.frame_stride;
-      static_for<0, 32>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        constexpr int jj = i / A, a = i % A;
-        const c32* row = reinterpret_cast<const c32*>(fb + a * (N / A) * 8 + lane_in_off);
-        v[i] = active ? row[jj] : c32{0.f, 0.f};
+      static_for<0, 16>([&](auto ic) {
+        constexpr int idx = decltype(ic)::value;
+        constexpr int jj = idx / H, i = idx % H;
+        const c32* row = reinterpret_cast<const c32*>(fb + 2 * i * (N / A) * 8 + lane_in_off);
+        v[idx] = active ? row[jj] : c32{0.f, 0.f};
       });
     } else {
       static_for<0, NRAW>([&](auto ic) { raw[decltype(ic)::value] ^= xm_v; });   // int8 -> offset binary
     }
-    if constexpr (!IN_C64 && SG >= 64) {
+    if constexpr (!IN_C64 && SG >= 32) {
       // byte formats, whole waves per frame: exact integer sums, DPP wave reduce, one int2 per wave
       int* redi = reinterpret_cast<int*>(red);
       if (p.dc_mode == DC_FRAME_MEAN) {
@@ -289,37 +325,33 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 2) spectrum_kernel(const Spec
       TDSA_SYNC();       // also the WAR fence between the previous frame's LDS reads and our writes
       TDSA_STAMP(2);
       if (p.dc_mode == DC_FRAME_MEAN) {
-        const int w0 = (slot * SG) >> 6;
-        int part[2 * C::WPF];
+        const int w0 = slot * C::WPF;
+        int ti = 0, tq = 0;
         if constexpr (C::WPF % 2 == 0) {
           static_for<0, C::WPF / 2>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const int4 q = *reinterpret_cast<const int4*>(&redi[(w0 + 2 * i) * 2]);
-            part[4 * i] = q.x; part[4 * i + 1] = q.y; part[4 * i + 2] = q.z; part[4 * i + 3] = q.w;
+            ti += q.x + q.z; tq += q.y + q.w;
           });
         } else {
           const int2 q = *reinterpret_cast<const int2*>(&redi[w0 * 2]);
-          part[0] = q.x; part[1] = q.y;
+          ti = q.x; tq = q.y;
         }
-        int ti = 0, tq = 0;
-        static_for<0, C::WPF>([&](auto ic) { constexpr int i = decltype(ic)::value; ti += part[2 * i]; tq += part[2 * i + 1]; });
         sub_re = float(ti) * (1.0f / N);     // exact: sums < 2^24, N a power of two
         sub_im = float(tq) * (1.0f / N);
-        if (p.dc_state != nullptr && frame == p.n_frames - 1 && t == 0)
+        if (p.dc_state != nullptr && frame == p.n_frames - 1 && t == 0 && h == 0)
           *p.dc_state = c32{(sub_re - p.in_off) * p.in_scale, (sub_im - p.in_off) * p.in_scale};
       } else if (p.dc_mode == DC_TRACKED && active) {
         const c32 sv = p.dc_sub[frame]; sub_re = sv.x; sub_im = sv.y;
       }
     } else if (p.dc_mode == DC_FRAME_MEAN) {
-      constexpr int W = SG < 64 ? SG : 64;
-      double s_re, s_im;
+      // generic path (complex64 input, or several frames per wave): double sums, shuffles
+      double s_re = 0.0, s_im = 0.0;
       if constexpr (IN_C64) {
-        s_re = 0.0; s_im = 0.0;
-        static_for<0, 32>([&](auto ic) {
+        static_for<0, 16>([&](auto ic) {
           constexpr int i = decltype(ic)::value;
           s_re += double(v[i].x); s_im += double(v[i].y);
         });
-        s_re = seg_sum<W>(s_re); s_im = seg_sum<W>(s_im);
       } else {
         unsigned si = 0, sq = 0;
         static_for<0, NRAW>([&](auto ic) {
@@ -327,48 +359,59 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 2) spectrum_kernel(const Spec
           si = __builtin_amdgcn_udot4(raw[i], 0x00010001u, si, false);
           sq = __builtin_amdgcn_udot4(raw[i], 0x01000100u, sq, false);
         });
-        s_re = double(seg_sum<W>(int(si))); s_im = double(seg_sum<W>(int(sq)));
+        s_re = double(si); s_im = double(sq);
       }
-      if constexpr (SG > 64) {
+      constexpr int W = SG < 32 ? SG : 32;                  // rows of this frame inside the half-wave
+      s_re = seg_sum<W>(s_re); s_im = seg_sum<W>(s_im);
+      s_re += __shfl_xor(s_re, 32); s_im += __shfl_xor(s_im, 32);   // the other half-thread's rows
+      if constexpr (SG > 32) {
         if ((tid & 63) == 0) { red[wave * 2] = s_re; red[wave * 2 + 1] = s_im; }
       }
-      __syncthreads();   // also the WAR fence between the previous frame's LDS reads and our writes
-      if constexpr (SG > 64) {
-        const int w0 = (slot * SG) >> 6;
+      TDSA_SYNC();
+      if constexpr (SG > 32) {
+        const int w0 = slot * C::WPF;
         s_re = 0.0; s_im = 0.0;
 #pragma unroll
         for (int i = 0; i < C::WPF; ++i) { s_re += red[(w0 + i) * 2]; s_im += red[(w0 + i) * 2 + 1]; }
       }
       sub_re = float(s_re * (1.0 / N));
       sub_im = float(s_im * (1.0 / N));
-      if (p.dc_state != nullptr && frame == p.n_frames - 1 && t == 0)
+      if (p.dc_state != nullptr && frame == p.n_frames - 1 && t == 0 && h == 0)
         *p.dc_state = c32{(sub_re - p.in_off) * p.in_scale, (sub_im - p.in_off) * p.in_scale};
     } else {
-      __syncthreads();
+      TDSA_SYNC();
       if (p.dc_mode == DC_TRACKED && active) { const c32 s = p.dc_sub[frame]; sub_re = s.x; sub_im = s.y; }
     }
     sub_re = in_vgpr(sub_re);
     sub_im = in_vgpr(sub_im);
+    float win[16];                                          // win[jj*H + i] = w[(2i+h)*(N/A) + t*M + jj]
+    static_for<0, H>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      uint32_t wq[M];
+      buf_load<M>(win_rsrc, win_voff, 2 * i * (N / A) * 4u, wq);
+      static_for<0, M>([&](auto jc) { constexpr int jj = decltype(jc)::value; win[jj * H + i] = __uint_as_float(wq[jj]); });
+    });
+
 
     // ---- unpack + DC removal + window ------------------------------------------------------------
     if constexpr (IN_C64) {
-      static_for<0, 32>([&](auto ic) {
+      static_for<0, 16>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         v[i] = c32{(v[i].x - sub_re) * win[i], (v[i].y - sub_im) * win[i]};
       });
     } else if constexpr (M == 1) {
-      static_for<0, 32>([&](auto ic) {
-        constexpr int a = decltype(ic)::value;
-        const uint32_t u = raw[a];
-        v[a] = c32{(float(u & 0xffu) - sub_re) * win[a], (float((u >> 8) & 0xffu) - sub_im) * win[a]};
+      static_for<0, 16>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const uint32_t u = raw[i];
+        v[i] = c32{(float(u & 0xffu) - sub_re) * win[i], (float((u >> 8) & 0xffu) - sub_im) * win[i]};
       });
     } else {
-      static_for<0, A>([&](auto ac) {
-        constexpr int a = decltype(ac)::value;
+      static_for<0, H>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
         static_for<0, DW>([&](auto dc) {
           constexpr int d = decltype(dc)::value;
-          const uint32_t u = raw[a * DW + d];
-          constexpr int i0 = (2 * d) * A + a, i1 = (2 * d + 1) * A + a;
+          const uint32_t u = raw[i * DW + d];
+          constexpr int i0 = (2 * d) * H + i, i1 = (2 * d + 1) * H + i;
           v[i0] = c32{(float(u & 0xffu) - sub_re) * win[i0], (float((u >> 8) & 0xffu) - sub_im) * win[i0]};
           v[i1] = c32{(float((u >> 16) & 0xffu) - sub_re) * win[i1], (float(u >> 24) - sub_im) * win[i1]};
         });
@@ -378,115 +421,159 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 2) spectrum_kernel(const Spec
     // raw registers are free again: start the next frame's HBM read now, it lands during the FFT
     if (unit + 1 < u1) load_frame_raw((unit + 1) * FPW + slot);
 
-    // ---- pass 1: M radix-A butterflies; each output is stored the moment it is final ------------
-    static_for<0, M>([&](auto jc) {
-      constexpr int jj = decltype(jc)::value;
-      dif_emit<A, jj * A, 32>(v, [&](auto rc) {
-        constexpr int r = decltype(rc)::value;                 // register jj*A + bitrev(ka)
-        constexpr int ka = bitrev(r - jj * A, LA);
-        if constexpr ((TDSA_ABLATE & 2) == 0) buf[wr1_base + jj * A + ka] = v[r];
-      });
+    // ---- pass 1: per lane M radix-H DFTs on the even (odd) rows, then the cross-lane combine ------
+    static_for<0, M>([&](auto jc) { dif<H, decltype(jc)::value * H, 16>(v); });
+    static_for<0, 8>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      constexpr int jj0 = u / H, k0 = u % H, jj1 = (u + 8) / H, k1 = (u + 8) % H;
+      constexpr int re = jj0 * H + bitrev(k0, LH), ro = jj1 * H + bitrev(k1, LH);
+      if constexpr ((TDSA_ABLATE & 32) == 0) swap_halves(v[re], v[ro]);   // v[re] = E of unit u + 8h, v[ro] = O
+      if constexpr (A == 32) combine32<u>(v[re], v[ro], odd_half);
+      else combine_const<k0, A>(v[re], v[ro]);               // (u + 8h) % H == u % H for H <= 8
+      constexpr int li = jj0 * A + k0;                       // + lane offset folded into wr1_base
+      if constexpr ((TDSA_ABLATE & 2) == 0) { buf[wr1_base + li] = v[re]; buf[wr1_base + li + H] = v[ro]; }
     });
     TDSA_STAMP(4);
     TDSA_SYNC();
     TDSA_STAMP(5);
 
-    // ---- middle radix-32 pass (3-pass sizes), IN PLACE: thread t owns the 32 slots it gathers -----
+    // ---- middle radix-32 pass (3-pass sizes), IN PLACE: a row's two half-threads own the 32 slots
+    //      they gather, so no barrier separates the gather from the scatter ----------------------------
     if constexpr (C::NPASS == 3) {
-      static_for<0, 32>([&](auto ic) {
-        constexpr int b = decltype(ic)::value;
-        if constexpr ((TDSA_ABLATE & 2) == 0) v[b] = buf[rd_base + b * rd_stride];
+      static_for<0, 16>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr ((TDSA_ABLATE & 2) == 0) v[i] = buf[rdA + i * 2 * rd_stride];
+      });
+      int tw_o = h * A + ka_mid;
+      asm volatile("" : "+v"(tw_o));                        // keep the table reads inside the loop
+      // two batches of eight table reads, each issued back to back and waited for once
+      static_for<0, 2>([&](auto bc) {
+        constexpr int b0 = decltype(bc)::value * 8;
+        c32 tw8[8];
+        static_for<0, 8>([&](auto ic) {
+          constexpr int i = b0 + decltype(ic)::value;
+          if constexpr ((TDSA_ABLATE & 16) == 0) tw8[i - b0] = twm[tw_o + i * 2 * A];
+          else tw8[i - b0] = twf_hi[i & 3];
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 8>([&](auto ic) {
+          constexpr int i = b0 + decltype(ic)::value;
+          v[i] = cmul(v[i], tw8[i - b0]);
+        });
+        __builtin_amdgcn_sched_barrier(0);
       });
       TDSA_STAMP(6);
-      int ka_o = ka_mid;
-      asm volatile("" : "+v"(ka_o));                        // keep the table reads inside the loop
-      static_for<1, 32>([&](auto ic) {
-        constexpr int b = decltype(ic)::value;
-        v[b] = cmul(v[b], twm[b * A + ka_o]);
-      });
-      dif_emit<32, 0, 32>(v, [&](auto rc) {
-        constexpr int r = decltype(rc)::value;
-        constexpr int kb = bitrev(r, 5);
-        if constexpr ((TDSA_ABLATE & 2) == 0) buf[rd_base + kb * rd_stride] = v[r];   // slot of element b = kb
+      dif<16, 0, 16>(v);
+      static_for<0, 8>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int re = bitrev(u, 4), ro = bitrev(u + 8, 4);
+        if constexpr ((TDSA_ABLATE & 32) == 0) swap_halves(v[re], v[ro]);
+        combine32<u>(v[re], v[ro], odd_half);                // outputs kb = u + 8h and kb + 16
+        if constexpr ((TDSA_ABLATE & 2) == 0) {
+          buf[wrM + u * rd_stride] = v[re];
+          buf[wrM + (u + 16) * rd_stride] = v[ro];
+        }
       });
       TDSA_STAMP(7);
       TDSA_SYNC();
       TDSA_STAMP(8);
-      static_for<0, 32>([&](auto ic) {                         // element (c, kb, ka) for this (kb, ka)
-        constexpr int c = decltype(ic)::value;
-        if constexpr ((TDSA_ABLATE & 2) == 0) v[c] = buf[rd3_base + c * A + ((c * A) >> 5)];
+      static_for<0, 16>([&](auto ic) {                       // element c = 2i + h of row (kb, ka)
+        constexpr int i = decltype(ic)::value;
+        if constexpr ((TDSA_ABLATE & 2) == 0) v[i] = buf[rd3A + 2 * i * A + ((2 * i * A) >> 5)];
       });
     } else {
-      static_for<0, 32>([&](auto ic) {
-        constexpr int b = decltype(ic)::value;
-        if constexpr (SG % 32 == 0) v[b] = buf[rd_base + b * rd_stride];
-        else { const int i = t + b * SG; v[b] = buf[i + (i >> 5)]; }
+      static_for<0, 16>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (SG % 32 == 0) v[i] = buf[rdA + i * 2 * rd_stride];
+        else { const int e = t + (2 * i + h) * SG; v[i] = buf[e + (e >> 5)]; }
       });
     }
     TDSA_STAMP(9);
     static_for<0, 3>([&](auto ic) { opaque(twf_lo[decltype(ic)::value]); });
-    static_for<0, 7>([&](auto ic) { opaque(twf_hi[decltype(ic)::value]); });
-    twiddle32(v, twf_lo, twf_hi);
-    dif<32, 0, 32>(v);
+    static_for<0, 4>([&](auto ic) { opaque(twf_hi[decltype(ic)::value]); });
+    static_for<0, 16>([&](auto ic) {                         // pre-twiddle W_N^(t*(2i+h)), i = 4a + j
+      constexpr int i = decltype(ic)::value;
+      constexpr int a = i >> 2, j = i & 3;
+      if constexpr (j == 0) v[i] = cmul(v[i], twf_hi[a]);
+      else v[i] = cmul(v[i], cmul(twf_hi[a], twf_lo[j - 1]));
+    });
+    dif<16, 0, 16>(v);
+    static_for<0, 8>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      constexpr int re = bitrev(u, 4), ro = bitrev(u + 8, 4);
+      if constexpr ((TDSA_ABLATE & 32) == 0) swap_halves(v[re], v[ro]);
+      combine32<u>(v[re], v[ro], odd_half);                  // bins kc = u + 8h (v[re]) and kc + 16 (v[ro])
+    });
     TDSA_STAMP(10);
 
     // ---- epilogue: |X|^2 -> dB -> hold ; bin k = t + kc*SG lands at k ^ N/2 (fftshift) -----------
+    // this thread's 16 bins: q < 8: kc = q + 8h (register bitrev(q)), q >= 8: kc = q + 8 + 8h (bitrev(q))
     if (active) {
       if (p.out_lin != nullptr) {
-        float* orow = p.out_lin + (long long)frame * N;
-        static_for<0, 32>([&](auto ic) {
-          constexpr int kc = decltype(ic)::value;
-          const c32 X = v[bitrev(kc, 5)];
-          (orow + (kc ^ 16) * SG)[t] = (X.x * X.x + X.y * X.y) * ps_v;
+        float* orow = p.out_lin + (long long)frame * N + t + 8 * h * SG;
+        static_for<0, 16>([&](auto ic) {
+          constexpr int q = decltype(ic)::value;
+          constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;       // shifted position of kc (without the 8h part)
+          const c32 X = v[bitrev(q, 4)];
+          orow[kcs * SG] = (X.x * X.x + X.y * X.y) * ps_v;
         });
       } else {
-        float db[32];
+        // from here on only |X|^2 is needed: the 32 registers of v die as pw[] is formed
+        float db[16];
         bool tiny = false;
-        static_for<0, 32>([&](auto ic) {
-          constexpr int kc = decltype(ic)::value;
-          const c32 X = v[bitrev(kc, 5)];
-          const float pw = X.x * X.x + X.y * X.y;
-          tiny |= pw < kMagExactBelow;
-          db[kc] = fmaf(k10Log10_2, __builtin_amdgcn_logf(fmaf(pw, ps_v, fl_v)), cal_v);
+        static_for<0, 16>([&](auto ic) {
+          constexpr int q = decltype(ic)::value;
+          const c32 X = v[bitrev(q, 4)];
+          db[q] = X.x * X.x + X.y * X.y;
+          tiny |= db[q] < kMagExactBelow;
         });
         if (mag_mode && __builtin_amdgcn_ballot_w64(tiny) != 0) {   // near-silent frame: exact DB_MAG
-          static_for<0, 32>([&](auto ic) {
-            constexpr int kc = decltype(ic)::value;
-            const c32 X = v[bitrev(kc, 5)];
-            const float mag = __builtin_amdgcn_sqrtf(X.x * X.x + X.y * X.y);
-            db[kc] = fmaf(2.0f * k10Log10_2, __builtin_amdgcn_logf(mag + p.log_floor), cal_v);
+          static_for<0, 16>([&](auto ic) {
+            constexpr int q = decltype(ic)::value;
+            const float mag = __builtin_amdgcn_sqrtf(db[q]);
+            db[q] = fmaf(2.0f * k10Log10_2, __builtin_amdgcn_logf(mag + p.log_floor), cal_v);
+          });
+        } else {
+          static_for<0, 16>([&](auto ic) {
+            constexpr int q = decltype(ic)::value;
+            if constexpr ((TDSA_ABLATE & 64) == 0) db[q] = fmaf(k10Log10_2, __builtin_amdgcn_logf(fmaf(db[q], ps_v, fl_v)), cal_v);
+            else db[q] = fmaf(k10Log10_2, fmaf(db[q], ps_v, fl_v), cal_v);
           });
         }
         if (p.tare != nullptr) {
-          static_for<0, 32>([&](auto ic) {
-            constexpr int kc = decltype(ic)::value;
-            db[kc] -= (p.tare + (kc ^ 16) * SG)[t];
+          const float* trow = p.tare + t + 8 * h * SG;
+          static_for<0, 16>([&](auto ic) {
+            constexpr int q = decltype(ic)::value;
+            constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
+            db[q] -= trow[kcs * SG];
           });
         }
         if ((TDSA_ABLATE & 4) == 0 && p.out_db != nullptr) {
           float* orow = p.out_db + (long long)frame * N;
           if constexpr (FPW == 1) {
             const rsrc_t r = make_rsrc(orow, N * 4u);
-            static_for<0, 32>([&](auto ic) {
-              constexpr int kc = decltype(ic)::value;
-              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(db[kc]), r, unsigned(t) * 4u,
-                                                    (kc ^ 16) * SG * 4u, 0);
+            static_for<0, 16>([&](auto ic) {
+              constexpr int q = decltype(ic)::value;
+              constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(db[q]), r, out_voff, kcs * SG * 4u, 0);
             });
           } else {
-            static_for<0, 32>([&](auto ic) {
-              constexpr int kc = decltype(ic)::value;
-              (orow + (kc ^ 16) * SG)[t] = db[kc];
+            float* orow_t = orow + t + 8 * h * SG;
+            static_for<0, 16>([&](auto ic) {
+              constexpr int q = decltype(ic)::value;
+              constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
+              orow_t[kcs * SG] = db[q];
             });
           }
         }
         if constexpr (HOLD != 0) {
           const bool nanfix = IN_C64 && (p.first_frame_index + frame == 0);
-          static_for<0, 32>([&](auto ic) {
-            constexpr int kc = decltype(ic)::value;
-            float dmx = db[kc], dmn = db[kc];
+          static_for<0, 16>([&](auto ic) {
+            constexpr int q = decltype(ic)::value;
+            float dmx = db[q], dmn = db[q];
             if (nanfix && dmx != dmx) { dmx = -500.f; dmn = 500.f; }            // _nan_safe, first frame
-            if constexpr ((HOLD & 1) != 0) hmax[kc] = hw_max(hmax[kc], dmx);    // np.fmax: NaN ignored
-            if constexpr ((HOLD & 2) != 0) hmin[kc] = hw_min(hmin[kc], dmn);
+            if constexpr ((HOLD & 1) != 0) hmax[q] = hw_max(hmax[q], dmx);      // np.fmax: NaN ignored
+            if constexpr ((HOLD & 2) != 0) hmin[q] = hw_min(hmin[q], dmn);
           });
         }
       }
@@ -497,14 +584,15 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 2) spectrum_kernel(const Spec
 #ifdef TDSA_TIMELINE
   __syncthreads();
   if (p.dbg != nullptr && blockIdx.x == 0)
-    for (int i = tid; i < 8 * 8 * 16; i += C::WGT) p.dbg[i] = tl[i];
+    for (int i = tid; i < 8 * 16 * 16; i += C::WGT) p.dbg[i] = tl[i];
 #endif
   if constexpr (HOLD != 0) {
-    const long long prow = ((long long)blockIdx.x * FPW + slot) * N;
-    static_for<0, 32>([&](auto ic) {
-      constexpr int kc = decltype(ic)::value;
-      if constexpr ((HOLD & 1) != 0) (p.part_max + prow + (kc ^ 16) * SG)[t] = hmax[kc];
-      if constexpr ((HOLD & 2) != 0) (p.part_min + prow + (kc ^ 16) * SG)[t] = hmin[kc];
+    const long long prow = ((long long)blockIdx.x * FPW + slot) * N + t + 8 * h * SG;
+    static_for<0, 16>([&](auto ic) {
+      constexpr int q = decltype(ic)::value;
+      constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
+      if constexpr ((HOLD & 1) != 0) p.part_max[prow + kcs * SG] = hmax[q];
+      if constexpr ((HOLD & 2) != 0) p.part_min[prow + kcs * SG] = hmin[q];
     });
   }
 }
@@ -518,7 +606,7 @@ inline LaunchGeom geom_for(int n_frames, int num_cu) {
   g.lds_bytes = C::LDS_ALLOC;
   int per_cu = int((160 * 1024) / C::LDS_BYTES);
   if (per_cu < 1) per_cu = 1;
-  const int by_waves = 2 * 4 * 64 / C::WGT;                   // kernel is built for 2 waves per SIMD
+  const int by_waves = 4 * 4 * 64 / C::WGT;                   // kernel is built for 4 waves per SIMD
   const int wg_per_cu = per_cu < by_waves ? per_cu : by_waves;
   const int units = (n_frames + C::FPW - 1) / C::FPW;
   int grid = num_cu * wg_per_cu;
