@@ -480,3 +480,76 @@ def test_c64_nan_first_frame_hold_semantics(pkg):
     assert np.isnan(out[0]).all() and np.isfinite(out[1:]).all()
     assert np.array_equal(mx, np.fmax(np.fmax(np.full(nfft, -500.0, np.float32), out[1]), out[2]))
     assert np.array_equal(mn, np.fmin(np.fmin(np.full(nfft, 500.0, np.float32), out[1]), out[2]))
+
+
+# ------------------------------------------------------------------------------------------------
+# C5: 2^20-point FFT, Welch averaging over K segments, calibration offset (four-step kernels)
+# ------------------------------------------------------------------------------------------------
+def _welch_gold(iq, nfft, k, cal, window="hanning", dc=False):
+    x = so.unpack_iq_int8(iq).astype(np.complex128)
+    w = so.rtl_window(window, nfft)
+    acc = np.zeros(nfft)
+    for s in range(k):
+        seg = x[s * nfft:(s + 1) * nfft]
+        if dc:
+            seg = seg - seg.mean()
+        acc += np.abs(np.fft.fftshift(np.fft.fft(seg * w))) ** 2
+    return 10 * np.log10(acc / k + so.POWER_LOG_FLOOR) + cal, acc / k
+
+
+def test_c5_million_point_welch(pkg):
+    nfft, k, cal = 1 << 20, 4, -0.8087054556396822
+    iq = so.synth_iq_int8(nfft * k, nfft, seed=5)
+    gold, gold_mean = _welch_gold(iq, nfft, k, cal)
+    with pkg.SpectrumEngine(nfft, max_frames=k) as e:
+        e.set_window(so.rtl_window("hanning", nfft).astype(np.float32))
+        e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=-1.0,
+                    avg=("lin", k), cal_offset_db=cal, hold_max=True)
+        out = e.process(iq, hop=nfft)
+        assert out.shape == (1, nfft)
+        _check(out[0], gold, "C5 one call")
+        mean, cnt = e.averaged()
+        assert cnt == k and np.max(np.abs(mean - gold_mean) / gold_mean.max()) < 1e-5
+        mx, _ = e.hold()
+        assert np.array_equal(mx, out[0])
+        # the same Welch average fed in two calls (state persists like TraceAverager._buffer)
+        e.reset()
+        e.process(iq[:2 * nfft * 1], hop=nfft)
+        out2 = e.process(iq[2 * nfft * 1:], hop=nfft)
+        assert np.max(np.abs(out2[0] - out[0])) < 1e-4
+        # peak where SURVEY.md 8(d) puts the strongest tone
+        assert int(np.argmax(out[0])) == nfft // 2 + nfft // 8
+
+
+def test_c5_single_frame_with_dc_removal(pkg):
+    nfft = 1 << 20
+    iq = so.synth_iq_int8(nfft, nfft, seed=6)
+    gold, _ = _welch_gold(iq, nfft, 1, 0.0, dc=True)
+    with pkg.SpectrumEngine(nfft, max_frames=1) as e:
+        e.set_window(so.rtl_window("hanning", nfft).astype(np.float32))
+        e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=1.0)
+        out = e.process(iq, hop=nfft)
+    _check(out[0], gold, "C5 single frame, DC removed")
+
+
+def test_c5_sharded_welch_combines_on_host(pkg):
+    """each GPU averages its share of the segments; the host merges mean + count."""
+    from topdogspectrumanalyser_amd import sharding
+    nfft, k = 1 << 20, 4
+    iq = so.synth_iq_int8(nfft * k, nfft, seed=8)
+    gold, gold_mean = _welch_gold(iq, nfft, k, 0.0)
+    means, counts = [], []
+    for rank in range(2):                              # two "GPUs" = two plans on the one device here
+        f0, f1 = sharding.shard_frames(k, rank, 2)
+        s0, s1 = sharding.shard_samples(f0, f1, nfft, nfft)
+        with pkg.SpectrumEngine(nfft, max_frames=f1 - f0) as e:
+            e.set_window(so.rtl_window("hanning", nfft).astype(np.float32))
+            e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=-1.0,
+                        avg=("lin", k))
+            e.process(iq[2 * s0:2 * s1], hop=nfft, want_db=False)
+            m, c = e.averaged()
+            means.append(m)
+            counts.append(c)
+    mean, total = sharding.combine_welch(means, counts)
+    assert total == k
+    _check(10 * np.log10(mean + so.POWER_LOG_FLOOR), gold, "sharded Welch")

@@ -72,6 +72,13 @@ struct tdsa_plan_s {
   float* d_trace_live = nullptr;
   long long frames_seen = 0;             // frames processed since the last hold reset (nan_safe rule)
   unsigned long long* d_dbg = nullptr;   // TDSA_TIMELINE developer builds
+  // 2^20-point plans (four-step path)
+  bool big = false;
+  uint16_t* d_xt = nullptr;              // [max_frames][n2][n1] transposed raw samples
+  float2* d_y = nullptr;                 // [max_frames][k1][n2] after the column pass
+  double* d_sum = nullptr;               // [N] Welch sums, natural order
+  float2* d_tw1k = nullptr;              // W_1024^m
+  float2* d_twlo = nullptr;              // W_N^m, m < 1024
   bool profiling = false;
   std::vector<hipEvent_t> prof_events;   // pairs (begin, end) around frame-kernel launches
   size_t prof_used = 0;
@@ -124,6 +131,53 @@ int launch_spectrum_profiled(tdsa_plan p, int in_c64, const SpecParams& sp, cons
   return TDSA_OK;
 }
 
+// 2^20-point plans: Welch accumulation over the frames of the call (and across calls while the averager
+// is "lin" and not yet capped); out_db_dev receives ONE row: the dB of the running mean.
+int process_big(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n_frames, float* out_db_dev) {
+  const tdsa_mode& m = p->mode;
+  if (in_format == TDSA_IN_C64) return fail(TDSA_ERR_ARG, "2^20-point plans take int8/uint8 IQ only");
+  const bool averaging = avg_active(m);
+  if (averaging && m.avg_mode != TDSA_AVG_LIN)
+    return fail(TDSA_ERR_ARG, "2^20-point plans support lin (Welch) averaging only");
+  if (averaging && (long long)p->avg_count + n_frames > m.avg_n)
+    return fail(TDSA_ERR_ARG, "2^20-point plans need avg_n >= total frames (count %d + %d > %d)", p->avg_count,
+                n_frames, m.avg_n);
+  if (!averaging && n_frames != 1) return fail(TDSA_ERR_ARG, "without averaging a 2^20-point plan takes one frame");
+  const size_t N = size_t(p->nfft);
+  if (!p->d_xt) HIPCHK(hipMalloc(&p->d_xt, size_t(p->max_frames) * N * sizeof(uint16_t)));
+  if (!p->d_y) HIPCHK(hipMalloc(&p->d_y, size_t(p->max_frames) * N * sizeof(float2)));
+  const unsigned xor_mask = in_format == TDSA_IN_I8 ? 0x80808080u : 0u;
+  const float in_off = in_format == TDSA_IN_I8 ? 128.0f : 127.5f;
+  const float in_scale = in_format == TDSA_IN_I8 ? 1.0f / 128.0f : 1.0f / 127.5f;
+  const long long stride = (long long)hop * 2;
+  if (!averaging || p->avg_count == 0) {
+    HIPCHK(hipMemsetAsync(p->d_sum, 0, N * sizeof(double), p->stream));
+    p->avg_count = 0;
+  }
+  const float2* dc_sub = nullptr;
+  if (m.dc_alpha >= 0.0f) {   // per-segment mean (alpha = 1) or tracker (alpha < 1)
+    HIPCHK(launch_frame_sums(iq_dev, 0, xor_mask, stride, p->nfft, n_frames, p->d_sums, p->stream));
+    HIPCHK(launch_dc_track(p->d_sums, p->nfft, n_frames, m.dc_alpha > 1.0f ? 1.0f : m.dc_alpha, in_off, in_scale,
+                           p->d_dc_state, p->d_dc_sub, p->stream));
+    dc_sub = p->d_dc_sub;
+  }
+  HIPCHK(launch_big_transpose(iq_dev, stride, n_frames, p->d_xt, p->stream));
+  HIPCHK(launch_big_cols(p->d_xt, p->d_window[in_format], p->d_tw1k, p->d_twlo, dc_sub, p->d_y, xor_mask, in_off,
+                         n_frames, p->stream));
+  HIPCHK(launch_big_rows(p->d_y, p->d_tw1k, n_frames, p->d_sum, p->stream));
+  p->avg_count += n_frames;
+  const bool hmax = (m.hold_flags & TDSA_HOLD_MAX) != 0, hmin = (m.hold_flags & TDSA_HOLD_MIN) != 0;
+  HIPCHK(launch_big_finish(p->d_sum, p->d_avg, p->avg_count, m.db_mode,
+                           m.db_mode == TDSA_DB_POW ? m.power_scale : 1.0f, m.log_floor, m.cal_offset_db,
+                           p->tare_active ? p->d_tare_base : nullptr, out_db_dev, hmax ? p->d_hold_max : nullptr,
+                           hmin ? p->d_hold_min : nullptr, p->held_max == 0, p->held_min == 0, p->stream));
+  if (hmax) p->held_max += 1;
+  if (hmin) p->held_min += 1;
+  p->frames_seen += n_frames;
+  if (!averaging) p->avg_count = 0;
+  return TDSA_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -140,8 +194,10 @@ int tdsa_device_count(int* count) {
 int tdsa_create(int device_id, int nfft, int max_frames, tdsa_plan* out) {
   if (!out) return fail(TDSA_ERR_ARG, "out is null");
   *out = nullptr;
-  if (nfft < (1 << kMinLog2N) || nfft > (1 << kMaxLog2N) || (nfft & (nfft - 1)))
-    return fail(TDSA_ERR_ARG, "nfft=%d: need a power of two in [%d, %d]", nfft, 1 << kMinLog2N, 1 << kMaxLog2N);
+  const bool big = nfft == (1 << kBigLog2N);
+  if (!big && (nfft < (1 << kMinLog2N) || nfft > (1 << kMaxLog2N) || (nfft & (nfft - 1))))
+    return fail(TDSA_ERR_ARG, "nfft=%d: need a power of two in [%d, %d] or %d", nfft, 1 << kMinLog2N,
+                1 << kMaxLog2N, 1 << kBigLog2N);
   if (max_frames < 1) return fail(TDSA_ERR_ARG, "max_frames=%d must be >= 1", max_frames);
   int ndev = 0;
   HIPCHK(hipGetDeviceCount(&ndev));
@@ -153,6 +209,7 @@ int tdsa_create(int device_id, int nfft, int max_frames, tdsa_plan* out) {
   p->nfft = nfft;
   p->log2n = ilog2i(nfft);
   p->max_frames = max_frames;
+  p->big = big;
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, device_id));
   p->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -181,6 +238,19 @@ int tdsa_create(int device_id, int nfft, int max_frames, tdsa_plan* out) {
     tw[m] = float2{float(std::cos(ang)), float(std::sin(ang))};
   }
   HIPCHK(hipMemcpy(p->d_tw, tw.data(), size_t(nfft) * sizeof(float2), hipMemcpyHostToDevice));
+  if (big) {
+    HIPCHK(hipMalloc(&p->d_sum, size_t(nfft) * sizeof(double)));
+    HIPCHK(hipMalloc(&p->d_tw1k, 1024 * sizeof(float2)));
+    HIPCHK(hipMalloc(&p->d_twlo, 1024 * sizeof(float2)));
+    std::vector<float2> t1(1024), t2(1024);
+    for (int m = 0; m < 1024; ++m) {
+      const double a1 = -2.0 * M_PI * double(m) / 1024.0, a2 = -2.0 * M_PI * double(m) / double(nfft);
+      t1[m] = float2{float(std::cos(a1)), float(std::sin(a1))};
+      t2[m] = float2{float(std::cos(a2)), float(std::sin(a2))};
+    }
+    HIPCHK(hipMemcpy(p->d_tw1k, t1.data(), 1024 * sizeof(float2), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->d_twlo, t2.data(), 1024 * sizeof(float2), hipMemcpyHostToDevice));
+  }
   int rc = reset_hold(p, true, true);
   if (rc != TDSA_OK) return rc;
   // defaults = HackRF plain branch (hackrf_samples.py:382-383)
@@ -204,7 +274,7 @@ int tdsa_destroy(tdsa_plan p) {
   void* bufs[] = {p->d_window[0], p->d_window[1], p->d_window[2], p->d_tw, p->d_hold_max, p->d_hold_min,
                   p->d_part_max, p->d_part_min, p->d_avg, p->d_lin, p->d_dc_state, p->d_sums, p->d_dc_sub,
                   p->d_tare_base, p->d_tare_acc, p->d_in_stage, p->d_out_stage, p->d_trace_in,
-                  p->d_trace_live};
+                  p->d_trace_live, p->d_xt, p->d_y, p->d_sum, p->d_tw1k, p->d_twlo, p->d_dbg};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (hipEvent_t e : p->prof_events) (void)hipEventDestroy(e);
@@ -217,7 +287,8 @@ int tdsa_destroy(tdsa_plan p) {
 
 int tdsa_get_info(tdsa_plan p, tdsa_info* out) {
   if (!p || !out) return fail(TDSA_ERR_ARG, "null argument");
-  LaunchGeom g = spectrum_geometry(p->log2n, p->max_frames, p->num_cu);
+  LaunchGeom g = p->big ? LaunchGeom{64 * p->max_frames, 512, 16, size_t(1024) * 17 * 8}
+                        : spectrum_geometry(p->log2n, p->max_frames, p->num_cu);
   out->nfft = p->nfft;
   out->max_frames = p->max_frames;
   out->device_id = p->device;
@@ -241,7 +312,12 @@ int tdsa_set_window(tdsa_plan p, const float* w_host, int n) {
   std::vector<float> tmp(n);
   HIPCHK(hipStreamSynchronize(p->stream));
   for (int f = 0; f < 3; ++f) {
-    for (int i = 0; i < n; ++i) tmp[i] = w_host[i] * scale[f];
+    if (p->big) {   // transposed [n2][n1] for the column pass
+      for (int n1 = 0; n1 < 1024; ++n1)
+        for (int n2 = 0; n2 < 1024; ++n2) tmp[size_t(n2) * 1024 + n1] = w_host[size_t(n1) * 1024 + n2] * scale[f];
+    } else {
+      for (int i = 0; i < n; ++i) tmp[i] = w_host[i] * scale[f];
+    }
     HIPCHK(hipMemcpy(p->d_window[f], tmp.data(), size_t(n) * sizeof(float), hipMemcpyHostToDevice));
   }
   p->window_set = true;
@@ -308,6 +384,7 @@ int tdsa_process_dev(tdsa_plan p, int in_format, const void* iq_dev, size_t n_sa
   if ((reinterpret_cast<uintptr_t>(iq_dev) % (bps == 8 ? 8 : 2)) != 0)
     return fail(TDSA_ERR_ARG, "iq pointer must be aligned to one sample (%d bytes)", bps);
   HIPCHK(hipSetDevice(p->device));
+  if (p->big) return process_big(p, in_format, iq_dev, hop, n_frames, out_db_dev);
 
   const tdsa_mode& m = p->mode;
   const bool averaging = avg_active(m);
@@ -418,12 +495,12 @@ static int process_host(tdsa_plan p, int fmt, const void* iq_host, size_t n_samp
     p->in_stage_bytes = in_bytes;
   }
   if (out_db_host && !p->d_out_stage)
-    HIPCHK(hipMalloc(&p->d_out_stage, size_t(p->max_frames) * p->nfft * sizeof(float)));
+    HIPCHK(hipMalloc(&p->d_out_stage, size_t(p->big ? 1 : p->max_frames) * p->nfft * sizeof(float)));
   HIPCHK(hipMemcpyAsync(p->d_in_stage, iq_host, in_bytes, hipMemcpyHostToDevice, p->stream));
   int rc = tdsa_process_dev(p, fmt, p->d_in_stage, need, hop, n_frames, out_db_host ? p->d_out_stage : nullptr);
   if (rc != TDSA_OK) return rc;
   if (out_db_host)
-    HIPCHK(hipMemcpyAsync(out_db_host, p->d_out_stage, size_t(n_frames) * p->nfft * sizeof(float),
+    HIPCHK(hipMemcpyAsync(out_db_host, p->d_out_stage, size_t(p->big ? 1 : n_frames) * p->nfft * sizeof(float),
                           hipMemcpyDeviceToHost, p->stream));
   HIPCHK(hipStreamSynchronize(p->stream));
   return TDSA_OK;

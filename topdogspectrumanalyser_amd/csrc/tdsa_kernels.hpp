@@ -98,4 +98,15 @@ hipError_t launch_avg_host_frame(const double* lin, int n, double* state, int co
 
 hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s);
 
+// ---- 2^20-point four-step path (tdsa_big.hip) ----
+constexpr int kBigLog2N = 20;
+hipError_t launch_big_transpose(const void* in, long long seg_stride, int n_seg, uint16_t* xt, hipStream_t s);
+hipError_t launch_big_cols(const uint16_t* xt, const float* wt, const float2* tw1k, const float2* twlo,
+                           const float2* dc_sub, float2* y, unsigned xor_mask, float in_off, int n_seg,
+                           hipStream_t s);
+hipError_t launch_big_rows(const float2* y, const float2* tw1k, int n_seg, double* sum, hipStream_t s);
+hipError_t launch_big_finish(const double* sum, double* mean_out, int count, int db_mode, float pscale,
+                             float log_floor, float cal_db, const float* tare, float* out_db, float* hold_max,
+                             float* hold_min, int max_first, int min_first, hipStream_t s);
+
 }  // namespace tdsa
