@@ -52,9 +52,6 @@ struct tdsa_plan_s {
   float* d_hold_max = nullptr;
   float* d_hold_min = nullptr;
   long long held_max = 0, held_min = 0;
-  float* d_part_max = nullptr;
-  float* d_part_min = nullptr;
-  int part_rows = 0;
   double* d_avg = nullptr;
   int avg_count = 0;
   float* d_lin = nullptr;                // [max_frames][N] linear power scratch (averaging modes)
@@ -99,16 +96,6 @@ int reset_hold(tdsa_plan p, bool mx, bool mn) {
     HIPCHK(launch_fill(p->d_hold_min, p->nfft, INFINITY, p->stream));
     p->held_min = 0;
   }
-  return TDSA_OK;
-}
-
-int ensure_partials(tdsa_plan p) {
-  if (p->d_part_max) return TDSA_OK;
-  LaunchGeom g = spectrum_geometry(p->log2n, p->max_frames, p->num_cu);
-  p->part_rows = g.grid * g.fpw;
-  const size_t bytes = size_t(p->part_rows) * p->nfft * sizeof(float);
-  HIPCHK(hipMalloc(&p->d_part_max, bytes));
-  HIPCHK(hipMalloc(&p->d_part_min, bytes));
   return TDSA_OK;
 }
 
@@ -272,7 +259,7 @@ int tdsa_destroy(tdsa_plan p) {
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   void* bufs[] = {p->d_window[0], p->d_window[1], p->d_window[2], p->d_tw, p->d_hold_max, p->d_hold_min,
-                  p->d_part_max, p->d_part_min, p->d_avg, p->d_lin, p->d_dc_state, p->d_sums, p->d_dc_sub,
+                  p->d_avg, p->d_lin, p->d_dc_state, p->d_sums, p->d_dc_sub,
                   p->d_tare_base, p->d_tare_acc, p->d_in_stage, p->d_out_stage, p->d_trace_in,
                   p->d_trace_live, p->d_xt, p->d_y, p->d_sum, p->d_tw1k, p->d_twlo, p->d_dbg};
   for (void* b : bufs)
@@ -453,18 +440,12 @@ int tdsa_process_dev(tdsa_plan p, int in_format, const void* iq_dev, size_t n_sa
   } else {
     sp.out_db = out_db_dev;
     sp.hold_flags = int(m.hold_flags & 3u);
-    if (hold) {
-      int rc = ensure_partials(p);
-      if (rc != TDSA_OK) return rc;
-      sp.part_max = p->d_part_max;
-      sp.part_min = p->d_part_min;
+    if (hold) {   // workgroups merge their register-resident traces into the plan's traces with atomics
+      sp.part_max = p->d_hold_max;
+      sp.part_min = p->d_hold_min;
     }
     int rc_p = launch_spectrum_profiled(p, in_c64, sp, g);
     if (rc_p != TDSA_OK) return rc_p;
-    if (hold)
-      HIPCHK(launch_hold_reduce((m.hold_flags & TDSA_HOLD_MAX) ? p->d_part_max : nullptr,
-                                (m.hold_flags & TDSA_HOLD_MIN) ? p->d_part_min : nullptr, g.grid * g.fpw,
-                                p->nfft, p->d_hold_max, p->d_hold_min, p->stream));
   }
   if (m.hold_flags & TDSA_HOLD_MAX) p->held_max += n_frames;
   if (m.hold_flags & TDSA_HOLD_MIN) p->held_min += n_frames;

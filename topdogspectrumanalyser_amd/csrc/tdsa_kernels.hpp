@@ -24,8 +24,8 @@ struct SpecParams {
   float* out_lin;            // [F][N] fftshift-ed linear power * pscale (averaging modes), or null
   const float2* dc_sub;      // [F] per-frame subtract value in raw-sample units (DC_TRACKED), or null
   float2* dc_state;          // last frame's mean in units of x is stored here (DC_FRAME_MEAN), or null
-  float* part_max;           // [grid*FPW][N] per-workgroup-slot partial max hold, or null
-  float* part_min;           // [grid*FPW][N]
+  float* part_max;           // [N] the plan's max-hold trace (merged into with float atomics), or null
+  float* part_min;           // [N] the plan's min-hold trace
   const float* tare;         // [N] dB baseline to subtract, or null
   unsigned xor_mask;         // 0x80808080 for int8 (-> offset binary), 0 for uint8
   float in_off;              // 128 (int8), 127.5 (uint8), 0 (c64): value of "zero" in raw units

@@ -105,6 +105,16 @@ __device__ __forceinline__ int dpp_wave_sum(int x) {
   return x;
 }
 
+// float max/min through integer atomics (IEEE-754 order trick); NaN candidates are skipped (np.fmax)
+__device__ __forceinline__ void atomic_fmax_dev(float* addr, float v) {
+  if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else if (v < 0.f) atomicMin(reinterpret_cast<unsigned*>(addr), __float_as_uint(v));
+}
+__device__ __forceinline__ void atomic_fmin_dev(float* addr, float v) {
+  if (v >= 0.f) atomicMin(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else if (v < 0.f) atomicMax(reinterpret_cast<unsigned*>(addr), __float_as_uint(v));
+}
+
 using rsrc_t = __amdgpu_buffer_rsrc_t;
 __device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, int(bytes), 0x00020000);
@@ -586,14 +596,21 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   if (p.dbg != nullptr && blockIdx.x == 0)
     for (int i = tid; i < 8 * 16 * 16; i += C::WGT) p.dbg[i] = tl[i];
 #endif
+  // fold this workgroup's register-resident hold traces straight into the plan's traces with
+  // integer-punned float atomics (max/min are associative; the traces start at -inf / +inf).
+  // (Issuing the bulk of them before the last frame to hide the tail was tried: the extra live state
+  //  pushed the kernel into 39 scratch spills and cost more than the ~6 us tail it removed.)
   if constexpr (HOLD != 0) {
-    const long long prow = ((long long)blockIdx.x * FPW + slot) * N + t + 8 * h * SG;
-    static_for<0, 16>([&](auto ic) {
-      constexpr int q = decltype(ic)::value;
-      constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
-      if constexpr ((HOLD & 1) != 0) p.part_max[prow + kcs * SG] = hmax[q];
-      if constexpr ((HOLD & 2) != 0) p.part_min[prow + kcs * SG] = hmin[q];
-    });
+    const long long prow = t + 8 * h * SG;
+    const bool any = (u1 > u0) && (FPW == 1 || u0 * FPW + slot < p.n_frames);
+    if (any) {
+      static_for<0, 16>([&](auto ic) {
+        constexpr int q = decltype(ic)::value;
+        constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
+        if constexpr ((HOLD & 1) != 0) atomic_fmax_dev(p.part_max + prow + kcs * SG, hmax[q]);
+        if constexpr ((HOLD & 2) != 0) atomic_fmin_dev(p.part_min + prow + kcs * SG, hmin[q]);
+      });
+    }
   }
 }
 
