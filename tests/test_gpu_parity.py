@@ -553,3 +553,26 @@ def test_c5_sharded_welch_combines_on_host(pkg):
     mean, total = sharding.combine_welch(means, counts)
     assert total == k
     _check(10 * np.log10(mean + so.POWER_LOG_FLOOR), gold, "sharded Welch")
+
+
+@pytest.mark.parametrize("avg", [("exp", 8), ("lin", 16), ("lin", 5000)])
+def test_long_batch_averaging_uses_chunked_scan(pkg, avg):
+    """> 128 frames: the averager runs as a three-pass chunked scan (frames x bins parallel); it must
+    reproduce the order-dependent recurrence of TraceAverager, also when the batch is split in two calls."""
+    nfft, nf = 1024, 700
+    iq = so.synth_iq_int8(nfft * nf, nfft, seed=61)
+    gold, gmax, gmin = so.hackrf_batch(iq, nfft, nfft, 20e6, precision="gold", avg=avg)
+    with pkg.SpectrumEngine(nfft, max_frames=nf) as e:
+        e.set_window(so.hackrf_window(nfft))
+        e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=1.0, avg=avg,
+                    hold_max=True, hold_min=True)
+        out = e.process(iq, hop=nfft)
+        _check(out, gold, f"chunked {avg}")
+        mx, mn = e.hold()
+        assert np.array_equal(mx, out.max(axis=0)) and np.array_equal(mn, out.min(axis=0))
+        buf, cnt = e.averaged()
+        assert cnt == (1 if avg[0] == "exp" else min(avg[1], nf))
+        e.reset()
+        a = e.process(iq[:2 * nfft * 300], hop=nfft)          # 300 frames (chunked), then 400 more
+        b = e.process(iq[2 * nfft * 300:], hop=nfft)
+        _check(np.concatenate([a, b]), gold, f"chunked split {avg}")

@@ -55,6 +55,7 @@ struct tdsa_plan_s {
   double* d_avg = nullptr;
   int avg_count = 0;
   float* d_lin = nullptr;                // [max_frames][N] linear power scratch (averaging modes)
+  double* d_carry = nullptr;             // [ceil(max_frames/64)][N] chunk carries of the averager scan
   float2* d_dc_state = nullptr;
   float2* d_sums = nullptr;
   float2* d_dc_sub = nullptr;
@@ -259,7 +260,7 @@ int tdsa_destroy(tdsa_plan p) {
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   void* bufs[] = {p->d_window[0], p->d_window[1], p->d_window[2], p->d_tw, p->d_hold_max, p->d_hold_min,
-                  p->d_avg, p->d_lin, p->d_dc_state, p->d_sums, p->d_dc_sub,
+                  p->d_avg, p->d_lin, p->d_carry, p->d_dc_state, p->d_sums, p->d_dc_sub,
                   p->d_tare_base, p->d_tare_acc, p->d_in_stage, p->d_out_stage, p->d_trace_in,
                   p->d_trace_live, p->d_xt, p->d_y, p->d_sum, p->d_tw1k, p->d_twlo, p->d_dbg};
   for (void* b : bufs)
@@ -412,6 +413,8 @@ int tdsa_process_dev(tdsa_plan p, int in_format, const void* iq_dev, size_t n_sa
   const LaunchGeom g = spectrum_geometry(p->log2n, n_frames, p->num_cu);
   if (averaging) {
     if (!p->d_lin) HIPCHK(hipMalloc(&p->d_lin, size_t(p->max_frames) * p->nfft * sizeof(float)));
+    if (!p->d_carry && p->max_frames > 128)
+      HIPCHK(hipMalloc(&p->d_carry, size_t(avg_scan_chunks(p->max_frames)) * p->nfft * sizeof(double)));
     sp.out_lin = p->d_lin;
     sp.hold_flags = 0;
     int rc_p = launch_spectrum_profiled(p, in_c64, sp, g);
@@ -430,7 +433,7 @@ int tdsa_process_dev(tdsa_plan p, int in_format, const void* iq_dev, size_t n_sa
     ap.out_db = out_db_dev;
     ap.state_max = (m.hold_flags & TDSA_HOLD_MAX) ? p->d_hold_max : nullptr;
     ap.state_min = (m.hold_flags & TDSA_HOLD_MIN) ? p->d_hold_min : nullptr;
-    HIPCHK(launch_avg_scan(ap, p->stream));
+    HIPCHK(launch_avg_scan(ap, p->stream, p->d_carry));
     if (m.avg_mode == TDSA_AVG_LIN) {
       long long c = (long long)p->avg_count + n_frames;
       p->avg_count = int(c < m.avg_n ? c : m.avg_n);

@@ -66,7 +66,9 @@ struct AvgParams {
   float* state_min;
   int first_frame_index;
 };
-hipError_t launch_avg_scan(const AvgParams& p, hipStream_t s);
+// carry: [ceil(n_frames/64)][n] doubles of scratch for the chunked scan (null: sequential kernel)
+hipError_t launch_avg_scan(const AvgParams& p, hipStream_t s, double* carry);
+int avg_scan_chunks(int n_frames);
 
 // per-frame sums for the DC tracker (dc_alpha in (0,1)): sums[f] = sum of raw I, raw Q (float2)
 hipError_t launch_frame_sums(const void* in, int in_c64, unsigned xor_mask, long long frame_stride,

@@ -102,7 +102,91 @@ __global__ void __launch_bounds__(64) avg_scan_kernel(const AvgParams p) {
   if (p.state_min != nullptr) p.state_min[k] = hmin;
 }
 
-hipError_t launch_avg_scan(const AvgParams& p, hipStream_t s) {
+// ---- chunked scan for long batches -------------------------------------------------------------------
+// Both recurrences are linear in the state with data-independent coefficients:
+//   s_f = a_f * s_(f-1) + b_f(P_f),   exp: a = 1 - 1/n, b = float(1/n) * P   (first ever frame: a = 0, b = P)
+//                                      lin: c_f = min(count_in + f + 1, n), a = 1 - 1/c_f, b = P / c_f
+// so a chunk can be scanned from a zero state (pass 1), the chunk carries chained per bin (pass 2) and the
+// chunk re-scanned from its true carry-in while the dB rows are written (pass 3).  Frames x bins parallel.
+__device__ __forceinline__ void avg_coeff(const AvgParams& p, int f, double& a, double& bscale, bool& b_in_float) {
+  const int seen = p.count_in + f;                 // frames folded in before this one
+  if (p.mode == 1) {                               // exp
+    if (seen == 0 && p.count_in == 0) { a = 0.0; bscale = 1.0; b_in_float = false; }
+    else { a = 1.0 - 1.0 / double(p.avg_n); bscale = 1.0 / double(p.avg_n); b_in_float = true; }
+  } else {                                         // lin
+    const int c = seen + 1 < p.avg_n ? seen + 1 : p.avg_n;
+    a = 1.0 - 1.0 / double(c); bscale = 1.0 / double(c); b_in_float = false;
+  }
+}
+__device__ __forceinline__ double avg_step(const AvgParams& p, int f, double s, float lin) {
+  // written exactly as the reference evaluates it (utils/signal_processing.py:47-59)
+  const int seen = p.count_in + f;
+  if (seen == 0) return double(lin);
+  if (p.mode == 1) {
+    s = s * (1.0 - 1.0 / double(p.avg_n));
+    return s + double(float(1.0 / double(p.avg_n)) * lin);
+  }
+  const int c = seen + 1 < p.avg_n ? seen + 1 : p.avg_n;
+  return s + (double(lin) - s) / double(c);
+}
+
+constexpr int kAvgChunk = 64;
+__global__ void __launch_bounds__(64) avg_chunk_local_kernel(const AvgParams p, double* carry) {
+  const int k = blockIdx.x * 64 + threadIdx.x, c = blockIdx.y;
+  if (k >= p.n) return;
+  const int f0 = c * kAvgChunk, f1 = f0 + kAvgChunk < p.n_frames ? f0 + kAvgChunk : p.n_frames;
+  double s = 0.0;
+  for (int f = f0; f < f1; ++f) {
+    double a, bs; bool bf;
+    avg_coeff(p, f, a, bs, bf);
+    const float lin = p.lin[(size_t)f * p.n + k];
+    s = a * s + (bf ? double(float(bs) * lin) : bs * double(lin));
+  }
+  carry[(size_t)c * p.n + k] = s;                  // chunk result from a zero carry-in
+}
+__global__ void __launch_bounds__(64) avg_chunk_chain_kernel(const AvgParams p, double* carry, int n_chunks) {
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  if (k >= p.n) return;
+  double s = p.count_in > 0 ? p.state[k] : 0.0;
+  for (int c = 0; c < n_chunks; ++c) {
+    const int f0 = c * kAvgChunk, f1 = f0 + kAvgChunk < p.n_frames ? f0 + kAvgChunk : p.n_frames;
+    double A = 1.0;
+    for (int f = f0; f < f1; ++f) { double a, bs; bool bf; avg_coeff(p, f, a, bs, bf); A *= a; }
+    const double local = carry[(size_t)c * p.n + k];
+    carry[(size_t)c * p.n + k] = s;                // carry-in of chunk c
+    s = local + A * s;
+  }
+  p.state[k] = s;
+}
+__global__ void __launch_bounds__(64) avg_chunk_final_kernel(const AvgParams p, const double* carry) {
+  const int k = blockIdx.x * 64 + threadIdx.x, c = blockIdx.y;
+  if (k >= p.n) return;
+  const int f0 = c * kAvgChunk, f1 = f0 + kAvgChunk < p.n_frames ? f0 + kAvgChunk : p.n_frames;
+  double s = carry[(size_t)c * p.n + k];
+  const float tare = p.tare != nullptr ? p.tare[k] : 0.f;
+  float hmax = -INFINITY, hmin = INFINITY;
+  for (int f = f0; f < f1; ++f) {
+    s = avg_step(p, f, s, p.lin[(size_t)f * p.n + k]);
+    const float db = fmaf(k10Log10_2f, __builtin_amdgcn_logf(float(s + double(p.log_floor))), p.cal_db) - tare;
+    if (p.out_db != nullptr) p.out_db[(size_t)f * p.n + k] = db;
+    hmax = fmaxf(hmax, db);
+    hmin = fminf(hmin, db);
+  }
+  if (p.state_max != nullptr) atomic_fmax(p.state_max + k, hmax);
+  if (p.state_min != nullptr) atomic_fmin(p.state_min + k, hmin);
+}
+
+int avg_scan_chunks(int n_frames) { return (n_frames + kAvgChunk - 1) / kAvgChunk; }
+
+hipError_t launch_avg_scan(const AvgParams& p, hipStream_t s, double* carry) {
+  if (carry != nullptr && p.n_frames > 2 * kAvgChunk) {
+    const int n_chunks = (p.n_frames + kAvgChunk - 1) / kAvgChunk;
+    const dim3 grid((p.n + 63) / 64, n_chunks);
+    hipLaunchKernelGGL(avg_chunk_local_kernel, grid, dim3(64), 0, s, p, carry);
+    hipLaunchKernelGGL(avg_chunk_chain_kernel, dim3((p.n + 63) / 64), dim3(64), 0, s, p, carry, n_chunks);
+    hipLaunchKernelGGL(avg_chunk_final_kernel, grid, dim3(64), 0, s, p, carry);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(avg_scan_kernel, dim3((p.n + 63) / 64), dim3(64), 0, s, p);
   return hipGetLastError();
 }
