@@ -134,6 +134,20 @@ int tdsa_process_c64(tdsa_plan p, const float* iq_host, size_t n_samples, int ho
 int tdsa_process_dev(tdsa_plan p, int in_format, const void* iq_dev, size_t n_samples, int hop,
                      int n_frames, float* out_db_dev);
 
+/* Real-input path of MicrophoneSamplesDataSource (datasources/audio_samples.py:121-184): frames of
+ * stereo float32 samples [L0,R0,L1,R1,...]; both channels ride ONE complex FFT (z = L + iR) and are
+ * separated afterwards.  Per frame: mean removal, window, N-point FFT, one-sided power with the
+ * non-DC / non-Nyquist bins doubled (:131), PSD scale, TraceAverager, 10*log10(. + floor).
+ * channel: TDSA_CH_MONO ((L+R)/2), _LEFT, _RIGHT -> out [n_frames][N/2+1];
+ *          TDSA_CH_STEREO -> out [n_frames][2][N/2+1] (left averaged, right not, as :158-171).
+ * Uses the plan's window, power_scale, log_floor and averager settings (db_mode must be TDSA_DB_POW). */
+#define TDSA_CH_MONO 0
+#define TDSA_CH_LEFT 1
+#define TDSA_CH_RIGHT 2
+#define TDSA_CH_STEREO 3
+int tdsa_process_real2(tdsa_plan p, const float* lr_host, size_t n_samples, int hop, int n_frames,
+                       int channel, float* out_db_host);
+
 /* Hold traces (mw.max_power_levels / mw.min_power_levels); either pointer may be NULL.
  * *frames_held = number of frames folded in (0: trace is empty, buffer left untouched). */
 int tdsa_get_hold(tdsa_plan p, float* max_host, float* min_host, int64_t* frames_held);

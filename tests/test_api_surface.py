@@ -89,7 +89,7 @@ def test_error_conventions_without_hardware():
     assert f[0] == 100_000_000 - 1_000_000 and f[-1] == 100_000_000 + 1_000_000
     a = pkg.MicrophoneSamplesDataSource()
     with pytest.raises(RuntimeError):
-        a.start(None)
+        a.start(None)                            # no sounddevice / PortAudio here
     p, f = a.get_power_levels()
     assert np.all(p == -120.0) and len(p) == 513
 

@@ -576,3 +576,88 @@ def test_long_batch_averaging_uses_chunked_scan(pkg, avg):
         a = e.process(iq[:2 * nfft * 300], hop=nfft)          # 300 frames (chunked), then 400 more
         b = e.process(iq[2 * nfft * 300:], hop=nfft)
         _check(np.concatenate([a, b]), gold, f"chunked split {avg}")
+
+
+# ------------------------------------------------------------------------------------------------
+# real-input (audio) path: two real channels in one complex FFT
+# ------------------------------------------------------------------------------------------------
+class _FakeStream:
+    def __init__(self, blocks):
+        self._blocks, self._i = list(blocks), 0
+
+    def start(self): pass
+    def stop(self): pass
+    def close(self): pass
+
+    def read(self, n):
+        b = self._blocks[self._i]
+        self._i += 1
+        assert len(b) == n
+        return np.array(b, copy=True), False
+
+
+@pytest.mark.parametrize("mode,chan,psd", [("mono", "mono", False), ("left", "left", False), ("mono_psd", "mono", True)])
+def test_audio_source_golden(pkg, golden_dir, mode, chan, psd):
+    g = np.load(os.path.join(golden_dir, "audio_1024.npz"))
+    n, nf, fs = int(g["nfft"]), int(g["n_frames"]), int(g["sample_rate"])
+    st = g["stereo_f32"]
+    blocks = [st[k * n:(k + 1) * n] for k in range(nf)]
+    src = pkg.MicrophoneSamplesDataSource(sample_rate=fs, stream_factory=lambda rate, block: _FakeStream(blocks))
+    src.set_fft_size(n)
+    src.set_channel_mode(chan)
+    src.set_psd_mode(psd)
+    src.start(None)
+    src._audio_block = n
+    win = so.rtl_window("hanning", n)
+    for k in range(nf):
+        p, fb = src.get_power_levels()
+        assert p.shape == (n // 2 + 1,) and np.array_equal(fb, g["freq_bins"])
+        blk = blocks[k].astype(np.float64)
+        sig = (blk[:, 0] + blk[:, 1]) * 0.5 if chan == "mono" else blk[:, 0]
+        gold = so.audio_db(so.audio_compute_power(sig, win, n, fs, psd, precision="gold"), psd)
+        _check(p, gold, f"audio {mode} frame {k} vs gold")
+        _check(p, g[mode][k], f"audio {mode} frame {k} vs reference")
+    src.stop()
+
+
+def test_audio_stereo_and_averaging(pkg, golden_dir):
+    g = np.load(os.path.join(golden_dir, "audio_1024.npz"))
+    n, nf, fs = int(g["nfft"]), int(g["n_frames"]), int(g["sample_rate"])
+    st = g["stereo_f32"]
+    win = so.rtl_window("hanning", n)
+    blocks = [st[k * n:(k + 1) * n] for k in range(nf)]
+    src = pkg.MicrophoneSamplesDataSource(sample_rate=fs, stream_factory=lambda rate, block: _FakeStream(blocks))
+    src.set_fft_size(n)
+    src.set_channel_mode("stereo")
+    src.set_averaging("lin", 3)
+    src.start(None)
+    src._audio_block = n
+    av = so.TraceAveragerOracle()
+    av.set_mode("lin", 3)
+    for k in range(nf):
+        (left, right), _ = src.get_power_levels()
+        blk = blocks[k].astype(np.float64)
+        pl = av.process(so.audio_compute_power(blk[:, 0], win, n, fs, False, precision="gold"))
+        pr = so.audio_compute_power(blk[:, 1], win, n, fs, False, precision="gold")
+        assert left.dtype == np.float64
+        _check(left, so.audio_db(np.array(pl), False), f"stereo left (averaged) {k}")
+        _check(right, so.audio_db(pr, False), f"stereo right {k}")
+    src.stop()
+
+
+def test_real2_batch_matches_per_frame(pkg):
+    n, nf = 2048, 6
+    rng = np.random.default_rng(3)
+    st = (0.1 * rng.standard_normal((n * nf, 2))).astype(np.float32)
+    with pkg.SpectrumEngine(n, max_frames=nf) as e:
+        e.set_window(np.hamming(n).astype(np.float32))
+        e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=1.0)
+        both = e.process_real2(st, "stereo")
+        assert both.shape == (nf, 2, n // 2 + 1)
+        for ch, name in ((0, "left"), (1, "right")):
+            one = e.process_real2(st, name)
+            assert np.array_equal(one, both[:, ch])
+            for k in (0, nf - 1):
+                gold = so.audio_db(so.audio_compute_power(st[k * n:(k + 1) * n, ch].astype(np.float64),
+                                                          np.hamming(n), n, 44100, False, precision="gold"), False)
+                _check(one[k], gold, f"real2 {name} {k}")

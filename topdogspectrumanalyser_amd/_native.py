@@ -16,6 +16,7 @@ IN_I8, IN_U8, IN_C64 = 0, 1, 2
 DB_MAG, DB_POW = 0, 1
 AVG_OFF, AVG_EXP, AVG_LIN = 0, 1, 2
 HOLD_MAX, HOLD_MIN = 1, 2
+CH_MONO, CH_LEFT, CH_RIGHT, CH_STEREO = 0, 1, 2, 3
 RESET_AVG, RESET_HOLD_MAX, RESET_HOLD_MIN, RESET_DC, RESET_TARE, RESET_ALL = 1, 2, 4, 8, 16, 31
 
 
@@ -50,6 +51,7 @@ _SIGNATURES = {
     "tdsa_process_u8": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, _P]),
     "tdsa_process_c64": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, _P]),
     "tdsa_process_dev": (C.c_int, [_P, C.c_int, _P, C.c_size_t, C.c_int, C.c_int, _P]),
+    "tdsa_process_real2": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, C.c_int, _P]),
     "tdsa_get_hold": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int64)]),
     "tdsa_get_avg": (C.c_int, [_P, _P, C.POINTER(C.c_int)]),
     "tdsa_get_dc": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),

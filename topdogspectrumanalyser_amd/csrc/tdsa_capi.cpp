@@ -56,6 +56,9 @@ struct tdsa_plan_s {
   int avg_count = 0;
   float* d_lin = nullptr;                // [max_frames][N] linear power scratch (averaging modes)
   double* d_carry = nullptr;             // [ceil(max_frames/64)][N] chunk carries of the averager scan
+  float2* d_cplx = nullptr;              // [max_frames][N] complex spectra (real-input path)
+  float* d_lin1 = nullptr;               // [max_frames][2][N/2+1] one-sided linear power (real-input path)
+  float* d_db1 = nullptr;                // same shape, dB
   float2* d_dc_state = nullptr;
   float2* d_sums = nullptr;
   float2* d_dc_sub = nullptr;
@@ -260,7 +263,7 @@ int tdsa_destroy(tdsa_plan p) {
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   void* bufs[] = {p->d_window[0], p->d_window[1], p->d_window[2], p->d_tw, p->d_hold_max, p->d_hold_min,
-                  p->d_avg, p->d_lin, p->d_carry, p->d_dc_state, p->d_sums, p->d_dc_sub,
+                  p->d_avg, p->d_lin, p->d_carry, p->d_cplx, p->d_lin1, p->d_db1, p->d_dc_state, p->d_sums, p->d_dc_sub,
                   p->d_tare_base, p->d_tare_acc, p->d_in_stage, p->d_out_stage, p->d_trace_in,
                   p->d_trace_live, p->d_xt, p->d_y, p->d_sum, p->d_tw1k, p->d_twlo, p->d_dbg};
   for (void* b : bufs)
@@ -501,6 +504,81 @@ int tdsa_process_u8(tdsa_plan p, const uint8_t* iq_host, size_t n_samples, int h
 int tdsa_process_c64(tdsa_plan p, const float* iq_host, size_t n_samples, int hop, int n_frames,
                      float* out_db_host) {
   return process_host(p, TDSA_IN_C64, iq_host, n_samples, hop, n_frames, out_db_host);
+}
+
+int tdsa_process_real2(tdsa_plan p, const float* lr_host, size_t n_samples, int hop, int n_frames, int channel,
+                       float* out_db_host) {
+  if (!p) return fail(TDSA_ERR_ARG, "null plan");
+  if (p->big) return fail(TDSA_ERR_ARG, "real-input path needs an LDS-resident FFT size");
+  if (channel < TDSA_CH_MONO || channel > TDSA_CH_STEREO) return fail(TDSA_ERR_ARG, "channel %d", channel);
+  if (n_frames == 0) return TDSA_OK;
+  if (!lr_host || !out_db_host) return fail(TDSA_ERR_ARG, "null buffer");
+  if (n_frames < 0 || n_frames > p->max_frames)
+    return fail(TDSA_ERR_ARG, "n_frames=%d outside [0, max_frames=%d]", n_frames, p->max_frames);
+  if (hop < 1) return fail(TDSA_ERR_ARG, "hop=%d must be >= 1", hop);
+  const size_t need = size_t(n_frames - 1) * size_t(hop) + size_t(p->nfft);
+  if (n_samples < need) return fail(TDSA_ERR_ARG, "n_samples=%zu too small", n_samples);
+  if (!p->window_set) return fail(TDSA_ERR_STATE, "tdsa_set_window has not been called");
+  const tdsa_mode& m = p->mode;
+  if (m.db_mode != TDSA_DB_POW) return fail(TDSA_ERR_ARG, "real-input path computes power dB: set TDSA_DB_POW");
+  HIPCHK(hipSetDevice(p->device));
+  const int n = p->nfft, nb = n / 2 + 1;
+  const size_t in_bytes = need * sizeof(float2);
+  if (in_bytes > p->in_stage_bytes) {
+    HIPCHK(hipStreamSynchronize(p->stream));
+    if (p->d_in_stage) HIPCHK(hipFree(p->d_in_stage));
+    p->d_in_stage = nullptr;
+    p->in_stage_bytes = 0;
+    HIPCHK(hipMalloc(&p->d_in_stage, in_bytes));
+    p->in_stage_bytes = in_bytes;
+  }
+  if (!p->d_cplx) HIPCHK(hipMalloc(&p->d_cplx, size_t(p->max_frames) * n * sizeof(float2)));
+  if (!p->d_lin1) HIPCHK(hipMalloc(&p->d_lin1, size_t(p->max_frames) * 2 * nb * sizeof(float)));
+  if (!p->d_db1) HIPCHK(hipMalloc(&p->d_db1, size_t(p->max_frames) * 2 * nb * sizeof(float)));
+  HIPCHK(hipMemcpyAsync(p->d_in_stage, lr_host, in_bytes, hipMemcpyHostToDevice, p->stream));
+  SpecParams sp{};
+  sp.in = p->d_in_stage;
+  sp.frame_stride = (long long)hop * sizeof(float2);
+  sp.n_frames = n_frames;
+  sp.first_frame_index = 1;
+  sp.window = p->d_window[TDSA_IN_C64];
+  sp.tw = p->d_tw;
+  sp.out_cplx = p->d_cplx;
+  sp.in_scale = 1.0f;
+  sp.dc_mode = DC_FRAME_MEAN;                       // signal - signal.mean()  (audio_samples.py:123)
+  sp.db_mode = TDSA_DB_POW;
+  sp.pscale = 1.0f;
+  const LaunchGeom g = spectrum_geometry(p->log2n, n_frames, p->num_cu);
+  HIPCHK(launch_spectrum(p->log2n, 1, sp, g, p->stream));
+  HIPCHK(launch_real_fold(p->d_cplx, n, n_frames, channel, m.power_scale, p->d_lin1, p->stream));
+  const int rows = channel == TDSA_CH_STEREO ? 2 * n_frames : n_frames;
+  if (avg_active(m)) {
+    if (channel == TDSA_CH_STEREO)
+      return fail(TDSA_ERR_ARG, "stereo with averaging: process frame by frame (left is averaged, right is not)");
+    AvgParams ap{};
+    ap.lin = p->d_lin1;
+    ap.n_frames = n_frames;
+    ap.n = nb;
+    ap.state = p->d_avg;
+    ap.count_in = p->avg_count;
+    ap.mode = m.avg_mode;
+    ap.avg_n = m.avg_n;
+    ap.log_floor = m.log_floor;
+    ap.cal_db = m.cal_offset_db;
+    ap.out_db = p->d_db1;
+    HIPCHK(launch_avg_scan(ap, p->stream, nullptr));
+    if (m.avg_mode == TDSA_AVG_LIN) {
+      long long c = (long long)p->avg_count + n_frames;
+      p->avg_count = int(c < m.avg_n ? c : m.avg_n);
+    } else {
+      p->avg_count = 1;
+    }
+  } else {
+    HIPCHK(launch_lin_to_db(p->d_lin1, size_t(rows) * nb, m.log_floor, m.cal_offset_db, p->d_db1, p->stream));
+  }
+  HIPCHK(hipMemcpyAsync(out_db_host, p->d_db1, size_t(rows) * nb * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  return TDSA_OK;
 }
 
 int tdsa_get_hold(tdsa_plan p, float* max_host, float* min_host, int64_t* frames_held) {

@@ -22,6 +22,7 @@ struct SpecParams {
   const float2* tw;          // [N] exp(-2 pi i m / N)
   float* out_db;             // [F][N] fftshift-ed dB, or null
   float* out_lin;            // [F][N] fftshift-ed linear power * pscale (averaging modes), or null
+  float2* out_cplx;          // [F][N] complex spectrum X[k] in natural bin order (real-input path), or null
   const float2* dc_sub;      // [F] per-frame subtract value in raw-sample units (DC_TRACKED), or null
   float2* dc_state;          // last frame's mean in units of x is stored here (DC_FRAME_MEAN), or null
   float* part_max;           // [N] the plan's max-hold trace (merged into with float atomics), or null
@@ -99,6 +100,13 @@ hipError_t launch_avg_host_frame(const double* lin, int n, double* state, int co
                                  int avg_n, hipStream_t s);
 
 hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s);
+
+// ---- real-input (audio) path: two real channels ride one complex FFT (z = left + i*right) ----
+// channel: 0 mono ((L+R)/2), 1 left, 2 right, 3 stereo (rows 2f = left, 2f+1 = right)
+hipError_t launch_real_fold(const float2* spec, int n, int n_frames, int channel, float pscale, float* lin,
+                            hipStream_t s);
+hipError_t launch_lin_to_db(const float* lin, size_t count, float log_floor, float cal_db, float* out_db,
+                            hipStream_t s);
 
 // ---- 2^20-point four-step path (tdsa_big.hip) ----
 constexpr int kBigLog2N = 20;

@@ -519,7 +519,14 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     // ---- epilogue: |X|^2 -> dB -> hold ; bin k = t + kc*SG lands at k ^ N/2 (fftshift) -----------
     // this thread's 16 bins: q < 8: kc = q + 8h (register bitrev(q)), q >= 8: kc = q + 8 + 8h (bitrev(q))
     if (active) {
-      if (p.out_lin != nullptr) {
+      if (p.out_cplx != nullptr) {            // real-input path: hand the complex bins to the fold kernel
+        c32* crow = p.out_cplx + (long long)frame * N + t + 8 * h * SG;
+        static_for<0, 16>([&](auto ic) {
+          constexpr int q = decltype(ic)::value;
+          constexpr int kc = (q < 8 ? q : q + 8);             // + 8h folded into crow; natural order
+          crow[kc * SG] = v[bitrev(q, 4)];
+        });
+      } else if (p.out_lin != nullptr) {
         float* orow = p.out_lin + (long long)frame * N + t + 8 * h * SG;
         static_for<0, 16>([&](auto ic) {
           constexpr int q = decltype(ic)::value;

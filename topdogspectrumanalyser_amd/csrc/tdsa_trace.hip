@@ -307,6 +307,60 @@ hipError_t launch_trace_update(const TraceParams& p, hipStream_t s) {
   return hipGetLastError();
 }
 
+// Real-input (audio) path, datasources/audio_samples.py:121-132 of the reference.  The frame kernel
+// transformed z = left + i*right; the spectra of the two real channels are recovered from Z[k] and
+// conj(Z[N-k]), the selected channel's one-sided power (non-DC, non-Nyquist bins doubled) is written out.
+__global__ void __launch_bounds__(256) real_fold_kernel(const float2* __restrict__ spec, int n, int n_frames,
+                                                        int channel, float pscale, float* __restrict__ lin) {
+  const int nb = n / 2 + 1;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)n_frames * nb) return;
+  const int f = int(idx / nb), k = int(idx - (long long)f * nb);
+  const float2 zk = spec[(long long)f * n + k];
+  const float2 zn = spec[(long long)f * n + ((n - k) & (n - 1))];
+  // L = (Z[k] + conj(Z[N-k]))/2 ; R = (Z[k] - conj(Z[N-k]))/(2i)
+  const float2 L = float2{0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y)};
+  const float2 R = float2{0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x)};
+  const float dbl = (k == 0 || k == n / 2) ? 1.0f : 2.0f;   // power[1:-1] *= 2
+  const float pl = (L.x * L.x + L.y * L.y) * pscale * dbl;
+  const float pr = (R.x * R.x + R.y * R.y) * pscale * dbl;
+  if (channel == 3) {
+    lin[((long long)f * 2) * nb + k] = pl;
+    lin[((long long)f * 2 + 1) * nb + k] = pr;
+  } else if (channel == 1) {
+    lin[idx] = pl;
+  } else if (channel == 2) {
+    lin[idx] = pr;
+  } else {
+    const float2 M = float2{0.5f * (L.x + R.x), 0.5f * (L.y + R.y)};
+    lin[idx] = (M.x * M.x + M.y * M.y) * pscale * dbl;
+  }
+}
+
+hipError_t launch_real_fold(const float2* spec, int n, int n_frames, int channel, float pscale, float* lin,
+                            hipStream_t s) {
+  const long long total = (long long)n_frames * (n / 2 + 1);
+  hipLaunchKernelGGL(real_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, spec, n, n_frames,
+                     channel, pscale, lin);
+  return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) lin_to_db_kernel(const float* __restrict__ lin, size_t count, float log_floor,
+                                                        float cal_db, float* __restrict__ out_db) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (; i < count; i += stride) out_db[i] = fmaf(k10Log10_2f, __builtin_amdgcn_logf(lin[i] + log_floor), cal_db);
+}
+
+hipError_t launch_lin_to_db(const float* lin, size_t count, float log_floor, float cal_db, float* out_db,
+                            hipStream_t s) {
+  size_t blocks = (count + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(lin_to_db_kernel, dim3((unsigned)blocks), dim3(256), 0, s, lin, count, log_floor, cal_db, out_db);
+  return hipGetLastError();
+}
+
 __global__ void __launch_bounds__(256) fill_kernel(float* p, size_t n, float v) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * 256;

@@ -110,6 +110,25 @@ class SpectrumEngine:
         nat.check(fn(self._h, _ptr(iq), n_samples, hop, n_frames, _ptr(out)))
         return out
 
+    def process_real2(self, stereo: np.ndarray, channel: str = "mono", hop: Optional[int] = None,
+                      n_frames: Optional[int] = None) -> np.ndarray:
+        """Real-input path: stereo float32 samples [samples, 2] -> one-sided dB rows
+        [frames, N/2+1] (or [frames, 2, N/2+1] for channel="stereo")."""
+        x = np.ascontiguousarray(stereo, dtype=np.float32)
+        if x.ndim != 2 or x.shape[1] != 2:
+            raise ValueError("stereo samples must have shape [samples, 2]")
+        ch = {"mono": nat.CH_MONO, "left": nat.CH_LEFT, "right": nat.CH_RIGHT, "stereo": nat.CH_STEREO}[channel]
+        hop = self.nfft if hop is None else int(hop)
+        ns = x.shape[0]
+        if n_frames is None:
+            n_frames = 0 if ns < self.nfft else (ns - self.nfft) // hop + 1
+        nb = self.nfft // 2 + 1
+        shape = (n_frames, 2, nb) if ch == nat.CH_STEREO else (n_frames, nb)
+        out = np.empty(shape, dtype=np.float32)
+        if n_frames:
+            nat.check(nat.lib.tdsa_process_real2(self._h, _ptr(x), ns, hop, n_frames, ch, _ptr(out)))
+        return out
+
     def process_device(self, in_format: int, iq_dev: int, n_samples: int, hop: int, n_frames: int,
                        out_db_dev: Optional[int]) -> None:
         """Raw device pointers, asynchronous on the plan's stream (bench path)."""
