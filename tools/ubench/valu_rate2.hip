@@ -35,6 +35,13 @@ __global__ void __launch_bounds__(512, 2) bench(float* out, int iters, float see
     else if constexpr (OP == 19) { REP8(asm volatile(OPS8("v_add_u32", ", %8") : REGS : "v"(cv));) }
     else if constexpr (OP == 20) { REP8(asm volatile(OPS8("v_mul_legacy_f32", ", %8") : REGS : "v"(cv));) }
     else if constexpr (OP == 21) { REP8(asm volatile(OPS8("v_max3_f32", ", %8, %8") : REGS : "v"(cv));) }
+    else if constexpr (OP == 22) { REP8(asm volatile("v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7\n"
+                                                     "v_permlane32_swap_b32 %1, %2\n v_permlane32_swap_b32 %3, %4\n v_permlane32_swap_b32 %5, %6\n v_permlane32_swap_b32 %7, %0\n" : REGS);) }
+    else if constexpr (OP == 23) { REP8(asm volatile(OPS8("v_cndmask_b32_e64", ", %8, vcc") : REGS : "v"(cv) : "vcc");) }
+    else if constexpr (OP == 24) { REP8(asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cmp_lt_f32 vcc, %1, %8\n v_cmp_lt_f32 vcc, %2, %8\n v_cmp_lt_f32 vcc, %3, %8\n"
+                                                     "v_cmp_lt_f32 vcc, %4, %8\n v_cmp_lt_f32 vcc, %5, %8\n v_cmp_lt_f32 vcc, %6, %8\n v_cmp_lt_f32 vcc, %7, %8\n" : REGS : "v"(cv) : "vcc");) }
+    else if constexpr (OP == 25) { REP8(asm volatile(OPS8("v_add_u32_dpp", ", %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") : REGS : "v"(cv));) }
+    else if constexpr (OP == 26) { REP8(asm volatile(OPS8("v_cndmask_b32_e32", ", %8, vcc") : REGS : "v"(cv) : "vcc");) }
   }
   out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
 }
@@ -62,5 +69,6 @@ int main() {
   run<12>("v_dot4_u32_u8", d);  run<13>("v_fmamk_f32 literal", d); run<14>("v_max_i32", d);     run<15>("v_and_b32 lit", d);
   run<16>("v_bfe_u32", d);      run<17>("v_exp_f32", d);      run<18>("v_rcp_f32", d);          run<19>("v_add_u32", d);
   run<20>("v_mul_legacy_f32", d); run<21>("v_max3_f32", d);
+  run<22>("v_permlane32_swap_b32", d); run<23>("v_cndmask_b32_e64 (vcc)", d); run<26>("v_cndmask_b32_e32 (vcc)", d); run<24>("v_cmp_lt_f32 -> vcc", d); run<25>("v_add_u32_dpp quad_perm", d);
   return 0;
 }

@@ -142,7 +142,8 @@ constexpr float k10Log10_2 = 3.01029995663981195214f;   // 10*log10(2)
 constexpr float kMagExactBelow = 1e-8f;                  // |X|^2 below this: the 1e-12 floor is visible
 
 // developer ablation builds (-DTDSA_ABLATE=mask): 1 no barriers, 2 no LDS exchange, 4 no dB stores,
-// 8 no raw/window loads.  Results are wrong by construction; timing only.
+// 16 no middle-pass table reads, 32 no half-wave swaps, 64 no log, 128 no last pre-twiddle, 256 no
+// middle pre-twiddle, 512 no last radix-16.  Results are wrong by construction; timing only.
 #ifndef TDSA_ABLATE
 #define TDSA_ABLATE 0
 #endif
@@ -161,6 +162,17 @@ constexpr float kMagExactBelow = 1e-8f;                  // |X|^2 below this: th
 #else
 #define TDSA_STAMP(i)
 #endif
+
+// LDS data accesses go through volatile 64-bit vectors: that keeps the backend from pairing them into
+// ds_read2_b64 / ds_write2_b64, which the gfx950 LDS pipe serves at 0.3 TB/s/CU against 0.53 TB/s/CU for
+// plain ds_read_b64 (tools/ubench/lds_rate.hip), while leaving waitcnt bookkeeping to the compiler.
+typedef float lds_v2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) volatile lds_v2* lds_vptr;
+__device__ __forceinline__ c32 lds_ld(const c32* p) {
+  const lds_v2 x = *(lds_vptr)(p);
+  return c32{x.x, x.y};
+}
+__device__ __forceinline__ void lds_st(c32* p, c32 v) { *(lds_vptr)(p) = lds_v2{v.x, v.y}; }
 
 // exchange the upper half-wave of `a` with the lower half-wave of `b` (one v_permlane32_swap per dword):
 // afterwards a = [a.lo | b.lo], b = [a.hi | b.hi]
@@ -336,16 +348,25 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       TDSA_STAMP(2);
       if (p.dc_mode == DC_FRAME_MEAN) {
         const int w0 = slot * C::WPF;
-        int ti = 0, tq = 0;
-        if constexpr (C::WPF % 2 == 0) {
-          static_for<0, C::WPF / 2>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            const int4 q = *reinterpret_cast<const int4*>(&redi[(w0 + 2 * i) * 2]);
-            ti += q.x + q.z; tq += q.y + q.w;
-          });
-        } else {
-          const int2 q = *reinterpret_cast<const int2*>(&redi[w0 * 2]);
-          ti = q.x; tq = q.y;
+        // lane (l mod WPF) fetches one wave's partial (a single conflict-free ds_read_b64 per wave),
+        // the WPF partials are then summed inside the 16-lane row with DPP adds
+        const int2 q = *reinterpret_cast<const int2*>(&redi[(w0 + (tid & (C::WPF - 1))) * 2]);
+        int ti = q.x, tq = q.y;
+        if constexpr (C::WPF >= 2) {
+          ti += __builtin_amdgcn_update_dpp(0, ti, 0xB1, 0xf, 0xf, false);
+          tq += __builtin_amdgcn_update_dpp(0, tq, 0xB1, 0xf, 0xf, false);
+        }
+        if constexpr (C::WPF >= 4) {
+          ti += __builtin_amdgcn_update_dpp(0, ti, 0x4E, 0xf, 0xf, false);
+          tq += __builtin_amdgcn_update_dpp(0, tq, 0x4E, 0xf, 0xf, false);
+        }
+        if constexpr (C::WPF >= 8) {
+          ti += __builtin_amdgcn_update_dpp(0, ti, 0x141, 0xf, 0xf, false);
+          tq += __builtin_amdgcn_update_dpp(0, tq, 0x141, 0xf, 0xf, false);
+        }
+        if constexpr (C::WPF >= 16) {
+          ti += __builtin_amdgcn_update_dpp(0, ti, 0x140, 0xf, 0xf, false);
+          tq += __builtin_amdgcn_update_dpp(0, tq, 0x140, 0xf, 0xf, false);
         }
         sub_re = float(ti) * (1.0f / N);     // exact: sums < 2^24, N a power of two
         sub_im = float(tq) * (1.0f / N);
@@ -441,7 +462,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       if constexpr (A == 32) combine32<u>(v[re], v[ro], odd_half);
       else combine_const<k0, A>(v[re], v[ro]);               // (u + 8h) % H == u % H for H <= 8
       constexpr int li = jj0 * A + k0;                       // + lane offset folded into wr1_base
-      if constexpr ((TDSA_ABLATE & 2) == 0) { buf[wr1_base + li] = v[re]; buf[wr1_base + li + H] = v[ro]; }
+      if constexpr ((TDSA_ABLATE & 2) == 0) { lds_st(&buf[wr1_base + li], v[re]); lds_st(&buf[wr1_base + li + H], v[ro]); }
     });
     TDSA_STAMP(4);
     TDSA_SYNC();
@@ -452,7 +473,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     if constexpr (C::NPASS == 3) {
       static_for<0, 16>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        if constexpr ((TDSA_ABLATE & 2) == 0) v[i] = buf[rdA + i * 2 * rd_stride];
+        if constexpr ((TDSA_ABLATE & 2) == 0) v[i] = lds_ld(&buf[rdA + i * 2 * rd_stride]);
       });
       int tw_o = h * A + ka_mid;
       asm volatile("" : "+v"(tw_o));                        // keep the table reads inside the loop
@@ -468,7 +489,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, 8>([&](auto ic) {
           constexpr int i = b0 + decltype(ic)::value;
-          v[i] = cmul(v[i], tw8[i - b0]);
+          if constexpr ((TDSA_ABLATE & 256) == 0) v[i] = cmul(v[i], tw8[i - b0]);
         });
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -480,8 +501,8 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
         if constexpr ((TDSA_ABLATE & 32) == 0) swap_halves(v[re], v[ro]);
         combine32<u>(v[re], v[ro], odd_half);                // outputs kb = u + 8h and kb + 16
         if constexpr ((TDSA_ABLATE & 2) == 0) {
-          buf[wrM + u * rd_stride] = v[re];
-          buf[wrM + (u + 16) * rd_stride] = v[ro];
+          lds_st(&buf[wrM + u * rd_stride], v[re]);
+          lds_st(&buf[wrM + (u + 16) * rd_stride], v[ro]);
         }
       });
       TDSA_STAMP(7);
@@ -489,13 +510,13 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       TDSA_STAMP(8);
       static_for<0, 16>([&](auto ic) {                       // element c = 2i + h of row (kb, ka)
         constexpr int i = decltype(ic)::value;
-        if constexpr ((TDSA_ABLATE & 2) == 0) v[i] = buf[rd3A + 2 * i * A + ((2 * i * A) >> 5)];
+        if constexpr ((TDSA_ABLATE & 2) == 0) v[i] = lds_ld(&buf[rd3A + 2 * i * A + ((2 * i * A) >> 5)]);
       });
     } else {
       static_for<0, 16>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        if constexpr (SG % 32 == 0) v[i] = buf[rdA + i * 2 * rd_stride];
-        else { const int e = t + (2 * i + h) * SG; v[i] = buf[e + (e >> 5)]; }
+        if constexpr (SG % 32 == 0) v[i] = lds_ld(&buf[rdA + i * 2 * rd_stride]);
+        else { const int e = t + (2 * i + h) * SG; v[i] = lds_ld(&buf[e + (e >> 5)]); }
       });
     }
     TDSA_STAMP(9);
@@ -504,10 +525,11 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     static_for<0, 16>([&](auto ic) {                         // pre-twiddle W_N^(t*(2i+h)), i = 4a + j
       constexpr int i = decltype(ic)::value;
       constexpr int a = i >> 2, j = i & 3;
-      if constexpr (j == 0) v[i] = cmul(v[i], twf_hi[a]);
+      if constexpr ((TDSA_ABLATE & 128) != 0) { /* dev ablation: skip the last pre-twiddle */ }
+      else if constexpr (j == 0) v[i] = cmul(v[i], twf_hi[a]);
       else v[i] = cmul(v[i], cmul(twf_hi[a], twf_lo[j - 1]));
     });
-    dif<16, 0, 16>(v);
+    if constexpr ((TDSA_ABLATE & 512) == 0) dif<16, 0, 16>(v);
     static_for<0, 8>([&](auto uc) {
       constexpr int u = decltype(uc)::value;
       constexpr int re = bitrev(u, 4), ro = bitrev(u + 8, 4);
