@@ -48,6 +48,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--ring", type=int, default=8, help="distinct input/output buffers cycled through")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="HIP streams consecutive steps rotate over (tdsa_set_overlap); 1 = strictly serial")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -103,6 +105,11 @@ def main() -> None:
         eng.set_window(np.hanning(nfft).astype(np.float32))
         eng.configure(db_mode="pow", power_scale=1.0, log_floor=1e-10, dc_alpha=-1.0, hold_max=True)
 
+    # consecutive seconds are independent (per-frame DC removal, no averaging): let the head of step i+1
+    # fill the ragged tail of step i's persistent launch (9 or 10 frames per workgroup at C3)
+    streams = max(1, min(4, args.streams)) if wl["branch"] != "welch" else 1
+    eng.set_overlap(streams)
+
     def step(i: int) -> None:
         r = i % ring
         if wl["branch"] == "welch":
@@ -128,7 +135,9 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- dominant kernel alone: HIP events on the plan's stream around every frame-kernel launch --
+    # ---- dominant kernel alone: HIP events on the plan's stream around every frame-kernel launch,
+    #      launches strictly serial so that one kernel owns the GPU while it is timed ---------------
+    eng.set_overlap(1)
     eng.profile_enable(True)
     for i in range(args.steps):
         step(i)
@@ -150,6 +159,16 @@ def main() -> None:
         dist.all_gather(gathered, torch.from_numpy(mx).to(dev))
         mx = np.fmax.reduce([g.cpu().numpy() for g in gathered])
 
+    # HBM bytes per launch from the committed rocprofv3 PMC passes of this same kernel and shape
+    # (profiles/r01_c3_pmc.json; counters cannot be read from inside the process)
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(ROOT, "profiles", f"r01_{args.config}_pmc.json")
+    if os.path.exists(pmc_path):
+        with open(pmc_path) as fh:
+            pmc = json.load(fh)
+        traffic = pmc["fetch_bytes_upper"] + pmc["write_bytes"]
+        traffic_src = f"profiles/r01_{args.config}_pmc.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, per launch)"
+
     result = None
     if rank == 0:
         value = world * frames * args.steps / elapsed
@@ -169,9 +188,12 @@ def main() -> None:
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {wl['desc']}", "nfft": nfft, "hop": hop,
                        "frames_per_step_per_gpu": frames, "input": "int8 IQ resident in HBM",
-                       "input_ring": ring, "parallelism": f"frames sharded over {world} GPU(s), no collective"},
+                       "input_ring": ring, "streams_per_gpu": streams,
+                       "parallelism": f"frames sharded over {world} GPU(s), no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": algo_bytes,
                          "kernel": "spectrum_kernel" if launches else "four-step chain (whole step)",
                          "kernel_avg_us": kern_s * 1e6,
                          "algorithmic_bytes_per_frame": bytes_per_frame},

@@ -161,6 +161,18 @@ int tdsa_get_dc(tdsa_plan p, float* re, float* im);
 
 int tdsa_synchronize(tdsa_plan p);
 
+/* Let consecutive tdsa_process_dev calls overlap on up to n_streams (1..4) HIP streams owned by the plan.
+ * A persistent launch ends ragged (2440 frames over 256 CUs = 9 or 10 frames per workgroup); with more
+ * than one stream the next call's workgroups start on the CUs that finish first and the inter-kernel
+ * gap disappears (C3: +17 % frames/s with 3 streams).  Only calls whose results do not depend on
+ * execution order rotate over the extra streams: no averaging, dc_alpha < 0 or >= 1 (hold traces are
+ * merged with atomics and stay exact).  Every other entry point first orders the plan's main stream
+ * after the work in flight, so the API stays sequentially consistent; with overlap on, tdsa_get_dc
+ * reports the last frame of whichever call finished last.  n_streams = 1 (default) restores strictly
+ * serial execution.  No counterpart in the reference (its path is one frame per 20 ms timer tick,
+ * core/ui_setup.py:60-61); this is the batch front end of SURVEY.md 8(a) a2. */
+int tdsa_set_overlap(tdsa_plan p, int n_streams);
+
 /* ---- trace objects: DataProcessor / TraceAverager arithmetic on host-provided rows ------------- */
 /* A trace object owns the per-bin state the reference keeps in numpy arrays on MainWindow /
  * DisplayManager / TraceAverager for ONE displayed trace of n bins (any n >= 1, not tied to an FFT

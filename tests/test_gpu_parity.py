@@ -661,3 +661,60 @@ def test_real2_batch_matches_per_frame(pkg):
                 gold = so.audio_db(so.audio_compute_power(st[k * n:(k + 1) * n, ch].astype(np.float64),
                                                           np.hamming(n), n, 44100, False, precision="gold"), False)
                 _check(one[k], gold, f"real2 {name} {k}")
+
+
+# ------------------------------------------------------------------------------------------------
+# overlapped launches (tdsa_set_overlap): same bits as serial execution, state ops stay ordered
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("streams", [2, 3, 4])
+def test_overlapped_launches_match_serial(pkg, streams):
+    import ctypes as C
+    nat = pkg._native
+    nfft, hop, nf, calls = 4096, 2048, 300, 7
+    ns = hop * (nf - 1) + nfft
+    batches = [so.synth_iq_int8(ns, nfft, seed=100 + i) for i in range(calls)]
+    serial, smax = [], None
+    with _hackrf_engine(pkg, nfft, nf, hold_max=True, hold_min=True) as e:
+        for iq in batches:
+            serial.append(e.process(iq, hop=hop))
+        smax, smin = e.hold()
+
+    d_in, d_out = [], []
+    for iq in batches:
+        a, b = C.c_void_p(), C.c_void_p()
+        nat.check(nat.lib.tdsa_dev_alloc(0, iq.nbytes, C.byref(a)))
+        nat.check(nat.lib.tdsa_dev_alloc(0, nf * nfft * 4, C.byref(b)))
+        nat.check(nat.lib.tdsa_memcpy_h2d(0, a, iq.ctypes.data_as(C.c_void_p), iq.nbytes))
+        d_in.append(a)
+        d_out.append(b)
+    try:
+        with _hackrf_engine(pkg, nfft, nf, hold_max=True, hold_min=True) as e:
+            e.set_overlap(streams)
+            for rep in range(2):                      # second round exercises reset + re-dirtied state
+                for a, b in zip(d_in, d_out):
+                    e.process_device(nat.IN_I8, a.value, ns, hop, nf, b.value)
+                mx, mn = e.hold()                     # joins the auxiliary streams
+                assert np.array_equal(mx, smax) and np.array_equal(mn, smin)
+                for i, b in enumerate(d_out):
+                    got = np.empty((nf, nfft), dtype=np.float32)
+                    nat.check(nat.lib.tdsa_memcpy_d2h(0, got.ctypes.data_as(C.c_void_p), b, got.nbytes))
+                    assert np.array_equal(got, serial[i]), f"call {i} differs with {streams} streams"
+                e.reset()
+                assert e.hold() == (None, None)
+            # an order-dependent mode must fall back to the main stream and still be right
+            e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=1.0, avg=("exp", 4))
+            gold, _, _ = so.hackrf_batch(batches[0], nfft, hop, 20e6, precision="gold", avg=("exp", 4))
+            out = e.process(batches[0], hop=hop)
+            _check(out, gold, "exp averaging with overlap enabled")
+    finally:
+        for a, b in zip(d_in, d_out):
+            nat.lib.tdsa_dev_free(0, a)
+            nat.lib.tdsa_dev_free(0, b)
+
+
+def test_set_overlap_rejects_bad_counts(pkg):
+    with _hackrf_engine(pkg, 1024, 4) as e:
+        for bad in (0, -1, 5):
+            with pytest.raises(Exception):
+                e.set_overlap(bad)
+        e.set_overlap(1)

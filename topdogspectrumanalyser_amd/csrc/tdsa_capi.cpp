@@ -44,6 +44,14 @@ int ilog2i(int x) {
 struct tdsa_plan_s {
   int device = 0, nfft = 0, log2n = 0, max_frames = 0, num_cu = 256;
   hipStream_t stream = nullptr;
+  // tdsa_set_overlap: extra streams consecutive order-independent launches rotate over, so the ragged
+  // tail of one persistent launch (and the inter-kernel gap) is filled by the head of the next
+  static constexpr int kMaxOverlap = 4;
+  hipStream_t aux[kMaxOverlap - 1] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_aux[kMaxOverlap - 1] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_state = nullptr;
+  int n_overlap = 1, rr = 0;
+  bool aux_busy = false, state_dirty = true;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   tdsa_mode mode{};
   bool window_set = false;
@@ -91,6 +99,42 @@ int bytes_per_sample(int fmt) { return fmt == TDSA_IN_C64 ? 8 : 2; }
 
 bool avg_active(const tdsa_mode& m) { return m.avg_mode != TDSA_AVG_OFF && m.avg_n > 1; }
 
+// Order the plan's main stream after everything in flight on the auxiliary streams.  Every entry point
+// that touches plan state or enqueues on the main stream calls this first; work it enqueues afterwards
+// is in turn waited for by the next overlapped launch (state_dirty).
+int join_streams(tdsa_plan p) {
+  if (p->aux_busy) {
+    for (int i = 0; i < p->n_overlap - 1; ++i) {
+      HIPCHK(hipEventRecord(p->ev_aux[i], p->aux[i]));
+      HIPCHK(hipStreamWaitEvent(p->stream, p->ev_aux[i], 0));
+    }
+    p->aux_busy = false;
+  }
+  p->state_dirty = true;
+  return TDSA_OK;
+}
+#define JOIN(p)                                  \
+  do {                                           \
+    int rc_join_ = join_streams(p);              \
+    if (rc_join_ != TDSA_OK) return rc_join_;    \
+  } while (0)
+
+// stream for the next frame-kernel launch of an order-independent call
+int pick_stream(tdsa_plan p, hipStream_t* out) {
+  *out = p->stream;
+  if (p->n_overlap <= 1) return TDSA_OK;
+  const int k = p->rr++ % p->n_overlap;
+  if (k == 0) return TDSA_OK;
+  if (p->state_dirty) {   // state set up on the main stream (window, fills, tare ...) must be visible
+    HIPCHK(hipEventRecord(p->ev_state, p->stream));
+    for (int i = 0; i < p->n_overlap - 1; ++i) HIPCHK(hipStreamWaitEvent(p->aux[i], p->ev_state, 0));
+    p->state_dirty = false;
+  }
+  *out = p->aux[k - 1];
+  p->aux_busy = true;
+  return TDSA_OK;
+}
+
 int reset_hold(tdsa_plan p, bool mx, bool mn) {
   if (mx) {
     HIPCHK(launch_fill(p->d_hold_max, p->nfft, -INFINITY, p->stream));
@@ -103,9 +147,10 @@ int reset_hold(tdsa_plan p, bool mx, bool mn) {
   return TDSA_OK;
 }
 
-int launch_spectrum_profiled(tdsa_plan p, int in_c64, const SpecParams& sp, const LaunchGeom& g) {
+int launch_spectrum_profiled(tdsa_plan p, int in_c64, const SpecParams& sp, const LaunchGeom& g,
+                             hipStream_t s = nullptr) {
   if (!p->profiling) {
-    HIPCHK(launch_spectrum(p->log2n, in_c64, sp, g, p->stream));
+    HIPCHK(launch_spectrum(p->log2n, in_c64, sp, g, s ? s : p->stream));
     return TDSA_OK;
   }
   if (p->prof_used + 2 > p->prof_events.size()) {
@@ -207,6 +252,7 @@ int tdsa_create(int device_id, int nfft, int max_frames, tdsa_plan* out) {
   HIPCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreate(&p->ev0));
   HIPCHK(hipEventCreate(&p->ev1));
+  HIPCHK(hipEventCreateWithFlags(&p->ev_state, hipEventDisableTiming));
   const size_t nb = size_t(nfft) * sizeof(float);
   for (int f = 0; f < 3; ++f) HIPCHK(hipMalloc(&p->d_window[f], nb));
   HIPCHK(hipMalloc(&p->d_tw, size_t(nfft) * sizeof(float2)));
@@ -261,6 +307,8 @@ int tdsa_create(int device_id, int nfft, int max_frames, tdsa_plan* out) {
 int tdsa_destroy(tdsa_plan p) {
   if (!p) return TDSA_OK;
   (void)hipSetDevice(p->device);
+  for (hipStream_t a : p->aux)
+    if (a) (void)hipStreamSynchronize(a);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   void* bufs[] = {p->d_window[0], p->d_window[1], p->d_window[2], p->d_tw, p->d_hold_max, p->d_hold_min,
                   p->d_avg, p->d_lin, p->d_carry, p->d_cplx, p->d_lin1, p->d_db1, p->d_dc_state, p->d_sums, p->d_dc_sub,
@@ -271,6 +319,11 @@ int tdsa_destroy(tdsa_plan p) {
   for (hipEvent_t e : p->prof_events) (void)hipEventDestroy(e);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
   if (p->ev1) (void)hipEventDestroy(p->ev1);
+  if (p->ev_state) (void)hipEventDestroy(p->ev_state);
+  for (hipEvent_t e : p->ev_aux)
+    if (e) (void)hipEventDestroy(e);
+  for (hipStream_t a : p->aux)
+    if (a) (void)hipStreamDestroy(a);
   if (p->stream) (void)hipStreamDestroy(p->stream);
   delete p;
   return TDSA_OK;
@@ -299,6 +352,7 @@ int tdsa_set_window(tdsa_plan p, const float* w_host, int n) {
   if (!p || !w_host) return fail(TDSA_ERR_ARG, "null argument");
   if (n != p->nfft) return fail(TDSA_ERR_ARG, "window length %d != nfft %d", n, p->nfft);
   HIPCHK(hipSetDevice(p->device));
+  JOIN(p);
   const float scale[3] = {1.0f / 128.0f, 1.0f / 127.5f, 1.0f};
   std::vector<float> tmp(n);
   HIPCHK(hipStreamSynchronize(p->stream));
@@ -329,9 +383,27 @@ int tdsa_set_mode(tdsa_plan p, const tdsa_mode* m) {
   return TDSA_OK;
 }
 
+int tdsa_set_overlap(tdsa_plan p, int n_streams) {
+  if (!p) return fail(TDSA_ERR_ARG, "null plan");
+  if (n_streams < 1 || n_streams > tdsa_plan_s::kMaxOverlap)
+    return fail(TDSA_ERR_ARG, "n_streams=%d outside [1, %d]", n_streams, tdsa_plan_s::kMaxOverlap);
+  HIPCHK(hipSetDevice(p->device));
+  JOIN(p);
+  for (int i = 0; i < n_streams - 1; ++i) {
+    if (!p->aux[i]) {
+      HIPCHK(hipStreamCreateWithFlags(&p->aux[i], hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&p->ev_aux[i], hipEventDisableTiming));
+    }
+  }
+  p->n_overlap = n_streams;
+  p->rr = 0;
+  return TDSA_OK;
+}
+
 int tdsa_reset_state(tdsa_plan p, uint32_t what) {
   if (!p) return fail(TDSA_ERR_ARG, "null plan");
   HIPCHK(hipSetDevice(p->device));
+  JOIN(p);
   if (what & TDSA_RESET_AVG) p->avg_count = 0;
   int rc = reset_hold(p, (what & TDSA_RESET_HOLD_MAX) != 0, (what & TDSA_RESET_HOLD_MIN) != 0);
   if (rc != TDSA_OK) return rc;
@@ -352,6 +424,7 @@ int tdsa_set_tare_baseline(tdsa_plan p, const float* baseline_db_host, int n) {
   }
   if (n != p->nfft) return fail(TDSA_ERR_ARG, "baseline length %d != nfft %d", n, p->nfft);
   HIPCHK(hipSetDevice(p->device));
+  JOIN(p);
   HIPCHK(hipStreamSynchronize(p->stream));
   HIPCHK(hipMemcpy(p->d_tare_base, baseline_db_host, size_t(n) * sizeof(float), hipMemcpyHostToDevice));
   p->tare_active = true;
@@ -375,10 +448,16 @@ int tdsa_process_dev(tdsa_plan p, int in_format, const void* iq_dev, size_t n_sa
   if ((reinterpret_cast<uintptr_t>(iq_dev) % (bps == 8 ? 8 : 2)) != 0)
     return fail(TDSA_ERR_ARG, "iq pointer must be aligned to one sample (%d bytes)", bps);
   HIPCHK(hipSetDevice(p->device));
-  if (p->big) return process_big(p, in_format, iq_dev, hop, n_frames, out_db_dev);
+  if (p->big) {
+    JOIN(p);
+    return process_big(p, in_format, iq_dev, hop, n_frames, out_db_dev);
+  }
 
   const tdsa_mode& m = p->mode;
   const bool averaging = avg_active(m);
+  // calls whose result does not depend on the order they execute in may overlap (tdsa_set_overlap)
+  const bool order_free = !averaging && (m.dc_alpha < 0.0f || m.dc_alpha >= 1.0f) && !p->profiling;
+  if (!order_free) JOIN(p);
   const bool hold = (m.hold_flags & 3u) != 0;
   const int in_c64 = in_format == TDSA_IN_C64;
 
@@ -450,7 +529,12 @@ int tdsa_process_dev(tdsa_plan p, int in_format, const void* iq_dev, size_t n_sa
       sp.part_max = p->d_hold_max;
       sp.part_min = p->d_hold_min;
     }
-    int rc_p = launch_spectrum_profiled(p, in_c64, sp, g);
+    hipStream_t s = p->stream;
+    if (order_free) {
+      int rc_s = pick_stream(p, &s);
+      if (rc_s != TDSA_OK) return rc_s;
+    }
+    int rc_p = launch_spectrum_profiled(p, in_c64, sp, g, s);
     if (rc_p != TDSA_OK) return rc_p;
   }
   if (m.hold_flags & TDSA_HOLD_MAX) p->held_max += n_frames;
@@ -472,6 +556,7 @@ static int process_host(tdsa_plan p, int fmt, const void* iq_host, size_t n_samp
     return fail(TDSA_ERR_ARG, "n_samples=%zu too small for %d frames of %d at hop %d", n_samples, n_frames,
                 p->nfft, hop);
   HIPCHK(hipSetDevice(p->device));
+  JOIN(p);
   const size_t in_bytes = need * bytes_per_sample(fmt);
   if (in_bytes > p->in_stage_bytes) {
     HIPCHK(hipStreamSynchronize(p->stream));
@@ -522,6 +607,7 @@ int tdsa_process_real2(tdsa_plan p, const float* lr_host, size_t n_samples, int 
   const tdsa_mode& m = p->mode;
   if (m.db_mode != TDSA_DB_POW) return fail(TDSA_ERR_ARG, "real-input path computes power dB: set TDSA_DB_POW");
   HIPCHK(hipSetDevice(p->device));
+  JOIN(p);
   const int n = p->nfft, nb = n / 2 + 1;
   const size_t in_bytes = need * sizeof(float2);
   if (in_bytes > p->in_stage_bytes) {
@@ -584,6 +670,7 @@ int tdsa_process_real2(tdsa_plan p, const float* lr_host, size_t n_samples, int 
 int tdsa_get_hold(tdsa_plan p, float* max_host, float* min_host, int64_t* frames_held) {
   if (!p) return fail(TDSA_ERR_ARG, "null plan");
   HIPCHK(hipSetDevice(p->device));
+  JOIN(p);
   HIPCHK(hipStreamSynchronize(p->stream));
   const size_t nb = size_t(p->nfft) * sizeof(float);
   if (max_host && p->held_max > 0) HIPCHK(hipMemcpy(max_host, p->d_hold_max, nb, hipMemcpyDeviceToHost));
@@ -595,6 +682,7 @@ int tdsa_get_hold(tdsa_plan p, float* max_host, float* min_host, int64_t* frames
 int tdsa_get_avg(tdsa_plan p, double* avg_linear_host, int* count) {
   if (!p) return fail(TDSA_ERR_ARG, "null plan");
   HIPCHK(hipSetDevice(p->device));
+  JOIN(p);
   HIPCHK(hipStreamSynchronize(p->stream));
   if (avg_linear_host && p->avg_count > 0)
     HIPCHK(hipMemcpy(avg_linear_host, p->d_avg, size_t(p->nfft) * sizeof(double), hipMemcpyDeviceToHost));
@@ -605,6 +693,7 @@ int tdsa_get_avg(tdsa_plan p, double* avg_linear_host, int* count) {
 int tdsa_get_dc(tdsa_plan p, float* re, float* im) {
   if (!p) return fail(TDSA_ERR_ARG, "null plan");
   HIPCHK(hipSetDevice(p->device));
+  JOIN(p);
   HIPCHK(hipStreamSynchronize(p->stream));
   float2 dc;
   HIPCHK(hipMemcpy(&dc, p->d_dc_state, sizeof(dc), hipMemcpyDeviceToHost));
@@ -616,6 +705,7 @@ int tdsa_get_dc(tdsa_plan p, float* re, float* im) {
 int tdsa_synchronize(tdsa_plan p) {
   if (!p) return fail(TDSA_ERR_ARG, "null plan");
   HIPCHK(hipSetDevice(p->device));
+  JOIN(p);
   HIPCHK(hipStreamSynchronize(p->stream));
   return TDSA_OK;
 }
@@ -813,6 +903,7 @@ int tdsa_memcpy_d2h(int device_id, void* dst_host, const void* src_dev, size_t b
 int tdsa_debug_timeline(tdsa_plan p, unsigned long long* host_out_1024) {
   if (!p) return fail(TDSA_ERR_ARG, "null plan");
   HIPCHK(hipSetDevice(p->device));
+  JOIN(p);
   if (!p->d_dbg) {
     HIPCHK(hipMalloc(&p->d_dbg, 2048 * sizeof(unsigned long long)));
     HIPCHK(hipMemset(p->d_dbg, 0, 2048 * sizeof(unsigned long long)));
@@ -833,6 +924,7 @@ int tdsa_profile_enable(tdsa_plan p, int enable) {
 int tdsa_profile_read(tdsa_plan p, int* launches, float* total_ms) {
   if (!p) return fail(TDSA_ERR_ARG, "null plan");
   HIPCHK(hipSetDevice(p->device));
+  JOIN(p);
   HIPCHK(hipStreamSynchronize(p->stream));
   float total = 0.f;
   for (size_t i = 0; i + 1 < p->prof_used; i += 2) {
@@ -849,12 +941,14 @@ int tdsa_profile_read(tdsa_plan p, int* launches, float* total_ms) {
 int tdsa_timer_begin(tdsa_plan p) {
   if (!p) return fail(TDSA_ERR_ARG, "null plan");
   HIPCHK(hipSetDevice(p->device));
+  JOIN(p);
   HIPCHK(hipEventRecord(p->ev0, p->stream));
   return TDSA_OK;
 }
 int tdsa_timer_end(tdsa_plan p, float* elapsed_ms) {
   if (!p) return fail(TDSA_ERR_ARG, "null plan");
   HIPCHK(hipSetDevice(p->device));
+  JOIN(p);
   HIPCHK(hipEventRecord(p->ev1, p->stream));
   HIPCHK(hipEventSynchronize(p->ev1));
   float ms = 0.f;

@@ -138,6 +138,11 @@ class SpectrumEngine:
     def synchronize(self) -> None:
         nat.check(nat.lib.tdsa_synchronize(self._h))
 
+    def set_overlap(self, n_streams: int) -> None:
+        """Let consecutive order-independent process_device() calls overlap on n_streams HIP streams
+        (tdsa_set_overlap); 1 = strictly serial (default)."""
+        nat.check(nat.lib.tdsa_set_overlap(self._h, int(n_streams)))
+
     # ------------------------------------------------------------------ state read-back
     def hold(self) -> Tuple[Optional[np.ndarray], Optional[np.ndarray]]:
         info = self.info()
