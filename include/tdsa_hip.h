@@ -174,6 +174,23 @@ int tdsa_synchronize(tdsa_plan p);
 int tdsa_set_overlap(tdsa_plan p, int n_streams);
 
 /* ---- trace objects: DataProcessor / TraceAverager arithmetic on host-provided rows ------------- */
+/* -------- host pipeline: pinned ring + asynchronous copy / compute / read-back legs -------------
+ * Batch counterpart of the reader-thread -> queue.Queue(4) -> get_power_levels() front end
+ * (datasources/hackrf_samples.py:54,102-107,191-305).  The producer writes IQ
+ * straight into a pinned slot (tdsa_pipe_acquire), tdsa_pipe_submit enqueues H2D -> frame kernel ->
+ * D2H on three streams and returns at once, tdsa_pipe_collect waits for the OLDEST submitted slot and
+ * hands back its dB rows (pinned, valid until that slot is acquired again).  Slots complete in
+ * submission order; plan state (hold traces, averager, DC tracker) advances exactly as if
+ * tdsa_process_i8 had been called per slot.  want_rows = 0 keeps only the plan state (hold / Welch
+ * traces) and skips the read-back leg.  One thread drives a pipe; destroy it before its plan. */
+typedef struct tdsa_pipe_s* tdsa_pipe;
+int tdsa_pipe_create(tdsa_plan p, int in_format, size_t slot_samples, int n_slots, int want_rows, tdsa_pipe* out);
+int tdsa_pipe_destroy(tdsa_pipe q);
+int tdsa_pipe_acquire(tdsa_pipe q, void** host_slot);
+int tdsa_pipe_submit(tdsa_pipe q, size_t n_samples, int hop, int n_frames);
+int tdsa_pipe_collect(tdsa_pipe q, const float** rows_host, int* n_frames);
+int tdsa_pipe_pending(tdsa_pipe q, int* pending);
+
 /* A trace object owns the per-bin state the reference keeps in numpy arrays on MainWindow /
  * DisplayManager / TraceAverager for ONE displayed trace of n bins (any n >= 1, not tied to an FFT
  * plan): hold traces (mw.max_power_levels / mw.min_power_levels, main.py:70-105), the tare

@@ -718,3 +718,103 @@ def test_set_overlap_rejects_bad_counts(pkg):
             with pytest.raises(Exception):
                 e.set_overlap(bad)
         e.set_overlap(1)
+
+
+# ------------------------------------------------------------------------------------------------
+# host pipeline (tdsa_pipe_*): pinned ring, async H2D / kernel / D2H; same results as tdsa_process_i8
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,streams", [(True, 1), (True, 3), (False, 2)])
+def test_host_pipe_matches_synchronous_calls(pkg, rows, streams):
+    nfft, hop, nf, chunks = 2048, 1024, 97, 9
+    ns = hop * (nf - 1) + nfft
+    batches = [so.synth_iq_int8(ns, nfft, seed=500 + i) for i in range(chunks)]
+    with _hackrf_engine(pkg, nfft, nf, hold_max=True) as e:
+        ref = [e.process(iq, hop=hop) for iq in batches]
+        ref_max, _ = e.hold()
+    with _hackrf_engine(pkg, nfft, nf, hold_max=True) as e:
+        e.set_overlap(streams)
+        with e.pipe(ns, n_slots=3, rows=rows) as q:
+            got, sub = [], 0
+            for iq in batches:
+                if q.pending == 3:                                   # ring full: drain the oldest first
+                    r = q.collect()
+                    got.append(None if r is None else r.copy())
+                slot = q.acquire()
+                assert slot.dtype == np.int8 and slot.size == 2 * ns
+                slot[: iq.size] = iq
+                q.submit(ns, hop, nf)
+                sub += 1
+            while q.pending:
+                r = q.collect()
+                got.append(None if r is None else r.copy())
+            assert len(got) == chunks
+            if rows:
+                for i, (g, r) in enumerate(zip(got, ref)):
+                    assert g.shape == r.shape and np.array_equal(g, r), f"chunk {i}"
+            else:
+                assert all(g is None for g in got)
+            mx, _ = e.hold()
+            assert np.array_equal(mx, ref_max)
+
+
+def test_host_pipe_state_modes_and_errors(pkg):
+    nfft, hop, nf = 1024, 1024, 16
+    ns = nfft * nf
+    iqs = [so.synth_iq_int8(ns, nfft, seed=700 + i) for i in range(4)]
+    gold, _, _ = so.hackrf_batch(np.concatenate(iqs), nfft, hop, 20e6, precision="gold", avg=("exp", 6))
+    with pkg.SpectrumEngine(nfft, max_frames=nf) as e:
+        e.set_window(so.hackrf_window(nfft))
+        e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=1.0, avg=("exp", 6))
+        with e.pipe(ns, n_slots=2) as q:
+            with pytest.raises(Exception):
+                q.collect()                                   # nothing submitted
+            with pytest.raises(Exception):
+                q.submit(ns, hop, nf)                         # nothing acquired
+            out = []
+            for iq in iqs:                                    # order-dependent mode: slots stay in order
+                if q.pending == 2:
+                    out.append(q.collect().copy())
+                q.acquire()[: iq.size] = iq
+                q.submit(ns, hop, nf)
+            with pytest.raises(Exception):
+                q.acquire()                                   # ring full: both slots in flight
+            out.append(q.collect().copy())
+            q.acquire()
+            with pytest.raises(Exception):
+                q.acquire()                                   # slot already handed out
+            with pytest.raises(Exception):
+                q.submit(ns + 1, hop, nf)                     # larger than the slot
+            q.submit(ns, hop, nf)                             # (the slot still holds iqs[2])
+            while q.pending:
+                out.append(q.collect().copy())
+        assert len(out) == 5
+        _check(np.concatenate(out[:4]), gold, "exp averaging through the pipe")
+    with pkg.SpectrumEngine(nfft, max_frames=nf) as e:
+        with pytest.raises(Exception):
+            e.pipe(nfft - 1)                                  # slot smaller than one frame
+        with pytest.raises(Exception):
+            e.pipe(ns, n_slots=0)
+
+
+def test_stream_spectra_helper(pkg):
+    from topdogspectrumanalyser_amd.utils.streaming import stream_spectra
+    nfft, hop = 4096, 2048
+    sizes = [40000, 40000, 17000, 4096, 39999]
+    chunks = [so.synth_iq_int8(s, nfft, seed=900 + i) for i, s in enumerate(sizes)]
+    nf_max = (sizes[0] - nfft) // hop + 1
+    with _hackrf_engine(pkg, nfft, nf_max, hold_max=True) as e:
+        ref = [e.process(c, hop=hop) for c in chunks]
+        ref_max, _ = e.hold()
+    with _hackrf_engine(pkg, nfft, nf_max, hold_max=True) as e:
+        got = list(stream_spectra(e, chunks, hop=hop))
+        mx, _ = e.hold()
+    assert len(got) == len(ref)
+    for g, r in zip(got, ref):
+        assert g.shape == r.shape and np.array_equal(g, r)
+    assert np.array_equal(mx, ref_max)
+    with _hackrf_engine(pkg, nfft, nf_max) as e:
+        assert list(stream_spectra(e, [])) == []
+        with pytest.raises(ValueError):
+            list(stream_spectra(e, [np.zeros(2 * 100, dtype=np.int8)]))
+        with pytest.raises(ValueError):
+            list(stream_spectra(e, [chunks[2], chunks[0]], hop=hop))       # later chunk larger than the slot

@@ -431,8 +431,9 @@ int tdsa_set_tare_baseline(tdsa_plan p, const float* baseline_db_host, int n) {
   return TDSA_OK;
 }
 
-int tdsa_process_dev(tdsa_plan p, int in_format, const void* iq_dev, size_t n_samples, int hop, int n_frames,
-                     float* out_db_dev) {
+// before / after: optional events the device work waits for / signals (tdsa_pipe: H2D and D2H legs)
+static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size_t n_samples, int hop, int n_frames,
+                            float* out_db_dev, hipEvent_t before, hipEvent_t after) {
   if (!p) return fail(TDSA_ERR_ARG, "null plan");
   if (in_format < TDSA_IN_I8 || in_format > TDSA_IN_C64) return fail(TDSA_ERR_ARG, "in_format %d", in_format);
   if (n_frames == 0) return TDSA_OK;
@@ -450,14 +451,24 @@ int tdsa_process_dev(tdsa_plan p, int in_format, const void* iq_dev, size_t n_sa
   HIPCHK(hipSetDevice(p->device));
   if (p->big) {
     JOIN(p);
-    return process_big(p, in_format, iq_dev, hop, n_frames, out_db_dev);
+    if (before) HIPCHK(hipStreamWaitEvent(p->stream, before, 0));
+    const int rc_big = process_big(p, in_format, iq_dev, hop, n_frames, out_db_dev);
+    if (rc_big == TDSA_OK && after) HIPCHK(hipEventRecord(after, p->stream));
+    return rc_big;
   }
 
   const tdsa_mode& m = p->mode;
   const bool averaging = avg_active(m);
   // calls whose result does not depend on the order they execute in may overlap (tdsa_set_overlap)
   const bool order_free = !averaging && (m.dc_alpha < 0.0f || m.dc_alpha >= 1.0f) && !p->profiling;
-  if (!order_free) JOIN(p);
+  hipStream_t s = p->stream;
+  if (order_free) {
+    int rc_s = pick_stream(p, &s);
+    if (rc_s != TDSA_OK) return rc_s;
+  } else {
+    JOIN(p);
+  }
+  if (before) HIPCHK(hipStreamWaitEvent(s, before, 0));
   const bool hold = (m.hold_flags & 3u) != 0;
   const int in_c64 = in_format == TDSA_IN_C64;
 
@@ -529,18 +540,19 @@ int tdsa_process_dev(tdsa_plan p, int in_format, const void* iq_dev, size_t n_sa
       sp.part_max = p->d_hold_max;
       sp.part_min = p->d_hold_min;
     }
-    hipStream_t s = p->stream;
-    if (order_free) {
-      int rc_s = pick_stream(p, &s);
-      if (rc_s != TDSA_OK) return rc_s;
-    }
     int rc_p = launch_spectrum_profiled(p, in_c64, sp, g, s);
     if (rc_p != TDSA_OK) return rc_p;
   }
+  if (after) HIPCHK(hipEventRecord(after, s));
   if (m.hold_flags & TDSA_HOLD_MAX) p->held_max += n_frames;
   if (m.hold_flags & TDSA_HOLD_MIN) p->held_min += n_frames;
   p->frames_seen += n_frames;
   return TDSA_OK;
+}
+
+int tdsa_process_dev(tdsa_plan p, int in_format, const void* iq_dev, size_t n_samples, int hop, int n_frames,
+                     float* out_db_dev) {
+  return process_dev_impl(p, in_format, iq_dev, n_samples, hop, n_frames, out_db_dev, nullptr, nullptr);
 }
 
 static int process_host(tdsa_plan p, int fmt, const void* iq_host, size_t n_samples, int hop, int n_frames,
@@ -958,3 +970,151 @@ int tdsa_timer_end(tdsa_plan p, float* elapsed_ms) {
 }
 
 }  // extern "C"
+
+// ================================================================================================
+// tdsa_pipe: pinned host ring + asynchronous H2D / frame kernel / D2H legs on separate streams.
+// Counterpart of the reader-thread -> queue.Queue(4) -> get_power_levels() front end of
+// HackrfSamplesDataSource (datasources/hackrf_samples.py:191-305) for batch users: the producer writes
+// IQ bytes straight into a pinned slot, the copy of slot k+1 and the read-back of slot k-1 overlap
+// the frame kernel of slot k.
+// ================================================================================================
+struct tdsa_pipe_s {
+  tdsa_plan plan = nullptr;
+  int fmt = TDSA_IN_I8;
+  size_t slot_samples = 0;
+  bool rows = false;
+  struct Slot {
+    void* h_in = nullptr;
+    void* d_in = nullptr;
+    float* h_out = nullptr;
+    float* d_out = nullptr;
+    hipEvent_t ev_h2d = nullptr, ev_done = nullptr, ev_d2h = nullptr;
+    int n_frames = 0;
+    bool acquired = false, in_flight = false;
+  };
+  std::vector<Slot> slots;
+  hipStream_t s_in = nullptr, s_out = nullptr;
+  size_t head = 0, tail = 0;   // next slot to acquire / to collect
+  int pending = 0;
+};
+
+int tdsa_pipe_create(tdsa_plan p, int in_format, size_t slot_samples, int n_slots, int want_rows, tdsa_pipe* out) {
+  if (!p || !out) return fail(TDSA_ERR_ARG, "null argument");
+  if (in_format < TDSA_IN_I8 || in_format > TDSA_IN_C64) return fail(TDSA_ERR_ARG, "in_format %d", in_format);
+  if (n_slots < 1 || n_slots > 16) return fail(TDSA_ERR_ARG, "n_slots=%d outside [1, 16]", n_slots);
+  if (slot_samples < size_t(p->nfft)) return fail(TDSA_ERR_ARG, "slot_samples=%zu < nfft", slot_samples);
+  HIPCHK(hipSetDevice(p->device));
+  tdsa_pipe q = new (std::nothrow) tdsa_pipe_s();
+  if (!q) return fail(TDSA_ERR_NOMEM, "out of host memory");
+  q->plan = p;
+  q->fmt = in_format;
+  q->slot_samples = slot_samples;
+  q->rows = want_rows != 0;
+  q->slots.resize(size_t(n_slots));
+  const size_t in_bytes = slot_samples * size_t(bytes_per_sample(in_format));
+  const size_t out_rows = p->big ? 1 : size_t(p->max_frames);
+  const size_t out_bytes = out_rows * size_t(p->nfft) * sizeof(float);
+  auto bail = [&](hipError_t e, const char* what) {
+    (void)tdsa_pipe_destroy(q);
+    return fail(TDSA_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+  };
+  hipError_t e;
+  if ((e = hipStreamCreateWithFlags(&q->s_in, hipStreamNonBlocking)) != hipSuccess) return bail(e, "stream");
+  if ((e = hipStreamCreateWithFlags(&q->s_out, hipStreamNonBlocking)) != hipSuccess) return bail(e, "stream");
+  for (auto& sl : q->slots) {
+    if ((e = hipHostMalloc(&sl.h_in, in_bytes, hipHostMallocDefault)) != hipSuccess) return bail(e, "pinned input slot");
+    if ((e = hipMalloc(&sl.d_in, in_bytes)) != hipSuccess) return bail(e, "device input slot");
+    if (q->rows) {
+      if ((e = hipHostMalloc(reinterpret_cast<void**>(&sl.h_out), out_bytes, hipHostMallocDefault)) != hipSuccess)
+        return bail(e, "pinned output slot");
+      if ((e = hipMalloc(reinterpret_cast<void**>(&sl.d_out), out_bytes)) != hipSuccess) return bail(e, "device output slot");
+    }
+    if ((e = hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming)) != hipSuccess) return bail(e, "event");
+    if ((e = hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming)) != hipSuccess) return bail(e, "event");
+    if ((e = hipEventCreateWithFlags(&sl.ev_d2h, hipEventDisableTiming)) != hipSuccess) return bail(e, "event");
+  }
+  *out = q;
+  return TDSA_OK;
+}
+
+int tdsa_pipe_destroy(tdsa_pipe q) {
+  if (!q) return TDSA_OK;
+  if (q->plan) (void)hipSetDevice(q->plan->device);
+  if (q->s_in) (void)hipStreamSynchronize(q->s_in);
+  if (q->plan) (void)tdsa_synchronize(q->plan);
+  if (q->s_out) (void)hipStreamSynchronize(q->s_out);
+  for (auto& sl : q->slots) {
+    if (sl.h_in) (void)hipHostFree(sl.h_in);
+    if (sl.d_in) (void)hipFree(sl.d_in);
+    if (sl.h_out) (void)hipHostFree(sl.h_out);
+    if (sl.d_out) (void)hipFree(sl.d_out);
+    if (sl.ev_h2d) (void)hipEventDestroy(sl.ev_h2d);
+    if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+    if (sl.ev_d2h) (void)hipEventDestroy(sl.ev_d2h);
+  }
+  if (q->s_in) (void)hipStreamDestroy(q->s_in);
+  if (q->s_out) (void)hipStreamDestroy(q->s_out);
+  delete q;
+  return TDSA_OK;
+}
+
+int tdsa_pipe_acquire(tdsa_pipe q, void** host_slot) {
+  if (!q || !host_slot) return fail(TDSA_ERR_ARG, "null argument");
+  auto& sl = q->slots[q->head % q->slots.size()];
+  if (sl.acquired) return fail(TDSA_ERR_STATE, "slot already acquired: submit it first");
+  if (sl.in_flight) return fail(TDSA_ERR_STATE, "all %zu slots in flight: collect one first", q->slots.size());
+  sl.acquired = true;
+  *host_slot = sl.h_in;
+  return TDSA_OK;
+}
+
+int tdsa_pipe_submit(tdsa_pipe q, size_t n_samples, int hop, int n_frames) {
+  if (!q) return fail(TDSA_ERR_ARG, "null pipe");
+  auto& sl = q->slots[q->head % q->slots.size()];
+  if (!sl.acquired) return fail(TDSA_ERR_STATE, "no acquired slot");
+  if (n_samples > q->slot_samples) return fail(TDSA_ERR_ARG, "n_samples=%zu exceeds the slot (%zu)", n_samples, q->slot_samples);
+  if (n_frames < 1) return fail(TDSA_ERR_ARG, "n_frames=%d", n_frames);
+  tdsa_plan p = q->plan;
+  HIPCHK(hipSetDevice(p->device));
+  const size_t in_bytes = n_samples * size_t(bytes_per_sample(q->fmt));
+  HIPCHK(hipMemcpyAsync(sl.d_in, sl.h_in, in_bytes, hipMemcpyHostToDevice, q->s_in));
+  HIPCHK(hipEventRecord(sl.ev_h2d, q->s_in));
+  const int rc = process_dev_impl(p, q->fmt, sl.d_in, n_samples, hop, n_frames, q->rows ? sl.d_out : nullptr,
+                                  sl.ev_h2d, sl.ev_done);
+  if (rc != TDSA_OK) {
+    sl.acquired = false;
+    return rc;
+  }
+  sl.n_frames = p->big ? 1 : n_frames;
+  if (q->rows) {
+    HIPCHK(hipStreamWaitEvent(q->s_out, sl.ev_done, 0));
+    HIPCHK(hipMemcpyAsync(sl.h_out, sl.d_out, size_t(sl.n_frames) * p->nfft * sizeof(float), hipMemcpyDeviceToHost,
+                          q->s_out));
+    HIPCHK(hipEventRecord(sl.ev_d2h, q->s_out));
+  }
+  sl.acquired = false;
+  sl.in_flight = true;
+  ++q->head;
+  ++q->pending;
+  return TDSA_OK;
+}
+
+int tdsa_pipe_collect(tdsa_pipe q, const float** rows_host, int* n_frames) {
+  if (!q) return fail(TDSA_ERR_ARG, "null pipe");
+  if (q->pending == 0) return fail(TDSA_ERR_STATE, "nothing submitted");
+  auto& sl = q->slots[q->tail % q->slots.size()];
+  HIPCHK(hipSetDevice(q->plan->device));
+  HIPCHK(hipEventSynchronize(q->rows ? sl.ev_d2h : sl.ev_done));
+  sl.in_flight = false;
+  if (rows_host) *rows_host = q->rows ? sl.h_out : nullptr;
+  if (n_frames) *n_frames = sl.n_frames;
+  ++q->tail;
+  --q->pending;
+  return TDSA_OK;
+}
+
+int tdsa_pipe_pending(tdsa_pipe q, int* pending) {
+  if (!q || !pending) return fail(TDSA_ERR_ARG, "null argument");
+  *pending = q->pending;
+  return TDSA_OK;
+}

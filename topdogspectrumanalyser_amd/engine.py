@@ -138,6 +138,10 @@ class SpectrumEngine:
     def synchronize(self) -> None:
         nat.check(nat.lib.tdsa_synchronize(self._h))
 
+    def pipe(self, slot_samples: int, n_slots: int = 3, rows: bool = True, in_format: int = nat.IN_I8) -> "HostPipe":
+        """Pinned host ring with asynchronous copy / compute / read-back legs (tdsa_pipe_*)."""
+        return HostPipe(self, slot_samples, n_slots, rows, in_format)
+
     def set_overlap(self, n_streams: int) -> None:
         """Let consecutive order-independent process_device() calls overlap on n_streams HIP streams
         (tdsa_set_overlap); 1 = strictly serial (default)."""
@@ -255,3 +259,70 @@ class TraceState:
         cnt = C.c_int()
         nat.check(nat.lib.tdsa_trace_avg_process(self._h, _ptr(x), int(x.size), _ptr(out), C.byref(cnt)))
         return out
+
+
+class HostPipe:
+    """Batch front end over `tdsa_pipe_*`: the producer fills pinned slots, H2D / frame kernel / D2H of
+    neighbouring slots overlap.  Counterpart of the reader thread + queue of HackrfSamplesDataSource
+    (datasources/hackrf_samples.py:191-305 of the reference) for recorders and offline analysis.
+
+        with eng.pipe(slot_samples) as q:
+            q.acquire()[: 2 * n] = iq_chunk           # int8 view of the pinned slot
+            q.submit(n, hop, n_frames)                # returns immediately
+            rows = q.collect()                        # oldest slot's dB rows (view, valid until reuse)
+    """
+
+    _DTYPES = {nat.IN_I8: (np.int8, 2), nat.IN_U8: (np.uint8, 2), nat.IN_C64: (np.complex64, 1)}
+
+    def __init__(self, engine: SpectrumEngine, slot_samples: int, n_slots: int, rows: bool, in_format: int):
+        self._eng = engine
+        self.slot_samples = int(slot_samples)
+        self.rows = bool(rows)
+        self.in_format = int(in_format)
+        self._q = C.c_void_p()
+        nat.check(nat.lib.tdsa_pipe_create(engine._h, self.in_format, self.slot_samples, int(n_slots),
+                                            int(self.rows), C.byref(self._q)))
+
+    def close(self) -> None:
+        if getattr(self, "_q", None) is not None and self._q:
+            nat.lib.tdsa_pipe_destroy(self._q)
+            self._q = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def acquire(self) -> np.ndarray:
+        """Next free pinned input slot as a numpy view (int8/uint8: interleaved I,Q; complex64: samples)."""
+        ptr = C.c_void_p()
+        nat.check(nat.lib.tdsa_pipe_acquire(self._q, C.byref(ptr)))
+        dt, per = self._DTYPES[self.in_format]
+        n = self.slot_samples * per
+        buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=dt, count=n)
+
+    def submit(self, n_samples: int, hop: int, n_frames: int) -> None:
+        nat.check(nat.lib.tdsa_pipe_submit(self._q, int(n_samples), int(hop), int(n_frames)))
+
+    def collect(self) -> Optional[np.ndarray]:
+        """Wait for the oldest submitted slot; its dB rows [n_frames, N] (None for a rows=False pipe)."""
+        rows = C.POINTER(C.c_float)()
+        nf = C.c_int()
+        nat.check(nat.lib.tdsa_pipe_collect(self._q, C.byref(rows), C.byref(nf)))
+        if not self.rows:
+            return None
+        return np.ctypeslib.as_array(rows, shape=(nf.value, self._eng.nfft))
+
+    @property
+    def pending(self) -> int:
+        n = C.c_int()
+        nat.check(nat.lib.tdsa_pipe_pending(self._q, C.byref(n)))
+        return n.value
