@@ -174,6 +174,54 @@ int tdsa_synchronize(tdsa_plan p);
 int tdsa_set_overlap(tdsa_plan p, int n_streams);
 
 /* ---- trace objects: DataProcessor / TraceAverager arithmetic on host-provided rows ------------- */
+/* -------- trace analytics on device-resident rows --------------------------
+ * rows_dev: [n_rows][n_bins] float32 dB rows on the plan's device, e.g. what tdsa_process_dev wrote;
+ * the calls are ordered after everything the plan has in flight and return with the results on the host.
+ *
+ * tdsa_rows_stats      per row: np.max (DutyCycleAnalyser.update_from_power, core/duty_cycle.py:36),
+ *                      np.argmax (marker snap fallback, core/marker_manager.py:97; first index of equal
+ *                      maxima, NaN wins like numpy) and MarkerManager._band_power over the inclusive bin
+ *                      range [band_lo, band_hi] (core/marker_manager.py:308-319: 10 log10(max(sum(10^(dB/10))
+ *                      * bin_width, 1e-30)); NaN when band_lo > band_hi = "no bin in the band" -> None).
+ *                      Any output pointer may be NULL.
+ * tdsa_rows_top_peaks  DataProcessor._find_top_peaks (core/display_data_processor.py:432-471): up to
+ *                      n_peaks (<= 8) strongest strict local maxima that are >= min_sep_bins apart and
+ *                      separated by a valley min_excursion_db below both; bins [n_rows][n_peaks] padded
+ *                      with -1 (dB padded with NaN).  n_bins <= 16384 (the row lives in LDS).  Equal-valued
+ *                      candidates are visited larger index first (the reference's order for ties is that
+ *                      of np.argsort's unstable sort). */
+int tdsa_rows_stats(tdsa_plan p, const float* rows_dev, int n_rows, int n_bins, int band_lo, int band_hi,
+                    double bin_width, float* peak_db_host, int32_t* peak_bin_host, double* band_db_host);
+int tdsa_rows_top_peaks(tdsa_plan p, const float* rows_dev, int n_rows, int n_bins, int n_peaks, int min_sep_bins,
+                        float min_excursion_db, int32_t* peak_bins_host, float* peak_db_host);
+
+/* -------- display accumulators kept on the device ---------------------------
+ * tdsa_density: DensityDisplay._hist (displays/density_display.py:300-320): float32 [n_bins][512]
+ * amplitude histogram over -200..+100 dB; every row first multiplies the histogram by `decay` (when
+ * decay < 1) and then adds 1 at int32((dB + 200) / 300 * 512) (truncation toward zero; NaN and out of
+ * range dropped), rows applied in order with float32 arithmetic.  _update_dev takes rows already on the
+ * device (p = the plan that produced them, or NULL), _update one host row (the per-tick call),
+ * _read copies the histogram or log1p(histogram) (what setImage receives).
+ * tdsa_waterfall: Waterfall._buf (displays/waterfall.py:163-180): double-height circular row buffer
+ * [2H][n_bins] initialised to min_db; a row that equals the previous pushed row (np.array_equal) is
+ * skipped (:330-336), a new one is written at ptr = (ptr - 1) % H and ptr + H; _view returns
+ * buf[ptr : ptr + H] (newest first).  These keep C4's 2 GiB of rows on the GPU: only the image leaves. */
+typedef struct tdsa_density_s* tdsa_density;
+int tdsa_density_create(int device_id, int n_bins, float decay, tdsa_density* out);
+int tdsa_density_destroy(tdsa_density d);
+int tdsa_density_set_decay(tdsa_density d, float decay);
+int tdsa_density_reset(tdsa_density d);
+int tdsa_density_update_dev(tdsa_density d, tdsa_plan p, const float* rows_dev, int n_rows);
+int tdsa_density_update(tdsa_density d, const float* row_host, int n);
+int tdsa_density_read(tdsa_density d, float* hist_host, int as_log1p);
+
+typedef struct tdsa_waterfall_s* tdsa_waterfall;
+int tdsa_waterfall_create(int device_id, int history_lines, int n_bins, float min_db, tdsa_waterfall* out);
+int tdsa_waterfall_destroy(tdsa_waterfall w);
+int tdsa_waterfall_push_dev(tdsa_waterfall w, tdsa_plan p, const float* rows_dev, int n_rows, int* n_new);
+int tdsa_waterfall_push(tdsa_waterfall w, const float* row_host, int n, int* is_new);
+int tdsa_waterfall_view(tdsa_waterfall w, float* view_host, int* ptr);
+
 /* -------- host pipeline: pinned ring + asynchronous copy / compute / read-back legs -------------
  * Batch counterpart of the reader-thread -> queue.Queue(4) -> get_power_levels() front end
  * (datasources/hackrf_samples.py:54,102-107,191-305).  The producer writes IQ

@@ -1,0 +1,103 @@
+"""oracle/analytics_oracle.py against the vectors captured from the imported reference
+(tests/golden/analytics.npz) and hand-derived known-answer cases for the two display accumulators the
+reference cannot run headless (PyQt6 / pyqtgraph absent: parity unpinned by the reference there)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import analytics_oracle as ao
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "analytics.npz"))
+
+
+def test_top_peaks_match_reference(gold):
+    for key in gold["peak_cases"]:
+        key = str(key)
+        n, kind, exc = key.split("_")[1:]
+        tr = gold[key + "_trace"]
+        min_sep, _ = ao.peak_list_params(int(n))
+        bins = ao.find_top_peak_bins(tr, n=5, min_sep_bins=min_sep, min_excursion_db=float(exc))
+        assert bins == list(gold[key + "_bins"]), key
+        assert np.array_equal(tr[bins].astype(np.float64), gold[key + "_pwr"]), key
+
+
+def test_top_peaks_edge_cases():
+    assert ao.find_top_peaks(np.arange(2.0), np.array([1.0, 2.0])) == []
+    assert ao.find_top_peaks(np.arange(5.0), np.array([5.0, 4, 3, 2, 1])) == []          # edges never count
+    flat = np.zeros(16)
+    assert ao.find_top_peaks(np.arange(16.0), flat) == []                                # strict maxima only
+    tr = np.full(64, -100.0)
+    tr[10], tr[30], tr[33] = -20.0, -30.0, -25.0
+    assert ao.find_top_peak_bins(tr, min_sep_bins=10, min_excursion_db=10.0) == [10, 33]   # 30 too close to 33
+    assert ao.find_top_peak_bins(tr, min_sep_bins=2, min_excursion_db=10.0) == [10, 33, 30]
+    tr2 = np.full(64, -100.0)
+    tr2[20:41] = -24.0
+    tr2[20], tr2[40] = -20.0, -21.0                        # valley between them only 3-4 dB deep
+    assert ao.find_top_peak_bins(tr2, min_sep_bins=5, min_excursion_db=10.0) == [20]
+
+
+def test_duty_cycle_matches_reference(gold):
+    d = ao.DutyCycleOracle()
+    frames = gold["duty_frames"]
+    for i, fr in enumerate(frames):
+        d.update_from_power(fr, threshold_dbm=-60.0 if i < 130 else -45.0)
+        assert d.duty_pct == gold["duty_pct"][i]
+        on, off = gold["duty_on"][i], gold["duty_off"][i]
+        assert (d.on_power_dbm is None and np.isnan(on)) or d.on_power_dbm == on
+        assert (d.off_power_dbm is None and np.isnan(off)) or d.off_power_dbm == off
+    d.reset()
+    assert d.duty_pct == 0.0 and d.on_power_dbm is None
+
+
+def test_band_power_matches_reference(gold):
+    bins, tr = gold["band_bins"], gold["band_trace"]
+    for (a, b), want in zip(gold["band_edges"], gold["band_db"]):
+        got = ao.band_power_db(bins, tr, a, b)
+        if np.isnan(want):
+            assert got is None
+            assert ao.band_bin_range(bins, a, b) == (0, -1)
+        else:
+            assert got == want
+            lo, hi = ao.band_bin_range(bins, a, b)
+            assert np.array_equal(np.where((bins >= min(a, b)) & (bins <= max(a, b)))[0], np.arange(lo, hi + 1))
+
+
+def test_frame_peak():
+    tr = np.array([-3.0, 7.5, 7.5, -1.0], dtype=np.float32)
+    assert ao.frame_peak(tr) == (7.5, 1)            # first of equal maxima
+
+
+def test_density_known_answers():
+    d = ao.DensityOracle(decay=0.5)
+    row = np.array([-200.0, -199.5, 99.9, 100.0, np.nan, -201.0, -200.1], dtype=np.float32)
+    h = d.update(row)
+    assert h.shape == (7, ao.AMP_BINS) and h.dtype == np.float32
+    assert h[0, 0] == 1 and h[1, 0] == 1 and h[2, 511] == 1          # 0.5 dB * 512/300 = 0.85 -> bin 0
+    assert h[3].sum() == 0 and h[4].sum() == 0 and h[5].sum() == 0   # == +100 dB, NaN, below range: dropped
+    assert h[6, 0] == 1                       # astype(int32) truncates toward zero: (-200.59, -200) -> bin 0
+    h = d.update(row)
+    assert h[0, 0] == 1.5 and h[2, 511] == 1.5
+    d.update(np.full(7, -50.0, dtype=np.float32))
+    assert d.hist[0, 0] == 0.75 and d.hist[0, int((150.0 / 300.0) * 512)] == 1.0
+    assert np.allclose(d.image(), np.log1p(d.hist))
+    d.update(np.zeros(3, dtype=np.float32))                           # size change: fresh histogram
+    assert d.hist.shape == (3, ao.AMP_BINS) and d.hist.sum() == 3.0
+    nodecay = ao.DensityOracle(decay=1.0)
+    for _ in range(4):
+        nodecay.update(np.array([0.0], dtype=np.float32))
+    assert nodecay.hist.sum() == 4.0
+
+
+def test_waterfall_known_answers():
+    w = ao.WaterfallOracle(history_lines=3, n_bins=2, min_db=-120.0)
+    assert np.all(w.view() == -120.0) and w.view().shape == (3, 2)
+    rows = [np.array([1.0, 2.0]), np.array([1.0, 2.0]), np.array([3.0, 4.0]), np.array([5.0, 6.0]),
+            np.array([7.0, 8.0])]
+    news = [w.update(r) for r in rows]
+    assert news == [True, False, True, True, True]                    # identical consecutive row is skipped
+    assert np.array_equal(w.view(), np.array([[7, 8], [5, 6], [3, 4]], dtype=np.float32))   # newest first
+    assert w.buf.shape == (6, 2) and np.array_equal(w.buf[:3], w.buf[3:])

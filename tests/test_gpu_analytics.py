@@ -1,0 +1,222 @@
+"""GPU parity of the trace analytics / display accumulators against
+oracle/analytics_oracle.py and the vectors captured from the imported reference."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import analytics_oracle as ao
+from oracle import spectrum_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import topdogspectrumanalyser_amd as p
+    return p
+
+
+@pytest.fixture(scope="module")
+def an():
+    from topdogspectrumanalyser_amd import analytics
+    return analytics
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "analytics.npz"))
+
+
+class DevRows:
+    """rows uploaded to the device for the duration of a with-block"""
+
+    def __init__(self, pkg, rows):
+        self.nat = pkg._native
+        self.rows = np.ascontiguousarray(rows, dtype=np.float32)
+        self.ptr = C.c_void_p()
+
+    def __enter__(self):
+        nat = self.nat
+        nat.check(nat.lib.tdsa_dev_alloc(0, self.rows.nbytes, C.byref(self.ptr)))
+        nat.check(nat.lib.tdsa_memcpy_h2d(0, self.ptr, self.rows.ctypes.data_as(C.c_void_p), self.rows.nbytes))
+        return self.ptr.value
+
+    def __exit__(self, *exc):
+        self.nat.lib.tdsa_dev_free(0, self.ptr)
+
+
+def test_top_peaks_match_reference_vectors(pkg, an, gold):
+    for key in gold["peak_cases"]:
+        key = str(key)
+        n, kind, exc = key.split("_")[1:]
+        n = int(n)
+        tr = gold[key + "_trace"]
+        with pkg.SpectrumEngine(max(n, 64), max_frames=1) as e, DevRows(pkg, tr[None, :]) as d:
+            bins, db = an.rows_top_peaks(e, d, 1, n_bins=n, n=5, min_excursion_db=float(exc))
+        want = list(gold[key + "_bins"])
+        got = [int(b) for b in bins[0] if b >= 0]
+        assert got == want, key
+        assert np.array_equal(db[0][: len(want)].astype(np.float64), gold[key + "_pwr"]), key
+        assert np.all(bins[0][len(want):] == -1) and np.all(np.isnan(db[0][len(want):]))
+
+
+def test_top_peaks_batch_on_spectra(pkg, an):
+    """Peak lists of real GPU spectra (C3 shape, 64 frames) equal the restated reference row by row."""
+    nfft, hop, nf = 16384, 8192, 64
+    iq = so.synth_iq_int8(hop * (nf - 1) + nfft, nfft, seed=77)
+    fb = so.shifted_freq_bins(nfft, 20e6, 2.45e9)
+    with pkg.SpectrumEngine(nfft, max_frames=nf) as e:
+        e.set_window(so.hackrf_window(nfft))
+        e.configure(db_mode="mag", log_floor=so.LOG_FLOOR, dc_alpha=1.0)
+        rows = e.process(iq, hop=hop)
+        with DevRows(pkg, rows) as d:
+            for exc in (6.0, 10.0):
+                bins, db = an.rows_top_peaks(e, d, nf, min_excursion_db=exc)
+                for r in range(nf):
+                    want = ao.find_top_peaks(fb, rows[r], 5, *ao.peak_list_params(nfft, exc))
+                    got = an.peaks_as_reference(fb, bins[r], db[r])
+                    assert got == want, (r, exc)
+
+
+def test_rows_stats_peak_argmax_band(pkg, an, gold):
+    bins, tr = gold["band_bins"], gold["band_trace"]
+    rng = np.random.default_rng(5)
+    rows = np.stack([tr, tr[::-1].copy(), np.roll(tr, 100), rng.normal(-80, 5, tr.size).astype(np.float32)])
+    rows[1, 7] = rows[1, 900] = rows[1].max() + 1.0          # equal maxima: first index wins
+    with pkg.SpectrumEngine(4096, max_frames=4) as e, DevRows(pkg, rows) as d:
+        for (a, b), want in zip(gold["band_edges"], gold["band_db"]):
+            peak, pbin, bdb = an.rows_stats(e, d, 4, freq_bins=bins, band=(a, b))
+            for r in range(4):
+                assert peak[r] == rows[r].max() and pbin[r] == int(np.argmax(rows[r]))
+                ref = ao.band_power_db(bins, rows[r], a, b)
+                if ref is None:
+                    assert np.isnan(bdb[r])
+                else:
+                    assert abs(bdb[r] - ref) <= 1e-4, (r, a, b)
+            if not np.isnan(want):
+                assert abs(bdb[0] - want) <= 1e-4                  # the value the reference itself returned
+        peak, pbin, bdb = an.rows_stats(e, d, 4)
+        assert bdb is None and pbin[1] == 7
+    nanrow = tr.copy()
+    nanrow[[300, 20]] = np.nan
+    with pkg.SpectrumEngine(4096, max_frames=1) as e, DevRows(pkg, nanrow[None, :]) as d:
+        peak, pbin, _ = an.rows_stats(e, d, 1)
+        assert np.isnan(peak[0]) and pbin[0] == 20 == int(np.argmax(nanrow))    # numpy: first NaN
+
+
+def test_duty_cycle_from_device_rows(pkg, an, gold):
+    frames = gold["duty_frames"]
+    d = an.DutyCycle()
+    with pkg.SpectrumEngine(1024, max_frames=130) as e:
+        with DevRows(pkg, frames[:130]) as a:
+            d.update_from_rows(e, a, 130, threshold_dbm=-60.0)
+        assert d.duty_pct == gold["duty_pct"][129]
+        with DevRows(pkg, frames[130:]) as b:
+            d.update_from_rows(e, b, 130, threshold_dbm=-45.0)
+    ref = ao.DutyCycleOracle()
+    for i, fr in enumerate(frames):
+        ref.update_from_power(fr, threshold_dbm=-60.0 if i < 130 else -45.0)
+    assert d.duty_pct == ref.duty_pct == gold["duty_pct"][-1]
+    assert d.on_power_dbm == ref.on_power_dbm and d.off_power_dbm == ref.off_power_dbm
+    h = an.DutyCycle()                                       # host-array entry point, reference sequence
+    for i, fr in enumerate(frames[:40]):
+        h.update_from_power(fr, threshold_dbm=-60.0)
+        assert h.duty_pct == gold["duty_pct"][i]
+
+
+@pytest.mark.parametrize("decay", [0.96, 0.5, 1.0])
+def test_density_histogram_matches_restatement(pkg, an, decay):
+    n, nf = 1000, 37                                         # n not a multiple of the 16-bin tile
+    rng = np.random.default_rng(int(decay * 100))
+    rows = rng.normal(-70, 25, size=(nf, n)).astype(np.float32)
+    rows[3, 5] = np.nan
+    rows[4, 6] = 100.0
+    rows[5, 7] = -200.3                                      # truncation toward zero lands in bin 0
+    rows[6, 8] = -201.0
+    rows[7, 9] = 99.99
+    ref = ao.DensityOracle(decay)
+    for r in rows:
+        ref.update(r)
+    with an.DensityHistogram(n, decay) as dh, DevRows(pkg, rows) as d:
+        dh.update_rows(None, d, nf)
+        h = dh.hist()
+        assert h.shape == (n, ao.AMP_BINS)
+        assert np.array_equal(h, ref.hist)                   # same float32 sequence: bit exact
+        assert np.allclose(dh.image(), np.log1p(ref.hist), rtol=2e-6, atol=1e-7)
+        one = an.DensityHistogram(n, decay)
+        for r in rows[:5]:
+            one.update(r)                                    # per-tick host entry point
+        ref5 = ao.DensityOracle(decay)
+        for r in rows[:5]:
+            ref5.update(r)
+        assert np.array_equal(one.hist(), ref5.hist)
+        one.reset()
+        assert one.hist().sum() == 0
+        with pytest.raises(Exception):
+            one.update(rows[0][:10])
+        one.close()
+
+
+def test_density_from_engine_rows(pkg, an):
+    nfft, nf = 2048, 50
+    iq = so.synth_iq_int8(nfft * nf, nfft, seed=9)
+    nat = pkg._native
+    with pkg.SpectrumEngine(nfft, max_frames=nf) as e, an.DensityHistogram(nfft, 0.9) as dh:
+        e.set_window(so.hackrf_window(nfft))
+        e.configure(db_mode="mag", log_floor=so.LOG_FLOOR, dc_alpha=1.0)
+        rows = e.process(iq, hop=nfft)
+        d_in, d_out = C.c_void_p(), C.c_void_p()
+        nat.check(nat.lib.tdsa_dev_alloc(0, iq.nbytes, C.byref(d_in)))
+        nat.check(nat.lib.tdsa_dev_alloc(0, rows.nbytes, C.byref(d_out)))
+        nat.check(nat.lib.tdsa_memcpy_h2d(0, d_in, iq.ctypes.data_as(C.c_void_p), iq.nbytes))
+        e.set_overlap(2)
+        e.process_device(nat.IN_I8, d_in.value, nfft * nf, nfft, nf, d_out.value)
+        dh.update_rows(e, d_out.value, nf)                   # ordered after the producer by the library
+        ref = ao.DensityOracle(0.9)
+        for r in rows:
+            ref.update(r)
+        assert np.array_equal(dh.hist(), ref.hist)
+        nat.lib.tdsa_dev_free(0, d_in)
+        nat.lib.tdsa_dev_free(0, d_out)
+
+
+def test_waterfall_ring_matches_restatement(pkg, an):
+    H, W = 7, 300
+    rng = np.random.default_rng(3)
+    base = rng.normal(-90, 3, size=(30, W)).astype(np.float32)
+    seq = [base[0], base[0], base[1], base[2], base[2], base[2], base[3]] + [base[i] for i in range(4, 20)]
+    nanrow = base[20].copy()
+    nanrow[5] = np.nan
+    seq += [nanrow, nanrow, base[21]]                        # NaN rows never compare equal
+    ref = ao.WaterfallOracle(H, W, -120.0)
+    with an.WaterfallRing(H, W, -120.0) as wf:
+        assert np.all(wf.view() == -120.0)
+        for row in seq[:9]:                                  # per-tick host entry point
+            assert wf.push(row) == ref.update(row)
+            assert wf.ptr == ref.ptr
+        assert np.array_equal(wf.view(), ref.view(), equal_nan=True)
+        rest = np.stack(seq[9:])
+        n_ref = sum(ref.update(r) for r in rest)
+        with DevRows(pkg, rest) as d:
+            assert wf.push_rows(None, d, len(rest)) == n_ref      # batch larger than the history
+        assert wf.ptr == ref.ptr
+        assert np.array_equal(wf.view(), ref.view(), equal_nan=True)
+        with pytest.raises(Exception):
+            wf.push(base[0][:10])
+
+
+def test_analytics_error_paths(pkg, an):
+    with pkg.SpectrumEngine(1024, max_frames=1) as e, DevRows(pkg, np.zeros((1, 1024), np.float32)) as d:
+        with pytest.raises(Exception):
+            an.rows_top_peaks(e, d, 1, n=9)
+        with pytest.raises(Exception):
+            an.rows_top_peaks(e, d, 1, n_bins=32768)
+        assert an.rows_top_peaks(e, d, 1)[0].tolist() == [[-1] * 5]          # flat row: no strict maximum
+        peak, pbin, _ = an.rows_stats(e, d, 1)
+        assert peak[0] == 0.0 and pbin[0] == 0
+    with pytest.raises(Exception):
+        an.DensityHistogram(0)
+    with pytest.raises(Exception):
+        an.WaterfallRing(0, 16, -100.0)

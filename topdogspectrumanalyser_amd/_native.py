@@ -57,6 +57,20 @@ _SIGNATURES = {
     "tdsa_get_dc": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "tdsa_synchronize": (C.c_int, [_P]),
     "tdsa_set_overlap": (C.c_int, [_P, C.c_int]),
+    "tdsa_rows_stats": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _P, _P, _P]),
+    "tdsa_rows_top_peaks": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P]),
+    "tdsa_density_create": (C.c_int, [C.c_int, C.c_int, C.c_float, C.POINTER(_P)]),
+    "tdsa_density_destroy": (C.c_int, [_P]),
+    "tdsa_density_set_decay": (C.c_int, [_P, C.c_float]),
+    "tdsa_density_reset": (C.c_int, [_P]),
+    "tdsa_density_update_dev": (C.c_int, [_P, _P, _P, C.c_int]),
+    "tdsa_density_update": (C.c_int, [_P, _P, C.c_int]),
+    "tdsa_density_read": (C.c_int, [_P, _P, C.c_int]),
+    "tdsa_waterfall_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(_P)]),
+    "tdsa_waterfall_destroy": (C.c_int, [_P]),
+    "tdsa_waterfall_push_dev": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_int)]),
+    "tdsa_waterfall_push": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
+    "tdsa_waterfall_view": (C.c_int, [_P, _P, C.POINTER(C.c_int)]),
     "tdsa_pipe_create": (C.c_int, [_P, C.c_int, C.c_size_t, C.c_int, C.c_int, C.POINTER(_P)]),
     "tdsa_pipe_destroy": (C.c_int, [_P]),
     "tdsa_pipe_acquire": (C.c_int, [_P, C.POINTER(_P)]),

@@ -1,0 +1,318 @@
+// tdsa_analytics.hip - what happens to the dB rows after the IQ -> spectrum path, kept on the device
+// (SURVEY.md 8(f) f-3 / f-4): per-row peak / argmax / band power, the top-N peak list, the density
+// histogram and the waterfall ring.  All kernels stream [rows][n] float32 rows that already sit in HBM
+// (the frame kernel's output) and hand back scalars or a small image: HBM-bound by construction.
+//
+//   rows_stats_kernel     np.max / np.argmax (core/duty_cycle.py:36, core/marker_manager.py:97) and
+//                         MarkerManager._band_power (core/marker_manager.py:308-319)
+//   top_peaks_kernel      DataProcessor._find_top_peaks (core/display_data_processor.py:432-471)
+//   density_kernel        DensityDisplay._update_hist (displays/density_display.py:306-318)
+//   rows_differ_kernel /  Waterfall new-row test + _add_row (displays/waterfall.py:171-175, 330-336)
+//   waterfall_scatter_kernel
+#include "tdsa_kernels.hpp"
+
+#include <math.h>
+
+namespace tdsa {
+
+namespace {
+
+struct PeakPair {
+  float v;
+  int i;
+};
+// np.max / np.argmax order: NaN beats everything, then larger value, then smaller index
+__device__ __forceinline__ bool better(PeakPair a, PeakPair b) {
+  const bool an = a.v != a.v, bn = b.v != b.v;
+  if (an || bn) return an && (!bn || a.i < b.i);
+  return a.v > b.v || (a.v == b.v && a.i < b.i);
+}
+__device__ __forceinline__ PeakPair wave_best(PeakPair p) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    PeakPair q{__shfl_xor(p.v, o), __shfl_xor(p.i, o)};
+    if (better(q, p)) p = q;
+  }
+  return p;
+}
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o);
+  return x;
+}
+__device__ __forceinline__ float wave_min(float x) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) x = fminf(x, __shfl_xor(x, o));
+  return x;
+}
+
+// ---- per-row peak / argmax / band power ------------------------------------------------------------
+__global__ void __launch_bounds__(256) rows_stats_kernel(const float* __restrict__ rows, int n, int band_lo,
+                                                         int band_hi, double bin_width, float* peak_db,
+                                                         int* peak_bin, double* band_db) {
+  const float* row = rows + (size_t)blockIdx.x * n;
+  PeakPair best{-INFINITY, 0x7fffffff};
+  double bsum = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float v = row[i];
+    const PeakPair c{v, i};
+    if (better(c, best)) best = c;
+    // 10 ** (levels / 10) in float32 like numpy does for a float32 trace, accumulated wider
+    if (i >= band_lo && i <= band_hi) bsum += (double)exp10f(v / 10.0f);
+  }
+  __shared__ PeakPair s_best[4];
+  __shared__ double s_sum[4];
+  best = wave_best(best);
+  bsum = wave_sum(bsum);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    s_best[w] = best;
+    s_sum[w] = bsum;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; ++k) {
+      if (better(s_best[k], best)) best = s_best[k];
+      bsum += s_sum[k];
+    }
+    if (peak_db) peak_db[blockIdx.x] = best.v;
+    if (peak_bin) peak_bin[blockIdx.x] = best.i;
+    if (band_db) {
+      const double total = bsum * bin_width;
+      band_db[blockIdx.x] = band_lo > band_hi ? NAN : 10.0 * log10(total > 1e-30 ? total : 1e-30);
+    }
+  }
+}
+
+// ---- top-N peak list ----------------------------------------------------------------------------------
+// One workgroup per row; the row and the candidate values live in LDS.  Candidates (strict interior local
+// maxima) are visited from the strongest down exactly like the reference's sorted loop: every round is a
+// block argmax over the live candidates plus one pass that forms the valley minimum against each peak
+// accepted so far.  Ends as soon as n_peaks are accepted or the candidates run out.
+constexpr int kPeakThreads = 1024;
+constexpr int kMaxPeaks = 8;
+
+__global__ void __launch_bounds__(kPeakThreads) top_peaks_kernel(const float* __restrict__ rows, int n, int n_peaks,
+                                                                 int min_sep, float excursion, int* out_bins,
+                                                                 float* out_db) {
+  extern __shared__ float smem[];
+  float* row = smem;             // [n]
+  float* cand = smem + n;        // [n]: value of a live candidate, -inf otherwise
+  __shared__ PeakPair s_best[kPeakThreads / 64];
+  __shared__ float s_min[kMaxPeaks][kPeakThreads / 64];
+  __shared__ int s_sel[kMaxPeaks];
+  __shared__ float s_selv[kMaxPeaks];
+  __shared__ int s_nsel, s_cur;
+  __shared__ float s_curv;
+
+  const float* src = rows + (size_t)blockIdx.x * n;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int i = tid; i < n; i += kPeakThreads) row[i] = src[i];
+  if (tid == 0) s_nsel = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += kPeakThreads) {
+    const bool is_max = i > 0 && i < n - 1 && row[i] > row[i - 1] && row[i] > row[i + 1];
+    cand[i] = is_max ? row[i] : -INFINITY;
+  }
+  __syncthreads();
+
+  for (;;) {
+    // strongest live candidate; equal values: larger index first (reversed ascending sort)
+    PeakPair best{-INFINITY, -1};
+    for (int i = tid; i < n; i += kPeakThreads) {
+      const float v = cand[i];
+      if (v > best.v || (v == best.v && v != -INFINITY && i > best.i)) best = PeakPair{v, i};
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const PeakPair q{__shfl_xor(best.v, o), __shfl_xor(best.i, o)};
+      if (q.v > best.v || (q.v == best.v && q.i > best.i)) best = q;
+    }
+    if (lane == 0) s_best[w] = best;
+    __syncthreads();
+    if (tid == 0) {
+      PeakPair b = s_best[0];
+      for (int k = 1; k < kPeakThreads / 64; ++k)
+        if (s_best[k].v > b.v || (s_best[k].v == b.v && s_best[k].i > b.i)) b = s_best[k];
+      s_cur = b.v == -INFINITY ? -1 : b.i;
+      s_curv = b.v;
+    }
+    __syncthreads();
+    const int cur = s_cur;
+    if (cur < 0) break;
+    const float curv = s_curv;
+    const int nsel = s_nsel;
+    // valley minimum between the candidate and every accepted peak, one pass over the row
+    float vmin[kMaxPeaks];
+#pragma unroll
+    for (int k = 0; k < kMaxPeaks; ++k) vmin[k] = INFINITY;
+    for (int i = tid; i < n; i += kPeakThreads) {
+      const float v = row[i];
+#pragma unroll
+      for (int k = 0; k < kMaxPeaks; ++k) {
+        if (k < nsel) {
+          const int s = s_sel[k];
+          const int lo = cur < s ? cur : s, hi = cur < s ? s : cur;
+          if (i >= lo && i <= hi) vmin[k] = fminf(vmin[k], v);   // (a NaN in the range would make np.min NaN and
+        }                                                         //  never reject; rows of this path carry none)
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kMaxPeaks; ++k) {
+      if (k < nsel) {
+        const float m = wave_min(vmin[k]);
+        if (lane == 0) s_min[k][w] = m;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      bool reject = false;
+      for (int k = 0; k < nsel && !reject; ++k) {
+        const int s = s_sel[k];
+        const int d = cur > s ? cur - s : s - cur;
+        if (d < min_sep) {
+          reject = true;
+          break;
+        }
+        float valley = s_min[k][0];
+        for (int j = 1; j < kPeakThreads / 64; ++j) valley = fminf(valley, s_min[k][j]);
+        // reference arithmetic: power[idx] - valley is float32 - Python float (float32 under numpy >= 2),
+        // sel_pwr - valley is Python float - Python float (double)
+        if (curv - valley < excursion || (double)s_selv[k] - (double)valley < (double)excursion) reject = true;
+      }
+      if (!reject) {
+        s_sel[nsel] = cur;
+        s_selv[nsel] = curv;
+        s_nsel = nsel + 1;
+      }
+      cand[cur] = -INFINITY;
+    }
+    __syncthreads();
+    if (s_nsel >= n_peaks) break;
+  }
+  if (tid < n_peaks) {
+    const bool have = tid < s_nsel;
+    out_bins[(size_t)blockIdx.x * n_peaks + tid] = have ? s_sel[tid] : -1;
+    if (out_db) out_db[(size_t)blockIdx.x * n_peaks + tid] = have ? s_selv[tid] : NAN;
+  }
+}
+
+// ---- density histogram ----------------------------------------------------------------------------------
+// hist[f][a] for kDensFreq neighbouring frequency bins per workgroup; thread a owns amplitude bin a of each.
+// Rows are applied in order with the reference's float32 arithmetic: hist *= decay (when decay < 1), then
+// += 1 at int32(((v - AMP_MIN) / AMP_RNG) * AMP_BINS) (truncation toward zero, NaN / out of range dropped).
+constexpr int kAmpBins = 512;
+constexpr int kDensFreq = 16;
+constexpr float kAmpMin = -200.0f, kAmpRng = 300.0f;
+
+__global__ void __launch_bounds__(kAmpBins) density_kernel(const float* __restrict__ rows, int n_rows, int n,
+                                                           float decay, float* hist) {
+  const int f0 = blockIdx.x * kDensFreq;
+  const int a = threadIdx.x;
+  float h[kDensFreq];
+#pragma unroll
+  for (int j = 0; j < kDensFreq; ++j) h[j] = (f0 + j < n) ? hist[(size_t)(f0 + j) * kAmpBins + a] : 0.0f;
+  const bool do_decay = decay < 1.0f;
+  for (int r = 0; r < n_rows; ++r) {
+    const float* row = rows + (size_t)r * n + f0;
+#pragma unroll
+    for (int j = 0; j < kDensFreq; ++j) {
+      if (do_decay) h[j] *= decay;
+      if (f0 + j < n) {
+        const float v = row[j];
+        const float x = (v - kAmpMin) / kAmpRng * float(kAmpBins);
+        // astype(int32) truncates toward zero; NaN and anything outside [0, AMP_BINS) is dropped
+        if (v == v && x > -1.0f && x < float(kAmpBins) && int(x) == a) h[j] += 1.0f;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kDensFreq; ++j)
+    if (f0 + j < n) hist[(size_t)(f0 + j) * kAmpBins + a] = h[j];
+}
+
+__global__ void log1p_kernel(const float* __restrict__ in, float* out, size_t count) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = log1pf(in[i]);
+}
+
+// ---- waterfall ring -------------------------------------------------------------------------------------
+// differs[r] = !np.array_equal(rows[r], previous row)  (previous of row 0 = `last`, or "no previous")
+__global__ void __launch_bounds__(256) rows_differ_kernel(const float* __restrict__ rows, const float* __restrict__ last,
+                                                          int have_last, int n, int* differs) {
+  const int r = blockIdx.x;
+  const float* cur = rows + (size_t)r * n;
+  const float* prev = r > 0 ? cur - n : last;
+  int diff = (r == 0 && !have_last) ? 1 : 0;
+  if (!diff)
+    for (int i = threadIdx.x; i < n; i += 256) diff |= (cur[i] != prev[i]) ? 1 : 0;    // NaN != NaN, as in numpy
+  diff = __syncthreads_or(diff);
+  if (threadIdx.x == 0) differs[r] = diff;
+}
+// copy row r to ring rows dst[r] and dst[r] + H (dst[r] < 0: duplicate, skipped)
+__global__ void __launch_bounds__(256) waterfall_scatter_kernel(const float* __restrict__ rows, const int* __restrict__ dst,
+                                                                int n, int history, float* ring) {
+  const int r = blockIdx.x;
+  const int d = dst[r];
+  if (d < 0) return;
+  const float* src = rows + (size_t)r * n;
+  float* a = ring + (size_t)d * n;
+  float* b = ring + (size_t)(d + history) * n;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float v = src[i];
+    a[i] = v;
+    b[i] = v;
+  }
+}
+
+}  // namespace
+
+hipError_t launch_rows_stats(const float* rows, int n_rows, int n, int band_lo, int band_hi, double bin_width,
+                             float* peak_db, int* peak_bin, double* band_db, hipStream_t s) {
+  if (n_rows <= 0) return hipSuccess;
+  rows_stats_kernel<<<n_rows, 256, 0, s>>>(rows, n, band_lo, band_hi, bin_width, peak_db, peak_bin, band_db);
+  return hipGetLastError();
+}
+
+hipError_t launch_top_peaks(const float* rows, int n_rows, int n, int n_peaks, int min_sep, float excursion,
+                            int* out_bins, float* out_db, hipStream_t s) {
+  if (n_rows <= 0) return hipSuccess;
+  const size_t lds = size_t(2) * n * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(top_peaks_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  top_peaks_kernel<<<n_rows, kPeakThreads, lds, s>>>(rows, n, n_peaks, min_sep, excursion, out_bins, out_db);
+  return hipGetLastError();
+}
+
+hipError_t launch_density(const float* rows, int n_rows, int n, float decay, float* hist, hipStream_t s) {
+  if (n_rows <= 0) return hipSuccess;
+  density_kernel<<<(n + kDensFreq - 1) / kDensFreq, kAmpBins, 0, s>>>(rows, n_rows, n, decay, hist);
+  return hipGetLastError();
+}
+
+hipError_t launch_log1p(const float* in, float* out, size_t count, hipStream_t s) {
+  if (count == 0) return hipSuccess;
+  log1p_kernel<<<unsigned((count + 255) / 256), 256, 0, s>>>(in, out, count);
+  return hipGetLastError();
+}
+
+hipError_t launch_rows_differ(const float* rows, const float* last, int have_last, int n_rows, int n, int* differs,
+                              hipStream_t s) {
+  if (n_rows <= 0) return hipSuccess;
+  rows_differ_kernel<<<n_rows, 256, 0, s>>>(rows, last, have_last, n, differs);
+  return hipGetLastError();
+}
+
+hipError_t launch_waterfall_scatter(const float* rows, const int* dst, int n_rows, int n, int history, float* ring,
+                                    hipStream_t s) {
+  if (n_rows <= 0) return hipSuccess;
+  waterfall_scatter_kernel<<<n_rows, 256, 0, s>>>(rows, dst, n, history, ring);
+  return hipGetLastError();
+}
+
+}  // namespace tdsa

@@ -1118,3 +1118,312 @@ int tdsa_pipe_pending(tdsa_pipe q, int* pending) {
   *pending = q->pending;
   return TDSA_OK;
 }
+
+// ================================================================================================
+// Trace analytics and display accumulators on device-resident dB rows
+// ================================================================================================
+namespace {
+
+// scratch that grows on demand, owned by the plan's device context (freed with the object that holds it)
+struct DevScratch {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t need) {
+    if (need <= bytes) return TDSA_OK;
+    if (ptr) HIPCHK(hipFree(ptr));
+    ptr = nullptr;
+    bytes = 0;
+    HIPCHK(hipMalloc(&ptr, need));
+    bytes = need;
+    return TDSA_OK;
+  }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+  }
+};
+thread_local DevScratch g_scratch[16];   // per device, per host thread
+
+}  // namespace
+
+int tdsa_rows_stats(tdsa_plan p, const float* rows_dev, int n_rows, int n_bins, int band_lo, int band_hi,
+                    double bin_width, float* peak_db_host, int32_t* peak_bin_host, double* band_db_host) {
+  if (!p) return fail(TDSA_ERR_ARG, "null plan");
+  if (n_rows == 0) return TDSA_OK;
+  if (!rows_dev || n_rows < 0 || n_bins < 1) return fail(TDSA_ERR_ARG, "bad rows (%p, %d x %d)", (const void*)rows_dev, n_rows, n_bins);
+  if (band_db_host && (band_lo < 0 || band_hi >= n_bins) && band_lo <= band_hi)
+    return fail(TDSA_ERR_ARG, "band [%d, %d] outside [0, %d)", band_lo, band_hi, n_bins);
+  HIPCHK(hipSetDevice(p->device));
+  JOIN(p);
+  DevScratch& sc = g_scratch[p->device & 15];
+  const size_t per = sizeof(float) + sizeof(int) + sizeof(double);
+  int rc = sc.ensure(size_t(n_rows) * per);
+  if (rc != TDSA_OK) return rc;
+  double* d_band = static_cast<double*>(sc.ptr);
+  float* d_peak = reinterpret_cast<float*>(d_band + n_rows);
+  int* d_bin = reinterpret_cast<int*>(d_peak + n_rows);
+  HIPCHK(launch_rows_stats(rows_dev, n_rows, n_bins, band_lo, band_hi, bin_width, d_peak, d_bin,
+                           band_db_host ? d_band : nullptr, p->stream));
+  if (peak_db_host) HIPCHK(hipMemcpyAsync(peak_db_host, d_peak, size_t(n_rows) * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+  if (peak_bin_host) HIPCHK(hipMemcpyAsync(peak_bin_host, d_bin, size_t(n_rows) * sizeof(int), hipMemcpyDeviceToHost, p->stream));
+  if (band_db_host) HIPCHK(hipMemcpyAsync(band_db_host, d_band, size_t(n_rows) * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  return TDSA_OK;
+}
+
+int tdsa_rows_top_peaks(tdsa_plan p, const float* rows_dev, int n_rows, int n_bins, int n_peaks, int min_sep_bins,
+                        float min_excursion_db, int32_t* peak_bins_host, float* peak_db_host) {
+  if (!p) return fail(TDSA_ERR_ARG, "null plan");
+  if (n_rows == 0) return TDSA_OK;
+  if (!rows_dev || !peak_bins_host || n_rows < 0) return fail(TDSA_ERR_ARG, "null / negative argument");
+  if (n_peaks < 1 || n_peaks > 8) return fail(TDSA_ERR_ARG, "n_peaks=%d outside [1, 8]", n_peaks);
+  if (n_bins < 1 || n_bins > 16384) return fail(TDSA_ERR_ARG, "n_bins=%d outside [1, 16384] (row must fit the LDS)", n_bins);
+  HIPCHK(hipSetDevice(p->device));
+  JOIN(p);
+  DevScratch& sc = g_scratch[p->device & 15];
+  const size_t cnt = size_t(n_rows) * n_peaks;
+  int rc = sc.ensure(cnt * (sizeof(int) + sizeof(float)));
+  if (rc != TDSA_OK) return rc;
+  int* d_bins = static_cast<int*>(sc.ptr);
+  float* d_db = reinterpret_cast<float*>(d_bins + cnt);
+  HIPCHK(launch_top_peaks(rows_dev, n_rows, n_bins, n_peaks, min_sep_bins, min_excursion_db, d_bins, d_db, p->stream));
+  HIPCHK(hipMemcpyAsync(peak_bins_host, d_bins, cnt * sizeof(int), hipMemcpyDeviceToHost, p->stream));
+  if (peak_db_host) HIPCHK(hipMemcpyAsync(peak_db_host, d_db, cnt * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+  HIPCHK(hipStreamSynchronize(p->stream));
+  return TDSA_OK;
+}
+
+// ---- density histogram --------------------------------------------------------------------------
+struct tdsa_density_s {
+  int device = 0, n = 0;
+  float decay = 0.96f;
+  float* d_hist = nullptr;     // [n][512]
+  float* d_img = nullptr;      // log1p image scratch
+  float* d_row = nullptr;      // staging for host rows
+  hipStream_t stream = nullptr;
+};
+
+int tdsa_density_create(int device_id, int n_bins, float decay, tdsa_density* out) {
+  if (!out) return fail(TDSA_ERR_ARG, "null out");
+  if (n_bins < 1) return fail(TDSA_ERR_ARG, "n_bins=%d", n_bins);
+  HIPCHK(hipSetDevice(device_id));
+  tdsa_density d = new (std::nothrow) tdsa_density_s();
+  if (!d) return fail(TDSA_ERR_NOMEM, "out of host memory");
+  d->device = device_id;
+  d->n = n_bins;
+  d->decay = decay;
+  const size_t hb = size_t(n_bins) * 512 * sizeof(float);
+  hipError_t e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc(&d->d_hist, hb);
+  if (e == hipSuccess) e = hipMalloc(&d->d_row, size_t(n_bins) * sizeof(float));
+  if (e == hipSuccess) e = hipMemsetAsync(d->d_hist, 0, hb, d->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+  if (e != hipSuccess) {
+    (void)tdsa_density_destroy(d);
+    return fail(TDSA_ERR_HIP, "density create: %s", hipGetErrorString(e));
+  }
+  *out = d;
+  return TDSA_OK;
+}
+
+int tdsa_density_destroy(tdsa_density d) {
+  if (!d) return TDSA_OK;
+  (void)hipSetDevice(d->device);
+  if (d->stream) (void)hipStreamSynchronize(d->stream);
+  if (d->d_hist) (void)hipFree(d->d_hist);
+  if (d->d_img) (void)hipFree(d->d_img);
+  if (d->d_row) (void)hipFree(d->d_row);
+  if (d->stream) (void)hipStreamDestroy(d->stream);
+  delete d;
+  return TDSA_OK;
+}
+
+int tdsa_density_set_decay(tdsa_density d, float decay) {
+  if (!d) return fail(TDSA_ERR_ARG, "null density");
+  d->decay = decay;
+  return TDSA_OK;
+}
+
+int tdsa_density_reset(tdsa_density d) {
+  if (!d) return fail(TDSA_ERR_ARG, "null density");
+  HIPCHK(hipSetDevice(d->device));
+  HIPCHK(hipMemsetAsync(d->d_hist, 0, size_t(d->n) * 512 * sizeof(float), d->stream));
+  HIPCHK(hipStreamSynchronize(d->stream));
+  return TDSA_OK;
+}
+
+// rows produced on plan p's stream (p may be NULL when the rows are otherwise known to be complete)
+int tdsa_density_update_dev(tdsa_density d, tdsa_plan p, const float* rows_dev, int n_rows) {
+  if (!d) return fail(TDSA_ERR_ARG, "null density");
+  if (n_rows == 0) return TDSA_OK;
+  if (!rows_dev || n_rows < 0) return fail(TDSA_ERR_ARG, "bad rows");
+  if (p && (p->device != d->device)) return fail(TDSA_ERR_ARG, "plan and histogram live on different devices");
+  HIPCHK(hipSetDevice(d->device));
+  if (p) {   // order after the producer: the plan's stream signals, ours waits
+    JOIN(p);
+    HIPCHK(hipEventRecord(p->ev_state, p->stream));
+    HIPCHK(hipStreamWaitEvent(d->stream, p->ev_state, 0));
+  }
+  HIPCHK(launch_density(rows_dev, n_rows, d->n, d->decay, d->d_hist, d->stream));
+  HIPCHK(hipStreamSynchronize(d->stream));
+  return TDSA_OK;
+}
+
+int tdsa_density_update(tdsa_density d, const float* row_host, int n) {
+  if (!d || !row_host) return fail(TDSA_ERR_ARG, "null argument");
+  if (n != d->n) return fail(TDSA_ERR_ARG, "row of %d bins, histogram has %d (re-create it: _ensure_hist)", n, d->n);
+  HIPCHK(hipSetDevice(d->device));
+  HIPCHK(hipMemcpyAsync(d->d_row, row_host, size_t(n) * sizeof(float), hipMemcpyHostToDevice, d->stream));
+  HIPCHK(launch_density(d->d_row, 1, d->n, d->decay, d->d_hist, d->stream));
+  HIPCHK(hipStreamSynchronize(d->stream));
+  return TDSA_OK;
+}
+
+int tdsa_density_read(tdsa_density d, float* hist_host, int as_log1p) {
+  if (!d || !hist_host) return fail(TDSA_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(d->device));
+  const size_t cnt = size_t(d->n) * 512;
+  const float* src = d->d_hist;
+  if (as_log1p) {
+    if (!d->d_img) HIPCHK(hipMalloc(&d->d_img, cnt * sizeof(float)));
+    HIPCHK(launch_log1p(d->d_hist, d->d_img, cnt, d->stream));
+    src = d->d_img;
+  }
+  HIPCHK(hipMemcpyAsync(hist_host, src, cnt * sizeof(float), hipMemcpyDeviceToHost, d->stream));
+  HIPCHK(hipStreamSynchronize(d->stream));
+  return TDSA_OK;
+}
+
+// ---- waterfall ring -----------------------------------------------------------------------------
+struct tdsa_waterfall_s {
+  int device = 0, n = 0, history = 0;
+  int ptr = 0;
+  bool have_last = false;
+  float* d_ring = nullptr;     // [2*history][n]
+  float* d_last = nullptr;     // [n] Waterfall._last_row
+  float* d_row = nullptr;      // staging for host rows
+  int* d_flags = nullptr;      // [cap] differs / destination per pushed row
+  int cap = 0;
+  std::vector<int> h_flags;
+  hipStream_t stream = nullptr;
+};
+
+int tdsa_waterfall_create(int device_id, int history_lines, int n_bins, float min_db, tdsa_waterfall* out) {
+  if (!out) return fail(TDSA_ERR_ARG, "null out");
+  if (history_lines < 1 || n_bins < 1) return fail(TDSA_ERR_ARG, "history=%d n_bins=%d", history_lines, n_bins);
+  HIPCHK(hipSetDevice(device_id));
+  tdsa_waterfall w = new (std::nothrow) tdsa_waterfall_s();
+  if (!w) return fail(TDSA_ERR_NOMEM, "out of host memory");
+  w->device = device_id;
+  w->n = n_bins;
+  w->history = history_lines;
+  const size_t cnt = size_t(2) * history_lines * n_bins;
+  hipError_t e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc(&w->d_ring, cnt * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&w->d_last, size_t(n_bins) * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&w->d_row, size_t(n_bins) * sizeof(float));
+  if (e == hipSuccess) e = launch_fill(w->d_ring, cnt, min_db, w->stream);    // np.full((2H, W), wf_min_db)
+  if (e == hipSuccess) e = hipStreamSynchronize(w->stream);
+  if (e != hipSuccess) {
+    (void)tdsa_waterfall_destroy(w);
+    return fail(TDSA_ERR_HIP, "waterfall create: %s", hipGetErrorString(e));
+  }
+  *out = w;
+  return TDSA_OK;
+}
+
+int tdsa_waterfall_destroy(tdsa_waterfall w) {
+  if (!w) return TDSA_OK;
+  (void)hipSetDevice(w->device);
+  if (w->stream) (void)hipStreamSynchronize(w->stream);
+  if (w->d_ring) (void)hipFree(w->d_ring);
+  if (w->d_last) (void)hipFree(w->d_last);
+  if (w->d_row) (void)hipFree(w->d_row);
+  if (w->d_flags) (void)hipFree(w->d_flags);
+  if (w->stream) (void)hipStreamDestroy(w->stream);
+  delete w;
+  return TDSA_OK;
+}
+
+static int waterfall_push_rows(tdsa_waterfall w, const float* rows_dev, int n_rows, int* n_new) {
+  if (n_rows > w->cap) {
+    if (w->d_flags) HIPCHK(hipFree(w->d_flags));
+    w->d_flags = nullptr;
+    w->cap = 0;
+    HIPCHK(hipMalloc(&w->d_flags, size_t(n_rows) * sizeof(int)));
+    w->cap = n_rows;
+  }
+  w->h_flags.resize(size_t(n_rows));
+  HIPCHK(launch_rows_differ(rows_dev, w->d_last, w->have_last ? 1 : 0, n_rows, w->n, w->d_flags, w->stream));
+  HIPCHK(hipMemcpyAsync(w->h_flags.data(), w->d_flags, size_t(n_rows) * sizeof(int), hipMemcpyDeviceToHost, w->stream));
+  HIPCHK(hipStreamSynchronize(w->stream));
+  // host walks the ring pointer exactly like _add_row: ptr = (ptr - 1) % H for every genuinely new row
+  int fresh = 0, last_new = -1;
+  for (int r = 0; r < n_rows; ++r) {
+    if (w->h_flags[size_t(r)]) {
+      w->ptr = (w->ptr - 1 + w->history) % w->history;
+      w->h_flags[size_t(r)] = w->ptr;
+      last_new = r;
+      ++fresh;
+    } else {
+      w->h_flags[size_t(r)] = -1;
+    }
+  }
+  // more new rows than history lines: later rows overwrite earlier ones, as they would one by one;
+  // keep only the last writer of every ring line so the scatter has no write races
+  if (fresh > w->history) {
+    std::vector<char> seen(size_t(w->history), 0);
+    for (int r = n_rows - 1; r >= 0; --r) {
+      const int dline = w->h_flags[size_t(r)];
+      if (dline < 0) continue;
+      if (seen[size_t(dline)]) w->h_flags[size_t(r)] = -1;
+      else seen[size_t(dline)] = 1;
+    }
+  }
+  if (fresh > 0) {
+    HIPCHK(hipMemcpyAsync(w->d_flags, w->h_flags.data(), size_t(n_rows) * sizeof(int), hipMemcpyHostToDevice, w->stream));
+    HIPCHK(launch_waterfall_scatter(rows_dev, w->d_flags, n_rows, w->n, w->history, w->d_ring, w->stream));
+    HIPCHK(hipMemcpyAsync(w->d_last, rows_dev + size_t(last_new) * w->n, size_t(w->n) * sizeof(float),
+                          hipMemcpyDeviceToDevice, w->stream));
+    w->have_last = true;
+    HIPCHK(hipStreamSynchronize(w->stream));
+  }
+  if (n_new) *n_new = fresh;
+  return TDSA_OK;
+}
+
+int tdsa_waterfall_push_dev(tdsa_waterfall w, tdsa_plan p, const float* rows_dev, int n_rows, int* n_new) {
+  if (!w) return fail(TDSA_ERR_ARG, "null waterfall");
+  if (n_new) *n_new = 0;
+  if (n_rows == 0) return TDSA_OK;
+  if (!rows_dev || n_rows < 0) return fail(TDSA_ERR_ARG, "bad rows");
+  if (p && p->device != w->device) return fail(TDSA_ERR_ARG, "plan and waterfall live on different devices");
+  HIPCHK(hipSetDevice(w->device));
+  if (p) {
+    JOIN(p);
+    HIPCHK(hipEventRecord(p->ev_state, p->stream));
+    HIPCHK(hipStreamWaitEvent(w->stream, p->ev_state, 0));
+  }
+  return waterfall_push_rows(w, rows_dev, n_rows, n_new);
+}
+
+int tdsa_waterfall_push(tdsa_waterfall w, const float* row_host, int n, int* is_new) {
+  if (!w || !row_host) return fail(TDSA_ERR_ARG, "null argument");
+  if (n != w->n) return fail(TDSA_ERR_ARG, "row of %d bins, ring has %d", n, w->n);
+  HIPCHK(hipSetDevice(w->device));
+  HIPCHK(hipMemcpyAsync(w->d_row, row_host, size_t(n) * sizeof(float), hipMemcpyHostToDevice, w->stream));
+  return waterfall_push_rows(w, w->d_row, 1, is_new);
+}
+
+int tdsa_waterfall_view(tdsa_waterfall w, float* view_host, int* ptr) {
+  if (!w) return fail(TDSA_ERR_ARG, "null waterfall");
+  HIPCHK(hipSetDevice(w->device));
+  if (view_host) {   // _display_view: buf[ptr : ptr + H], newest row first
+    HIPCHK(hipMemcpyAsync(view_host, w->d_ring + size_t(w->ptr) * w->n, size_t(w->history) * w->n * sizeof(float),
+                          hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(hipStreamSynchronize(w->stream));
+  }
+  if (ptr) *ptr = w->ptr;
+  return TDSA_OK;
+}

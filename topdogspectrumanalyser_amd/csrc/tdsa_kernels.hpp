@@ -119,4 +119,17 @@ hipError_t launch_big_finish(const double* sum, double* mean_out, int count, int
                              float log_floor, float cal_db, const float* tare, float* out_db, float* hold_max,
                              float* hold_min, int max_first, int min_first, hipStream_t s);
 
+
+// ---- trace analytics / accumulators (tdsa_analytics.hip) ---------------------------------------------
+hipError_t launch_rows_stats(const float* rows, int n_rows, int n, int band_lo, int band_hi, double bin_width,
+                             float* peak_db, int* peak_bin, double* band_db, hipStream_t s);
+hipError_t launch_top_peaks(const float* rows, int n_rows, int n, int n_peaks, int min_sep, float excursion,
+                            int* out_bins, float* out_db, hipStream_t s);
+hipError_t launch_density(const float* rows, int n_rows, int n, float decay, float* hist, hipStream_t s);
+hipError_t launch_log1p(const float* in, float* out, size_t count, hipStream_t s);
+hipError_t launch_rows_differ(const float* rows, const float* last, int have_last, int n_rows, int n, int* differs,
+                              hipStream_t s);
+hipError_t launch_waterfall_scatter(const float* rows, const int* dst, int n_rows, int n, int history, float* ring,
+                                    hipStream_t s);
+
 }  // namespace tdsa
