@@ -205,24 +205,36 @@ constexpr int kAmpBins = 512;
 constexpr int kDensFreq = 16;
 constexpr float kAmpMin = -200.0f, kAmpRng = 300.0f;
 
+constexpr int kDensRows = kAmpBins / kDensFreq;   // rows whose bin indices one pass of the workgroup forms
+
 __global__ void __launch_bounds__(kAmpBins) density_kernel(const float* __restrict__ rows, int n_rows, int n,
                                                            float decay, float* hist) {
+  __shared__ int s_idx[kDensRows][kDensFreq];
   const int f0 = blockIdx.x * kDensFreq;
   const int a = threadIdx.x;
+  const int rr = a / kDensFreq, jj = a % kDensFreq;     // this thread forms the index of (row r0 + rr, bin f0 + jj)
   float h[kDensFreq];
 #pragma unroll
   for (int j = 0; j < kDensFreq; ++j) h[j] = (f0 + j < n) ? hist[(size_t)(f0 + j) * kAmpBins + a] : 0.0f;
   const bool do_decay = decay < 1.0f;
-  for (int r = 0; r < n_rows; ++r) {
-    const float* row = rows + (size_t)r * n + f0;
+  for (int r0 = 0; r0 < n_rows; r0 += kDensRows) {
+    int idx = -1;
+    if (r0 + rr < n_rows && f0 + jj < n) {
+      const float v = rows[(size_t)(r0 + rr) * n + f0 + jj];
+      const float x = (v - kAmpMin) / kAmpRng * float(kAmpBins);
+      // astype(int32) truncates toward zero; NaN and anything outside [0, AMP_BINS) is dropped
+      if (v == v && x > -1.0f && x < float(kAmpBins)) idx = int(x);
+    }
+    __syncthreads();                 // previous chunk fully consumed
+    s_idx[rr][jj] = idx;
+    __syncthreads();
+    const int lim = n_rows - r0 < kDensRows ? n_rows - r0 : kDensRows;
+    for (int r = 0; r < lim; ++r) {
 #pragma unroll
-    for (int j = 0; j < kDensFreq; ++j) {
-      if (do_decay) h[j] *= decay;
-      if (f0 + j < n) {
-        const float v = row[j];
-        const float x = (v - kAmpMin) / kAmpRng * float(kAmpBins);
-        // astype(int32) truncates toward zero; NaN and anything outside [0, AMP_BINS) is dropped
-        if (v == v && x > -1.0f && x < float(kAmpBins) && int(x) == a) h[j] += 1.0f;
+      for (int j = 0; j < kDensFreq; ++j) {
+        float t = do_decay ? __fmul_rn(h[j], decay) : h[j];      // two roundings, like `hist *= d; hist[..] += 1`
+        if (s_idx[r][j] == a) t = __fadd_rn(t, 1.0f);
+        h[j] = t;
       }
     }
   }
