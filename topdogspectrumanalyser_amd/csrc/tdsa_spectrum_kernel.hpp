@@ -375,23 +375,46 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       } else if (p.dc_mode == DC_TRACKED && active) {
         const c32 sv = p.dc_sub[frame]; sub_re = sv.x; sub_im = sv.y;
       }
-    } else if (p.dc_mode == DC_FRAME_MEAN) {
-      // generic path (complex64 input, or several frames per wave): double sums, shuffles
-      double s_re = 0.0, s_im = 0.0;
-      if constexpr (IN_C64) {
-        static_for<0, 16>([&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          s_re += double(v[i].x); s_im += double(v[i].y);
-        });
-      } else {
-        unsigned si = 0, sq = 0;
-        static_for<0, NRAW>([&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          si = __builtin_amdgcn_udot4(raw[i], 0x00010001u, si, false);
-          sq = __builtin_amdgcn_udot4(raw[i], 0x01000100u, sq, false);
-        });
-        s_re = double(si); s_im = double(sq);
+    } else if (!IN_C64 && p.dc_mode == DC_FRAME_MEAN) {
+      // byte formats, several frames per wave (N < 1024): exact integer sums again, reduced over the
+      // SG rows of the frame inside one 16-lane DPP row, then across the two half-threads
+      unsigned si = 0, sq = 0;
+      static_for<0, NRAW>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        si = __builtin_amdgcn_udot4(raw[i], 0x00010001u, si, false);
+        sq = __builtin_amdgcn_udot4(raw[i], 0x01000100u, sq, false);
+      });
+      int ti = int(si), tq = int(sq);
+      if constexpr (SG >= 2) {
+        ti += __builtin_amdgcn_update_dpp(0, ti, 0xB1, 0xf, 0xf, false);
+        tq += __builtin_amdgcn_update_dpp(0, tq, 0xB1, 0xf, 0xf, false);
       }
+      if constexpr (SG >= 4) {
+        ti += __builtin_amdgcn_update_dpp(0, ti, 0x4E, 0xf, 0xf, false);
+        tq += __builtin_amdgcn_update_dpp(0, tq, 0x4E, 0xf, 0xf, false);
+      }
+      if constexpr (SG >= 8) {
+        ti += __builtin_amdgcn_update_dpp(0, ti, 0x141, 0xf, 0xf, false);
+        tq += __builtin_amdgcn_update_dpp(0, tq, 0x141, 0xf, 0xf, false);
+      }
+      if constexpr (SG >= 16) {
+        ti += __builtin_amdgcn_update_dpp(0, ti, 0x140, 0xf, 0xf, false);
+        tq += __builtin_amdgcn_update_dpp(0, tq, 0x140, 0xf, 0xf, false);
+      }
+      ti += __shfl_xor(ti, 32);
+      tq += __shfl_xor(tq, 32);
+      TDSA_SYNC();
+      sub_re = float(ti) * (1.0f / N);     // exact: sums < 2^24, N a power of two
+      sub_im = float(tq) * (1.0f / N);
+      if (p.dc_state != nullptr && frame == p.n_frames - 1 && t == 0 && h == 0)
+        *p.dc_state = c32{(sub_re - p.in_off) * p.in_scale, (sub_im - p.in_off) * p.in_scale};
+    } else if (p.dc_mode == DC_FRAME_MEAN) {
+      // complex64 input: double sums, shuffles
+      double s_re = 0.0, s_im = 0.0;
+      static_for<0, 16>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        s_re += double(v[i].x); s_im += double(v[i].y);
+      });
       constexpr int W = SG < 32 ? SG : 32;                  // rows of this frame inside the half-wave
       s_re = seg_sum<W>(s_re); s_im = seg_sum<W>(s_im);
       s_re += __shfl_xor(s_re, 32); s_im += __shfl_xor(s_im, 32);   // the other half-thread's rows
@@ -630,15 +653,43 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   // (Issuing the bulk of them before the last frame to hide the tail was tried: the extra live state
   //  pushed the kernel into 39 scratch spills and cost more than the ~6 us tail it removed.)
   if constexpr (HOLD != 0) {
-    const long long prow = t + 8 * h * SG;
+    const int prow = t + 8 * h * SG;
     const bool any = (u1 > u0) && (FPW == 1 || u0 * FPW + slot < p.n_frames);
-    if (any) {
-      static_for<0, 16>([&](auto ic) {
-        constexpr int q = decltype(ic)::value;
-        constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
-        if constexpr ((HOLD & 1) != 0) atomic_fmax_dev(p.part_max + prow + kcs * SG, hmax[q]);
-        if constexpr ((HOLD & 2) != 0) atomic_fmin_dev(p.part_min + prow + kcs * SG, hmin[q]);
-      });
+    if constexpr (FPW == 1) {
+      if (any) {
+        static_for<0, 16>([&](auto ic) {
+          constexpr int q = decltype(ic)::value;
+          constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
+          if constexpr ((HOLD & 1) != 0) atomic_fmax_dev(p.part_max + prow + kcs * SG, hmax[q]);
+          if constexpr ((HOLD & 2) != 0) atomic_fmin_dev(p.part_min + prow + kcs * SG, hmin[q]);
+        });
+      }
+    } else {
+      // several frames per workgroup hold the same bins: fold them in LDS first, then one global atomic
+      // per bin and workgroup (at N = 64 the direct version put 65536 atomics on every address)
+      float* lmax = reinterpret_cast<float*>(smem);
+      float* lmin = lmax + N;
+      __syncthreads();
+      for (int i = tid; i < N; i += C::WGT) {
+        lmax[i] = -INFINITY;
+        lmin[i] = INFINITY;
+      }
+      __syncthreads();
+      if (any) {
+        static_for<0, 16>([&](auto ic) {
+          constexpr int q = decltype(ic)::value;
+          constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
+          if constexpr ((HOLD & 1) != 0) atomic_fmax_dev(lmax + prow + kcs * SG, hmax[q]);
+          if constexpr ((HOLD & 2) != 0) atomic_fmin_dev(lmin + prow + kcs * SG, hmin[q]);
+        });
+      }
+      __syncthreads();
+      if (u1 > u0) {
+        for (int i = tid; i < N; i += C::WGT) {
+          if constexpr ((HOLD & 1) != 0) atomic_fmax_dev(p.part_max + i, lmax[i]);
+          if constexpr ((HOLD & 2) != 0) atomic_fmin_dev(p.part_min + i, lmin[i]);
+        }
+      }
     }
   }
 }
