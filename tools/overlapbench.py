@@ -2,6 +2,9 @@
 """Developer experiment: do consecutive frame-kernel launches overlap usefully when issued on two streams?
 Two plans (each with its own stream) take alternate steps; compares wall time per step with one plan."""
 import ctypes as C
+import os as _os
+if _os.environ.get("TDSA_TORCH_FIRST"):
+    import torch  # noqa: F401  (same HIP runtime as bench.py)
 import os
 import sys
 import time
@@ -29,21 +32,39 @@ def main():
     for _ in range(3):
         e = SpectrumEngine(n, max_frames=F)
         e.set_window(np.hanning(n).astype(np.float32))
-        e.configure(db_mode="mag", log_floor=1e-12, dc_alpha=1.0, hold_max=True)
+        e.configure(db_mode="mag", log_floor=1e-12, dc_alpha=1.0, hold_max=bool(int(os.environ.get("HOLD", "1"))))
         engs.append(e)
-    for k in (1, 2, 3):
+    def run_plans(k):
         use = engs[:k]
-        for i in range(10):
-            use[i % k].process_device(nat.IN_I8, ins[i % ring], ns, hop, F, outs[i % ring])
         for e in use:
-            e.synchronize()
-        t0 = time.perf_counter()
+            e.set_overlap(1)
         for i in range(steps):
             use[i % k].process_device(nat.IN_I8, ins[i % ring], ns, hop, F, outs[i % ring])
         for e in use:
             e.synchronize()
-        dt = (time.perf_counter() - t0) / steps
-        print(f"{k} stream(s): {dt*1e6:.1f} us per step -> {F/dt/1e6:.2f} Mframes/s")
+
+    def run_overlap(k):
+        e = engs[0]
+        e.set_overlap(k)
+        for i in range(steps):
+            e.process_device(nat.IN_I8, ins[i % ring], ns, hop, F, outs[i % ring])
+        e.synchronize()
+
+    configs = [("1 plan, 1 stream", lambda: run_overlap(1)), ("1 plan, set_overlap(2)", lambda: run_overlap(2)),
+               ("1 plan, set_overlap(3)", lambda: run_overlap(3)), ("1 plan, set_overlap(4)", lambda: run_overlap(4)),
+               ("2 plans", lambda: run_plans(2)), ("3 plans", lambda: run_plans(3))]
+    for _ in range(5):                       # warm the clocks up
+        run_overlap(1)
+    acc = {name: [] for name, _ in configs}
+    for rep in range(4):                     # interleaved repetitions: drift hits every configuration alike
+        for name, fn in configs:
+            t0 = time.perf_counter()
+            fn()
+            acc[name].append((time.perf_counter() - t0) / steps)
+    for name, _ in configs:
+        v = np.array(acc[name]) * 1e6
+        print(f"{name:24s}: median {np.median(v):6.1f} us per step (min {v.min():.1f}, max {v.max():.1f}) -> "
+              f"{F/np.median(v):.2f} Mframes/s")
 
 
 if __name__ == "__main__":

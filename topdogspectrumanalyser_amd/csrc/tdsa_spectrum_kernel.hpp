@@ -657,11 +657,26 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     const bool any = (u1 > u0) && (FPW == 1 || u0 * FPW + slot < p.n_frames);
     if constexpr (FPW == 1) {
       if (any) {
+        // The traces only ever grow (shrink), so a value read earlier - even a stale one from this XCD's
+        // L2 - is a valid lower (upper) bound: the atomic is issued only when this workgroup would
+        // actually move the trace.  In a long capture that is rare, and the 4.2 M device-scope atomics
+        // per C3 launch (5-10 us) all but disappear.
+        float cmax[(HOLD & 1) ? 16 : 1], cmin[(HOLD & 2) ? 16 : 1];
         static_for<0, 16>([&](auto ic) {
           constexpr int q = decltype(ic)::value;
           constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
-          if constexpr ((HOLD & 1) != 0) atomic_fmax_dev(p.part_max + prow + kcs * SG, hmax[q]);
-          if constexpr ((HOLD & 2) != 0) atomic_fmin_dev(p.part_min + prow + kcs * SG, hmin[q]);
+          if constexpr ((HOLD & 1) != 0) cmax[q] = p.part_max[prow + kcs * SG];
+          if constexpr ((HOLD & 2) != 0) cmin[q] = p.part_min[prow + kcs * SG];
+        });
+        static_for<0, 16>([&](auto ic) {
+          constexpr int q = decltype(ic)::value;
+          constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
+          if constexpr ((HOLD & 1) != 0) {
+            if (hmax[q] > cmax[q]) atomic_fmax_dev(p.part_max + prow + kcs * SG, hmax[q]);
+          }
+          if constexpr ((HOLD & 2) != 0) {
+            if (hmin[q] < cmin[q]) atomic_fmin_dev(p.part_min + prow + kcs * SG, hmin[q]);
+          }
         });
       }
     } else {
@@ -686,8 +701,12 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       __syncthreads();
       if (u1 > u0) {
         for (int i = tid; i < N; i += C::WGT) {
-          if constexpr ((HOLD & 1) != 0) atomic_fmax_dev(p.part_max + i, lmax[i]);
-          if constexpr ((HOLD & 2) != 0) atomic_fmin_dev(p.part_min + i, lmin[i]);
+          if constexpr ((HOLD & 1) != 0) {
+            if (lmax[i] > p.part_max[i]) atomic_fmax_dev(p.part_max + i, lmax[i]);
+          }
+          if constexpr ((HOLD & 2) != 0) {
+            if (lmin[i] < p.part_min[i]) atomic_fmin_dev(p.part_min + i, lmin[i]);
+          }
         }
       }
     }
