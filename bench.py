@@ -44,8 +44,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--config", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--ring", type=int, default=8, help="distinct input/output buffers cycled through")
     ap.add_argument("--streams", type=int, default=3,
