@@ -50,6 +50,7 @@ def main() -> None:
     ap.add_argument("--ring", type=int, default=8, help="distinct input/output buffers cycled through")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams consecutive steps rotate over (tdsa_set_overlap); 1 = strictly serial")
+    ap.add_argument("--preroll-seconds", type=float, default=0.4, help="untimed load before the warm-up steps")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -122,6 +123,15 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # clocks: an idle MI355X needs a few hundred ms of load before shader/fabric clocks settle; this
+    # untimed pre-roll keeps short --steps/--warmup runs from measuring the ramp
+    t_pre = time.perf_counter()
+    i_pre = 0
+    while time.perf_counter() - t_pre < args.preroll_seconds:
+        for _ in range(50):
+            step(i_pre)
+            i_pre += 1
+        eng.synchronize()
     for i in range(args.warmup):
         step(i)
     fence()
