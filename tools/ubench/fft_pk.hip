@@ -30,6 +30,22 @@ __global__ void __launch_bounds__(1024, 1) k_packed(const c32* in, c32* out, int
   }
   for (int i = 0; i < 16; ++i) out[(blockIdx.x * 1024 + threadIdx.x) * 16 + i] = to_c(v[i]);
 }
+// straight-line body of REP passes (code size ~ REP x 1.8 KB), 16 waves per CU, all at their own PC
+template <int REP>
+__global__ void __launch_bounds__(1024, 1) k_big(const c32* in, c32* out, int iters) {
+  c32 v[16], w[16];
+  for (int i = 0; i < 16; ++i) { v[i] = in[threadIdx.x + 1024 * i]; w[i] = in[threadIdx.x + 7 + 1024 * i]; }
+  // de-phase the waves so that they do not walk the code in lock step
+  for (int d = 0; d < (threadIdx.x >> 6) * 37; ++d) asm volatile("s_nop 7");
+  for (int it = 0; it < iters; ++it) {
+    static_for<0, REP>([&](auto rc) {
+      static_for<0, 16>([&](auto ic) { constexpr int i = decltype(ic)::value; opq(w[i]); v[i] = cmul(v[i], w[i]); });
+      dif<16, 0, 16>(v);
+      static_for<0, 16>([&](auto ic) { opq(v[decltype(ic)::value]); });
+    });
+  }
+  for (int i = 0; i < 16; ++i) out[(blockIdx.x * 1024 + threadIdx.x) * 16 + i] = v[i];
+}
 // correctness: one pass of each on the same data
 __global__ void k_check(const c32* in, float* err) {
   c32 a[16]; p32 b[16];
@@ -67,5 +83,15 @@ int main() {
   printf("scalar 16 cmul + dif<16>: %.3f ms -> %6.1f ns\n", ms, ms * 1e6 / 4000 / 4);
   ms = timeit([&](int it) { k_packed<true><<<256, 1024>>>(in, out, it); });
   printf("packed 16 pmul + difp   : %.3f ms -> %6.1f ns\n", ms, ms * 1e6 / 4000 / 4);
+  ms = timeit([&](int it) { k_big<1><<<256, 1024>>>(in, out, it); });
+  printf("straight-line x1  (%4.1f KB): %.3f ms -> %6.1f ns per pass\n", 1.8, ms, ms * 1e6 / 4000 / 4);
+  ms = timeit([&](int it) { k_big<4><<<256, 1024>>>(in, out, it / 4); });
+  printf("straight-line x4  (%4.1f KB): %.3f ms -> %6.1f ns per pass\n", 7.2, ms, ms * 1e6 / 4000 / 4);
+  ms = timeit([&](int it) { k_big<8><<<256, 1024>>>(in, out, it / 8); });
+  printf("straight-line x8  (%4.1f KB): %.3f ms -> %6.1f ns per pass\n", 14.4, ms, ms * 1e6 / 4000 / 4);
+  ms = timeit([&](int it) { k_big<16><<<256, 1024>>>(in, out, it / 16); });
+  printf("straight-line x16 (%4.1f KB): %.3f ms -> %6.1f ns per pass\n", 28.8, ms, ms * 1e6 / 4000 / 4);
+  ms = timeit([&](int it) { k_big<32><<<256, 1024>>>(in, out, it / 32); });
+  printf("straight-line x32 (%4.1f KB): %.3f ms -> %6.1f ns per pass\n", 57.6, ms, ms * 1e6 / 4000 / 4);
   return 0;
 }
