@@ -50,10 +50,6 @@ LaunchGeom spectrum_geometry(int log2n, int n_frames, int num_cu);
 hipError_t launch_spectrum(int log2n, int in_c64, const SpecParams& p, const LaunchGeom& g,
                            hipStream_t s);
 
-// fold [rows][n] partial hold traces into the persistent state
-hipError_t launch_hold_reduce(const float* part_max, const float* part_min, int rows, int n,
-                              float* state_max, float* state_min, hipStream_t s);
-
 struct AvgParams {
   const float* lin;       // [F][N] linear power (already PSD-scaled)
   int n_frames, n;

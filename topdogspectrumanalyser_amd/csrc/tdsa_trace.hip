@@ -1,6 +1,4 @@
 // tdsa_trace.hip - trace-domain kernels around the frame kernel:
-//   hold_reduce   : fold per-workgroup partial max/min hold rows into the persistent hold traces
-//                   (core/display_data_processor.py:371-395: np.fmax / np.fmin in the dB domain)
 //   avg_scan      : TraceAverager recurrence over the frames of a batch, one bin per thread, float64
 //                   state (utils/signal_processing.py:35-61) + dB + cal offset + tare + hold
 //   frame_sums / dc_track : the HackRF DC tracker for dc_alpha < 1 (hackrf_samples.py:360-365)
@@ -20,46 +18,6 @@ __device__ __forceinline__ void atomic_fmax(float* addr, float v) {
 __device__ __forceinline__ void atomic_fmin(float* addr, float v) {
   if (v >= 0.f) atomicMin(reinterpret_cast<int*>(addr), __float_as_int(v));
   else atomicMax(reinterpret_cast<unsigned*>(addr), __float_as_uint(v));
-}
-
-// grid = (n/256 column groups of 4 bins x 64 lanes, row slices): every thread folds kRowsPerSlice rows of
-// four adjacent bins with independent 16-byte loads, then merges into the state with one atomic per bin.
-constexpr int kRowsPerSlice = 16;
-__global__ void __launch_bounds__(64) hold_reduce_kernel(const float* __restrict__ part_max,
-                                                         const float* __restrict__ part_min, int rows,
-                                                         int n, float* state_max, float* state_min) {
-  const int k = (blockIdx.x * 64 + threadIdx.x) * 4;
-  if (k >= n) return;
-  const int r0 = blockIdx.y * kRowsPerSlice;
-  const int r1 = r0 + kRowsPerSlice < rows ? r0 + kRowsPerSlice : rows;
-  if (part_max != nullptr) {
-    float4 m = float4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-#pragma unroll 8
-    for (int r = r0; r < r1; ++r) {
-      const float4 v = *reinterpret_cast<const float4*>(part_max + (size_t)r * n + k);
-      m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
-    }
-    atomic_fmax(state_max + k, m.x); atomic_fmax(state_max + k + 1, m.y);
-    atomic_fmax(state_max + k + 2, m.z); atomic_fmax(state_max + k + 3, m.w);
-  }
-  if (part_min != nullptr) {
-    float4 m = float4{INFINITY, INFINITY, INFINITY, INFINITY};
-#pragma unroll 8
-    for (int r = r0; r < r1; ++r) {
-      const float4 v = *reinterpret_cast<const float4*>(part_min + (size_t)r * n + k);
-      m.x = fminf(m.x, v.x); m.y = fminf(m.y, v.y); m.z = fminf(m.z, v.z); m.w = fminf(m.w, v.w);
-    }
-    atomic_fmin(state_min + k, m.x); atomic_fmin(state_min + k + 1, m.y);
-    atomic_fmin(state_min + k + 2, m.z); atomic_fmin(state_min + k + 3, m.w);
-  }
-}
-
-hipError_t launch_hold_reduce(const float* part_max, const float* part_min, int rows, int n,
-                              float* state_max, float* state_min, hipStream_t s) {
-  const dim3 grid((n / 4 + 63) / 64, (rows + kRowsPerSlice - 1) / kRowsPerSlice);
-  hipLaunchKernelGGL(hold_reduce_kernel, grid, dim3(64), 0, s, part_max, part_min, rows, n, state_max,
-                     state_min);
-  return hipGetLastError();
 }
 
 // One thread per bin walks the batch in frame order (the recurrence is order dependent: SURVEY.md 7).
