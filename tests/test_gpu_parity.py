@@ -818,3 +818,55 @@ def test_stream_spectra_helper(pkg):
             list(stream_spectra(e, [np.zeros(2 * 100, dtype=np.int8)]))
         with pytest.raises(ValueError):
             list(stream_spectra(e, [chunks[2], chunks[0]], hop=hop))       # later chunk larger than the slot
+
+
+# ------------------------------------------------------------------------------------------------
+# seeded random sweep over sizes x formats x hops x modes: a wider net than the hand-picked cases
+# ------------------------------------------------------------------------------------------------
+def _random_case(rng):
+    nfft = int(2 ** rng.integers(6, 15))
+    nf = int(rng.integers(1, 24))
+    hop = int(rng.choice([nfft, nfft // 2, nfft // 4 + 1, int(rng.integers(1, 2 * nfft))]))
+    branch = str(rng.choice(["hackrf", "rtl"]))
+    avg = [("off", 1), ("exp", int(rng.integers(2, 9))), ("lin", int(rng.integers(2, 30)))][int(rng.integers(0, 3))]
+    return dict(nfft=nfft, nf=nf, hop=hop, branch=branch, avg=avg, psd=bool(rng.integers(0, 2)),
+                dc_alpha=float(rng.choice([1.0, 1.0, 0.25])), cal=float(rng.choice([0.0, -0.8087, 3.5])),
+                window=str(rng.choice(["hanning", "hamming", "rectangle"])), seed=int(rng.integers(1, 1 << 30)))
+
+
+@pytest.mark.parametrize("case_id", range(48))
+def test_random_configuration_sweep(pkg, case_id):
+    c = _random_case(np.random.default_rng(4242 + case_id))
+    nfft, nf, hop = c["nfft"], c["nf"], c["hop"]
+    iq = so.synth_iq_int8(hop * (nf - 1) + nfft, nfft, seed=c["seed"])
+    fs = 20e6 if c["branch"] == "hackrf" else 2e6
+    averaging = c["avg"][0] != "off" and c["avg"][1] > 1
+    if c["branch"] == "hackrf":
+        gold, gmax, gmin = so.hackrf_batch(iq, nfft, hop, fs, use_psd=c["psd"], avg=c["avg"], dc_alpha=c["dc_alpha"],
+                                           cal_offset_db=c["cal"], precision="gold")
+        window, dc = so.hackrf_window(nfft), c["dc_alpha"]
+    else:
+        gold, gmax, gmin = so.rtl_batch(iq, nfft, hop, fs, window=c["window"], use_psd=c["psd"], avg=c["avg"],
+                                        cal_offset_db=c["cal"], precision="gold")
+        window, dc = so.rtl_window(c["window"], nfft), -1.0
+    if c["psd"]:
+        mode = dict(db_mode="pow", power_scale=1.0 / (fs * nfft), log_floor=so.LOG_FLOOR)
+    elif averaging or c["branch"] == "rtl":
+        mode = dict(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR)
+    else:
+        mode = dict(db_mode="mag", log_floor=so.LOG_FLOOR)
+    with pkg.SpectrumEngine(nfft, max_frames=nf) as e:
+        e.set_window(window)
+        e.configure(dc_alpha=dc, avg=c["avg"], cal_offset_db=c["cal"], hold_max=True, hold_min=True, **mode)
+        cut = int(np.random.default_rng(case_id).integers(0, nf + 1))       # state must carry across calls
+        parts = []
+        if cut > 0:
+            parts.append(e.process(iq[: 2 * (hop * (cut - 1) + nfft)], hop=hop, n_frames=cut))
+        if cut < nf:
+            parts.append(e.process(iq[2 * hop * cut:], hop=hop, n_frames=nf - cut))
+        out = np.concatenate(parts)
+        mx, mn = e.hold()
+    what = f"case {case_id}: {c}"
+    _check(out, gold, what)
+    _check(mx, gmax, what + " max hold")
+    _check(mn, gmin, what + " min hold")
