@@ -41,6 +41,37 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
 
+def cpu_all_cores(wl: dict, workers: int, seconds: float) -> dict:
+    """SURVEY.md 8(d) CPU baseline (ii): the same numpy restatement in `workers` independent processes
+    (one frame stream each, started together), frames/s = sum of frames / slowest worker's wall time."""
+    import subprocess
+    cmd = [sys.executable, "-m", "oracle.cpu_worker", wl["branch"] if wl["branch"] != "welch" else "rtl",
+           str(wl["nfft"]), str(wl["hop"]), str(wl["fs"]), str(seconds)]
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen(cmd + [str(100 + i)], cwd=ROOT, env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                              text=True) for i in range(workers)]
+    try:
+        for p in procs:
+            if p.stdout.readline().strip() != "ready":
+                raise RuntimeError("cpu worker failed to start")
+        for p in procs:
+            p.stdin.write("go\n")
+            p.stdin.flush()
+        frames, slowest = 0, 0.0
+        for p in procs:
+            n, dt = p.stdout.readline().split()
+            frames += int(n)
+            slowest = max(slowest, float(dt))
+            p.wait(timeout=30)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return {"value": frames / slowest, "unit": "frames/s", "cores": workers, "kind": "port",
+            "sample": f"{workers} processes x {seconds:.0f} s of the numpy restatement, one synthetic frame stream each",
+            "host_cores_available": os.cpu_count()}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -51,8 +82,11 @@ def main() -> None:
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams consecutive steps rotate over (tdsa_set_overlap); 1 = strictly serial")
     ap.add_argument("--preroll-seconds", type=float, default=0.4, help="untimed load before the warm-up steps")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the single-thread CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-workers", type=int, default=min(32, os.cpu_count() or 1),
+                    help="processes of the all-cores CPU baseline leg (0 = skip)")
+    ap.add_argument("--cpu-pool-seconds", type=float, default=6.0)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -220,8 +254,9 @@ def main() -> None:
             gold = so.RtlBranchOracle(nfft, wl["fs"], precision="gold")
         t_cpu0 = time.perf_counter()
         done = 0
-        while done < frames and time.perf_counter() - t_cpu0 < args.cpu_seconds:
-            x = so.unpack_iq_int8(base[2 * done * hop: 2 * (done * hop + nfft)])
+        while time.perf_counter() - t_cpu0 < args.cpu_seconds:      # the same second of IQ, over and over
+            k = done % frames
+            x = so.unpack_iq_int8(base[2 * k * hop: 2 * (k * hop + nfft)])
             br.power_levels(x)
             done += 1
         cpu_s = time.perf_counter() - t_cpu0
@@ -236,11 +271,14 @@ def main() -> None:
             rel, ddb = so.parity_metrics(outs[0][k].cpu().numpy(), g)
             worst_rel, worst_db = max(worst_rel, rel), max(worst_db, ddb)
         result["cpu_baseline"] = {"value": done / cpu_s, "unit": "frames/s", "cores": 1, "kind": "port",
-                                  "sample": f"first {done} frames of the same second, single thread, numpy "
-                                            f"{np.__version__} restatement of get_power_levels incl. int8 unpack",
+                                  "sample": f"{done} frames ({args.cpu_seconds:.0f} s) cycling through the same second "
+                                            f"of IQ, single thread, numpy {np.__version__} restatement of "
+                                            f"get_power_levels incl. int8 unpack",
                                   "host_cores_available": os.cpu_count()}
         result["parity"] = {"max_rel_power_err": worst_rel, "max_db_err_top60dB": worst_db,
                             "frames_checked": 4, "against": "float64 gold oracle"}
+        if args.cpu_workers > 0:
+            result["cpu_baseline_all_cores"] = cpu_all_cores(wl, args.cpu_workers, args.cpu_pool_seconds)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
