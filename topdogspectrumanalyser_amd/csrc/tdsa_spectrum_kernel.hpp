@@ -147,9 +147,21 @@ constexpr float kMagExactBelow = 1e-8f;                  // |X|^2 below this: th
 #ifndef TDSA_ABLATE
 #define TDSA_ABLATE 0
 #endif
-#define TDSA_SYNC()                                  \
-  do {                                               \
-    if constexpr ((TDSA_ABLATE & 1) == 0) __syncthreads(); \
+// Phase boundary inside the frame loop.  When a frame lives inside one wave (N <= 1024) everything the
+// phases exchange through LDS is private to that wave: its DS operations execute in order, so only the
+// compiler has to be kept from reordering across the boundary and the waves of a workgroup run free of
+// each other.  Larger frames span several waves and need the workgroup barrier.
+#define TDSA_SYNC()                                                        \
+  do {                                                                     \
+    if constexpr ((TDSA_ABLATE & 1) == 0) {                                \
+      if constexpr (C::TPF <= 64) {                                        \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");             \
+        __builtin_amdgcn_wave_barrier();                                   \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");             \
+      } else {                                                             \
+        __syncthreads();                                                   \
+      }                                                                    \
+    }                                                                      \
   } while (0)
 
 #ifdef TDSA_TIMELINE
