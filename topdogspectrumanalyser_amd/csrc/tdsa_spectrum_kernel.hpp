@@ -47,7 +47,12 @@ struct Cfg {
   static constexpr int NWAVE = WGT / 64;
   static constexpr int TWM = (NPASS == 3) ? 32 * A : 0;   // middle-pass twiddle table entries [b][ka]
   static constexpr size_t DATA_BYTES = size_t(FPW) * NPAD * sizeof(c32);
-  static constexpr size_t LDS_BYTES = DATA_BYTES + size_t(TWM) * sizeof(c32) + NWAVE * 2 * sizeof(double);
+  // Frames that live inside one wave (N <= 1024) run without workgroup barriers, so nothing absorbs the
+  // wait for the previous frame's stores that a global window load behind them would pick up (gfx9 counts
+  // loads and stores in one in-order vmcnt): those sizes keep the window table in LDS instead.
+  static constexpr bool WIN_LDS = TPF <= 64;
+  static constexpr size_t WIN_BYTES = WIN_LDS ? size_t(N) * sizeof(float) : 0;
+  static constexpr size_t LDS_BYTES = DATA_BYTES + size_t(TWM) * sizeof(c32) + NWAVE * 2 * sizeof(double) + WIN_BYTES;
   static constexpr size_t LDS_ALLOC = LDS_BYTES
 #ifdef TDSA_TIMELINE
       + 16 * 8 * 16 * 8
@@ -257,6 +262,11 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
 
   // ---- frame-invariant per-thread state ---------------------------------------------------------
   const rsrc_t win_rsrc = make_rsrc(p.window, N * 4u);
+  float* win_lds = reinterpret_cast<float*>(smem + C::LDS_BYTES - C::WIN_BYTES);
+  if constexpr (C::WIN_LDS) {
+    for (int i = tid; i < N; i += C::WGT) win_lds[i] = p.window[i];
+    __syncthreads();
+  }
   const unsigned win_voff = unsigned(h) * (N / A) * 4u + unsigned(t) * (M * 4u);
   const bool odd_half = h != 0;   // upper half-wave: its radix-32 combine twiddle is W_32^(u+8) = -i * W_32^u
   c32 twf_lo[3], twf_hi[4];   // last pass: W_N^(t*(2i+h)), i = 4a + j  ->  hi[a] = W^(t(8a+h)), lo[j-1] = W^(2tj)
@@ -454,7 +464,14 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     static_for<0, H>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       uint32_t wq[M];
-      buf_load<M>(win_rsrc, win_voff, 2 * i * (N / A) * 4u, wq);
+      if constexpr (C::WIN_LDS) {
+        static_for<0, M>([&](auto jc) {
+          constexpr int jj = decltype(jc)::value;
+          wq[jj] = __float_as_uint(win_lds[(2 * i + h) * (N / A) + t * M + jj]);
+        });
+      } else {
+        buf_load<M>(win_rsrc, win_voff, 2 * i * (N / A) * 4u, wq);
+      }
       static_for<0, M>([&](auto jc) { constexpr int jj = decltype(jc)::value; win[jj * H + i] = __uint_as_float(wq[jj]); });
     });
 
