@@ -306,6 +306,27 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
                                unsigned(h) * (IN_C64 ? (N / A) * 8u : unsigned(ROWB));
   const unsigned out_voff = unsigned(t) * 4u + unsigned(h) * (8u * SG * 4u);
 
+  // Window slice of this thread (sizes that keep the table in global memory): (re)loaded at the END of a
+  // frame, ahead of that frame's dB stores.  gfx9 counts loads and stores in one in-order vmcnt, so a load
+  // issued behind the stores can only be waited for together with them - the waves that reach the next
+  // barrier last would sit through their own stores' round trip to memory on the critical path.  The
+  // reload is unconditional (the last one is simply unused) so that the old values are dead in between.
+  float win[16];                                            // win[jj*H + i] = w[(2i+h)*(N/A) + t*M + jj]
+  auto load_window = [&] {
+    static_for<0, H>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      uint32_t wq[M];
+      if constexpr (C::WIN_LDS) {
+        static_for<0, M>([&](auto jc) {
+          constexpr int jj = decltype(jc)::value;
+          wq[jj] = __float_as_uint(win_lds[(2 * i + h) * (N / A) + t * M + jj]);
+        });
+      } else {
+        buf_load<M>(win_rsrc, win_voff, 2 * i * (N / A) * 4u, wq);
+      }
+      static_for<0, M>([&](auto jc) { constexpr int jj = decltype(jc)::value; win[jj * H + i] = __uint_as_float(wq[jj]); });
+    });
+  };
   uint32_t raw[NRAW];
   auto load_frame_raw = [&](int frame) {
     if constexpr (!IN_C64) {
@@ -332,6 +353,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     }
   };
   if (u0 < u1) load_frame_raw(u0 * FPW + slot);
+  if constexpr (!C::WIN_LDS) load_window();
 
   for (int unit = u0; unit < u1; ++unit) {
     const int frame = unit * FPW + slot;
@@ -460,21 +482,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     }
     sub_re = in_vgpr(sub_re);
     sub_im = in_vgpr(sub_im);
-    float win[16];                                          // win[jj*H + i] = w[(2i+h)*(N/A) + t*M + jj]
-    static_for<0, H>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      uint32_t wq[M];
-      if constexpr (C::WIN_LDS) {
-        static_for<0, M>([&](auto jc) {
-          constexpr int jj = decltype(jc)::value;
-          wq[jj] = __float_as_uint(win_lds[(2 * i + h) * (N / A) + t * M + jj]);
-        });
-      } else {
-        buf_load<M>(win_rsrc, win_voff, 2 * i * (N / A) * 4u, wq);
-      }
-      static_for<0, M>([&](auto jc) { constexpr int jj = decltype(jc)::value; win[jj * H + i] = __uint_as_float(wq[jj]); });
-    });
-
+    if constexpr (C::WIN_LDS) load_window();
 
     // ---- unpack + DC removal + window ------------------------------------------------------------
     if constexpr (IN_C64) {
@@ -594,6 +602,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     // this thread's 16 bins: q < 8: kc = q + 8h (register bitrev(q)), q >= 8: kc = q + 8 + 8h (bitrev(q))
     if (active) {
       if (p.out_cplx != nullptr) {            // real-input path: hand the complex bins to the fold kernel
+        if constexpr (!C::WIN_LDS) load_window();
         c32* crow = p.out_cplx + (long long)frame * N + t + 8 * h * SG;
         static_for<0, 16>([&](auto ic) {
           constexpr int q = decltype(ic)::value;
@@ -601,6 +610,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
           crow[kc * SG] = v[bitrev(q, 4)];
         });
       } else if (p.out_lin != nullptr) {
+        if constexpr (!C::WIN_LDS) load_window();
         float* orow = p.out_lin + (long long)frame * N + t + 8 * h * SG;
         static_for<0, 16>([&](auto ic) {
           constexpr int q = decltype(ic)::value;
@@ -639,6 +649,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
             db[q] -= trow[kcs * SG];
           });
         }
+        if constexpr (!C::WIN_LDS) load_window();     // next frame's window, ahead of this frame's stores
         if ((TDSA_ABLATE & 4) == 0 && p.out_db != nullptr) {
           float* orow = p.out_db + (long long)frame * N;
           if constexpr (FPW == 1) {
@@ -668,6 +679,9 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
           });
         }
       }
+    }
+    else {
+      if constexpr (!C::WIN_LDS) load_window();
     }
     TDSA_STAMP(11);
   }
