@@ -834,7 +834,7 @@ def _random_case(rng):
                 window=str(rng.choice(["hanning", "hamming", "rectangle"])), seed=int(rng.integers(1, 1 << 30)))
 
 
-@pytest.mark.parametrize("case_id", range(48))
+@pytest.mark.parametrize("case_id", range(int(os.environ.get("TDSA_SWEEP_CASES", "48"))))
 def test_random_configuration_sweep(pkg, case_id):
     c = _random_case(np.random.default_rng(4242 + case_id))
     nfft, nf, hop = c["nfft"], c["nf"], c["hop"]
