@@ -227,6 +227,8 @@ int tdsa_device_count(int* count) {
   return TDSA_OK;
 }
 
+static int plan_init(tdsa_plan p);
+
 int tdsa_create(int device_id, int nfft, int max_frames, tdsa_plan* out) {
   if (!out) return fail(TDSA_ERR_ARG, "out is null");
   *out = nullptr;
@@ -246,6 +248,18 @@ int tdsa_create(int device_id, int nfft, int max_frames, tdsa_plan* out) {
   p->log2n = ilog2i(nfft);
   p->max_frames = max_frames;
   p->big = big;
+  const int rc_init = plan_init(p);          // a failure half way leaves nothing behind
+  if (rc_init != TDSA_OK) {
+    (void)tdsa_destroy(p);
+    return rc_init;
+  }
+  *out = p;
+  return TDSA_OK;
+}
+
+static int plan_init(tdsa_plan p) {
+  const int device_id = p->device, nfft = p->nfft, max_frames = p->max_frames;
+  const bool big = p->big;
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, device_id));
   p->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -300,7 +314,6 @@ int tdsa_create(int device_id, int nfft, int max_frames, tdsa_plan* out) {
   p->mode.cal_offset_db = 0.0f;
   p->mode.hold_flags = 0;
   HIPCHK(hipStreamSynchronize(p->stream));
-  *out = p;
   return TDSA_OK;
 }
 
@@ -752,16 +765,17 @@ int tdsa_trace_create(int device_id, int n, tdsa_trace* out) {
   if (!t) return fail(TDSA_ERR_NOMEM, "host allocation failed");
   t->device = device_id;
   t->n = n;
-  HIPCHK(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
   const size_t nb = size_t(n) * sizeof(float);
-  HIPCHK(hipMalloc(&t->d_in, nb));
-  HIPCHK(hipMalloc(&t->d_live, nb));
-  HIPCHK(hipMalloc(&t->d_hold_max, nb));
-  HIPCHK(hipMalloc(&t->d_hold_min, nb));
-  HIPCHK(hipMalloc(&t->d_tare_base, nb));
-  HIPCHK(hipMalloc(&t->d_tare_acc, nb));
-  HIPCHK(hipMalloc(&t->d_avg, size_t(n) * sizeof(double)));
-  HIPCHK(hipMalloc(&t->d_avg_in, size_t(n) * sizeof(double)));
+  hipError_t e = hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking);
+  float** fbufs[] = {&t->d_in, &t->d_live, &t->d_hold_max, &t->d_hold_min, &t->d_tare_base, &t->d_tare_acc};
+  for (float** b : fbufs)
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(b), nb);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&t->d_avg), size_t(n) * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&t->d_avg_in), size_t(n) * sizeof(double));
+  if (e != hipSuccess) {                     // a failure half way leaves nothing behind
+    (void)tdsa_trace_destroy(t);
+    return fail(TDSA_ERR_HIP, "trace create: %s", hipGetErrorString(e));
+  }
   *out = t;
   return TDSA_OK;
 }
