@@ -290,13 +290,9 @@ hipError_t launch_top_peaks(const float* rows, int n_rows, int n, int n_peaks, i
                             int* out_bins, float* out_db, hipStream_t s) {
   if (n_rows <= 0) return hipSuccess;
   const size_t lds = size_t(2) * n * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(top_peaks_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> attr_done{0};
+  const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(top_peaks_kernel), 140 * 1024, attr_done);
+  if (e != hipSuccess) return e;
   top_peaks_kernel<<<n_rows, kPeakThreads, lds, s>>>(rows, n, n_peaks, min_sep, excursion, out_bins, out_db);
   return hipGetLastError();
 }

@@ -175,13 +175,9 @@ hipError_t launch_big_cols(const uint16_t* xt, const float* wt, const float2* tw
                            hipStream_t s) {
   BigColsParams p{xt, wt, tw1k, twlo, dc_sub, y, xor_mask, in_off};
   const size_t lds = size_t(kB1) * (kColRows + 1) * sizeof(c32);    // 136 KiB tile (>= 16 exchange areas)
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(big_cols_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
+  static std::atomic<unsigned long long> attr_done{0};
+  const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(big_cols_kernel), int(lds), attr_done);
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(big_cols_kernel, dim3(kB1 / kColRows, n_seg), dim3(kColRows * 32), lds, s, p);
   return hipGetLastError();
 }

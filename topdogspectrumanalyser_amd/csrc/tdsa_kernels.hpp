@@ -5,7 +5,22 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace tdsa {
+
+// Raise a kernel's dynamic-LDS limit once per DEVICE (function attributes belong to the device the
+// module is loaded on; a process may hold plans on several GPUs).  `done` is a per-kernel bit mask.
+inline hipError_t ensure_dynamic_lds(const void* fn, int bytes, std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+  return e;
+}
 
 constexpr int kMinLog2N = 6;    // 64
 constexpr int kMaxLog2N = 14;   // 16384 : largest frame whose c64 working set fits the 160 KiB LDS

@@ -778,13 +778,9 @@ inline LaunchGeom geom_for(int n_frames, int num_cu) {
 template <int LOG2N, bool IN_C64, int HOLD>
 inline hipError_t launch_one(const SpecParams& p, const LaunchGeom& g, hipStream_t s) {
   auto k = spectrum_kernel<LOG2N, IN_C64, HOLD>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(g.lds_bytes));
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> attr_done{0};
+  const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), int(g.lds_bytes), attr_done);
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3(g.grid), dim3(g.block), g.lds_bytes, s, p);
   return hipGetLastError();
 }
