@@ -229,14 +229,18 @@ int tdsa_waterfall_view(tdsa_waterfall w, float* view_host, int* ptr);
  * D2H on three streams and returns at once, tdsa_pipe_collect waits for the OLDEST submitted slot and
  * hands back its dB rows (pinned, valid until that slot is acquired again).  Slots complete in
  * submission order; plan state (hold traces, averager, DC tracker) advances exactly as if
- * tdsa_process_i8 had been called per slot.  want_rows = 0 keeps only the plan state (hold / Welch
- * traces) and skips the read-back leg.  One thread drives a pipe; destroy it before its plan. */
+ * tdsa_process_i8 had been called per slot.  want_rows: 0 keeps only the plan state (hold / Welch
+ * traces); 1 reads the dB rows back into pinned host memory (tdsa_pipe_collect); 2 keeps them in the
+ * slot's device buffer for the analytics / accumulators below (tdsa_pipe_collect_dev hands out the device
+ * pointer, valid until that slot is acquired again) and skips the read-back leg.  One thread drives a
+ * pipe; destroy it before its plan. */
 typedef struct tdsa_pipe_s* tdsa_pipe;
 int tdsa_pipe_create(tdsa_plan p, int in_format, size_t slot_samples, int n_slots, int want_rows, tdsa_pipe* out);
 int tdsa_pipe_destroy(tdsa_pipe q);
 int tdsa_pipe_acquire(tdsa_pipe q, void** host_slot);
 int tdsa_pipe_submit(tdsa_pipe q, size_t n_samples, int hop, int n_frames);
 int tdsa_pipe_collect(tdsa_pipe q, const float** rows_host, int* n_frames);
+int tdsa_pipe_collect_dev(tdsa_pipe q, const float** rows_dev, int* n_frames);
 int tdsa_pipe_pending(tdsa_pipe q, int* pending);
 
 /* A trace object owns the per-bin state the reference keeps in numpy arrays on MainWindow /

@@ -870,3 +870,46 @@ def test_random_configuration_sweep(pkg, case_id):
     _check(out, gold, what)
     _check(mx, gmax, what + " max hold")
     _check(mn, gmin, what + " min hold")
+
+
+def test_host_pipe_device_rows_feed_analytics(pkg):
+    """rows="device": the dB rows of every slot stay on the GPU and are handed to the analytics as a device
+    pointer; results equal those computed from rows read back the ordinary way."""
+    from topdogspectrumanalyser_amd import analytics as an
+    import ctypes as C
+    nat = pkg._native
+    nfft, hop, nf, chunks = 4096, 2048, 60, 5
+    ns = hop * (nf - 1) + nfft
+    batches = [so.synth_iq_int8(ns, nfft, seed=1200 + i) for i in range(chunks)]
+    with _hackrf_engine(pkg, nfft, nf) as e:
+        ref = [e.process(iq, hop=hop) for iq in batches]
+    with _hackrf_engine(pkg, nfft, nf) as e, e.pipe(ns, n_slots=2, rows="device") as q:
+        with pytest.raises(Exception):
+            q.collect_device()
+        seen = 0
+
+        def check():
+            nonlocal seen
+            ptr, n = q.collect_device()
+            assert n == nf and ptr
+            got = np.empty((nf, nfft), dtype=np.float32)
+            nat.check(nat.lib.tdsa_memcpy_d2h(0, got.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), got.nbytes))
+            assert np.array_equal(got, ref[seen])
+            peak, pbin, _ = an.rows_stats(e, ptr, n)
+            assert np.array_equal(peak, ref[seen].max(axis=1)) and np.array_equal(pbin, ref[seen].argmax(axis=1))
+            seen += 1
+
+        for iq in batches:
+            if q.pending == 2:
+                check()
+            q.acquire()[: iq.size] = iq
+            q.submit(ns, hop, nf)
+        while q.pending:
+            check()
+        assert seen == chunks
+    with _hackrf_engine(pkg, nfft, nf) as e, e.pipe(ns, rows=False) as q:
+        q.acquire()[: batches[0].size] = batches[0]
+        q.submit(ns, hop, nf)
+        with pytest.raises(Exception):
+            q.collect_device()                                  # this pipe keeps no rows
+        q.collect()

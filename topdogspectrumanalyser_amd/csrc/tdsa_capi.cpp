@@ -996,7 +996,8 @@ struct tdsa_pipe_s {
   tdsa_plan plan = nullptr;
   int fmt = TDSA_IN_I8;
   size_t slot_samples = 0;
-  bool rows = false;
+  bool rows = false;        // dB rows are produced (kept per slot on the device)
+  bool rows_host = false;   // ... and read back into pinned host memory
   struct Slot {
     void* h_in = nullptr;
     void* d_in = nullptr;
@@ -1023,7 +1024,9 @@ int tdsa_pipe_create(tdsa_plan p, int in_format, size_t slot_samples, int n_slot
   q->plan = p;
   q->fmt = in_format;
   q->slot_samples = slot_samples;
+  if (want_rows < 0 || want_rows > 2) return fail(TDSA_ERR_ARG, "want_rows=%d (0 none, 1 host, 2 device)", want_rows);
   q->rows = want_rows != 0;
+  q->rows_host = want_rows == 1;
   q->slots.resize(size_t(n_slots));
   const size_t in_bytes = slot_samples * size_t(bytes_per_sample(in_format));
   const size_t out_rows = p->big ? 1 : size_t(p->max_frames);
@@ -1039,7 +1042,8 @@ int tdsa_pipe_create(tdsa_plan p, int in_format, size_t slot_samples, int n_slot
     if ((e = hipHostMalloc(&sl.h_in, in_bytes, hipHostMallocDefault)) != hipSuccess) return bail(e, "pinned input slot");
     if ((e = hipMalloc(&sl.d_in, in_bytes)) != hipSuccess) return bail(e, "device input slot");
     if (q->rows) {
-      if ((e = hipHostMalloc(reinterpret_cast<void**>(&sl.h_out), out_bytes, hipHostMallocDefault)) != hipSuccess)
+      if (q->rows_host &&
+          (e = hipHostMalloc(reinterpret_cast<void**>(&sl.h_out), out_bytes, hipHostMallocDefault)) != hipSuccess)
         return bail(e, "pinned output slot");
       if ((e = hipMalloc(reinterpret_cast<void**>(&sl.d_out), out_bytes)) != hipSuccess) return bail(e, "device output slot");
     }
@@ -1100,7 +1104,7 @@ int tdsa_pipe_submit(tdsa_pipe q, size_t n_samples, int hop, int n_frames) {
     return rc;
   }
   sl.n_frames = p->big ? 1 : n_frames;
-  if (q->rows) {
+  if (q->rows_host) {
     HIPCHK(hipStreamWaitEvent(q->s_out, sl.ev_done, 0));
     HIPCHK(hipMemcpyAsync(sl.h_out, sl.d_out, size_t(sl.n_frames) * p->nfft * sizeof(float), hipMemcpyDeviceToHost,
                           q->s_out));
@@ -1113,18 +1117,28 @@ int tdsa_pipe_submit(tdsa_pipe q, size_t n_samples, int hop, int n_frames) {
   return TDSA_OK;
 }
 
-int tdsa_pipe_collect(tdsa_pipe q, const float** rows_host, int* n_frames) {
+static int pipe_collect(tdsa_pipe q, const float** rows_host, const float** rows_dev, int* n_frames) {
   if (!q) return fail(TDSA_ERR_ARG, "null pipe");
   if (q->pending == 0) return fail(TDSA_ERR_STATE, "nothing submitted");
   auto& sl = q->slots[q->tail % q->slots.size()];
   HIPCHK(hipSetDevice(q->plan->device));
-  HIPCHK(hipEventSynchronize(q->rows ? sl.ev_d2h : sl.ev_done));
+  HIPCHK(hipEventSynchronize(q->rows_host ? sl.ev_d2h : sl.ev_done));
   sl.in_flight = false;
-  if (rows_host) *rows_host = q->rows ? sl.h_out : nullptr;
+  if (rows_host) *rows_host = q->rows_host ? sl.h_out : nullptr;
+  if (rows_dev) *rows_dev = q->rows ? sl.d_out : nullptr;
   if (n_frames) *n_frames = sl.n_frames;
   ++q->tail;
   --q->pending;
   return TDSA_OK;
+}
+
+int tdsa_pipe_collect(tdsa_pipe q, const float** rows_host, int* n_frames) {
+  return pipe_collect(q, rows_host, nullptr, n_frames);
+}
+
+int tdsa_pipe_collect_dev(tdsa_pipe q, const float** rows_dev, int* n_frames) {
+  if (q && !q->rows) return fail(TDSA_ERR_STATE, "this pipe keeps no dB rows (want_rows = 0)");
+  return pipe_collect(q, nullptr, rows_dev, n_frames);
 }
 
 int tdsa_pipe_pending(tdsa_pipe q, int* pending) {

@@ -138,8 +138,10 @@ class SpectrumEngine:
     def synchronize(self) -> None:
         nat.check(nat.lib.tdsa_synchronize(self._h))
 
-    def pipe(self, slot_samples: int, n_slots: int = 3, rows: bool = True, in_format: int = nat.IN_I8) -> "HostPipe":
-        """Pinned host ring with asynchronous copy / compute / read-back legs (tdsa_pipe_*)."""
+    def pipe(self, slot_samples: int, n_slots: int = 3, rows=True, in_format: int = nat.IN_I8) -> "HostPipe":
+        """Pinned host ring with asynchronous copy / compute / read-back legs (tdsa_pipe_*).
+        rows: True / "host" = dB rows come back to pinned host memory, "device" = they stay on the GPU
+        (collect_device), False / None = plan state only."""
         return HostPipe(self, slot_samples, n_slots, rows, in_format)
 
     def set_overlap(self, n_streams: int) -> None:
@@ -277,11 +279,12 @@ class HostPipe:
     def __init__(self, engine: SpectrumEngine, slot_samples: int, n_slots: int, rows: bool, in_format: int):
         self._eng = engine
         self.slot_samples = int(slot_samples)
-        self.rows = bool(rows)
+        self.rows_mode = {True: 1, "host": 1, "device": 2, False: 0, None: 0}[rows]
+        self.rows = self.rows_mode == 1
         self.in_format = int(in_format)
         self._q = C.c_void_p()
         nat.check(nat.lib.tdsa_pipe_create(engine._h, self.in_format, self.slot_samples, int(n_slots),
-                                            int(self.rows), C.byref(self._q)))
+                                            self.rows_mode, C.byref(self._q)))
 
     def close(self) -> None:
         if getattr(self, "_q", None) is not None and self._q:
@@ -320,6 +323,14 @@ class HostPipe:
         if not self.rows:
             return None
         return np.ctypeslib.as_array(rows, shape=(nf.value, self._eng.nfft))
+
+    def collect_device(self) -> Tuple[int, int]:
+        """Wait for the oldest submitted slot of a rows="device" pipe: (device pointer of its dB rows,
+        n_frames); the rows stay valid until that slot is acquired again."""
+        rows = C.POINTER(C.c_float)()
+        nf = C.c_int()
+        nat.check(nat.lib.tdsa_pipe_collect_dev(self._q, C.byref(rows), C.byref(nf)))
+        return C.cast(rows, C.c_void_p).value, nf.value
 
     @property
     def pending(self) -> int:
