@@ -1,336 +1,341 @@
-"""DataProcessor - the per-frame display pipeline behind the reference's API
-(core/display_data_processor.py: class :27-480, constructor (main_window, display_manager)).
+"""DataProcessor: what happens to a trace between the data source and the screen, on the GPU.
 
-update_data() routes exactly like the reference (:52-93).  The frame arithmetic - calibration offset
-(:317-327), tare collect / subtract (:329-369), max / min hold (:371-395) - is done by HIP kernels
-through a TraceState (tdsa_trace_update in include/tdsa_hip.h); the host arrays on `mw`
-(live_power_levels, max_power_levels, min_power_levels, baseline_power_levels) are refreshed from the
-device after every frame so widgets and markers read them as before.
+Drop-in for the reference's core/display_data_processor.py (constructor `(main_window, display_manager)`,
+timer entry point `update_data()`, and the private method set its test_smoke.py:222-236 asserts).  The
+arithmetic that belongs to the hot path - calibration offset (:317-327 there), tare collect / subtract
+(:329-369), max / min hold (:371-395) - runs in `trace_update_kernel` through a `TraceState`
+(`tdsa_trace_update`, include/tdsa_hip.h); the attributes other code reads on the window object
+(`live_power_levels`, `max_power_levels`, `min_power_levels`, `baseline_power_levels`) are refreshed
+from the device after every frame.
 
-Deliberately different from the reference: the max and min hold traces are independent buffers; the
-reference lets both alias one ndarray when they are enabled on the same first frame (SURVEY.md 8(a)
-quirk ii), which turns both traces into the live frame.
-
-Peak list, duty cycle, zero span and constellation feeds are GUI-side scalar work (SURVEY.md 2 row 6:
-out of the GPU scope); they are kept as thin host helpers so the method set the reference's
-test_smoke.py:222-236 asserts is complete.
+Scope notes
+  * The two hold traces are independent buffers.  The reference lets them alias ONE ndarray when both
+    are switched on for the same first frame (SURVEY.md 8(a) quirk ii), after which both just follow
+    the live trace; that accident is pinned in the oracle and not reproduced.
+  * Everything that is GUI plumbing rather than signal processing (which widget is showing, sweep
+    sources, constellation and zero-span feeds) is kept to the minimum that keeps a window object
+    written for the reference working; batch users go through `analytics.py` instead.
 """
 import logging
 import time
+from typing import Callable, List, Optional, Tuple
 
 import numpy as np
 
+from .. import _native as nat
 from ..datasources.base import SampleDataSource, SweepDataSource
 from ..engine import TraceState
 from ..utils.constants import DisplayMode, UIConstants
 from ..utils.signal_processing import TraceAverager
-from .. import _native as nat
 from .tare_state import TareState
 
-_STALE_DATA_TIMEOUT = 3.0
-logger = logging.getLogger(__name__)
+log = logging.getLogger(__name__)
+
+STALE_AFTER_S = 3.0                       # a sample source that has been silent this long gets a status note
+_REDRAW_ON_TIMER = (DisplayMode.TWO_D, DisplayMode.THREE_D, DisplayMode.SURFACE, DisplayMode.RIBBON,
+                    DisplayMode.DENSITY)
+_IQ_VIEWS = {DisplayMode.CONSTELLATION_2D: "constellation_2d_widget",
+             DisplayMode.CONSTELLATION_3D: "constellation_3d_widget"}
+
+
+def _plural(n: int, word: str) -> str:
+    return f"{n} {word}" + ("" if n == 1 else "s")
 
 
 class DataProcessor:
-    _DISPLAY_TIMER_MODES = frozenset({DisplayMode.TWO_D, DisplayMode.THREE_D, DisplayMode.SURFACE,
-                                      DisplayMode.RIBBON, DisplayMode.DENSITY})
-
     def __init__(self, main_window, display_manager, gpu_device: int = 0):
         self.mw = main_window
         self.dm = display_manager
+        self._device = gpu_device
+        self._state: Optional[TraceState] = None          # device-side trace state, sized on first use
         self._sweep_averager = TraceAverager(device=gpu_device)
-        self._sweep_rate_update_counter = 0
-        self._gpu_device = gpu_device
-        self._trace = None            # TraceState for the current trace length
+        self._sweeps_since_axis_refresh = 0
 
+    # ================================================================== public
     def reset_sweep_averager(self) -> None:
         self._sweep_averager.reset()
 
-    # ------------------------------------------------------------------ device state
-    def _trace_for(self, n: int) -> TraceState:
-        if self._trace is None or self._trace.n != n:
-            if self._trace is not None:
-                self._trace.close()
-            self._trace = TraceState(n, device=self._gpu_device)
-        return self._trace
-
-    # ------------------------------------------------------------------ timer entry point
     def update_data(self) -> None:
-        mw, dm = self.mw, self.dm
-        if mw.current_source is None or mw.paused:
+        """One display-timer tick: fetch a frame from the current source, process it, show it."""
+        mw = self.mw
+        source = mw.current_source
+        if source is None or mw.paused:
             return
         self._check_stale_data()
-        is_sample = isinstance(mw.current_source, SampleDataSource)
-        if getattr(dm, "zero_span_active", False) and is_sample:
-            self._process_zero_span_data()
-            return
-        if getattr(mw, "analysis_mode", None) == "constellation" and is_sample:
-            self._process_constellation_data()
-            mw.marker_manager.update()
-            return
-        widget = self._get_active_widget()
-        if widget is None:
+        handler = self._select_handler(source)
+        if handler is None:
             return
         try:
-            if is_sample:
-                self._process_sample_data()
-            elif isinstance(mw.current_source, SweepDataSource):
-                self._process_sweep_data()
-            else:
-                mw.status_label.setText(f"Invalid source type: {type(mw.current_source)}")
-                return
-            if mw.current_stacked_index == DisplayMode.WATERFALL:
-                tpr = dm._calc_time_per_row()
-                if tpr > 0:
-                    mw.waterfall_widget.set_time_per_row(tpr)
-                self._dispatch_widget_data(widget)
-            else:
-                self._refresh_display()
-        except Exception as e:
-            mw.status_label.setText(f"Error updating data: {e}")
-            logger.error("Error updating data: %s", e)
+            handler()
+        except Exception as exc:                        # never let a bad frame kill the timer
+            self._say(f"Error updating data: {exc}")
+            log.error("update_data failed: %s", exc)
 
-    # ------------------------------------------------------------------ display routing
+    # ================================================================== routing (GUI plumbing)
+    def _select_handler(self, source) -> Optional[Callable[[], None]]:
+        mw, dm = self.mw, self.dm
+        sampled = isinstance(source, SampleDataSource)
+        if sampled and getattr(dm, "zero_span_active", False):
+            return self._process_zero_span_data
+        if sampled and getattr(mw, "analysis_mode", None) == "constellation":
+            return self._constellation_tick
+        if self._get_active_widget() is None:
+            return None
+        if sampled:
+            return lambda: self._spectrum_tick(self._process_sample_data)
+        if isinstance(source, SweepDataSource):
+            return lambda: self._spectrum_tick(self._process_sweep_data)
+        self._say(f"Invalid source type: {type(source)}")
+        return None
+
+    def _constellation_tick(self) -> None:
+        self._process_constellation_data()
+        self.mw.marker_manager.update()
+
+    def _spectrum_tick(self, produce: Callable[[], None]) -> None:
+        produce()
+        mw = self.mw
+        if mw.current_stacked_index == DisplayMode.WATERFALL:
+            seconds_per_row = self.dm._calc_time_per_row()
+            if seconds_per_row > 0:
+                mw.waterfall_widget.set_time_per_row(seconds_per_row)
+            self._dispatch_widget_data(self._get_active_widget())
+        else:
+            self._refresh_display()
+
     def _get_active_widget(self):
-        getter = self.dm.DISPLAY_WIDGETS_MAP.get(self.mw.current_stacked_index)
-        return getter(self.mw) if getter else None
+        lookup = self.dm.DISPLAY_WIDGETS_MAP.get(self.mw.current_stacked_index)
+        return None if lookup is None else lookup(self.mw)
+
+    def _refresh_display(self) -> None:
+        if self.mw.current_stacked_index in _REDRAW_ON_TIMER:
+            widget = self._get_active_widget()
+            if widget is not None:
+                self._dispatch_widget_data(widget)
 
     def _dispatch_widget_data(self, widget) -> None:
         mw = self.mw
         if mw.live_power_levels is None or mw.frequency_bins is None:
             return
+        clone = getattr(mw, "popout_clone_widget", None) if getattr(mw, "is_popped_out", False) else None
+        target = clone if clone else (widget if widget.isVisible() else None)
         try:
-            target = None
-            if getattr(mw, "is_popped_out", False) and getattr(mw, "popout_clone_widget", None):
-                target = mw.popout_clone_widget
-            elif widget.isVisible():
-                target = widget
             if target is not None:
                 target.update_widget_data(mw.live_power_levels, mw.max_power_levels, mw.frequency_bins,
                                           mw.min_power_levels)
             mw.marker_manager.update()
-        except Exception as e:
-            mw.status_label.setText(f"Error updating display: {e}")
-            logger.error("Error updating display: %s", e)
-
-    def _refresh_display(self) -> None:
-        if self.mw.current_stacked_index not in self._DISPLAY_TIMER_MODES:
-            return
-        widget = self._get_active_widget()
-        if widget is not None:
-            self._dispatch_widget_data(widget)
+        except Exception as exc:
+            self._say(f"Error updating display: {exc}")
+            log.error("widget update failed: %s", exc)
 
     def _check_stale_data(self) -> None:
         mw = self.mw
-        if not isinstance(mw.current_source, SampleDataSource) or mw.live_power_levels is None:
+        src = mw.current_source
+        if mw.live_power_levels is None or not isinstance(src, SampleDataSource) or src.last_data_time <= 0:
             return
-        t = mw.current_source.last_data_time
-        if t > 0 and (time.monotonic() - t) > _STALE_DATA_TIMEOUT:
-            mw.status_label.setText(f"No data for {time.monotonic() - t:.1f}s — source may have stopped")
+        silent_for = time.monotonic() - src.last_data_time
+        if silent_for > STALE_AFTER_S:
+            self._say(f"No data for {silent_for:.1f}s — source may have stopped")
 
-    # ------------------------------------------------------------------ source paths
+    def _say(self, text: str) -> None:
+        self.mw.status_label.setText(text)
+
+    # ================================================================== the sample path
     def _process_sample_data(self) -> None:
         mw = self.mw
-        result, freq_bins = mw.current_source.get_power_levels()
-        if isinstance(result, tuple):                     # audio stereo: (left_db, right_db)
-            left_db, right_db = result
-            if left_db is None or len(left_db) == 0:
-                return
-            left_db = self._apply_cal_offset(left_db)
-            right_db = self._apply_cal_offset(right_db)
-            mw.frequency_bins = freq_bins
-            mw.live_power_levels = (left_db, right_db)
-            self._update_max_hold(left_db)
-            self._update_min_hold(left_db)
+        levels, axis = mw.current_source.get_power_levels()
+        if isinstance(levels, tuple):                     # stereo microphone: (left, right) dB traces
+            self._stereo_frame(levels, axis)
             return
-        power_levels = result
-        if power_levels is None or len(power_levels) == 0:
+        if levels is None or len(levels) == 0:
             return
-        mw.frequency_bins = freq_bins
-        power_levels = self._apply_cal_offset(power_levels)
-        power_levels = self._apply_tare(power_levels)
-        mw.live_power_levels = power_levels
-        self._update_max_hold(power_levels)
-        self._update_min_hold(power_levels)
-        self._update_duty_cycle(power_levels)
-        self._update_peak_list(freq_bins, power_levels)
+        mw.frequency_bins = axis
+        trace = self._apply_tare(self._apply_cal_offset(levels))
+        mw.live_power_levels = trace
+        self._update_max_hold(trace)
+        self._update_min_hold(trace)
+        self._update_duty_cycle(trace)
+        self._update_peak_list(axis, trace)
 
-    def _process_sweep_data(self) -> None:
-        """Sweep sources (external CLI wrappers) are outside this build's scope; the routing is kept."""
-        mw = self.mw
-        power_levels = mw.current_source.get_data()
-        if power_levels is None or len(power_levels) == 0:
+    def _stereo_frame(self, pair: Tuple[np.ndarray, np.ndarray], axis) -> None:
+        left, right = pair
+        if left is None or len(left) == 0:
             return
-        mw.frequency_bins = np.linspace(mw.frequency.start, mw.frequency.stop, len(power_levels))
-        power_levels = self._apply_cal_offset(power_levels)
-        if np.all(np.isnan(power_levels)):
-            return
-        if self._sweep_averager.is_active:
-            linear = 10.0 ** (np.asarray(power_levels, dtype=np.float64) / 10.0)
-            power_levels = 10.0 * np.log10(np.maximum(self._sweep_averager.process(linear), 1e-30))
-        mw.live_power_levels = power_levels
-        self._update_max_hold(power_levels)
-        self._update_min_hold(power_levels)
-        self._update_peak_list(mw.frequency_bins, power_levels)
-        self._sweep_rate_update_counter += 1
-        if self._sweep_rate_update_counter >= UIConstants.SWEEP_RATE_UPDATE_INTERVAL:
-            self._sweep_rate_update_counter = 0
-            mw.frequency_manager.update_frequency_values()
+        left, right = self._apply_cal_offset(left), self._apply_cal_offset(right)
+        self.mw.frequency_bins = axis
+        self.mw.live_power_levels = (left, right)
+        self._update_max_hold(left)                       # the hold traces follow the left channel
+        self._update_min_hold(left)
 
-    def _process_constellation_data(self) -> None:
-        mw = self.mw
-        samples = mw.current_source.read_samples_only()
-        if samples is None or len(samples) == 0:
-            return
-        idx = mw.current_stacked_index
-        widget = {DisplayMode.CONSTELLATION_2D: getattr(mw, "constellation_2d_widget", None),
-                  DisplayMode.CONSTELLATION_3D: getattr(mw, "constellation_3d_widget", None)}.get(idx)
-        if widget is not None:
-            widget.update_iq_data(samples)
+    # ------------------------------------------------------------------ device-side trace state
+    def _trace_for(self, n_bins: int) -> TraceState:
+        if self._state is not None and self._state.n != n_bins:
+            self._state.close()
+            self._state = None
+        if self._state is None:
+            self._state = TraceState(n_bins, device=self._device)
+        return self._state
 
-    def _process_zero_span_data(self) -> None:
-        mw = self.mw
-        raw = mw.current_source.read_samples_only()
-        if raw is None or len(raw) == 0:
-            return
-        if raw.ndim == 2:
-            raw = raw.mean(axis=1)
-        samples = (raw.real if np.iscomplexobj(raw) else raw.ravel()).astype(np.float32)
-        fs = float(getattr(mw.current_source, "sample_rate", 44100))
-        buf = self.dm.zero_span_buffer
-        buf = samples if buf is None else np.concatenate((buf, samples))
-        buf = buf[-int(2.0 * fs):]
-        self.dm.zero_span_buffer = buf
-        n_display = max(int(self.dm.zero_span_time_window * fs), 4)
-        chunk = buf[-n_display:]
-        mw.zero_span_widget.update_zero_span_data(np.arange(len(chunk), dtype=np.float32) / fs, chunk)
-
-    # ------------------------------------------------------------------ DSP helpers (HIP-backed)
     def _cal_offset_value(self) -> float:
-        mw = self.mw
-        cal = getattr(mw, "calibration_manager", None)
-        if cal is None:
-            return 0.0
-        source_type = mw.source_manager.last_source_type
-        if not source_type:
-            return 0.0
-        return float(cal.get_offset(source_type))
+        cal = getattr(self.mw, "calibration_manager", None)
+        kind = self.mw.source_manager.last_source_type if cal is not None else None
+        return float(cal.get_offset(kind)) if kind else 0.0
 
     def _apply_cal_offset(self, power_levels: np.ndarray) -> np.ndarray:
-        offset = self._cal_offset_value()
-        if offset == 0.0:
-            return power_levels
-        live, _, _, _ = self._trace_for(len(power_levels)).update(power_levels, cal_offset_db=offset)
-        return live
+        offset_db = self._cal_offset_value()
+        if offset_db == 0.0:
+            return power_levels                           # untouched object, as the reference returns it
+        return self._trace_for(len(power_levels)).update(power_levels, cal_offset_db=offset_db)[0]
 
     def _apply_tare(self, power_levels: np.ndarray) -> np.ndarray:
         mw, dm = self.mw, self.dm
-        ts = dm.tare_state
-        tr = self._trace_for(len(power_levels))
-        collecting = bool(ts.collecting)
-        if collecting and ts.count == 0:
-            tr.reset(nat.RESET_TARE)                      # fresh collection: drop any previous baseline
-        if mw.tare_active and mw.baseline_power_levels is not None \
-                and power_levels.shape != mw.baseline_power_levels.shape:
-            dm._clear_tare()
-            tr.reset(nat.RESET_TARE)
-            mw.status_label.setText("Tare cleared — frequency range changed")
+        run = dm.tare_state
+        gpu = self._trace_for(len(power_levels))
+        collecting = bool(run.collecting)
+        if collecting and run.count == 0:
+            gpu.reset(nat.RESET_TARE)                     # a new run starts from an empty accumulator
+        baseline = mw.baseline_power_levels if mw.tare_active else None
+        if baseline is not None and baseline.shape != power_levels.shape:
+            dm._clear_tare()                              # the span changed under an active baseline
+            gpu.reset(nat.RESET_TARE)
+            self._say("Tare cleared — frequency range changed")
+            baseline = mw.baseline_power_levels if mw.tare_active else None
             if not collecting:
                 return power_levels
-        subtract = bool(mw.tare_active and mw.baseline_power_levels is not None)
-        if not collecting and not subtract:
+        subtract = baseline is not None
+        if not (collecting or subtract):
             return power_levels
-        if subtract and not tr.tare_is_active():       # baseline set from outside (preset recall)
-            tr.set_tare_baseline(mw.baseline_power_levels)
-        live, _, _, done = tr.update(power_levels, tare_collect=collecting,
-                                     tare_total=UIConstants.TARE_NUM_SAMPLES, tare_subtract=subtract)
+        if subtract and not gpu.tare_is_active():
+            gpu.set_tare_baseline(baseline)               # baseline restored from a preset, not collected here
+        live, _, _, complete = gpu.update(power_levels, tare_collect=collecting,
+                                          tare_total=UIConstants.TARE_NUM_SAMPLES, tare_subtract=subtract)
         if collecting:
-            ts.count += 1
-            remaining = UIConstants.TARE_NUM_SAMPLES - ts.count
-            mw.status_label.setText(f"Collecting normalisation baseline... {remaining} "
-                                    f"frame{'s' if remaining != 1 else ''} remaining")
-            if done:
-                mw.baseline_power_levels = tr.tare_baseline()
+            run.count += 1
+            left = UIConstants.TARE_NUM_SAMPLES - run.count
+            self._say(f"Collecting normalisation baseline... {_plural(left, 'frame')} remaining")
+            if complete:
+                mw.baseline_power_levels = gpu.tare_baseline()
                 mw.tare_active = True
                 dm.tare_state = TareState()
                 dm._update_tare_button_label("Clear\nNormalisation")
-                mw.status_label.setText("Tare active — baseline captured")
+                self._say("Tare active — baseline captured")
         return live
 
-    def _update_max_hold(self, power_levels: np.ndarray) -> None:
+    def _hold(self, trace: np.ndarray, *, attr: str, enabled: bool, reset_bit: int, which: str) -> None:
+        """Common part of the two hold traces: `attr` on the window is the host copy of the device trace."""
         mw = self.mw
-        if not self.dm.max_peak_search_enabled:
-            if mw.max_power_levels is not None and mw.max_power_levels.shape != power_levels.shape:
-                mw.max_power_levels = None
+        held = getattr(mw, attr)
+        fits = held is not None and held.shape == trace.shape
+        if not enabled:
+            if held is not None and not fits:
+                setattr(mw, attr, None)                   # a stale trace of another length is dropped
             return
-        tr = self._trace_for(len(power_levels))
-        if mw.max_power_levels is None or mw.max_power_levels.shape != power_levels.shape:
-            tr.reset(nat.RESET_HOLD_MAX)                  # adopt this frame (NaN -> -500)
-        _, mx, _, _ = tr.update(power_levels, hold_max=True)
-        mw.max_power_levels = mx
+        gpu = self._trace_for(len(trace))
+        if not fits:
+            gpu.reset(reset_bit)                          # first frame is adopted (NaN -> -500 / +500)
+        _, mx, mn, _ = gpu.update(trace, **{which: True})
+        setattr(mw, attr, mx if which == "hold_max" else mn)
+
+    def _update_max_hold(self, power_levels: np.ndarray) -> None:
+        self._hold(power_levels, attr="max_power_levels", enabled=bool(self.dm.max_peak_search_enabled),
+                   reset_bit=nat.RESET_HOLD_MAX, which="hold_max")
 
     def _update_min_hold(self, power_levels: np.ndarray) -> None:
-        mw = self.mw
-        if not mw.min_hold_enabled:
-            if mw.min_power_levels is not None and mw.min_power_levels.shape != power_levels.shape:
-                mw.min_power_levels = None
-            return
-        tr = self._trace_for(len(power_levels))
-        if mw.min_power_levels is None or mw.min_power_levels.shape != power_levels.shape:
-            tr.reset(nat.RESET_HOLD_MIN)
-        _, _, mn, _ = tr.update(power_levels, hold_min=True)
-        mw.min_power_levels = mn
+        self._hold(power_levels, attr="min_power_levels", enabled=bool(self.mw.min_hold_enabled),
+                   reset_bit=nat.RESET_HOLD_MIN, which="hold_min")
 
-    # ------------------------------------------------------------------ GUI-side scalar helpers
+    # ================================================================== per-tick scalars (host side)
     def _update_duty_cycle(self, power_levels: np.ndarray) -> None:
-        if not getattr(self.dm, "duty_cycle_enabled", False):
-            return
-        self.dm.duty_cycle_analyser.update_from_power(power_levels)
-        readout = getattr(self.mw, "marker_readout_label", None)
-        if readout is not None:
-            readout.setText(self.dm.duty_cycle_analyser.get_readout())
+        if getattr(self.dm, "duty_cycle_enabled", False):
+            analyser = self.dm.duty_cycle_analyser
+            analyser.update_from_power(power_levels)
+            label = getattr(self.mw, "marker_readout_label", None)
+            if label is not None:
+                label.setText(analyser.get_readout())
 
     def _update_peak_list(self, freq_bins: np.ndarray, power_levels: np.ndarray) -> None:
         if not getattr(self.dm, "peak_list_enabled", False):
             return
-        widget = self.mw.two_d_widget
-        if not hasattr(widget, "set_peak_list"):
-            return
-        peaks = self._find_top_peaks(freq_bins, power_levels, n=5, min_sep_bins=max(10, len(freq_bins) // 50),
-                                     min_excursion_db=getattr(self.mw, "peak_excursion", 10.0))
-        widget.set_peak_list(peaks)
+        plot = self.mw.two_d_widget
+        if hasattr(plot, "set_peak_list"):
+            plot.set_peak_list(self._find_top_peaks(
+                freq_bins, power_levels, n=5, min_sep_bins=max(10, len(freq_bins) // 50),
+                min_excursion_db=getattr(self.mw, "peak_excursion", 10.0)))
 
     @staticmethod
     def _find_top_peaks(freq_bins, power, n: int = 5, min_sep_bins: int = 10,
-                        min_excursion_db: float = 10.0) -> list:
-        """Up to n (freq, power) local maxima, strongest first; two candidates count as one signal unless
-        they are min_sep_bins apart AND separated by a valley min_excursion_db below both."""
-        power = np.asarray(power)
-        if len(power) < 3:
+                        min_excursion_db: float = 10.0) -> List[Tuple[float, float]]:
+        """Up to n (frequency, level) pairs, strongest first.  A strict local maximum is taken unless an
+        already taken one is nearer than min_sep_bins or the lowest point between the two is less than
+        min_excursion_db below either (device version for whole batches: analytics.rows_top_peaks)."""
+        level = np.asarray(power)
+        if level.size < 3:
             return []
-        cand = np.flatnonzero((power[1:-1] > power[:-2]) & (power[1:-1] > power[2:])) + 1
-        chosen = []
-        for idx in cand[np.argsort(power[cand])[::-1]]:
-            if len(chosen) >= n:
+        inner = level[1:-1]
+        candidates = 1 + np.flatnonzero((inner > level[:-2]) & (inner > level[2:]))
+        taken: List[int] = []
+        for c in candidates[np.argsort(level[candidates])[::-1]]:
+            if len(taken) == n:
                 break
-            ok = True
-            for prev in chosen:
-                lo, hi = (idx, prev) if idx < prev else (prev, idx)
-                valley = float(power[lo:hi + 1].min())
-                if abs(idx - prev) < min_sep_bins or power[idx] - valley < min_excursion_db \
-                        or power[prev] - valley < min_excursion_db:
-                    ok = False
+            for t in taken:
+                a, b = sorted((int(c), t))
+                floor = float(level[a:b + 1].min())
+                if b - a < min_sep_bins or level[c] - floor < min_excursion_db or level[t] - floor < min_excursion_db:
                     break
-            if ok:
-                chosen.append(int(idx))
-        return [(float(freq_bins[i]), float(power[i])) for i in chosen]
+            else:
+                taken.append(int(c))
+        return [(float(freq_bins[i]), float(level[i])) for i in taken]
 
     @staticmethod
     def _nan_safe(arr: np.ndarray, fill: float) -> np.ndarray:
-        """arr with NaN replaced by fill; clean arrays are returned as they are (no copy)."""
-        mask = np.isnan(arr)
-        if not mask.any():
+        """NaN -> fill; an array without NaN comes back as the same object."""
+        bad = np.isnan(arr)
+        if not bad.any():
             return arr
-        out = arr.copy()
-        out[mask] = fill
-        return out
+        return np.where(bad, fill, arr).astype(arr.dtype, copy=False)
+
+    # ================================================================== feeds outside the spectrum path
+    def _process_sweep_data(self) -> None:
+        """Sweep sources hand over finished dB traces (external tools; no FFT on our side)."""
+        mw = self.mw
+        trace = mw.current_source.get_data()
+        if trace is None or len(trace) == 0:
+            return
+        mw.frequency_bins = np.linspace(mw.frequency.start, mw.frequency.stop, len(trace))
+        trace = self._apply_cal_offset(trace)
+        if np.isnan(trace).all():
+            return
+        if self._sweep_averager.is_active:               # averaging is done on linear power
+            mean_lin = self._sweep_averager.process(np.power(10.0, np.asarray(trace, dtype=np.float64) / 10.0))
+            trace = 10.0 * np.log10(np.maximum(mean_lin, 1e-30))
+        mw.live_power_levels = trace
+        self._update_max_hold(trace)
+        self._update_min_hold(trace)
+        self._update_peak_list(mw.frequency_bins, trace)
+        self._sweeps_since_axis_refresh += 1
+        if self._sweeps_since_axis_refresh >= UIConstants.SWEEP_RATE_UPDATE_INTERVAL:
+            self._sweeps_since_axis_refresh = 0
+            mw.frequency_manager.update_frequency_values()
+
+    def _process_constellation_data(self) -> None:
+        iq = self.mw.current_source.read_samples_only()
+        if iq is None or len(iq) == 0:
+            return
+        view = getattr(self.mw, _IQ_VIEWS.get(self.mw.current_stacked_index, ""), None)
+        if view is not None:
+            view.update_iq_data(iq)
+
+    def _process_zero_span_data(self) -> None:
+        """Time-domain view: keep the last two seconds of (real) samples, show the configured window."""
+        mw, dm = self.mw, self.dm
+        block = mw.current_source.read_samples_only()
+        if block is None or len(block) == 0:
+            return
+        if block.ndim == 2:
+            block = block.mean(axis=1)                    # stereo -> mono
+        block = np.real(block).ravel().astype(np.float32)
+        rate = float(getattr(mw.current_source, "sample_rate", 44100))
+        history = block if dm.zero_span_buffer is None else np.concatenate((dm.zero_span_buffer, block))
+        dm.zero_span_buffer = history = history[-int(2.0 * rate):]
+        shown = history[-max(int(dm.zero_span_time_window * rate), 4):]
+        mw.zero_span_widget.update_zero_span_data(np.arange(shown.size, dtype=np.float32) / rate, shown)
