@@ -58,7 +58,7 @@ def test_fft_size_changes(size):
         assert np.array_equal(r.window, np.hanning(size))     # reference quirk: size change -> Hann again
     a = pkg.MicrophoneSamplesDataSource()
     a.sample_count = size
-    assert a.fft_size == size and len(a.window) == size and len(a._freq_bins()) == size // 2 + 1
+    assert a.fft_size == size and len(a.window) == size and len(a.get_power_levels()[1]) == size // 2 + 1
 
 
 def test_rbw():
