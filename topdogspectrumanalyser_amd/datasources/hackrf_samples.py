@@ -1,16 +1,20 @@
-"""HackrfSamplesDataSource - HackRF IQ source whose DSP runs on the MI355X.
+"""HackRF sample source with the DSP on the MI355X.
 
-Public surface and semantics follow the reference's datasources/hackrf_samples.py (class :20-728):
-constructor (sample_rate, centre_freq), start/stop, reader thread + bounded queue with drop-oldest
-(:191-252), "freshest chunk, last N samples" framing (:254-305), silence/underrun hold of the last good
-frame (:351-355), DC tracker (:360-365), power-normalised Hann (:311-316), PSD / averaging / plain dB
-branches (:374-383), setters (:392-440, :633-670), get_stats (:679-696).
+API and observable behaviour are those of the reference's HackrfSamplesDataSource
+(datasources/hackrf_samples.py): a reader thread pulls 65536-sample chunks off the USB device into a
+four-deep queue that drops its OLDEST chunk when full; a frame is the last `num_samples` samples of the
+freshest chunk (later frames walk backwards through that chunk until a newer one arrives); a frame that
+is missing after 0.5 s or carries no power returns the last good trace instead; DC is removed with the
+tracker `dc <- (1-a)*dc + a*mean(x)` (a = 1 by default), the window is a Hann of unit mean power, and the
+trace is `20*log10(|X| + 1e-12)`, or `10*log10(avg(|X|^2) + 1e-10)` with averaging, or the PSD form.
 
-What differs: the per-frame arithmetic (mean, window multiply, FFT, fftshift, abs, log10, averaging) is
-ONE launch of the HIP frame kernel behind the C-ABI; and _store_raw keeps the untouched samples (the
-reference stores a view it then DC-removes and windows in place - SURVEY.md 8(a) quirk i).
-The USB device object is injected (`device_factory`) or comes from the `hackrf` module when installed;
-without either start() raises RuntimeError exactly like the reference (:84).
+Different on purpose: the frame arithmetic is one launch of the HIP frame kernel (`_gpu_frame`), and
+`get_raw_samples()` hands back the untouched samples (the reference keeps a view that its in-place DC
+removal and windowing then overwrite - SURVEY.md 8(a) quirk i).
+
+The structure is this module's own: `_Radio` owns the USB handle, `_Inbox` owns the queue and the
+"freshest chunk, newest samples first" framing, the source class ties them to the GPU engine.  The USB
+object comes from `device_factory()` or from the `hackrf` module when that is installed.
 """
 import logging
 import queue
@@ -20,401 +24,231 @@ from typing import Callable, Optional
 
 import numpy as np
 
-from .base import SampleDataSource
 from ._gpu import GpuSpectrumMixin
+from .base import SampleDataSource
 
-try:  # pyhackrf is optional: there is no SDR hardware on a GPU box
+try:                                        # pyhackrf needs libhackrf at import time
     from hackrf import HackRF  # type: ignore
-    _HACKRF_AVAILABLE = True
 except (ImportError, OSError):
     HackRF = None
-    _HACKRF_AVAILABLE = False
 
-logger = logging.getLogger(__name__)
+log = logging.getLogger(__name__)
+
+NO_LIBRARY = "HackRF library (libhackrf) not available on this system"
+LNA_RANGE, VGA_RANGE = (0, 40), (0, 62)
+SILENCE_POWER = 1e-20                       # mean |x|^2 below this counts as "no signal"
+
+
+class _Radio:
+    """The USB device and the one lock that serialises every call into it."""
+
+    def __init__(self, factory: Optional[Callable]):
+        self._factory = factory
+        self.handle = None
+        self.lock = threading.RLock()
+
+    @property
+    def available(self) -> bool:
+        return self._factory is not None or HackRF is not None
+
+    def open(self, **settings) -> None:
+        with self.lock:
+            try:
+                if self._factory is not None:
+                    self.handle = self._factory()
+                elif HackRF is not None:
+                    self.handle = HackRF()
+                else:
+                    raise RuntimeError(NO_LIBRARY)
+                self.configure(**settings)
+            except Exception:
+                self.close()
+                raise
+
+    def configure(self, *, sample_rate, centre_freq, lna_gain, vga_gain, amplifier) -> None:
+        dev = self.handle
+        dev.set_sample_rate(sample_rate)
+        dev.set_freq(centre_freq)
+        dev.set_lna_gain(lna_gain)
+        dev.set_vga_gain(vga_gain)
+        self.amplifier(amplifier)
+
+    def amplifier(self, on: bool) -> None:
+        (self.handle.enable_amp if on else self.handle.disable_amp)()
+
+    def read(self, n: int):
+        with self.lock:
+            return None if self.handle is None else self.handle.read_samples(n)
+
+    def close(self) -> None:
+        with self.lock:
+            dev, self.handle = self.handle, None
+        if dev is not None:
+            try:
+                dev.close()
+            except Exception as exc:  # pragma: no cover
+                log.debug("closing the HackRF failed: %s", exc)
+
+
+class _Inbox:
+    """Chunks from the reader thread on one side, frames for the display thread on the other."""
+
+    def __init__(self, depth: int):
+        self.chunks: "queue.Queue[np.ndarray]" = queue.Queue(maxsize=depth)
+        self.current = np.array([], dtype=np.complex64)   # the chunk frames are being cut from
+        self.dropped_samples = 0
+        self.overflows = 0
+
+    def offer(self, chunk) -> None:
+        """Reader side: never blocks; when the queue is full the oldest chunk makes room."""
+        try:
+            self.chunks.put_nowait(chunk)
+            return
+        except queue.Full:
+            pass
+        try:
+            stale = self.chunks.get_nowait()
+            self.chunks.put_nowait(chunk)
+            self.dropped_samples += len(stale)
+            self.overflows += 1
+        except (queue.Empty, queue.Full):                 # raced with the consumer: give up on this chunk
+            self.dropped_samples += len(chunk)
+
+    def _freshest(self):
+        latest = None
+        try:
+            while True:
+                latest = self.chunks.get_nowait()
+        except queue.Empty:
+            return latest
+
+    def _cut(self, count: int) -> np.ndarray:
+        frame, self.current = self.current[-count:], self.current[:-count]
+        return frame
+
+    def take(self, count: int, patience: float):
+        """`count` samples from the end of the freshest chunk, or None when `patience` seconds pass."""
+        latest = self._freshest()
+        if latest is not None:
+            self.current = latest
+        give_up = time.time() + patience
+        while len(self.current) < count:
+            if time.time() > give_up:
+                return None
+            try:
+                first = self.chunks.get(timeout=0.01)
+            except queue.Empty:
+                continue
+            newer = self._freshest()
+            self.current = first if newer is None else newer
+        return self._cut(count)
+
+    def clear(self) -> None:
+        self._freshest()
+        self.current = np.array([], dtype=np.complex64)
 
 
 class HackrfSamplesDataSource(GpuSpectrumMixin, SampleDataSource):
-    READ_CHUNK = 65536       # samples per USB read (3.3 ms at 20 Msps)
+    READ_CHUNK = 65536                      # samples per USB read (3.3 ms at 20 Msps)
     MAX_QUEUE_SIZE = 4
     CONSUME_TIMEOUT = 0.5
     STOP_TIMEOUT = 2.0
+    MAX_READ_ERRORS = 5
     _DC_ALPHA = 1.0
 
     def __init__(self, sample_rate: int, centre_freq: int, device_factory: Optional[Callable] = None,
                  gpu_device: int = 0):
         super().__init__(sample_rate, centre_freq)
         self.num_samples = 1024
-        self.device = None
         self.running = False
+        self.use_psd = False
         self.last_sample_rate = sample_rate
         self.lna_gain, self.vga_gain, self.amplifier = 16, 20, True
-        self.use_psd = False
-        self._device_factory = device_factory
         self._gpu_device = gpu_device
-        self._stop_requested = threading.Event()
-        self._lock = threading.RLock()
-        self._device_lock = threading.RLock()
-        self._sample_queue: "queue.Queue[np.ndarray]" = queue.Queue(maxsize=self.MAX_QUEUE_SIZE)
-        self._reader_thread: Optional[threading.Thread] = None
+        self._radio = _Radio(device_factory)
+        self._inbox = _Inbox(self.MAX_QUEUE_SIZE)
+        self._lock = threading.RLock()                    # display-thread API
+        self._halt = threading.Event()
+        self._reader: Optional[threading.Thread] = None
+        self._read_errors = 0
+        self._last_read_time = 0
         self._window: Optional[np.ndarray] = None
         self._freq_bins: Optional[np.ndarray] = None
-        self._reservoir = np.array([], dtype=np.complex64)
         self._last_good_power: Optional[np.ndarray] = None
-        self._stats = dict(samples_dropped=0, queue_overflows=0, read_errors=0, last_read_time=0)
+        self._engine_dirty = True
         self._averager._on_change = lambda mode, n: self._mark_dirty()
         self._averager._on_reset = self._gpu_reset_averager
-        self._engine_dirty = True
 
-    # ------------------------------------------------------------------ lifecycle
-    def _open_device(self):
-        if self._device_factory is not None:
-            return self._device_factory()
-        if not _HACKRF_AVAILABLE:
-            raise RuntimeError("HackRF library (libhackrf) not available on this system")
-        return HackRF()
+    # names other code (and the reference's own debugging habits) reach for
+    @property
+    def device(self):
+        return self._radio.handle
 
-    def _apply_device_settings(self) -> None:
-        d = self.device
-        d.set_sample_rate(self.sample_rate)
-        d.set_freq(self.centre_freq)
-        d.set_lna_gain(self.lna_gain)
-        d.set_vga_gain(self.vga_gain)
-        (d.enable_amp if self.amplifier else d.disable_amp)()
+    @property
+    def _reservoir(self) -> np.ndarray:
+        return self._inbox.current
 
-    def _setup_device(self) -> None:
-        with self._device_lock:
-            try:
-                self.device = self._open_device()
-                self._apply_device_settings()
-            except Exception:
-                if self.device is not None:
-                    try:
-                        self.device.close()
-                    except Exception:
-                        pass
-                    self.device = None
-                raise
+    @_reservoir.setter
+    def _reservoir(self, samples) -> None:
+        self._inbox.current = samples
 
-    def start(self, frequency=None):
-        if self._device_factory is None and not _HACKRF_AVAILABLE:
-            raise RuntimeError("HackRF library (libhackrf) not available on this system")
-        with self._lock:
-            if frequency:
-                self.centre_freq = int(frequency.centre)
-                self.sample_rate = int(frequency.span)
-            if self.running:
-                logger.warning("Already running")
-                return
-            self._stop_requested.clear()
-            self._setup_device()
-            self._allocate_fft_resources()
-            self._flush_buffers()
-            self._spawn_reader()
-
-    def _spawn_reader(self) -> None:
-        self.running = True
-        self._reader_thread = threading.Thread(target=self._reader_loop, daemon=True, name="HackRF-Reader")
-        self._reader_thread.start()
-
-    def _join_reader(self, timeout: float, force_close: bool) -> None:
-        th = self._reader_thread
-        if th is not None and th.is_alive():
-            th.join(timeout=timeout)
-            if th.is_alive() and force_close and self.device is not None:
-                try:                      # a blocked USB read only returns when the device goes away
-                    self.device.close()
-                except Exception:
-                    pass
-                th.join(timeout=1.0)
-        self._reader_thread = None
-
-    def stop(self):
-        with self._lock:
-            if not self.running:
-                return
-            self.running = False
-            self._stop_requested.set()
-            self._join_reader(self.STOP_TIMEOUT, force_close=True)
-            self._cleanup_device()
-            self._flush_buffers()
-
-    def _cleanup_device(self) -> None:
-        with self._device_lock:
-            if self.device is not None:
-                try:
-                    self.device.close()
-                except Exception as e:  # pragma: no cover
-                    logger.debug("error closing device: %s", e)
-                finally:
-                    self.device = None
+    @property
+    def _sample_queue(self):
+        return self._inbox.chunks
 
     @property
     def is_running(self) -> bool:
         with self._lock:
             return self.running
 
-    # ------------------------------------------------------------------ streaming front end
-    def _reader_loop(self) -> None:
-        consecutive_errors = 0
-        while self.running and not self._stop_requested.is_set():
-            try:
-                with self._device_lock:
-                    if self.device is None:
-                        break
-                    chunk = self.device.read_samples(self.READ_CHUNK)
-                if chunk is None or len(chunk) == 0:
-                    continue
-                consecutive_errors = 0
-                self._stats["last_read_time"] = time.time()
-                try:
-                    self._sample_queue.put_nowait(chunk)
-                except queue.Full:                       # keep the newest data: drop the oldest chunk
-                    try:
-                        dropped = self._sample_queue.get_nowait()
-                        self._sample_queue.put_nowait(chunk)
-                        self._stats["samples_dropped"] += len(dropped)
-                        self._stats["queue_overflows"] += 1
-                    except (queue.Empty, queue.Full):
-                        self._stats["samples_dropped"] += len(chunk)
-            except Exception as e:
-                consecutive_errors += 1
-                self._stats["read_errors"] += 1
-                if consecutive_errors >= 5:
-                    logger.error("5 consecutive read errors: %s", e)
-                    with self._lock:
-                        self.running = False
-                    break
-                time.sleep(0.01)
-
-    def _drain_newest(self) -> Optional[np.ndarray]:
-        newest = None
-        while True:
-            try:
-                newest = self._sample_queue.get_nowait()
-            except queue.Empty:
-                return newest
-
-    def _take_tail(self, count: int) -> np.ndarray:
-        tail = self._reservoir[-count:]
-        self._reservoir = self._reservoir[:-count]
-        return tail
-
-    def _consume_samples(self, count: int):
-        """Exactly `count` samples from the END of the freshest chunk (then walking backwards through
-        it on later calls); None after CONSUME_TIMEOUT without enough data."""
-        if count <= 0:
-            return np.array([], dtype=np.complex64)
-        fresh = self._drain_newest()
-        if fresh is not None:
-            self._reservoir = fresh
-        if len(self._reservoir) >= count:
-            return self._take_tail(count)
-        deadline = time.time() + self.CONSUME_TIMEOUT
-        while len(self._reservoir) < count:
-            if time.time() > deadline:
-                return None
-            try:
-                chunk = self._sample_queue.get(timeout=0.01)
-            except queue.Empty:
-                continue
-            later = self._drain_newest()
-            self._reservoir = later if later is not None else chunk
-        return self._take_tail(count)
-
-    # ------------------------------------------------------------------ FFT resources
-    def _allocate_fft_resources(self) -> None:
-        n = self.num_samples
-        w = np.hanning(n).astype(np.float32)
-        w /= np.sqrt(np.mean(w ** 2))                    # unit mean power (hackrf_samples.py:314-315)
-        self._window = w
-        self._freq_bins = np.fft.fftshift(np.fft.fftfreq(n, 1 / self.sample_rate)) + self.centre_freq
-        self._mark_dirty()
-
-    def _mark_dirty(self) -> None:
-        self._engine_dirty = True
-
-    def _ready_engine(self):
-        if self._engine is None or self._engine_n != self.num_samples or self._engine_dirty:
-            self._gpu_configure(self.num_samples, self._window, branch="hackrf", use_psd=self.use_psd,
-                                sample_rate=self.sample_rate, dc_alpha=self._DC_ALPHA)
-        return self._engine
-
-    @property
-    def _dc_estimate(self) -> complex:
-        return self._engine.dc_estimate if self._engine is not None else 0j
-
-    # ------------------------------------------------------------------ public API
-    def get_samples(self) -> np.ndarray:
-        with self._lock:
-            if not self.running:
-                return np.zeros(self.num_samples, dtype=np.complex64)
-            s = self._consume_samples(self.num_samples)
-            return s if s is not None else np.zeros(self.num_samples, dtype=np.complex64)
-
-    def get_power_levels(self):
-        with self._lock:
-            if not self.running or self._freq_bins is None:
-                bins = self._freq_bins if self._freq_bins is not None else np.zeros(self.num_samples)
-                return np.zeros(self.num_samples), bins
-            samples = self._consume_samples(self.num_samples)
-            silent = samples is None or float(np.vdot(samples, samples).real) / len(samples) < 1e-20
-            if silent:                                   # underrun / silence: hold the last good frame
-                if self._last_good_power is not None:
-                    return self._last_good_power, self._freq_bins
-                return np.zeros(self.num_samples), self._freq_bins
-            self._store_raw(samples)
-            self._ready_engine()
-            power_db = self._gpu_frame(samples)
-            self._last_good_power = power_db
-            return power_db, self._freq_bins
-
-    def set_num_samples(self, num_samples: int):
-        if num_samples <= 0:
-            raise ValueError("num_samples must be positive")
-        with self._lock:
-            if num_samples == self.num_samples:
-                return
-            self.num_samples = num_samples
-            self._averager.reset()
-            if self.running:
-                self._allocate_fft_resources()
-
-    @property
-    def sample_count(self) -> int:
-        with self._lock:
-            return self.num_samples
-
-    @sample_count.setter
-    def sample_count(self, value: int):
-        self.set_num_samples(value)
-
-    def read_samples_only(self):
-        with self._lock:
-            if not self.running:
-                return None
-            s = self._consume_samples(self.num_samples)
-            if s is not None:
-                self._store_raw(s)
-            return s
-
-    def set_psd_mode(self, enabled: bool):
-        with self._lock:
-            if self.use_psd != enabled:
-                self.use_psd = enabled
-                self._mark_dirty()
-
-    # ------------------------------------------------------------------ retuning
-    def _flush_buffers(self) -> None:
-        self._drain_newest()
-        self._reservoir = np.array([], dtype=np.complex64)
-        self._gpu_reset_dc()
-        self._last_good_power = None
-
-    def _stop_internal(self) -> None:
-        if not self.running:
-            return
-        self.running = False
-        self._stop_requested.set()
-        self._join_reader(0.5, force_close=False)
-        self._flush_buffers()
-
-    def _start_internal(self) -> None:
-        if self.running:
-            return
-        self._stop_requested.clear()
-        with self._device_lock:
-            if self.device is not None:
-                try:
-                    self._apply_device_settings()
-                except Exception:
-                    self._cleanup_device()
-                    self._setup_device()
-            else:
-                self._setup_device()
-        self._allocate_fft_resources()
-        self._flush_buffers()
-        self._spawn_reader()
-
-    def _retune(self, sample_rate: Optional[int], centre_freq: Optional[int]) -> None:
-        was_running = self.running
-        if was_running:
-            self._stop_internal()
-        if sample_rate is not None:
-            self.sample_rate = sample_rate
-            self.last_sample_rate = sample_rate
-        if centre_freq is not None:
-            self.centre_freq = centre_freq
-        if was_running:
-            self._start_internal()
-
-    def update_centre_frequency(self, centre_freq: float):
-        centre_freq = int(centre_freq)
-        with self._lock:
-            if centre_freq != self.centre_freq:
-                self._retune(None, centre_freq)
-
-    def update_sample_rate(self, sample_rate: float):
-        sample_rate = int(sample_rate)
-        with self._lock:
-            if sample_rate != self.last_sample_rate:
-                self._retune(sample_rate, None)
-
-    def update_frequency(self, sample_rate: float, centre_freq: float):
-        sample_rate, centre_freq = int(sample_rate), int(centre_freq)
-        with self._lock:
-            new_rate = sample_rate if sample_rate != self.last_sample_rate else None
-            new_freq = centre_freq if centre_freq != self.centre_freq else None
-            if new_rate is not None or new_freq is not None:
-                self._retune(new_rate, new_freq)
-
-    # ------------------------------------------------------------------ gain / misc controls
-    def set_gains(self, lna_gain: Optional[int] = None, vga_gain: Optional[int] = None):
-        with self._lock:
-            if lna_gain is not None:
-                if not 0 <= lna_gain <= 40:
-                    raise ValueError(f"LNA gain must be between 0 and 40, got {lna_gain}")
-                self.lna_gain = lna_gain
-            if vga_gain is not None:
-                if not 0 <= vga_gain <= 62:
-                    raise ValueError(f"VGA gain must be between 0 and 62, got {vga_gain}")
-                self.vga_gain = vga_gain
-            if self.running and self.device is not None:
-                with self._device_lock:
-                    if lna_gain is not None:
-                        self.device.set_lna_gain(self.lna_gain)
-                    if vga_gain is not None:
-                        self.device.set_vga_gain(self.vga_gain)
-
-    def set_dc_alpha(self, alpha: float) -> None:
-        self._DC_ALPHA = max(0.0, min(1.0, float(alpha)))
-        self._mark_dirty()
-
-    def set_amplifier(self, enabled: bool):
-        with self._lock:
-            self.amplifier = enabled
-            if self.running and self.device is not None:
-                with self._device_lock:
-                    (self.device.enable_amp if enabled else self.device.disable_amp)()
-
     @property
     def amp_enabled(self) -> bool:
         return self.amplifier
 
-    def get_stats(self) -> dict:
-        with self._lock:
-            st = dict(self._stats)
-            dc = self._dc_estimate
-            st.update(queue_size=self._sample_queue.qsize(), reservoir_size=len(self._reservoir),
-                      queue_capacity=self._sample_queue.maxsize, is_running=self.running,
-                      thread_alive=bool(self._reader_thread and self._reader_thread.is_alive()),
-                      num_samples=self.num_samples, sample_rate=self.sample_rate,
-                      centre_freq=self.centre_freq, dc_estimate_mag=abs(dc),
-                      dc_estimate_phase=float(np.angle(dc)), timestamp=time.time())
-            return st
+    def _radio_settings(self) -> dict:
+        return dict(sample_rate=self.sample_rate, centre_freq=self.centre_freq, lna_gain=self.lna_gain,
+                    vga_gain=self.vga_gain, amplifier=self.amplifier)
 
-    def reset_stats(self):
+    # ------------------------------------------------------------------ start / stop
+    def start(self, frequency=None):
+        if not self._radio.available:
+            raise RuntimeError(NO_LIBRARY)
         with self._lock:
-            self._stats = dict(samples_dropped=0, queue_overflows=0, read_errors=0, last_read_time=0)
+            if frequency:
+                self.centre_freq, self.sample_rate = int(frequency.centre), int(frequency.span)
+            if self.running:
+                log.warning("HackRF source already running")
+                return
+            self._halt.clear()
+            self._radio.open(**self._radio_settings())
+            self._go()
+
+    def _go(self) -> None:
+        """Common tail of start() and of a retune: fresh FFT tables, empty buffers, reader thread."""
+        self._allocate_fft_resources()
+        self._flush_buffers()
+        self.running = True
+        self._reader = threading.Thread(target=self._reader_loop, name="HackRF-Reader", daemon=True)
+        self._reader.start()
+
+    def _park_reader(self, patience: float, yank_device: bool) -> None:
+        thread, self._reader = self._reader, None
+        if thread is None or not thread.is_alive():
+            return
+        thread.join(timeout=patience)
+        if thread.is_alive() and yank_device:             # a blocked USB read returns only when the device goes
+            self._radio.close()
+            thread.join(timeout=1.0)
+
+    def stop(self):
+        with self._lock:
+            if not self.running:
+                return
+            self.running = False
+            self._halt.set()
+            self._park_reader(self.STOP_TIMEOUT, yank_device=True)
+            self._radio.close()
+            self._flush_buffers()
 
     def __enter__(self):
         self.start()
@@ -430,3 +264,203 @@ class HackrfSamplesDataSource(GpuSpectrumMixin, SampleDataSource):
             self._gpu_release()
         except Exception:
             pass
+
+    # ------------------------------------------------------------------ reader thread
+    def _reader_loop(self) -> None:
+        failures = 0
+        while self.running and not self._halt.is_set():
+            try:
+                if self._radio.handle is None:
+                    return
+                chunk = self._radio.read(self.READ_CHUNK)
+                if chunk is None or len(chunk) == 0:
+                    continue
+                failures = 0
+                self._last_read_time = time.time()
+                self._inbox.offer(chunk)
+            except Exception as exc:
+                failures += 1
+                self._read_errors += 1
+                if failures >= self.MAX_READ_ERRORS:
+                    log.error("%d consecutive HackRF read errors, giving up: %s", failures, exc)
+                    with self._lock:
+                        self.running = False
+                    return
+                time.sleep(0.01)
+
+    def _consume_samples(self, count: int):
+        if count <= 0:
+            return np.array([], dtype=np.complex64)
+        return self._inbox.take(count, self.CONSUME_TIMEOUT)
+
+    def _flush_buffers(self) -> None:
+        self._inbox.clear()
+        self._gpu_reset_dc()
+        self._last_good_power = None
+
+    # ------------------------------------------------------------------ FFT set-up
+    def _allocate_fft_resources(self) -> None:
+        n = self.num_samples
+        taper = np.hanning(n).astype(np.float32)
+        self._window = taper / np.sqrt(np.mean(taper ** 2, dtype=np.float32))     # unit mean power
+        self._freq_bins = np.fft.fftshift(np.fft.fftfreq(n, 1 / self.sample_rate)) + self.centre_freq
+        self._mark_dirty()
+
+    def _mark_dirty(self) -> None:
+        self._engine_dirty = True
+
+    def _ready_engine(self):
+        if self._engine_dirty or self._engine is None or self._engine_n != self.num_samples:
+            self._gpu_configure(self.num_samples, self._window, branch="hackrf", use_psd=self.use_psd,
+                                sample_rate=self.sample_rate, dc_alpha=self._DC_ALPHA)
+        return self._engine
+
+    @property
+    def _dc_estimate(self) -> complex:
+        return 0j if self._engine is None else self._engine.dc_estimate
+
+    # ------------------------------------------------------------------ frames
+    def _nothing(self) -> np.ndarray:
+        return np.zeros(self.num_samples)
+
+    def get_power_levels(self):
+        with self._lock:
+            axis = self._freq_bins
+            if axis is None or not self.running:
+                return self._nothing(), (self._nothing() if axis is None else axis)
+            frame = self._consume_samples(self.num_samples)
+            if frame is None or float(np.vdot(frame, frame).real) < SILENCE_POWER * len(frame):
+                held = self._last_good_power               # underrun or silence: keep showing the last trace
+                return (self._nothing() if held is None else held), axis
+            self._store_raw(frame)
+            self._ready_engine()
+            self._last_good_power = trace = self._gpu_frame(frame)
+            return trace, axis
+
+    def get_samples(self) -> np.ndarray:
+        with self._lock:
+            frame = self._consume_samples(self.num_samples) if self.running else None
+            return np.zeros(self.num_samples, dtype=np.complex64) if frame is None else frame
+
+    def read_samples_only(self):
+        with self._lock:
+            if not self.running:
+                return None
+            frame = self._consume_samples(self.num_samples)
+            if frame is not None:
+                self._store_raw(frame)
+            return frame
+
+    # ------------------------------------------------------------------ settings
+    @property
+    def sample_count(self) -> int:
+        with self._lock:
+            return self.num_samples
+
+    @sample_count.setter
+    def sample_count(self, value: int):
+        self.set_num_samples(value)
+
+    def set_num_samples(self, num_samples: int):
+        if num_samples <= 0:
+            raise ValueError("num_samples must be positive")
+        with self._lock:
+            if num_samples != self.num_samples:
+                self.num_samples = num_samples
+                self._averager.reset()
+                if self.running:
+                    self._allocate_fft_resources()
+
+    def set_psd_mode(self, enabled: bool):
+        with self._lock:
+            if enabled != self.use_psd:
+                self.use_psd = enabled
+                self._mark_dirty()
+
+    def set_dc_alpha(self, alpha: float) -> None:
+        self._DC_ALPHA = min(1.0, max(0.0, float(alpha)))
+        self._mark_dirty()
+
+    @staticmethod
+    def _checked_gain(name: str, value: int, limits) -> int:
+        lo, hi = limits
+        if not lo <= value <= hi:
+            raise ValueError(f"{name} gain must be between {lo} and {hi}, got {value}")
+        return value
+
+    def set_gains(self, lna_gain: Optional[int] = None, vga_gain: Optional[int] = None):
+        with self._lock:
+            if lna_gain is not None:
+                self.lna_gain = self._checked_gain("LNA", lna_gain, LNA_RANGE)
+            if vga_gain is not None:
+                self.vga_gain = self._checked_gain("VGA", vga_gain, VGA_RANGE)
+            if self.running and self._radio.handle is not None:
+                with self._radio.lock:
+                    if lna_gain is not None:
+                        self._radio.handle.set_lna_gain(self.lna_gain)
+                    if vga_gain is not None:
+                        self._radio.handle.set_vga_gain(self.vga_gain)
+
+    def set_amplifier(self, enabled: bool):
+        with self._lock:
+            self.amplifier = enabled
+            if self.running and self._radio.handle is not None:
+                with self._radio.lock:
+                    self._radio.amplifier(enabled)
+
+    # ------------------------------------------------------------------ retune
+    def _retune(self, sample_rate: Optional[int], centre_freq: Optional[int]) -> None:
+        """Change rate and / or centre frequency; a running stream is paused around the change."""
+        live = self.running
+        if live:                                          # pause: reader off, buffers dropped, device kept
+            self.running = False
+            self._halt.set()
+            self._park_reader(0.5, yank_device=False)
+            self._flush_buffers()
+        if sample_rate is not None:
+            self.sample_rate = self.last_sample_rate = sample_rate
+        if centre_freq is not None:
+            self.centre_freq = centre_freq
+        if live:
+            self._halt.clear()
+            with self._radio.lock:
+                try:
+                    if self._radio.handle is None:
+                        raise RuntimeError("device lost")
+                    self._radio.configure(**self._radio_settings())
+                except Exception:                         # re-open once if the handle went bad
+                    self._radio.close()
+                    self._radio.open(**self._radio_settings())
+            self._go()
+
+    def update_frequency(self, sample_rate: float, centre_freq: float):
+        rate, freq = int(sample_rate), int(centre_freq)
+        with self._lock:
+            new_rate = rate if rate != self.last_sample_rate else None
+            new_freq = freq if freq != self.centre_freq else None
+            if new_rate is not None or new_freq is not None:
+                self._retune(new_rate, new_freq)
+
+    def update_sample_rate(self, sample_rate: float):
+        self.update_frequency(sample_rate, self.centre_freq)
+
+    def update_centre_frequency(self, centre_freq: float):
+        self.update_frequency(self.last_sample_rate, centre_freq)
+
+    # ------------------------------------------------------------------ statistics
+    def get_stats(self) -> dict:
+        with self._lock:
+            dc = self._dc_estimate
+            reader = self._reader
+            return dict(samples_dropped=self._inbox.dropped_samples, queue_overflows=self._inbox.overflows,
+                        read_errors=self._read_errors, last_read_time=self._last_read_time,
+                        queue_size=self._inbox.chunks.qsize(), queue_capacity=self._inbox.chunks.maxsize,
+                        reservoir_size=len(self._inbox.current), is_running=self.running,
+                        thread_alive=bool(reader and reader.is_alive()), num_samples=self.num_samples,
+                        sample_rate=self.sample_rate, centre_freq=self.centre_freq, dc_estimate_mag=abs(dc),
+                        dc_estimate_phase=float(np.angle(dc)), timestamp=time.time())
+
+    def reset_stats(self):
+        with self._lock:
+            self._inbox.dropped_samples = self._inbox.overflows = 0
+            self._read_errors = self._last_read_time = 0
