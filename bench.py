@@ -278,7 +278,10 @@ def main() -> None:
         result["parity"] = {"max_rel_power_err": worst_rel, "max_db_err_top60dB": worst_db,
                             "frames_checked": 4, "against": "float64 gold oracle"}
         if args.cpu_workers > 0:
-            result["cpu_baseline_all_cores"] = cpu_all_cores(wl, args.cpu_workers, args.cpu_pool_seconds)
+            try:
+                result["cpu_baseline_all_cores"] = cpu_all_cores(wl, args.cpu_workers, args.cpu_pool_seconds)
+            except Exception as exc:               # a reported extra, never a reason to lose the bench line
+                result["cpu_baseline_all_cores"] = {"value": None, "error": str(exc)}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
