@@ -913,3 +913,23 @@ def test_host_pipe_device_rows_feed_analytics(pkg):
         with pytest.raises(Exception):
             q.collect_device()                                  # this pipe keeps no rows
         q.collect()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_process_sharded_threads(pkg, world):
+    """Frame sharding from one process: a thread + plan per shard (all on GPU 0 here), halo handled, rows
+    and hold traces identical to the unsharded run."""
+    from topdogspectrumanalyser_amd.sharding import process_sharded
+    nfft, hop, nf = 2048, 768, 101
+    iq = so.synth_iq_int8(hop * (nf - 1) + nfft, nfft, seed=77)
+    w = so.hackrf_window(nfft)
+    with _hackrf_engine(pkg, nfft, nf, hold_max=True, hold_min=True) as e:
+        ref = e.process(iq, hop=hop)
+        rmx, rmn = e.hold()
+    rows, mx, mn = process_sharded(iq, nfft, hop, [0] * world, w, hold="maxmin", db_mode="mag",
+                                   log_floor=so.LOG_FLOOR, dc_alpha=1.0)
+    assert np.array_equal(rows, ref) and np.array_equal(mx, rmx) and np.array_equal(mn, rmn)
+    with pytest.raises(ValueError):
+        process_sharded(iq, nfft, hop, [0], w, avg=("exp", 4))
+    short, _, _ = process_sharded(iq[: 2 * 100], nfft, hop, [0, 0], w)
+    assert short.shape == (0, nfft)

@@ -45,3 +45,55 @@ def combine_welch(means: Sequence[np.ndarray], counts: Sequence[int]) -> Tuple[n
         if c:
             acc += np.asarray(m, dtype=np.float64) * c
     return acc / total, total
+
+
+def process_sharded(iq: np.ndarray, nfft: int, hop: int, devices: Sequence[int], window: np.ndarray,
+                    hold: str = "", **configure):
+    """One capture over several GPUs from ONE process: a thread and a SpectrumEngine per entry of `devices`
+    (the C-ABI calls release the GIL), each taking its contiguous frame range plus halo; returns
+    (dB rows [frames, nfft] in capture order, combined max-hold trace or None, combined min-hold or None).
+
+    Only order-independent modes make sense here (no "exp" / capped "lin" averaging: replicas only).  A
+    device may appear more than once - two plans then share that GPU - which is also how this is tested
+    on a single-GPU box.  `configure` goes to SpectrumEngine.configure; `hold` is "", "max", "min" or "maxmin".
+    """
+    import threading
+    from .engine import SpectrumEngine
+
+    if configure.get("avg", ("off", 1))[0] != "off":
+        raise ValueError("order-dependent averaging cannot be sharded (SURVEY.md 8(e): replicas only)")
+    iq = np.ascontiguousarray(iq)
+    per_sample = 1 if np.iscomplexobj(iq) else 2           # interleaved bytes: two array elements per sample
+    n_samples = iq.size // per_sample
+    n_frames = 0 if n_samples < nfft else (n_samples - nfft) // hop + 1
+    world = len(devices)
+    rows = np.empty((n_frames, nfft), dtype=np.float32)
+    holds = [None] * world
+    errors = [None] * world
+
+    def work(rank: int) -> None:
+        try:
+            f0, f1 = shard_frames(n_frames, rank, world)
+            if f1 <= f0:
+                return
+            s0, s1 = shard_samples(f0, f1, nfft, hop)
+            with SpectrumEngine(nfft, max_frames=f1 - f0, device=devices[rank]) as eng:
+                eng.set_window(window)
+                eng.configure(hold_max="max" in hold, hold_min="min" in hold, **configure)
+                rows[f0:f1] = eng.process(iq[per_sample * s0: per_sample * s1], hop=hop, n_frames=f1 - f0)
+                holds[rank] = eng.hold()
+        except Exception as exc:                          # surfaced by the caller's thread
+            errors[rank] = exc
+
+    threads = [threading.Thread(target=work, args=(r,), name=f"tdsa-shard-{r}") for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for exc in errors:
+        if exc is not None:
+            raise exc
+    got = [h for h in holds if h is not None]
+    mx = combine_hold([h[0] for h in got], "max") if "max" in hold and got else None
+    mn = combine_hold([h[1] for h in got], "min") if "min" in hold and got else None
+    return rows, mx, mn
