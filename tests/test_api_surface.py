@@ -147,3 +147,22 @@ def test_replay_devices_unpack_convention():
     assert np.array_equal(d.read_samples(1024), so.unpack_iq_int8(iq)[1024:2048])
     r = ReplayRtlSdr(iq, sample_rate=2e6, center_freq=1e8)
     assert r.get_sample_rate() == 2e6 and r.get_center_freq() == 1e8 and len(r.read_samples(512)) == 512
+
+
+def test_unsupported_fft_size_never_raises():
+    """set_num_samples() is unbounded in the reference (hackrf_samples.py:392-405) and get_power_levels()
+    never raises (:342-355): a size the device library has no plan for yields zeros + the frequency axis."""
+    from topdogspectrumanalyser_amd.datasources.replay import ReplayHackRF
+    iq = synth_iq_int8(65536, 1024, 3)
+    h = pkg.HackrfSamplesDataSource(sample_rate=20_000_000, centre_freq=100_000_000,
+                                    device_factory=lambda: ReplayHackRF(iq))
+    h.start()
+    try:
+        h.set_num_samples(3000)                  # not a power of two: no GPU plan
+        p, f = h.get_power_levels()
+        assert p.shape == (3000,) and not p.any() and f.shape == (3000,)
+        assert abs((f[1] - f[0]) - 20e6 / 3000) < 1e-6
+        p2, _ = h.get_power_levels()             # and again (the failure is remembered, not re-raised)
+        assert p2.shape == (3000,) and not p2.any()
+    finally:
+        h.stop()

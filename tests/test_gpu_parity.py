@@ -7,6 +7,7 @@ Tolerances (BASELINE.json north_star: 1e-4 relative float32):
     value the reference's own float32 path does not reproduce either
 """
 import os
+import time
 
 import numpy as np
 import pytest
@@ -199,6 +200,68 @@ def test_hackrf_source_streaming_front_end(pkg):
     assert not src.is_running
     z, _ = src.get_power_levels()
     assert not z.any()
+
+
+class _ScriptedHackRF:
+    """Replay device whose stream can be switched to silence or to a stall (reader gets nothing)."""
+
+    def __init__(self, iq):
+        from topdogspectrumanalyser_amd.datasources.replay import ReplayHackRF
+        self._inner = ReplayHackRF(iq)
+        self.mode = "play"
+
+    def read_samples(self, n):
+        if self.mode == "stall":
+            time.sleep(0.005)
+            return np.array([], dtype=np.complex64)
+        x = self._inner.read_samples(n)
+        return np.zeros_like(x) if self.mode == "silent" else x
+
+    def __getattr__(self, name):
+        return getattr(self._inner, name)
+
+
+def test_hackrf_source_holds_last_good_frame(pkg):
+    """a3 (hackrf_samples.py:351-355): a silent frame and an underrun both return the PREVIOUS trace
+    object; before any good frame they return zeros; a good frame afterwards replaces it."""
+    n = 1024
+    iq = so.synth_iq_int8(65536 * 2, n, seed=17)
+    dev = _ScriptedHackRF(iq)
+    src = pkg.HackrfSamplesDataSource(sample_rate=20_000_000, centre_freq=2_450_000_000,
+                                      device_factory=lambda: dev)
+    src.CONSUME_TIMEOUT = 0.1
+
+    def switch(mode):
+        dev.mode = mode
+        time.sleep(0.05)                       # every chunk read from now on is of the new kind
+        with src._lock:
+            src._inbox.clear()
+
+    dev.mode = "silent"
+    src.start()
+    try:
+        switch("silent")
+        z, fb = src.get_power_levels()         # silence before any good frame: zeros + axis
+        assert z.shape == (n,) and not z.any() and fb.shape == (n,)
+        switch("play")
+        good, _ = src.get_power_levels()
+        assert np.isfinite(good).all() and good.any()
+        gold = so.HackrfBranchOracle(n, 20e6, precision="gold").power_levels(src.get_raw_samples())
+        _check(good, gold, "good frame")
+        keep = good.copy()
+        switch("silent")
+        held, fb2 = src.get_power_levels()
+        assert held is good and np.array_equal(held, keep) and fb2 is fb
+        switch("stall")
+        t0 = time.time()
+        held2, _ = src.get_power_levels()      # underrun: _consume_samples gives up -> None
+        assert held2 is good and time.time() - t0 >= 0.09
+        switch("play")
+        fresh, _ = src.get_power_levels()
+        assert fresh is not good and np.isfinite(fresh).all()
+        assert src._last_good_power is fresh
+    finally:
+        src.stop()
 
 
 @pytest.mark.parametrize("mode", ["hanning", "hamming", "rectangle", "psd", "lin3"])
@@ -710,6 +773,26 @@ def test_overlapped_launches_match_serial(pkg, streams):
         for a, b in zip(d_in, d_out):
             nat.lib.tdsa_dev_free(0, a)
             nat.lib.tdsa_dev_free(0, b)
+
+
+@pytest.mark.parametrize("streams", [2, 3, 4])
+def test_host_entry_points_stay_consistent_with_overlap(pkg, streams):
+    """tdsa_process_i8 after tdsa_set_overlap(n > 1): the frame kernel may run on an auxiliary stream, the
+    read-back must still wait for it (include/tdsa_hip.h: every other entry point stays sequentially
+    consistent).  Large batches in an order-free mode, rows compared bit for bit with a serial plan."""
+    nfft, hop, nf, calls = 16384, 8192, 400, 8
+    ns = hop * (nf - 1) + nfft
+    batches = [so.synth_iq_int8(ns, nfft, seed=300 + i) for i in range(calls)]
+    with _hackrf_engine(pkg, nfft, nf, hold_max=True) as e:
+        serial = [e.process(iq, hop=hop) for iq in batches]
+        smax, _ = e.hold()
+    with _hackrf_engine(pkg, nfft, nf, hold_max=True) as e:
+        e.set_overlap(streams)
+        for i, iq in enumerate(batches):
+            got = e.process(iq, hop=hop)
+            assert np.array_equal(got, serial[i]), f"host call {i} returned stale rows with {streams} streams"
+        mx, _ = e.hold()
+        assert np.array_equal(mx, smax)
 
 
 def test_set_overlap_rejects_bad_counts(pkg):

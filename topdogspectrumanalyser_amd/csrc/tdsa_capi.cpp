@@ -596,6 +596,9 @@ static int process_host(tdsa_plan p, int fmt, const void* iq_host, size_t n_samp
   HIPCHK(hipMemcpyAsync(p->d_in_stage, iq_host, in_bytes, hipMemcpyHostToDevice, p->stream));
   int rc = tdsa_process_dev(p, fmt, p->d_in_stage, need, hop, n_frames, out_db_host ? p->d_out_stage : nullptr);
   if (rc != TDSA_OK) return rc;
+  // with tdsa_set_overlap(n > 1) the frame kernel may have gone to an auxiliary stream: order the main
+  // stream (read-back + the synchronize below) behind it, so the host call stays sequentially consistent
+  JOIN(p);
   if (out_db_host)
     HIPCHK(hipMemcpyAsync(out_db_host, p->d_out_stage, size_t(p->big ? 1 : n_frames) * p->nfft * sizeof(float),
                           hipMemcpyDeviceToHost, p->stream));

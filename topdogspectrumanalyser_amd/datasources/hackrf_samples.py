@@ -176,6 +176,7 @@ class HackrfSamplesDataSource(GpuSpectrumMixin, SampleDataSource):
         self._freq_bins: Optional[np.ndarray] = None
         self._last_good_power: Optional[np.ndarray] = None
         self._engine_dirty = True
+        self._engine_failed = False
         self._averager._on_change = lambda mode, n: self._mark_dirty()
         self._averager._on_reset = self._gpu_reset_averager
 
@@ -329,12 +330,20 @@ class HackrfSamplesDataSource(GpuSpectrumMixin, SampleDataSource):
             if axis is None or not self.running:
                 return self._nothing(), (self._nothing() if axis is None else axis)
             frame = self._consume_samples(self.num_samples)
-            if frame is None or float(np.vdot(frame, frame).real) < SILENCE_POWER * len(frame):
+            if frame is None or np.mean(np.abs(frame) ** 2) < SILENCE_POWER:
                 held = self._last_good_power               # underrun or silence: keep showing the last trace
                 return (self._nothing() if held is None else held), axis
             self._store_raw(frame)
-            self._ready_engine()
-            self._last_good_power = trace = self._gpu_frame(frame)
+            try:
+                self._ready_engine()
+                trace = self._gpu_frame(frame)
+            except (ValueError, RuntimeError) as exc:      # e.g. an FFT size the device library has no plan
+                if not self._engine_failed:                # for: get_power_levels() never raises
+                    log.error("GPU spectrum path unavailable for %d points: %s", self.num_samples, exc)
+                self._engine_failed = True
+                return self._nothing(), axis
+            self._engine_failed = False
+            self._last_good_power = trace
             return trace, axis
 
     def get_samples(self) -> np.ndarray:
