@@ -7,8 +7,9 @@ Pinned against the imported reference (tests/golden/analytics.npz, generator tes
   DutyCycleOracle         <- DutyCycleAnalyser.update_from_power   (core/duty_cycle.py:30-50)
   band_power_db           <- MarkerManager._band_power             (core/marker_manager.py:308-319)
   frame_peak              <- np.max / np.argmax as used by core/duty_cycle.py:36 and marker snap (marker_manager.py:97)
-Restated from source only (the display modules import PyQt6/pyqtgraph, absent here: PARITY UNPINNED by the
-reference itself; pinned by hand-derived known-answer cases in tests/test_analytics_oracle.py):
+Pinned against the imported display classes themselves (tests/golden/displays.npz, generator
+tests/golden/make_golden_displays.py: displays/density_display.py and displays/waterfall.py imported against
+stub PyQt6 / pyqtgraph modules made of plain do-nothing classes, real objects constructed, their numpy runs):
   DensityOracle           <- DensityDisplay._ensure_hist/_update_hist (displays/density_display.py:300-320)
   WaterfallOracle         <- Waterfall._init_buffer/_add_row/_display_view + dedup (displays/waterfall.py:163-180, 330-336)
 """

@@ -380,15 +380,38 @@ def synth_iq_int8(n_samples: int, nfft: int, seed: int) -> np.ndarray:
     return out
 
 
-def parity_metrics(db_gpu: np.ndarray, db_gold: np.ndarray, floor_rel_db: float = 60.0):
-    """SURVEY.md 8(d) parity definition: per frame, linear power error relative to the frame
-    maximum, and |dB| error on bins within ``floor_rel_db`` of the frame maximum."""
+AMP_FLOOR = 4e-8     # two thirds of a float32 ulp of the frame's largest amplitude
+
+
+def parity_metrics(db_gpu: np.ndarray, db_gold: np.ndarray, floor_rel_db: float = 100.0,
+                   amp_floor: float = AMP_FLOOR):
+    """SURVEY.md 8(d) parity definition, per frame:
+      rel - linear power error relative to the frame maximum (bound 1e-4, every bin);
+      ddb - |dB| error on the bins within ``floor_rel_db`` (100 dB) of the frame maximum, bound 1e-3 dB.
+    A float32 FFT cannot resolve an amplitude difference below about one ulp of the LARGEST amplitude it
+    carries: where a bin is so deep that ``amp_floor`` * A_max (0.7 ulp) is worth more than 1e-3 dB of that
+    bin - from 69 dB below the maximum on - the allowance is that amplitude instead.  (On MI355X the errors
+    sit at 1.2e-8 * A_max in the 31 bins that share the last radix-32 butterfly with a strong tone and at
+    5e-10 * A_max elsewhere; numpy's own float32 path reaches 6e-7 * A_max next to a tone.)  `ddb` is
+    returned scaled to the 1e-3 dB bound, i.e. max(|dB error| / allowance) * 1e-3, so ``ddb <= 1e-3`` is
+    the test."""
     db_gpu = np.asarray(db_gpu, dtype=np.float64)
     db_gold = np.asarray(db_gold, dtype=np.float64)
     p_gpu = 10.0 ** (db_gpu / 10.0)
     p_gold = 10.0 ** (db_gold / 10.0)
     pmax = p_gold.max(axis=-1, keepdims=True)
     rel = np.abs(p_gpu - p_gold) / pmax
+    depth = db_gold.max(axis=-1, keepdims=True) - db_gold
+    mask = depth <= floor_rel_db
+    allowance = np.maximum(1e-3, (20.0 / np.log(10.0)) * amp_floor * 10.0 ** (depth / 20.0))
+    with np.errstate(invalid="ignore"):
+        ddb = np.where(mask, np.abs(db_gpu - db_gold) / allowance, 0.0) * 1e-3
+    return float(rel.max()), float(np.nanmax(ddb))
+
+
+def parity_raw_db(db_gpu: np.ndarray, db_gold: np.ndarray, floor_rel_db: float) -> float:
+    """largest plain |dB| error over the bins within ``floor_rel_db`` of the frame maximum (reporting)"""
+    db_gpu = np.asarray(db_gpu, dtype=np.float64)
+    db_gold = np.asarray(db_gold, dtype=np.float64)
     mask = db_gold >= (db_gold.max(axis=-1, keepdims=True) - floor_rel_db)
-    ddb = np.where(mask, np.abs(db_gpu - db_gold), 0.0)
-    return float(rel.max()), float(ddb.max())
+    return float(np.where(mask, np.abs(db_gpu - db_gold), 0.0).max())

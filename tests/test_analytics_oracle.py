@@ -101,3 +101,27 @@ def test_waterfall_known_answers():
     assert news == [True, False, True, True, True]                    # identical consecutive row is skipped
     assert np.array_equal(w.view(), np.array([[7, 8], [5, 6], [3, 4]], dtype=np.float32))   # newest first
     assert w.buf.shape == (6, 2) and np.array_equal(w.buf[:3], w.buf[3:])
+
+
+# ---- display accumulators pinned to the imported reference classes (tests/golden/displays.npz) ----
+@pytest.mark.parametrize("mode", ["medium", "fast", "off"])
+def test_density_oracle_matches_reference_fixture(golden_dir, mode):
+    g = np.load(os.path.join(golden_dir, "displays.npz"))
+    d = ao.DensityOracle(decay=float(g[f"density_{mode}_decay"]))
+    snaps = {int(r): i for i, r in enumerate(g["density_snap_rows"])}
+    for r, row in enumerate(g["density_rows"]):
+        with np.errstate(invalid="ignore"):
+            d.update(row)
+        if r in snaps:
+            assert np.array_equal(d.hist, g[f"density_{mode}_hist"][snaps[r]]), (mode, r)
+
+
+def test_waterfall_oracle_matches_reference_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, "displays.npz"))
+    w = ao.WaterfallOracle(int(g["wf_history_lines"]), g["wf_rows"].shape[1], float(g["wf_min_db"]))
+    steps = {int(s): i for i, s in enumerate(g["wf_view_steps"])}
+    for step, idx in enumerate(g["wf_order"]):
+        assert w.update(g["wf_rows"][idx]) == bool(g["wf_added"][step])
+        assert w.ptr == int(g["wf_ptr"][step])
+        if step in steps:
+            assert np.array_equal(w.view(), g["wf_views"][steps[step]])

@@ -207,6 +207,47 @@ def test_waterfall_ring_matches_restatement(pkg, an):
             wf.push(base[0][:10])
 
 
+@pytest.mark.parametrize("mode", ["medium", "fast", "off"])
+def test_density_histogram_matches_reference_fixture(pkg, an, golden_dir, mode):
+    """density_kernel against DensityDisplay._update_hist of the imported reference (displays.npz): NaN,
+    -inf, out-of-range and on-the-edge values included, histogram bit for bit after rows 0, 7 and 47."""
+    g = np.load(os.path.join(golden_dir, "displays.npz"))
+    rows = np.ascontiguousarray(g["density_rows"])
+    decay = float(g[f"density_{mode}_decay"])
+    prev = 0
+    with an.DensityHistogram(rows.shape[1], decay) as dh:
+        for i, r in enumerate(g["density_snap_rows"]):
+            chunk = np.ascontiguousarray(rows[prev:int(r) + 1])
+            with DevRows(pkg, chunk) as d:
+                dh.update_rows(None, d, len(chunk))         # batch entry point, state carried across calls
+            assert np.array_equal(dh.hist(), g[f"density_{mode}_hist"][i]), (mode, int(r))
+            prev = int(r) + 1
+    with an.DensityHistogram(rows.shape[1], decay) as one:      # per-tick host entry point
+        for row in rows[:8]:
+            one.update(row)
+        assert np.array_equal(one.hist(), g[f"density_{mode}_hist"][1])
+
+
+def test_waterfall_ring_matches_reference_fixture(pkg, an, golden_dir):
+    """waterfall ring against Waterfall.update_widget_data of the imported reference: pointer walk, row
+    de-duplication and the displayed view at five points of a 40-update sequence."""
+    g = np.load(os.path.join(golden_dir, "displays.npz"))
+    H, W = int(g["wf_history_lines"]), g["wf_rows"].shape[1]
+    steps = {int(s): i for i, s in enumerate(g["wf_view_steps"])}
+    with an.WaterfallRing(H, W, float(g["wf_min_db"])) as wf:
+        for step, idx in enumerate(g["wf_order"]):
+            assert wf.push(g["wf_rows"][idx]) == bool(g["wf_added"][step])
+            assert wf.ptr == int(g["wf_ptr"][step])
+            if step in steps:
+                assert np.array_equal(wf.view(), g["wf_views"][steps[step]])
+    with an.WaterfallRing(H, W, float(g["wf_min_db"])) as wf:    # the same sequence as ONE device batch
+        seq = np.ascontiguousarray(g["wf_rows"][g["wf_order"]])
+        with DevRows(pkg, seq) as d:
+            assert wf.push_rows(None, d, len(seq)) == int(g["wf_added"].sum())
+        assert wf.ptr == int(g["wf_ptr"][-1])
+        assert np.array_equal(wf.view(), g["wf_views"][-1])
+
+
 def test_analytics_error_paths(pkg, an):
     with pkg.SpectrumEngine(1024, max_frames=1) as e, DevRows(pkg, np.zeros((1, 1024), np.float32)) as d:
         with pytest.raises(Exception):

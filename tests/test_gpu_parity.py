@@ -1,10 +1,10 @@
 """GPU parity: HIP path (through the C-ABI) vs the float64 gold oracle on identical IQ.
 
-Tolerances (BASELINE.json north_star: 1e-4 relative float32):
+Tolerances (BASELINE.json north_star: 1e-4 relative float32; SURVEY.md 8(d)):
   * linear power error <= 1e-4 * frame maximum on every bin  (REL_TOL)
-  * |dB error| <= 2e-3 dB on every bin within 60 dB of the frame maximum (DB_TOL); the synthetic
-    signal's noise floor sits ~60 dB below the strongest tone, deeper bins are random nulls whose dB
-    value the reference's own float32 path does not reproduce either
+  * |dB error| <= 1e-3 dB on every bin within 100 dB of the frame maximum (DB_TOL), where the allowance
+    of a bin deeper than 69 dB is 0.7 float32 ulp of the frame's largest AMPLITUDE instead (4e-8 * A_max:
+    no float32 FFT resolves less; oracle/spectrum_oracle.py::parity_metrics states the rule)
 """
 import os
 import time
@@ -17,7 +17,7 @@ from oracle import spectrum_oracle as so
 pytestmark = pytest.mark.gpu
 
 REL_TOL = 1e-4
-DB_TOL = 2e-3
+DB_TOL = 1e-3
 
 
 @pytest.fixture(scope="module")
@@ -343,18 +343,26 @@ def test_data_processor_sequence_golden(pkg, golden_dir, holds):
         src._reservoir = np.array(fr, copy=True)
         dp._process_sample_data()
         live = mw.live_power_levels
-        # bins within 60 dB of the frame maximum (judged before the tare subtraction) must agree to
-        # DB_TOL; the random deep nulls below that are only held to a loose bound (float32 reference)
-        untared = g["live"][k] + (g["baseline"] if mw.tare_active else 0.0)
-        strong = untared >= untared.max() - 60.0
+        # both sides are float32 computations here (GPU vs the reference's own numpy float32 vectors), so
+        # the allowance of parity_metrics applies twice: 1e-3 dB, or 2 x 0.7 ulp of the frame's largest
+        # amplitude where that is worth more (depth judged before the tare subtraction)
+        base = g["baseline"] if mw.tare_active else 0.0
+        untared = g["live"][k] + base
+        top = untared.max()
+
+        def allowance(level_db):
+            return np.maximum(DB_TOL, (20.0 / np.log(10.0)) * 2 * so.AMP_FLOOR * 10.0 ** ((top - level_db) / 20.0))
+
         d = np.abs(live - g["live"][k])
-        assert d[strong].max() < DB_TOL and d.max() < 5e-2, (k, d[strong].max(), d.max())
+        assert np.all(d <= allowance(untared)), (k, float((d / allowance(untared)).max()))
         if holds in ("max", "both"):
-            assert np.abs(mw.max_power_levels - ref_max[k])[strong].max() < DB_TOL, k
+            dm_ = np.abs(mw.max_power_levels - ref_max[k])
+            assert np.all(dm_ <= allowance(ref_max[k] + base)), (k, float(dm_.max()))
         if holds in ("min", "both"):
-            assert np.abs(mw.min_power_levels - ref_min[k]).max() < 5e-2, k
+            dn_ = np.abs(mw.min_power_levels - ref_min[k])
+            assert np.all(dn_ <= allowance(ref_min[k] + base)), (k, float(dn_.max()))
     assert mw.tare_active == bool(g["tare_active_at_end"])
-    assert np.abs(mw.baseline_power_levels - g["baseline"]).max() < 2e-3
+    assert np.abs(mw.baseline_power_levels - g["baseline"]).max() < DB_TOL
     assert dm.tare_state.collecting is False
     src.running = False
 
@@ -512,7 +520,7 @@ def test_hold_and_averager_state_across_calls(pkg):
         _check(mx, gmax, "hold across calls")
         buf, cnt = e.averaged()
         assert cnt == 5
-        assert np.allclose(10 * np.log10(buf + so.POWER_LOG_FLOOR), gold[-1], atol=2e-3)
+        _check(10 * np.log10(buf + so.POWER_LOG_FLOOR), gold[-1], "averager state read-back")
         e.reset()
         assert e.hold() == (None, None) and e.averaged()[1] == 0
         again = e.process(iq[:2 * nfft], hop=hop)
@@ -528,7 +536,7 @@ def test_tare_baseline_and_cal_offset_in_batch(pkg):
         e.set_tare_baseline(base)
         out = e.process(iq, hop=nfft)
         mx, _ = e.hold()
-    assert np.max(np.abs(out - (gold - base))) < 2e-3
+    _check(out + base, gold, "tare baseline + cal offset in the batch kernel")
     assert np.array_equal(mx, out.max(axis=0))
 
 

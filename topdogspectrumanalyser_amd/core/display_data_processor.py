@@ -12,9 +12,9 @@ Scope notes
   * The two hold traces are independent buffers.  The reference lets them alias ONE ndarray when both
     are switched on for the same first frame (SURVEY.md 8(a) quirk ii), after which both just follow
     the live trace; that accident is pinned in the oracle and not reproduced.
-  * Everything that is GUI plumbing rather than signal processing (which widget is showing, sweep
-    sources, constellation and zero-span feeds) is kept to the minimum that keeps a window object
-    written for the reference working; batch users go through `analytics.py` instead.
+  * The GUI feeds around the spectrum path (sweep traces, constellation + EVM read-out, zero-span with
+    its rise / fall trigger, peak-list read-out) behave as the reference's do, on the host: they are
+    per-tick scalar work with no GPU side; batch users go through `analytics.py` instead.
 """
 import logging
 import time
@@ -25,7 +25,7 @@ import numpy as np
 from .. import _native as nat
 from ..datasources.base import SampleDataSource, SweepDataSource
 from ..engine import TraceState
-from ..utils.constants import DisplayMode, UIConstants
+from ..utils.constants import DisplayMode, FrequencyPresets, UIConstants, format_hz
 from ..utils.signal_processing import TraceAverager
 from .tare_state import TareState
 
@@ -50,6 +50,7 @@ class DataProcessor:
         self._state: Optional[TraceState] = None          # device-side trace state, sized on first use
         self._sweep_averager = TraceAverager(device=gpu_device)
         self._sweeps_since_axis_refresh = 0
+        self._fused: Optional[dict] = None                # results of the current frame's fused device call
 
     # ================================================================== public
     def reset_sweep_averager(self) -> None:
@@ -150,10 +151,16 @@ class DataProcessor:
         if levels is None or len(levels) == 0:
             return
         mw.frequency_bins = axis
-        trace = self._apply_tare(self._apply_cal_offset(levels))
-        mw.live_power_levels = trace
-        self._update_max_hold(trace)
-        self._update_min_hold(trace)
+        # cal offset + tare + both holds in ONE tdsa_trace_update launch; the four methods the reference
+        # calls next (kept for API parity, test_smoke.py:222-236) are served from this frame's results
+        self._fused = self._fuse_frame(levels)
+        try:
+            trace = self._apply_tare(self._apply_cal_offset(levels))
+            mw.live_power_levels = trace
+            self._update_max_hold(trace)
+            self._update_min_hold(trace)
+        finally:
+            self._fused = None
         self._update_duty_cycle(trace)
         self._update_peak_list(axis, trace)
 
@@ -181,13 +188,70 @@ class DataProcessor:
         kind = self.mw.source_manager.last_source_type if cal is not None else None
         return float(cal.get_offset(kind)) if kind else 0.0
 
+    def _hold_plan(self, n_bins: int, attr: str, enabled: bool):
+        """(wanted, must_reset) for one hold trace whose host copy is `attr` on the window object."""
+        held = getattr(self.mw, attr)
+        fits = held is not None and held.shape == (n_bins,)
+        return bool(enabled), bool(enabled) and not fits
+
+    def _fuse_frame(self, levels: np.ndarray) -> Optional[dict]:
+        """Everything _process_sample_data does to one frame between the source and the window object
+        (display_data_processor.py:177-181 of the reference: + cal offset, tare collect / subtract, fmax /
+        fmin hold) as ONE device call.  Returns None when the frame needs the step-by-step route (a tare
+        baseline of another length has to be cleared first)."""
+        mw, dm = self.mw, self.dm
+        n = len(levels)
+        run = dm.tare_state
+        collecting = bool(run.collecting)
+        baseline = mw.baseline_power_levels if mw.tare_active else None
+        if baseline is not None and np.shape(baseline) != np.shape(levels):
+            return None
+        gpu = self._trace_for(n)
+        if collecting and run.count == 0:
+            gpu.reset(nat.RESET_TARE)                     # a new run starts from an empty accumulator
+        subtract = baseline is not None
+        if subtract and not gpu.tare_is_active():
+            gpu.set_tare_baseline(baseline)               # baseline restored from a preset, not collected here
+        want_max, reset_max = self._hold_plan(n, "max_power_levels", dm.max_peak_search_enabled)
+        want_min, reset_min = self._hold_plan(n, "min_power_levels", mw.min_hold_enabled)
+        if reset_max or reset_min:                        # first frame is adopted (NaN -> -500 / +500)
+            gpu.reset((nat.RESET_HOLD_MAX if reset_max else 0) | (nat.RESET_HOLD_MIN if reset_min else 0))
+        offset_db = self._cal_offset_value()
+        live, mx, mn, complete = gpu.update(levels, cal_offset_db=offset_db, tare_collect=collecting,
+                                            tare_total=UIConstants.TARE_NUM_SAMPLES, tare_subtract=subtract,
+                                            hold_max=want_max, hold_min=want_min)
+        touched = offset_db != 0.0 or collecting or subtract
+        return dict(raw=levels, live=live if touched else levels, max=mx, min=mn, complete=complete,
+                    collecting=collecting, subtract=subtract, offset=offset_db)
+
     def _apply_cal_offset(self, power_levels: np.ndarray) -> np.ndarray:
+        fused = getattr(self, "_fused", None)
+        if fused is not None and power_levels is fused["raw"]:
+            return power_levels                           # the offset is inside the fused result (_apply_tare)
         offset_db = self._cal_offset_value()
         if offset_db == 0.0:
             return power_levels                           # untouched object, as the reference returns it
         return self._trace_for(len(power_levels)).update(power_levels, cal_offset_db=offset_db)[0]
 
+    def _tare_bookkeeping(self, gpu: TraceState, complete: bool) -> None:
+        mw, dm = self.mw, self.dm
+        run = dm.tare_state
+        run.count += 1
+        left = UIConstants.TARE_NUM_SAMPLES - run.count
+        self._say(f"Collecting normalisation baseline... {_plural(left, 'frame')} remaining")
+        if complete:
+            mw.baseline_power_levels = gpu.tare_baseline()
+            mw.tare_active = True
+            dm.tare_state = TareState()
+            dm._update_tare_button_label("Clear\nNormalisation")
+            self._say("Tare active — baseline captured")
+
     def _apply_tare(self, power_levels: np.ndarray) -> np.ndarray:
+        fused = getattr(self, "_fused", None)
+        if fused is not None and power_levels is fused["raw"]:
+            if fused["collecting"]:
+                self._tare_bookkeeping(self._state, fused["complete"])
+            return fused["live"]
         mw, dm = self.mw, self.dm
         run = dm.tare_state
         gpu = self._trace_for(len(power_levels))
@@ -210,15 +274,7 @@ class DataProcessor:
         live, _, _, complete = gpu.update(power_levels, tare_collect=collecting,
                                           tare_total=UIConstants.TARE_NUM_SAMPLES, tare_subtract=subtract)
         if collecting:
-            run.count += 1
-            left = UIConstants.TARE_NUM_SAMPLES - run.count
-            self._say(f"Collecting normalisation baseline... {_plural(left, 'frame')} remaining")
-            if complete:
-                mw.baseline_power_levels = gpu.tare_baseline()
-                mw.tare_active = True
-                dm.tare_state = TareState()
-                dm._update_tare_button_label("Clear\nNormalisation")
-                self._say("Tare active — baseline captured")
+            self._tare_bookkeeping(gpu, complete)
         return live
 
     def _hold(self, trace: np.ndarray, *, attr: str, enabled: bool, reset_bit: int, which: str) -> None:
@@ -229,6 +285,10 @@ class DataProcessor:
         if not enabled:
             if held is not None and not fits:
                 setattr(mw, attr, None)                   # a stale trace of another length is dropped
+            return
+        fused = getattr(self, "_fused", None)
+        if fused is not None and trace is fused["live"]:
+            setattr(mw, attr, fused["max" if which == "hold_max" else "min"])
             return
         gpu = self._trace_for(len(trace))
         if not fits:
@@ -257,10 +317,15 @@ class DataProcessor:
         if not getattr(self.dm, "peak_list_enabled", False):
             return
         plot = self.mw.two_d_widget
-        if hasattr(plot, "set_peak_list"):
-            plot.set_peak_list(self._find_top_peaks(
-                freq_bins, power_levels, n=5, min_sep_bins=max(10, len(freq_bins) // 50),
-                min_excursion_db=getattr(self.mw, "peak_excursion", 10.0)))
+        if not hasattr(plot, "set_peak_list"):
+            return
+        found = self._find_top_peaks(freq_bins, power_levels, n=5, min_sep_bins=max(10, len(freq_bins) // 50),
+                                     min_excursion_db=getattr(self.mw, "peak_excursion", 10.0))
+        plot.set_peak_list(found)
+        label = getattr(self.mw, "marker_readout_label", None)
+        if label is not None:                             # numbered table under the plot, strongest first
+            label.setText("\n".join(f"{rank}: Freq: {format_hz(f)}, Power: {p:.1f} dBm"
+                                    for rank, (f, p) in enumerate(found, start=1)))
 
     @staticmethod
     def _find_top_peaks(freq_bins, power, n: int = 5, min_sep_bins: int = 10,
@@ -301,7 +366,11 @@ class DataProcessor:
         trace = mw.current_source.get_data()
         if trace is None or len(trace) == 0:
             return
-        mw.frequency_bins = np.linspace(mw.frequency.start, mw.frequency.stop, len(trace))
+        span = mw.frequency
+        if span.start is None or span.stop is None:      # lost range: fall back to the HackRF default span
+            log.warning("frequency range unset, restoring the default span")
+            span.set_start_stop(FrequencyPresets.HACKRF_DEFAULT_START, FrequencyPresets.HACKRF_DEFAULT_STOP)
+        mw.frequency_bins = np.linspace(span.start, span.stop, len(trace))
         trace = self._apply_cal_offset(trace)
         if np.isnan(trace).all():
             return
@@ -318,15 +387,44 @@ class DataProcessor:
             mw.frequency_manager.update_frequency_values()
 
     def _process_constellation_data(self) -> None:
-        iq = self.mw.current_source.read_samples_only()
+        mw = self.mw
+        iq = mw.current_source.read_samples_only()
         if iq is None or len(iq) == 0:
             return
-        view = getattr(self.mw, _IQ_VIEWS.get(self.mw.current_stacked_index, ""), None)
-        if view is not None:
-            view.update_iq_data(iq)
+        attr = _IQ_VIEWS.get(mw.current_stacked_index)
+        if attr is None:                                  # constellation mode but another page is up: switch to it
+            self.dm.set_display(mw._resolve_display_index(), UIConstants.BUTTON_ACTIVE_STYLE, None)
+            return
+        view = getattr(mw, attr, None)
+        if view is None:
+            return
+        view.update_iq_data(iq)
+        label = getattr(mw, "marker_readout_label", None)
+        if label is None:
+            return
+        evm = getattr(view, "last_evm_rms", None)         # error vector magnitude the widget just measured
+        if evm is None or evm <= 0:
+            label.setText("")
+            return
+        scheme = getattr(self.dm, "constellation_modulation", "").upper()
+        label.setText(f"EVM  {scheme}\n{evm * 100.0:.1f}%  ({20.0 * np.log10(evm):+.1f} dB)")
+
+    @staticmethod
+    def _trigger_start(history: np.ndarray, shown: int, mode: str, level: float) -> Optional[int]:
+        """Index where a triggered zero-span trace starts: the LAST crossing of `level` (upward for "rise",
+        downward otherwise) inside the 8 display windows that precede the newest one; None = no crossing."""
+        last_start = len(history) - shown
+        first = max(0, last_start - 8 * shown)
+        if last_start <= first:
+            return None
+        before, after = history[first:last_start - 1], history[first + 1:last_start]
+        hit = (before < level) & (after >= level) if mode == "rise" else (before >= level) & (after < level)
+        where = np.flatnonzero(hit)
+        return None if where.size == 0 else first + int(where[-1]) + 1
 
     def _process_zero_span_data(self) -> None:
-        """Time-domain view: keep the last two seconds of (real) samples, show the configured window."""
+        """Time-domain view: keep the last two seconds of (real) samples, show the configured window,
+        free running or aligned to the most recent trigger crossing."""
         mw, dm = self.mw, self.dm
         block = mw.current_source.read_samples_only()
         if block is None or len(block) == 0:
@@ -337,5 +435,10 @@ class DataProcessor:
         rate = float(getattr(mw.current_source, "sample_rate", 44100))
         history = block if dm.zero_span_buffer is None else np.concatenate((dm.zero_span_buffer, block))
         dm.zero_span_buffer = history = history[-int(2.0 * rate):]
-        shown = history[-max(int(dm.zero_span_time_window * rate), 4):]
+        n_shown = max(int(dm.zero_span_time_window * rate), 4)
+        mode = getattr(dm, "zero_span_trigger_mode", "free_run")
+        start = None
+        if len(history) >= n_shown and mode != "free_run":
+            start = self._trigger_start(history, n_shown, mode, getattr(dm, "zero_span_trigger_level", 0.0))
+        shown = history[-n_shown:] if start is None else history[start:start + n_shown]
         mw.zero_span_widget.update_zero_span_data(np.arange(shown.size, dtype=np.float32) / rate, shown)

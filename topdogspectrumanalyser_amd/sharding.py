@@ -53,7 +53,8 @@ def process_sharded(iq: np.ndarray, nfft: int, hop: int, devices: Sequence[int],
     (the C-ABI calls release the GIL), each taking its contiguous frame range plus halo; returns
     (dB rows [frames, nfft] in capture order, combined max-hold trace or None, combined min-hold or None).
 
-    Only order-independent modes make sense here (no "exp" / capped "lin" averaging: replicas only).  A
+    Only order-independent modes can be sharded: no "exp" / capped "lin" averaging and no tracked DC remover
+    (dc_alpha in [0, 1) carries dc_state across frames) - those raise ValueError: replicas only.  A
     device may appear more than once - two plans then share that GPU - which is also how this is tested
     on a single-GPU box.  `configure` goes to SpectrumEngine.configure; `hold` is "", "max", "min" or "maxmin".
     """
@@ -62,6 +63,9 @@ def process_sharded(iq: np.ndarray, nfft: int, hop: int, devices: Sequence[int],
 
     if configure.get("avg", ("off", 1))[0] != "off":
         raise ValueError("order-dependent averaging cannot be sharded (SURVEY.md 8(e): replicas only)")
+    if 0.0 <= float(configure.get("dc_alpha", 1.0)) < 1.0:
+        raise ValueError("the tracked DC remover (0 <= dc_alpha < 1) carries state from frame to frame and cannot "
+                         "be sharded: use dc_alpha >= 1 (per-frame mean) or < 0 (off)")
     iq = np.ascontiguousarray(iq)
     per_sample = 1 if np.iscomplexobj(iq) else 2           # interleaved bytes: two array elements per sample
     n_samples = iq.size // per_sample

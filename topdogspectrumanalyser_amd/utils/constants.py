@@ -69,6 +69,7 @@ class UIConstants:
     DEFAULT_FFT_SIZE = FFTSize.SIZE_1024.value
     SWEEP_RATE_UPDATE_INTERVAL = 50
     TARE_NUM_SAMPLES = 32          # frames averaged to build the tare baseline
+    BUTTON_ACTIVE_STYLE = "background-color: #666666; color: white; font-weight: bold;"
 
 
 class DSPConstants:
@@ -82,3 +83,20 @@ class SourceType(str, Enum):
     RTL_SAMPLES = "rtl_samples"
     MICROPHONE_SAMPLES = "microphone_samples"
     HACKRF_SAMPLES = "hackrf_samples"
+
+
+class FrequencyPresets:
+    """Default spans the GUI falls back to (utils/constants.py:90-100 of the reference)."""
+    HACKRF_DEFAULT_START = 2400e6
+    HACKRF_DEFAULT_STOP = 2500e6
+    MICROPHONE_DEFAULT_START = 0
+    MICROPHONE_DEFAULT_STOP = 22050
+
+
+def format_hz(hz: float, precision: int = 4) -> str:
+    """'98 MHz', '1.42 GHz', '440.0 Hz': engineering prefix, `precision` significant figures
+    (utils/frequency_helpers.py:80-97 of the reference; the peak-list read-out uses it)."""
+    for scale, unit in ((1e9, "GHz"), (1e6, "MHz"), (1e3, "kHz")):
+        if abs(hz) >= scale:
+            return f"{hz / scale:.{precision}g} {unit}"
+    return f"{hz:.1f} Hz"
