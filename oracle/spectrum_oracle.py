@@ -380,7 +380,7 @@ def synth_iq_int8(n_samples: int, nfft: int, seed: int) -> np.ndarray:
     return out
 
 
-AMP_FLOOR = 4e-8     # two thirds of a float32 ulp of the frame's largest amplitude
+AMP_FLOOR = 2.0 ** -24   # 5.96e-8: the float32 rounding unit, relative to the frame's largest amplitude
 
 
 def parity_metrics(db_gpu: np.ndarray, db_gold: np.ndarray, floor_rel_db: float = 100.0,
@@ -389,8 +389,8 @@ def parity_metrics(db_gpu: np.ndarray, db_gold: np.ndarray, floor_rel_db: float 
       rel - linear power error relative to the frame maximum (bound 1e-4, every bin);
       ddb - |dB| error on the bins within ``floor_rel_db`` (100 dB) of the frame maximum, bound 1e-3 dB.
     A float32 FFT cannot resolve an amplitude difference below about one ulp of the LARGEST amplitude it
-    carries: where a bin is so deep that ``amp_floor`` * A_max (0.7 ulp) is worth more than 1e-3 dB of that
-    bin - from 69 dB below the maximum on - the allowance is that amplitude instead.  (On MI355X the errors
+    carries: where a bin is so deep that ``amp_floor`` * A_max (2^-24 A_max, the float32 rounding unit) is worth
+    more than 1e-3 dB of that bin - from 66 dB below the maximum on - the allowance is that amplitude instead.  (On MI355X the errors
     sit at 1.2e-8 * A_max in the 31 bins that share the last radix-32 butterfly with a strong tone and at
     5e-10 * A_max elsewhere; numpy's own float32 path reaches 6e-7 * A_max next to a tone.)  `ddb` is
     returned scaled to the 1e-3 dB bound, i.e. max(|dB error| / allowance) * 1e-3, so ``ddb <= 1e-3`` is

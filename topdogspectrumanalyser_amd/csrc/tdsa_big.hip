@@ -1,144 +1,122 @@
-// tdsa_big.hip - the 2^20-point path (BASELINE.json config C5: 1M-pt FFT, Welch averaging, cal offset).
+// tdsa_big.hip - frames that do not fit the LDS: N = 2^15 ... 2^20 points (BASELINE.json config C5 is the
+// 2^20-point Welch average; HackrfSamplesDataSource.set_num_samples of the reference is unbounded,
+// datasources/hackrf_samples.py:392-405).
 //
-// A 2^20-point frame (8 MiB as complex64) cannot live in LDS, so it is done as a four-step FFT over
-// N = N1 * N2 = 1024 * 1024 with n = n1*N2 + n2 and k = k1 + N1*k2:
-//   (0) transpose_in : raw IQ bytes [n1][n2] -> [n2][n1]                (2N bytes read, 2N written)
-//   (1) cols_kernel  : per n2: window, DC, 1024-pt FFT over n1, * W_N^(n2*k1); written as Y[k1][n2]
-//                      through an LDS tile so every store is a full 128-byte line (8N bytes written)
-//   (2) rows_kernel  : per k1: 1024-pt FFT over n2, |X|^2, accumulated over the K Welch segments in
-//                      float64 registers, one atomic add per bin per workgroup (8N bytes read)
-//   (3) finish_kernel: mean -> 10*log10(. * scale + floor) + cal (- tare) -> fftshift-ed dB row, hold
-// Replaces np.fft.fft on a 2^20 frame + TraceAverager("lin") + _apply_cal_offset of the reference
-// (hackrf_samples.py:370, utils/signal_processing.py:56-59, core/display_data_processor.py:317-327).
-// Every 1024-point FFT is one half-wave (32 lanes x 32 points): radix-32, wave-local LDS transpose,
-// twiddle, radix-32.
+// Four-step FFT over N = N1 * N2 with N2 = 16384 (the largest LDS-resident size) and N1 = N / 16384 = 2..64;
+// n = n1*N2 + n2, k = k1 + N1*k2:
+//   (1) cols_kernel<N1> : per n2: unpack + DC + window, N1-point DFT over n1 entirely in registers (the N1
+//                         inputs of a column sit N2 samples apart: every load is a coalesced run along n2),
+//                         times W_N^(n2*k1), written as complex64 rows Z[seg][k1][n2]  (2N B in, 8N B out)
+//   (2) the frame kernel (tdsa_spectrum_kernel.hpp, ACC variant): every row Z[seg][k1][.] is one 16384-point
+//                         frame; |X|^2 of the K segments of one k1 is summed in registers and leaves as one
+//                         float atomic per bin: S[k1][k2]                             (8N B in, 4N/K B out)
+//   (3) gather_kernel   : S[k1][k2] -> natural bin order k = k1 + N1*k2, fftshift, float64 (LDS tile transpose)
+//   (4) finish_kernel   : mean / averager state -> 10*log10(. * scale + floor) + cal (- tare) -> dB row, hold
+// Replaces np.fft.fft on a long frame + TraceAverager + _apply_cal_offset of the reference
+// (hackrf_samples.py:370, utils/signal_processing.py:35-61, core/display_data_processor.py:317-327).
 #include "tdsa_fft.hpp"
 #include "tdsa_kernels.hpp"
 
 namespace tdsa {
 
-constexpr int kB1 = 1024;            // N1 = N2
-constexpr int kBigN = kB1 * kB1;
-
-// 1024-point FFT held by a half-wave: lane j (0..31) enters with v[i] = x[j + 32*i] and leaves with
-// v[m] = X[j + 32*m].  xch: this half-wave's private 33*32 complex LDS scratch.  tw1k: W_1024^m table.
-__device__ __forceinline__ void fft1024_halfwave(c32 (&v)[32], c32* xch, const c32* __restrict__ tw1k, int j) {
-  dif<32, 0, 32>(v);                                        // X1[k] (k = 0..31) at v[bitrev(k)]
-  static_for<0, 32>([&](auto ic) {
-    constexpr int k = decltype(ic)::value;
-    xch[j * 33 + k] = v[bitrev(k, 5)];
-  });
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  // lane j now takes output residue k = j: needs X1_{j'}[k = j] for all j' = 0..31, times W_1024^(j' * j)
-  static_for<0, 32>([&](auto ic) {
-    constexpr int jp = decltype(ic)::value;
-    const c32 x = xch[jp * 33 + j];
-    v[jp] = jp == 0 ? x : cmul(x, tw1k[(jp * j) & 1023]);
-  });
-  __builtin_amdgcn_wave_barrier();
-  dif<32, 0, 32>(v);                                        // X[j + 32*m] at v[bitrev(m)]
-  c32 t[32];
-  static_for<0, 32>([&](auto ic) { constexpr int m = decltype(ic)::value; t[m] = v[bitrev(m, 5)]; });
-  static_for<0, 32>([&](auto ic) { constexpr int m = decltype(ic)::value; v[m] = t[m]; });
-}
-
-// (0) raw bytes: in[seg*stride + (n1*1024 + n2)*2 .. +1]  ->  xt[seg][n2][n1] (2 bytes per sample)
-__global__ void __launch_bounds__(256) big_transpose_in(const unsigned char* in, long long seg_stride,
-                                                        uint16_t* xt) {
-  __shared__ uint16_t tile[32][33];
-  const int seg = blockIdx.z, n1b = blockIdx.y * 32, n2b = blockIdx.x * 32;
-  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;   // 32 x 8
-  const unsigned char* src = in + (long long)seg * seg_stride;
-#pragma unroll
-  for (int r = 0; r < 32; r += 8) {
-    const long long s = (long long)(n1b + ly + r) * kB1 + n2b + lx;
-    tile[ly + r][lx] = uint16_t(src[2 * s]) | (uint16_t(src[2 * s + 1]) << 8);   // byte loads: any alignment
-  }
-  __syncthreads();
-  uint16_t* dst = xt + (long long)seg * kBigN;
-#pragma unroll
-  for (int r = 0; r < 32; r += 8) dst[(long long)(n2b + ly + r) * kB1 + n1b + lx] = tile[lx][ly + r];
-}
+constexpr int kRowLog2 = 14, kRowN = 1 << kRowLog2;    // N2
 
 struct BigColsParams {
-  const uint16_t* xt;        // [K][n2][n1]
-  const float* wt;           // [n2][n1] window * input scale (transposed)
-  const float2* tw1k;        // W_1024^m
-  const float2* twlo;        // W_N^m, m < 1024
-  const float2* dc_sub;      // [K] per-segment subtract value (raw units) or null
-  float2* y;                 // [K][k1][n2]
+  const unsigned char* in;   // interleaved int8/uint8 IQ, or complex64 samples (in_c64)
+  int in_c64;
+  long long seg_stride;      // bytes between segment starts
+  const float* window;       // [N] window * input scale, natural order
+  const float2* tw_hi;       // W_(N/1024)^m, m < N/1024 : W_N^e = tw_hi[e >> 10] * tw_lo[e & 1023]
+  const float2* tw_lo;       // W_N^m, m < 1024
+  const float2* dc_sub;      // [K] per-segment DC estimate MINUS in_off, raw units (small: keeps float32 exact), or null
+  float2* z;                 // [K][N1][N2]
   unsigned xor_mask;
   float in_off;
 };
 
-constexpr int kColRows = 16;  // n2 values per workgroup -> 128-byte output lines
-__global__ void __launch_bounds__(kColRows * 32, 2) big_cols_kernel(const BigColsParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  c32* lds = reinterpret_cast<c32*>(smem);                 // 16 * 33*32 exchange; later the [1024][16] tile
-  const int tid = threadIdx.x, j = tid & 31, row = tid >> 5;
-  const int seg = blockIdx.y, n2 = blockIdx.x * kColRows + row;
-  const uint16_t* x = p.xt + ((long long)seg * kB1 + n2) * kB1;
-  const float* w = p.wt + (long long)n2 * kB1;
-  float sub_re = p.in_off, sub_im = p.in_off;
-  if (p.dc_sub != nullptr) { const c32 s = p.dc_sub[seg]; sub_re = s.x; sub_im = s.y; }
-  c32 v[32];
-  static_for<0, 32>([&](auto ic) {
-    constexpr int i = decltype(ic)::value;
-    const unsigned u = (unsigned(x[j + 32 * i]) ^ p.xor_mask) & 0xffffu;
-    const float ww = w[j + 32 * i];
-    v[i] = c32{(float(u & 0xffu) - sub_re) * ww, (float(u >> 8) - sub_im) * ww};
-  });
-  fft1024_halfwave(v, lds + row * (33 * 32), p.tw1k, j);    // v[m] = Y[k1 = j + 32m] of column n2
-  __syncthreads();                                          // all exchanges done: reuse LDS as the tile
-  static_for<0, 32>([&](auto ic) {
-    constexpr int m = decltype(ic)::value;
-    const int k1 = j + 32 * m;
-    const unsigned e = unsigned(n2) * unsigned(k1);          // < 2^20 : W_N^e = W_1024^(e >> 10) * W_N^(e & 1023)
-    const c32 tw = cmul(p.tw1k[e >> 10], p.twlo[e & 1023]);
-    lds[k1 * (kColRows + 1) + row] = cmul(v[m], tw);     // 17-element lines: conflict-free stores
-  });
-  __syncthreads();
-  // 1024 lines of 16 complex (one full 128-byte line each): 16 threads per line
-  c32* yo = p.y + (long long)seg * kBigN + (long long)blockIdx.x * kColRows;
-#pragma unroll 4
-  for (int it = 0; it < 32; ++it) {
-    const int k1 = it * 32 + (tid >> 4), q = tid & 15;
-    yo[(long long)k1 * kB1 + q] = lds[k1 * (kColRows + 1) + q];
-  }
+__device__ __forceinline__ c32 big_twiddle(const BigColsParams& p, unsigned e) {
+  return cmul(p.tw_hi[e >> 10], p.tw_lo[e & 1023]);
 }
 
-constexpr int kRowRows = 4;   // k1 rows per workgroup
-__global__ void __launch_bounds__(kRowRows * 32, 2) big_rows_kernel(const float2* y, const float2* tw1k, int n_seg,
-                                                                    double* sum) {
-  __shared__ __attribute__((aligned(16))) c32 lds[kRowRows * 33 * 32];
-  const int tid = threadIdx.x, j = tid & 31, row = tid >> 5;
-  const int k1 = blockIdx.x * kRowRows + row;
-  const int s0 = int((long long)blockIdx.y * n_seg / gridDim.y), s1 = int((long long)(blockIdx.y + 1) * n_seg / gridDim.y);
-  double acc[32];
-  static_for<0, 32>([&](auto ic) { acc[decltype(ic)::value] = 0.0; });
-  for (int seg = s0; seg < s1; ++seg) {
-    const c32* yr = y + ((long long)seg * kB1 + k1) * kB1;
-    c32 v[32];
-    static_for<0, 32>([&](auto ic) { constexpr int i = decltype(ic)::value; v[i] = yr[j + 32 * i]; });
-    fft1024_halfwave(v, lds + row * (33 * 32), tw1k, j);   // v[m] = X[k1 + 1024*(j + 32m)]
-    static_for<0, 32>([&](auto ic) {
-      constexpr int m = decltype(ic)::value;
-      acc[m] += double(v[m].x * v[m].x + v[m].y * v[m].y);
+// One thread per column n2.  X[k1] of the column sits in v[bitrev(k1)] after the in-register DIF.
+template <int LOG2N1>
+__global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
+  constexpr int N1 = 1 << LOG2N1;
+  const int n2 = blockIdx.x * 256 + threadIdx.x;
+  const int seg = blockIdx.y;
+  const float* w = p.window + n2;
+  // (x - in_off) is exact in float32 (small integers / halves); the DC estimate is passed as its small
+  // residual so that no 24-bit rounding of "128 + something" enters (at 2^20 points that rounding alone
+  // left 3e-7 * A_max in the DC bin)
+  const float off = p.in_off;
+  float sub_re = 0.f, sub_im = 0.f;
+  if (p.dc_sub != nullptr) { const c32 s = p.dc_sub[seg]; sub_re = s.x; sub_im = s.y; }
+  c32 v[N1];
+  if (p.in_c64) {
+    const c32* src = reinterpret_cast<const c32*>(p.in + (long long)seg * p.seg_stride) + n2;
+    static_for<0, N1>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const c32 x = src[(long long)i * kRowN];
+      const float ww = w[(long long)i * kRowN];
+      v[i] = c32{((x.x - off) - sub_re) * ww, ((x.y - off) - sub_im) * ww};
+    });
+  } else {
+    const unsigned char* src = p.in + (long long)seg * p.seg_stride + 2ll * n2;
+    const unsigned xm = p.xor_mask & 0xffffu;
+    static_for<0, N1>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const unsigned u = unsigned(*reinterpret_cast<const uint16_t*>(src + 2ll * i * kRowN)) ^ xm;
+      const float ww = w[(long long)i * kRowN];
+      v[i] = c32{((float(u & 0xffu) - off) - sub_re) * ww, ((float(u >> 8) - off) - sub_im) * ww};
     });
   }
-  if (s1 > s0) {
-    static_for<0, 32>([&](auto ic) {
-      constexpr int m = decltype(ic)::value;
-      const int k2 = j + 32 * m;
-      atomicAdd(&sum[(long long)k2 * kB1 + k1], acc[m]);    // natural order k = k1 + 1024*k2
+  dif<N1, 0, N1>(v);
+  // W_N^(n2*k1), k1 = a + 8b: seeds W^(n2*a) (a < 8) and W^(n2*8b) come from the two-level table (one
+  // rounded product each), the rest is one more product
+  constexpr int NA = N1 < 8 ? N1 : 8, NB = N1 / NA;
+  c32 lo[NA];
+  static_for<1, NA>([&](auto ac) { constexpr int a = decltype(ac)::value; lo[a] = big_twiddle(p, unsigned(n2) * a); });
+  float2* zo = p.z + ((long long)seg * N1) * kRowN + n2;
+  static_for<0, NB>([&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    c32 hb = c32{1.f, 0.f};
+    if constexpr (b > 0) hb = big_twiddle(p, unsigned(n2) * (8u * b));
+    static_for<0, NA>([&](auto ac) {
+      constexpr int a = decltype(ac)::value;
+      constexpr int k1 = a + 8 * b;
+      c32 x = v[bitrev(k1, LOG2N1)];
+      if constexpr (b == 0 && a > 0) x = cmul(x, lo[a]);
+      else if constexpr (b > 0 && a == 0) x = cmul(x, hb);
+      else if constexpr (b > 0) x = cmul(x, cmul(hb, lo[a]));
+      zo[(long long)k1 * kRowN] = x;
     });
+  });
+}
+
+// S[k1][k2] (float, this call's power sums) -> dst[ks] (double), ks = (k1 + N1*k2) ^ N/2 ; add = accumulate
+template <int LOG2N1>
+__global__ void __launch_bounds__(256) big_gather_kernel(const float* s, double* dst, int add) {
+  constexpr int N1 = 1 << LOG2N1, T = 64;                 // tile: all N1 rows x 64 columns k2
+  __shared__ float tile[N1][T + 1];
+  const int k2b = blockIdx.x * T;
+  for (int i = threadIdx.x; i < N1 * T; i += 256) {
+    const int k1 = i / T, c = i % T;
+    tile[k1][c] = s[(long long)k1 * kRowN + k2b + c];
+  }
+  __syncthreads();
+  constexpr long long half = (long long)N1 * kRowN / 2;
+  for (int i = threadIdx.x; i < N1 * T; i += 256) {
+    const int c = i / N1, k1 = i % N1;
+    const long long k = (long long)(k2b + c) * N1 + k1;
+    const long long ks = k ^ half;
+    const double x = double(tile[k1][c]);
+    dst[ks] = add ? dst[ks] + x : x;
   }
 }
 
 struct BigFinishParams {
-  const double* sum;   // [N] natural order, sum over all segments seen so far
-  double* mean_out;    // [N] fftshift-ed running mean (TraceAverager._buffer) or null
+  const double* src;   // [N] fftshift-ed: sum over `count` segments, or the averager state (count = 1)
+  double* mean_out;    // [N] running mean (TraceAverager._buffer) or null
   int count;
   int db_mode;         // 0: 20log10(sqrt(mean)+floor), 1: 10log10(mean*scale+floor)
   float pscale, log_floor, cal_db;
@@ -149,9 +127,8 @@ struct BigFinishParams {
   int max_first, min_first;
 };
 __global__ void __launch_bounds__(256) big_finish_kernel(const BigFinishParams p) {
-  const int ks = blockIdx.x * 256 + threadIdx.x;            // shifted index
-  const int k = ks ^ (kBigN / 2);
-  const double mean = p.sum[k] / double(p.count);
+  const long long ks = (long long)blockIdx.x * 256 + threadIdx.x;
+  const double mean = p.src[ks] / double(p.count);
   if (p.mean_out != nullptr) p.mean_out[ks] = mean;
   float db;
   if (p.db_mode == 0) db = 20.0f * log10f(sqrtf(float(mean)) + p.log_floor);
@@ -163,37 +140,111 @@ __global__ void __launch_bounds__(256) big_finish_kernel(const BigFinishParams p
   if (p.hold_min != nullptr) p.hold_min[ks] = p.min_first ? ((db != db) ? 500.f : db) : fminf(p.hold_min[ks], db);
 }
 
+// ---- DC of long frames: exact sums (integers for byte formats), tracker in double ---------------------------
+template <bool IN_C64>
+__global__ void __launch_bounds__(256) big_sums_kernel(const void* in, unsigned xor_mask, long long frame_stride,
+                                                       int n, double* sums) {   // sums[2f], sums[2f+1] (zeroed)
+  __shared__ double red[8];
+  const int f = blockIdx.y;
+  const int per = n / gridDim.x, i0 = blockIdx.x * per;
+  const unsigned char* fb = static_cast<const unsigned char*>(in) + (long long)f * frame_stride;
+  double sr = 0.0, si = 0.0;
+  if constexpr (IN_C64) {
+    const float2* x = reinterpret_cast<const float2*>(fb);
+    for (int i = i0 + threadIdx.x; i < i0 + per; i += 256) { sr += double(x[i].x); si += double(x[i].y); }
+  } else {
+    const uint16_t* x = reinterpret_cast<const uint16_t*>(fb);
+    unsigned ui = 0, uq = 0;
+    for (int i = i0 + threadIdx.x; i < i0 + per; i += 256) {
+      const unsigned u = (unsigned(x[i]) ^ xor_mask) & 0xffffu;
+      ui += u & 0xffu; uq += u >> 8;
+    }
+    sr = double(ui); si = double(uq);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { sr += __shfl_xor(sr, off); si += __shfl_xor(si, off); }
+  if ((threadIdx.x & 63) == 0) { red[(threadIdx.x >> 6) * 2] = sr; red[(threadIdx.x >> 6) * 2 + 1] = si; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&sums[2 * f], red[0] + red[2] + red[4] + red[6]);       // integer-valued doubles: exact in any order
+    atomicAdd(&sums[2 * f + 1], red[1] + red[3] + red[5] + red[7]);
+  }
+}
+
+// dc <- (1 - alpha) dc + alpha mean  (hackrf_samples.py:361-364), in double; dc_res[f] = dc / in_scale (raw units)
+__global__ void big_dc_kernel(const double* sums, int n, int n_frames, double alpha, double in_off, double in_scale,
+                              float2* dc_state, float2* dc_res) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double dr = double(dc_state->x), di = double(dc_state->y);
+  for (int f = 0; f < n_frames; ++f) {
+    const double mr = (sums[2 * f] / double(n) - in_off) * in_scale;
+    const double mi = (sums[2 * f + 1] / double(n) - in_off) * in_scale;
+    dr = (1.0 - alpha) * dr + alpha * mr;
+    di = (1.0 - alpha) * di + alpha * mi;
+    dc_res[f] = float2{float(dr / in_scale), float(di / in_scale)};
+  }
+  *dc_state = float2{float(dr), float(di)};
+}
+
 // ---- host launchers ------------------------------------------------------------------------------------
-hipError_t launch_big_transpose(const void* in, long long seg_stride, int n_seg, uint16_t* xt, hipStream_t s) {
-  hipLaunchKernelGGL(big_transpose_in, dim3(32, 32, n_seg), dim3(256), 0, s, static_cast<const unsigned char*>(in),
-                     seg_stride, xt);
+template <int L>
+static hipError_t cols_launch(const BigColsParams& p, int n_seg, hipStream_t s) {
+  hipLaunchKernelGGL(big_cols_kernel<L>, dim3(kRowN / 256, n_seg), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+template <int L>
+static hipError_t gather_launch(const float* src, double* dst, int add, hipStream_t s) {
+  hipLaunchKernelGGL(big_gather_kernel<L>, dim3(kRowN / 64), dim3(256), 0, s, src, dst, add);
   return hipGetLastError();
 }
 
-hipError_t launch_big_cols(const uint16_t* xt, const float* wt, const float2* tw1k, const float2* twlo,
-                           const float2* dc_sub, float2* y, unsigned xor_mask, float in_off, int n_seg,
-                           hipStream_t s) {
-  BigColsParams p{xt, wt, tw1k, twlo, dc_sub, y, xor_mask, in_off};
-  const size_t lds = size_t(kB1) * (kColRows + 1) * sizeof(c32);    // 136 KiB tile (>= 16 exchange areas)
-  static std::atomic<unsigned long long> attr_done{0};
-  const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(big_cols_kernel), int(lds), attr_done);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(big_cols_kernel, dim3(kB1 / kColRows, n_seg), dim3(kColRows * 32), lds, s, p);
-  return hipGetLastError();
+hipError_t launch_big_cols(int log2n, const void* in, int in_c64, long long seg_stride, int n_seg, const float* window,
+                           const float2* tw_hi, const float2* tw_lo, const float2* dc_sub, float2* z,
+                           unsigned xor_mask, float in_off, hipStream_t s) {
+  const BigColsParams p{static_cast<const unsigned char*>(in), in_c64, seg_stride, window, tw_hi, tw_lo, dc_sub, z, xor_mask,
+                        in_off};
+  switch (log2n - kRowLog2) {
+    case 1: return cols_launch<1>(p, n_seg, s);
+    case 2: return cols_launch<2>(p, n_seg, s);
+    case 3: return cols_launch<3>(p, n_seg, s);
+    case 4: return cols_launch<4>(p, n_seg, s);
+    case 5: return cols_launch<5>(p, n_seg, s);
+    case 6: return cols_launch<6>(p, n_seg, s);
+    default: return hipErrorInvalidValue;
+  }
 }
 
-hipError_t launch_big_rows(const float2* y, const float2* tw1k, int n_seg, double* sum, hipStream_t s) {
-  int split = n_seg >= 4 ? 4 : n_seg;
-  hipLaunchKernelGGL(big_rows_kernel, dim3(kB1 / kRowRows, split), dim3(kRowRows * 32), 0, s, y, tw1k, n_seg, sum);
-  return hipGetLastError();
+hipError_t launch_big_gather(int log2n, const float* s_rows, double* dst, int add, hipStream_t s) {
+  switch (log2n - kRowLog2) {
+    case 1: return gather_launch<1>(s_rows, dst, add, s);
+    case 2: return gather_launch<2>(s_rows, dst, add, s);
+    case 3: return gather_launch<3>(s_rows, dst, add, s);
+    case 4: return gather_launch<4>(s_rows, dst, add, s);
+    case 5: return gather_launch<5>(s_rows, dst, add, s);
+    case 6: return gather_launch<6>(s_rows, dst, add, s);
+    default: return hipErrorInvalidValue;
+  }
 }
 
-hipError_t launch_big_finish(const double* sum, double* mean_out, int count, int db_mode, float pscale,
+hipError_t launch_big_finish(const double* src, long long n, double* mean_out, int count, int db_mode, float pscale,
                              float log_floor, float cal_db, const float* tare, float* out_db, float* hold_max,
                              float* hold_min, int max_first, int min_first, hipStream_t s) {
-  BigFinishParams p{sum, mean_out, count, db_mode, pscale, log_floor, cal_db, tare, out_db, hold_max, hold_min,
+  BigFinishParams p{src, mean_out, count, db_mode, pscale, log_floor, cal_db, tare, out_db, hold_max, hold_min,
                     max_first, min_first};
-  hipLaunchKernelGGL(big_finish_kernel, dim3(kBigN / 256), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(big_finish_kernel, dim3(unsigned(n / 256)), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_big_dc(const void* in, int in_c64, unsigned xor_mask, long long frame_stride, int n, int n_frames,
+                         double alpha, double in_off, double in_scale, double* sums, float2* dc_state, float2* dc_res,
+                         hipStream_t s) {
+  hipError_t e = hipMemsetAsync(sums, 0, size_t(n_frames) * 2 * sizeof(double), s);
+  if (e != hipSuccess) return e;
+  const dim3 grid(n / 16384, n_frames);
+  if (in_c64) hipLaunchKernelGGL(big_sums_kernel<true>, grid, dim3(256), 0, s, in, xor_mask, frame_stride, n, sums);
+  else hipLaunchKernelGGL(big_sums_kernel<false>, grid, dim3(256), 0, s, in, xor_mask, frame_stride, n, sums);
+  hipLaunchKernelGGL(big_dc_kernel, dim3(1), dim3(64), 0, s, sums, n, n_frames, alpha, in_off, in_scale, dc_state,
+                     dc_res);
   return hipGetLastError();
 }
 

@@ -81,13 +81,18 @@ struct tdsa_plan_s {
   float* d_trace_live = nullptr;
   long long frames_seen = 0;             // frames processed since the last hold reset (nan_safe rule)
   unsigned long long* d_dbg = nullptr;   // TDSA_TIMELINE developer builds
-  // 2^20-point plans (four-step path)
+  // long-frame plans, N = 2^15 .. 2^20 = N1 x 16384 (tdsa_big.hip)
   bool big = false;
-  uint16_t* d_xt = nullptr;              // [max_frames][n2][n1] transposed raw samples
-  float2* d_y = nullptr;                 // [max_frames][k1][n2] after the column pass
-  double* d_sum = nullptr;               // [N] Welch sums, natural order
-  float2* d_tw1k = nullptr;              // W_1024^m
-  float2* d_twlo = nullptr;              // W_N^m, m < 1024
+  float2* d_z = nullptr;                 // [group][N1][16384] complex64 rows after the column pass
+  float* d_acc = nullptr;                // [N1][16384] power sums of the current call (row pass output)
+  double* d_sum = nullptr;               // [N] fftshift-ed sums over the segments averaged so far
+  double* d_lin64 = nullptr;             // [N] fftshift-ed power of one frame (exp / capped lin averaging)
+  double* d_sums64 = nullptr;            // [max_frames][2] exact I / Q sums of the frames of a call
+  float2* d_tw_hi = nullptr;             // W_(N/1024)^m
+  float2* d_tw_lo = nullptr;             // W_N^m, m < 1024
+  float2* d_tw_row = nullptr;            // W_16384^m : the row pass's twiddle table
+  float* d_ones = nullptr;               // [16384] unit window for the row pass
+  int big_group = 8;                     // segments per column-pass / row-pass round (Z stays cache resident)
   bool profiling = false;
   std::vector<hipEvent_t> prof_events;   // pairs (begin, end) around frame-kernel launches
   size_t prof_used = 0;
@@ -167,50 +172,101 @@ int launch_spectrum_profiled(tdsa_plan p, int in_c64, const SpecParams& sp, cons
   return TDSA_OK;
 }
 
-// 2^20-point plans: Welch accumulation over the frames of the call (and across calls while the averager
-// is "lin" and not yet capped); out_db_dev receives ONE row: the dB of the running mean.
+// Long-frame plans.  Modes (decided by the plan's averaging settings):
+//   * "lin" with avg_n >= frames seen so far + n_frames: Welch - the K segments of the call (and of earlier
+//     calls since the last reset) are averaged, out_db_dev receives ONE row, the dB of the running mean;
+//   * otherwise one frame per call (n_frames == 1): plain dB, or TraceAverager exp / capped lin on the
+//     float64 state exactly as for the LDS-resident sizes.
 int process_big(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n_frames, float* out_db_dev) {
   const tdsa_mode& m = p->mode;
-  if (in_format == TDSA_IN_C64) return fail(TDSA_ERR_ARG, "2^20-point plans take int8/uint8 IQ only");
   const bool averaging = avg_active(m);
-  if (averaging && m.avg_mode != TDSA_AVG_LIN)
-    return fail(TDSA_ERR_ARG, "2^20-point plans support lin (Welch) averaging only");
-  if (averaging && (long long)p->avg_count + n_frames > m.avg_n)
-    return fail(TDSA_ERR_ARG, "2^20-point plans need avg_n >= total frames (count %d + %d > %d)", p->avg_count,
-                n_frames, m.avg_n);
-  if (!averaging && n_frames != 1) return fail(TDSA_ERR_ARG, "without averaging a 2^20-point plan takes one frame");
+  const bool welch = averaging && m.avg_mode == TDSA_AVG_LIN && (long long)p->avg_count + n_frames <= m.avg_n;
+  if (!welch && n_frames != 1)
+    return fail(TDSA_ERR_ARG, "a %d-point plan takes one frame per call unless it is Welch-averaging "
+                "(avg lin with avg_n >= total frames: count %d + %d > %d)", p->nfft, p->avg_count, n_frames,
+                averaging ? m.avg_n : 0);
   const size_t N = size_t(p->nfft);
-  if (!p->d_xt) HIPCHK(hipMalloc(&p->d_xt, size_t(p->max_frames) * N * sizeof(uint16_t)));
-  if (!p->d_y) HIPCHK(hipMalloc(&p->d_y, size_t(p->max_frames) * N * sizeof(float2)));
+  const int n1 = p->nfft >> 14;
+  const int group = n_frames < p->big_group ? n_frames : p->big_group;
+  if (!p->d_z) HIPCHK(hipMalloc(&p->d_z, size_t(p->max_frames < p->big_group ? p->max_frames : p->big_group) * N * sizeof(float2)));
+  const int in_c64 = in_format == TDSA_IN_C64;
   const unsigned xor_mask = in_format == TDSA_IN_I8 ? 0x80808080u : 0u;
-  const float in_off = in_format == TDSA_IN_I8 ? 128.0f : 127.5f;
-  const float in_scale = in_format == TDSA_IN_I8 ? 1.0f / 128.0f : 1.0f / 127.5f;
-  const long long stride = (long long)hop * 2;
-  if (!averaging || p->avg_count == 0) {
-    HIPCHK(hipMemsetAsync(p->d_sum, 0, N * sizeof(double), p->stream));
-    p->avg_count = 0;
-  }
+  const float in_off = in_format == TDSA_IN_I8 ? 128.0f : (in_c64 ? 0.0f : 127.5f);
+  const float in_scale = in_format == TDSA_IN_I8 ? 1.0f / 128.0f : (in_c64 ? 1.0f : 1.0f / 127.5f);
+  const long long stride = (long long)hop * bytes_per_sample(in_format);
   const float2* dc_sub = nullptr;
   if (m.dc_alpha >= 0.0f) {   // per-segment mean (alpha = 1) or tracker (alpha < 1)
-    HIPCHK(launch_frame_sums(iq_dev, 0, xor_mask, stride, p->nfft, n_frames, p->d_sums, p->stream));
-    HIPCHK(launch_dc_track(p->d_sums, p->nfft, n_frames, m.dc_alpha > 1.0f ? 1.0f : m.dc_alpha, in_off, in_scale,
-                           p->d_dc_state, p->d_dc_sub, p->stream));
+    if (!p->d_sums64) HIPCHK(hipMalloc(&p->d_sums64, size_t(p->max_frames) * 2 * sizeof(double)));
+    HIPCHK(launch_big_dc(iq_dev, in_c64, xor_mask, stride, p->nfft, n_frames, m.dc_alpha > 1.0f ? 1.0 : double(m.dc_alpha),
+                         double(in_off), double(in_scale), p->d_sums64, p->d_dc_state, p->d_dc_sub, p->stream));
     dc_sub = p->d_dc_sub;
   }
-  HIPCHK(launch_big_transpose(iq_dev, stride, n_frames, p->d_xt, p->stream));
-  HIPCHK(launch_big_cols(p->d_xt, p->d_window[in_format], p->d_tw1k, p->d_twlo, dc_sub, p->d_y, xor_mask, in_off,
-                         n_frames, p->stream));
-  HIPCHK(launch_big_rows(p->d_y, p->d_tw1k, n_frames, p->d_sum, p->stream));
-  p->avg_count += n_frames;
+  HIPCHK(hipMemsetAsync(p->d_acc, 0, N * sizeof(float), p->stream));
+  // column pass and row pass alternate over groups of segments: the 8N-byte rows of a group are consumed
+  // right after they are produced, out of the Infinity Cache rather than HBM
+  for (int s0 = 0; s0 < n_frames; s0 += group) {
+    const int ns = n_frames - s0 < group ? n_frames - s0 : group;
+    HIPCHK(launch_big_cols(p->log2n, static_cast<const unsigned char*>(iq_dev) + (long long)s0 * stride, in_c64, stride, ns,
+                           p->d_window[in_format], p->d_tw_hi, p->d_tw_lo, dc_sub ? dc_sub + s0 : nullptr, p->d_z,
+                           xor_mask, in_off, p->stream));
+    SpecParams sp{};
+    sp.in = p->d_z;
+    sp.frame_stride = (long long)N * sizeof(float2);            // segment to segment
+    sp.group = ns;
+    sp.group_stride = (long long)(1 << 14) * sizeof(float2);    // k1 row to k1 row
+    sp.n_frames = n1 * ns;
+    sp.first_frame_index = 1;
+    sp.window = p->d_ones;
+    sp.tw = p->d_tw_row;
+    sp.in_scale = 1.0f;
+    sp.dc_mode = DC_NONE;
+    sp.db_mode = TDSA_DB_POW;
+    sp.pscale = 1.0f;
+    sp.acc = p->d_acc;
+    const LaunchGeom g = spectrum_geometry(14, sp.n_frames, p->num_cu);
+    if (p->profiling) {
+      if (p->prof_used + 2 > p->prof_events.size()) {
+        hipEvent_t a, b;
+        HIPCHK(hipEventCreate(&a));
+        HIPCHK(hipEventCreate(&b));
+        p->prof_events.push_back(a);
+        p->prof_events.push_back(b);
+      }
+      HIPCHK(hipEventRecord(p->prof_events[p->prof_used], p->stream));
+    }
+    HIPCHK(launch_spectrum_acc(sp, g, p->stream));
+    if (p->profiling) {
+      HIPCHK(hipEventRecord(p->prof_events[p->prof_used + 1], p->stream));
+      p->prof_used += 2;
+    }
+  }
   const bool hmax = (m.hold_flags & TDSA_HOLD_MAX) != 0, hmin = (m.hold_flags & TDSA_HOLD_MIN) != 0;
-  HIPCHK(launch_big_finish(p->d_sum, p->d_avg, p->avg_count, m.db_mode,
-                           m.db_mode == TDSA_DB_POW ? m.power_scale : 1.0f, m.log_floor, m.cal_offset_db,
+  const float pscale = m.db_mode == TDSA_DB_POW ? m.power_scale : 1.0f;
+  const double* src = nullptr;
+  double* mean_out = nullptr;
+  int count = 1;
+  if (welch) {
+    HIPCHK(launch_big_gather(p->log2n, p->d_acc, p->d_sum, p->avg_count > 0, p->stream));
+    p->avg_count += n_frames;
+    src = p->d_sum;
+    mean_out = p->d_avg;
+    count = p->avg_count;
+  } else if (averaging) {    // TraceAverager exp / capped lin, one frame (signal_processing.py:35-61)
+    HIPCHK(launch_big_gather(p->log2n, p->d_acc, p->d_lin64, 0, p->stream));
+    HIPCHK(launch_avg_host_frame(p->d_lin64, p->nfft, p->d_avg, p->avg_count, m.avg_mode, m.avg_n, p->stream));
+    if (p->avg_count == 0) p->avg_count = 1;
+    else if (m.avg_mode == TDSA_AVG_LIN && p->avg_count < m.avg_n) p->avg_count += 1;
+    src = p->d_avg;
+  } else {
+    HIPCHK(launch_big_gather(p->log2n, p->d_acc, p->d_lin64, 0, p->stream));
+    src = p->d_lin64;
+  }
+  HIPCHK(launch_big_finish(src, (long long)N, mean_out, count, m.db_mode, pscale, m.log_floor, m.cal_offset_db,
                            p->tare_active ? p->d_tare_base : nullptr, out_db_dev, hmax ? p->d_hold_max : nullptr,
                            hmin ? p->d_hold_min : nullptr, p->held_max == 0, p->held_min == 0, p->stream));
   if (hmax) p->held_max += 1;
   if (hmin) p->held_min += 1;
   p->frames_seen += n_frames;
-  if (!averaging) p->avg_count = 0;
   return TDSA_OK;
 }
 
@@ -232,10 +288,9 @@ static int plan_init(tdsa_plan p);
 int tdsa_create(int device_id, int nfft, int max_frames, tdsa_plan* out) {
   if (!out) return fail(TDSA_ERR_ARG, "out is null");
   *out = nullptr;
-  const bool big = nfft == (1 << kBigLog2N);
-  if (!big && (nfft < (1 << kMinLog2N) || nfft > (1 << kMaxLog2N) || (nfft & (nfft - 1))))
-    return fail(TDSA_ERR_ARG, "nfft=%d: need a power of two in [%d, %d] or %d", nfft, 1 << kMinLog2N,
-                1 << kMaxLog2N, 1 << kBigLog2N);
+  if (nfft < (1 << kMinLog2N) || nfft > (1 << kBigMaxLog2N) || (nfft & (nfft - 1)))
+    return fail(TDSA_ERR_ARG, "nfft=%d: need a power of two in [%d, %d]", nfft, 1 << kMinLog2N, 1 << kBigMaxLog2N);
+  const bool big = nfft > (1 << kMaxLog2N);
   if (max_frames < 1) return fail(TDSA_ERR_ARG, "max_frames=%d must be >= 1", max_frames);
   int ndev = 0;
   HIPCHK(hipGetDeviceCount(&ndev));
@@ -291,16 +346,31 @@ static int plan_init(tdsa_plan p) {
   HIPCHK(hipMemcpy(p->d_tw, tw.data(), size_t(nfft) * sizeof(float2), hipMemcpyHostToDevice));
   if (big) {
     HIPCHK(hipMalloc(&p->d_sum, size_t(nfft) * sizeof(double)));
-    HIPCHK(hipMalloc(&p->d_tw1k, 1024 * sizeof(float2)));
-    HIPCHK(hipMalloc(&p->d_twlo, 1024 * sizeof(float2)));
-    std::vector<float2> t1(1024), t2(1024);
-    for (int m = 0; m < 1024; ++m) {
-      const double a1 = -2.0 * M_PI * double(m) / 1024.0, a2 = -2.0 * M_PI * double(m) / double(nfft);
+    HIPCHK(hipMalloc(&p->d_lin64, size_t(nfft) * sizeof(double)));
+    HIPCHK(hipMalloc(&p->d_acc, size_t(nfft) * sizeof(float)));
+    const int nhi = nfft / 1024, nrow = 1 << kMaxLog2N;
+    HIPCHK(hipMalloc(&p->d_tw_hi, size_t(nhi) * sizeof(float2)));
+    HIPCHK(hipMalloc(&p->d_tw_lo, 1024 * sizeof(float2)));
+    HIPCHK(hipMalloc(&p->d_tw_row, size_t(nrow) * sizeof(float2)));
+    HIPCHK(hipMalloc(&p->d_ones, size_t(nrow) * sizeof(float)));
+    std::vector<float2> t1(nhi), t2(1024), t3(nrow);
+    for (int m = 0; m < nhi; ++m) {
+      const double a1 = -2.0 * M_PI * double(m) / double(nhi);
       t1[m] = float2{float(std::cos(a1)), float(std::sin(a1))};
+    }
+    for (int m = 0; m < 1024; ++m) {
+      const double a2 = -2.0 * M_PI * double(m) / double(nfft);
       t2[m] = float2{float(std::cos(a2)), float(std::sin(a2))};
     }
-    HIPCHK(hipMemcpy(p->d_tw1k, t1.data(), 1024 * sizeof(float2), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(p->d_twlo, t2.data(), 1024 * sizeof(float2), hipMemcpyHostToDevice));
+    for (int m = 0; m < nrow; ++m) {
+      const double a3 = -2.0 * M_PI * double(m) / double(nrow);
+      t3[m] = float2{float(std::cos(a3)), float(std::sin(a3))};
+    }
+    std::vector<float> ones(nrow, 1.0f);
+    HIPCHK(hipMemcpy(p->d_tw_hi, t1.data(), size_t(nhi) * sizeof(float2), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->d_tw_lo, t2.data(), 1024 * sizeof(float2), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->d_tw_row, t3.data(), size_t(nrow) * sizeof(float2), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->d_ones, ones.data(), size_t(nrow) * sizeof(float), hipMemcpyHostToDevice));
   }
   int rc = reset_hold(p, true, true);
   if (rc != TDSA_OK) return rc;
@@ -326,7 +396,8 @@ int tdsa_destroy(tdsa_plan p) {
   void* bufs[] = {p->d_window[0], p->d_window[1], p->d_window[2], p->d_tw, p->d_hold_max, p->d_hold_min,
                   p->d_avg, p->d_lin, p->d_carry, p->d_cplx, p->d_lin1, p->d_db1, p->d_dc_state, p->d_sums, p->d_dc_sub,
                   p->d_tare_base, p->d_tare_acc, p->d_in_stage, p->d_out_stage, p->d_trace_in,
-                  p->d_trace_live, p->d_xt, p->d_y, p->d_sum, p->d_tw1k, p->d_twlo, p->d_dbg};
+                  p->d_trace_live, p->d_z, p->d_acc, p->d_sum, p->d_lin64, p->d_sums64, p->d_tw_hi, p->d_tw_lo, p->d_tw_row, p->d_ones,
+                  p->d_dbg};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (hipEvent_t e : p->prof_events) (void)hipEventDestroy(e);
@@ -344,7 +415,7 @@ int tdsa_destroy(tdsa_plan p) {
 
 int tdsa_get_info(tdsa_plan p, tdsa_info* out) {
   if (!p || !out) return fail(TDSA_ERR_ARG, "null argument");
-  LaunchGeom g = p->big ? LaunchGeom{64 * p->max_frames, 512, 16, size_t(1024) * 17 * 8}
+  LaunchGeom g = p->big ? spectrum_geometry(kMaxLog2N, (p->nfft >> kMaxLog2N) * (p->max_frames < p->big_group ? p->max_frames : p->big_group), p->num_cu)
                         : spectrum_geometry(p->log2n, p->max_frames, p->num_cu);
   out->nfft = p->nfft;
   out->max_frames = p->max_frames;
@@ -370,12 +441,7 @@ int tdsa_set_window(tdsa_plan p, const float* w_host, int n) {
   std::vector<float> tmp(n);
   HIPCHK(hipStreamSynchronize(p->stream));
   for (int f = 0; f < 3; ++f) {
-    if (p->big) {   // transposed [n2][n1] for the column pass
-      for (int n1 = 0; n1 < 1024; ++n1)
-        for (int n2 = 0; n2 < 1024; ++n2) tmp[size_t(n2) * 1024 + n1] = w_host[size_t(n1) * 1024 + n2] * scale[f];
-    } else {
-      for (int i = 0; i < n; ++i) tmp[i] = w_host[i] * scale[f];
-    }
+    for (int i = 0; i < n; ++i) tmp[i] = w_host[i] * scale[f];
     HIPCHK(hipMemcpy(p->d_window[f], tmp.data(), size_t(n) * sizeof(float), hipMemcpyHostToDevice));
   }
   p->window_set = true;

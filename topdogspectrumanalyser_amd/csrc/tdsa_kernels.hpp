@@ -53,6 +53,13 @@ struct SpecParams {
   float cal_db;              // calibration offset added to dB
   int hold_flags;            // bit0 max, bit1 min
   unsigned long long* dbg;   // developer timeline buffer (TDSA_TIMELINE builds only), else null
+  // ---- row pass of the N1 x 16384 big-FFT path (tdsa_big.hip): complex64 rows Z[seg][k1][n2] ----
+  // frame f reads from  in + (f % group) * frame_stride + (f / group) * group_stride  (group = 0: plain
+  // f * frame_stride) and ADDS its linear power |X|^2 into acc[(f / group) * N + bin] (bin in natural order,
+  // no dB, no fftshift): frames of one group (the K Welch segments of one k1) are summed in registers
+  int group;
+  long long group_stride;
+  float* acc;
 };
 
 struct LaunchGeom {
@@ -119,14 +126,21 @@ hipError_t launch_real_fold(const float2* spec, int n, int n_frames, int channel
 hipError_t launch_lin_to_db(const float* lin, size_t count, float log_floor, float cal_db, float* out_db,
                             hipStream_t s);
 
-// ---- 2^20-point four-step path (tdsa_big.hip) ----
-constexpr int kBigLog2N = 20;
-hipError_t launch_big_transpose(const void* in, long long seg_stride, int n_seg, uint16_t* xt, hipStream_t s);
-hipError_t launch_big_cols(const uint16_t* xt, const float* wt, const float2* tw1k, const float2* twlo,
-                           const float2* dc_sub, float2* y, unsigned xor_mask, float in_off, int n_seg,
-                           hipStream_t s);
-hipError_t launch_big_rows(const float2* y, const float2* tw1k, int n_seg, double* sum, hipStream_t s);
-hipError_t launch_big_finish(const double* sum, double* mean_out, int count, int db_mode, float pscale,
+// ---- long frames, N = 2^15 .. 2^20 = N1 x 16384 (tdsa_big.hip) ----
+constexpr int kBigMinLog2N = 15, kBigMaxLog2N = 20;
+// column pass: raw IQ of n_seg segments -> Z[seg][k1][n2] (complex64), W_N^e = tw_hi[e >> 10] * tw_lo[e & 1023]
+hipError_t launch_big_cols(int log2n, const void* in, int in_c64, long long seg_stride, int n_seg, const float* window,
+                           const float2* tw_hi, const float2* tw_lo, const float2* dc_sub, float2* z,
+                           unsigned xor_mask, float in_off, hipStream_t s);
+// exact per-frame sums + DC tracker in double; dc_res[f] = DC estimate in raw units MINUS in_off (small)
+hipError_t launch_big_dc(const void* in, int in_c64, unsigned xor_mask, long long frame_stride, int n, int n_frames,
+                         double alpha, double in_off, double in_scale, double* sums, float2* dc_state, float2* dc_res,
+                         hipStream_t s);
+// row pass: the 16384-point frame kernel on complex64 rows, power summed per group into p.acc
+hipError_t launch_spectrum_acc(const SpecParams& p, const LaunchGeom& g, hipStream_t s);
+// S[k1][k2] float -> dst[(k1 + N1*k2) ^ N/2] double (overwrite or accumulate)
+hipError_t launch_big_gather(int log2n, const float* s_rows, double* dst, int add, hipStream_t s);
+hipError_t launch_big_finish(const double* src, long long n, double* mean_out, int count, int db_mode, float pscale,
                              float log_floor, float cal_db, const float* tare, float* out_db, float* hold_max,
                              float* hold_min, int max_first, int min_first, hipStream_t s);
 

@@ -15,4 +15,7 @@ template <>
 LaunchGeom geom_size<TDSA_LOG2N>(int n_frames, int num_cu) {
   return geom_for<TDSA_LOG2N>(n_frames, num_cu);
 }
+#if TDSA_LOG2N == 14
+hipError_t launch_spectrum_acc(const SpecParams& p, const LaunchGeom& g, hipStream_t s) { return launch_acc<14>(p, g, s); }
+#endif
 }  // namespace tdsa

@@ -231,7 +231,7 @@ __device__ __forceinline__ void combine_const(c32& e, c32& o) {
 // halves do full butterflies and no lane idles.  16 points per thread keeps the kernel under 128 VGPRs:
 // 4 waves per SIMD, which is what it takes to keep the VALU fed (one wave issues at most one VALU op
 // every 4 clocks; the SIMD retires one every 2).
-template <int LOG2N, bool IN_C64, int HOLD>   // HOLD: bit0 = max trace, bit1 = min trace
+template <int LOG2N, bool IN_C64, int HOLD, bool ACC = false>   // HOLD: bit0 = max trace, bit1 = min trace
 __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const SpecParams p) {
   using C = Cfg<LOG2N>;
   constexpr int N = C::N, SG = C::SG, A = C::A, M = C::M, H = C::H, FPW = C::FPW, NPAD = C::NPAD;
@@ -278,6 +278,8 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       twm[tid] = p.tw[ka * b * (N / (32 * A))];
     }
   }
+  float pacc[ACC ? 16 : 1];                 // ACC: linear power summed over the frames of one group
+  static_for<0, (ACC ? 16 : 1)>([&](auto ic) { pacc[decltype(ic)::value] = 0.f; });
   float hmax[(HOLD & 1) ? 16 : 1], hmin[(HOLD & 2) ? 16 : 1];
   static_for<0, 16>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
@@ -365,6 +367,11 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     // ---- frame sums for DC removal ---------------------------------------------------------------
     if constexpr (IN_C64) {
       const unsigned char* fb = static_cast<const unsigned char*>(p.in) + (long long)frame * p.frame_stride;
+      if constexpr (ACC) {
+        const int fg = frame / p.group;
+        fb = static_cast<const unsigned char*>(p.in) + (long long)(frame - fg * p.group) * p.frame_stride +
+             (long long)fg * p.group_stride;
+      }
       static_for<0, 16>([&](auto ic) {
         constexpr int idx = decltype(ic)::value;
         constexpr int jj = idx / H, i = idx % H;
@@ -600,6 +607,28 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
 
     // ---- epilogue: |X|^2 -> dB -> hold ; bin k = t + kc*SG lands at k ^ N/2 (fftshift) -----------
     // this thread's 16 bins: q < 8: kc = q + 8h (register bitrev(q)), q >= 8: kc = q + 8 + 8h (bitrev(q))
+    if constexpr (ACC) {
+      // row pass of the big-FFT path: |X|^2 of bin k = t + kc*SG (natural order) joins the group's sum;
+      // the sums leave the registers (one float atomic per bin) when the group ends or this workgroup does
+      if (active) {
+        static_for<0, 16>([&](auto ic) {
+          constexpr int q = decltype(ic)::value;
+          const c32 X = v[bitrev(q, 4)];
+          pacc[q] = fmaf(X.x, X.x, fmaf(X.y, X.y, pacc[q]));
+        });
+        const int fg = frame / p.group;
+        if (unit + 1 == u1 || (frame + 1) / p.group != fg) {
+          float* arow = p.acc + (long long)fg * N + t + 8 * h * SG;
+          static_for<0, 16>([&](auto ic) {
+            constexpr int q = decltype(ic)::value;
+            constexpr int kc = (q < 8 ? q : q + 8);
+            unsafeAtomicAdd(arow + kc * SG, pacc[q]);
+            pacc[q] = 0.f;
+          });
+        }
+      }
+      if constexpr (!C::WIN_LDS) load_window();
+    } else
     if (active) {
       if (p.out_cplx != nullptr) {            // real-input path: hand the complex bins to the fold kernel
         if constexpr (!C::WIN_LDS) load_window();
@@ -802,6 +831,17 @@ hipError_t launch_n(int in_c64, const SpecParams& p, const LaunchGeom& g, hipStr
     case 2: return launch_one<LOG2N, false, 2>(p, g, s);
     default: return launch_one<LOG2N, false, 3>(p, g, s);
   }
+}
+
+// row pass of the big-FFT path: complex64 rows in, power sums out (size 14 only)
+template <int LOG2N>
+inline hipError_t launch_acc(const SpecParams& p, const LaunchGeom& g, hipStream_t s) {
+  auto k = spectrum_kernel<LOG2N, true, 0, true>;
+  static std::atomic<unsigned long long> attr_done{0};
+  const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), int(g.lds_bytes), attr_done);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k, dim3(g.grid), dim3(g.block), g.lds_bytes, s, p);
+  return hipGetLastError();
 }
 
 // one translation unit per size (tdsa_spectrum_inst.hip, -DTDSA_LOG2N=k) provides these

@@ -43,7 +43,7 @@ class FFTSize(IntEnum):
 
 
 GPU_MIN_FFT = 64
-GPU_MAX_FFT = 16384
+GPU_MAX_FFT = 1 << 20      # 64 .. 16384 in one LDS-resident pass, 2^15 .. 2^20 as N1 x 16384 (two passes)
 
 
 class WindowType(str, Enum):
