@@ -93,26 +93,12 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
   });
 }
 
-// S[k1][k2] (float, this call's power sums) -> dst[ks] (double), ks = (k1 + N1*k2) ^ N/2 ; add = accumulate
-template <int LOG2N1>
-__global__ void __launch_bounds__(256) big_gather_kernel(const float* s, double* dst, int add) {
-  constexpr int N1 = 1 << LOG2N1, T = 64;                 // tile: all N1 rows x 64 columns k2
-  __shared__ float tile[N1][T + 1];
-  const int k2b = blockIdx.x * T;
-  for (int i = threadIdx.x; i < N1 * T; i += 256) {
-    const int k1 = i / T, c = i % T;
-    tile[k1][c] = s[(long long)k1 * kRowN + k2b + c];
-  }
-  __syncthreads();
-  constexpr long long half = (long long)N1 * kRowN / 2;
-  for (int i = threadIdx.x; i < N1 * T; i += 256) {
-    const int c = i / N1, k1 = i % N1;
-    const long long k = (long long)(k2b + c) * N1 + k1;
-    const long long ks = k ^ half;
-    const double x = double(tile[k1][c]);
-    dst[ks] = add ? dst[ks] + x : x;
-  }
-}
+// S[k1][k2] (float, this call's power sums; cleared here for the next call) -> natural bin order
+// k = k1 + N1*k2, fftshift-ed (ks = k ^ N/2), through an LDS tile so that reads and writes are coalesced.
+//   fin == null : dst[ks] = (add ? dst[ks] : 0) + S   (float64; the averager step follows separately)
+//   fin != null : the same, then the finish arithmetic of big_finish_kernel on dst[ks] in the same thread
+struct BigFinishParams;
+__device__ __forceinline__ void big_finish_bin(const BigFinishParams& p, long long ks, double sum);
 
 struct BigFinishParams {
   const double* src;   // [N] fftshift-ed: sum over `count` segments, or the averager state (count = 1)
@@ -126,9 +112,8 @@ struct BigFinishParams {
   float* hold_min;
   int max_first, min_first;
 };
-__global__ void __launch_bounds__(256) big_finish_kernel(const BigFinishParams p) {
-  const long long ks = (long long)blockIdx.x * 256 + threadIdx.x;
-  const double mean = p.src[ks] / double(p.count);
+__device__ __forceinline__ void big_finish_bin(const BigFinishParams& p, long long ks, double sum) {
+  const double mean = sum / double(p.count);
   if (p.mean_out != nullptr) p.mean_out[ks] = mean;
   float db;
   if (p.db_mode == 0) db = 20.0f * log10f(sqrtf(float(mean)) + p.log_floor);
@@ -138,6 +123,35 @@ __global__ void __launch_bounds__(256) big_finish_kernel(const BigFinishParams p
   if (p.out_db != nullptr) p.out_db[ks] = db;
   if (p.hold_max != nullptr) p.hold_max[ks] = p.max_first ? ((db != db) ? -500.f : db) : fmaxf(p.hold_max[ks], db);
   if (p.hold_min != nullptr) p.hold_min[ks] = p.min_first ? ((db != db) ? 500.f : db) : fminf(p.hold_min[ks], db);
+}
+
+__global__ void __launch_bounds__(256) big_finish_kernel(const BigFinishParams p) {
+  const long long ks = (long long)blockIdx.x * 256 + threadIdx.x;
+  big_finish_bin(p, ks, p.src[ks]);
+}
+
+template <int LOG2N1>
+__global__ void __launch_bounds__(256) big_gather_kernel(float* s, double* dst, int add, BigFinishParams fin, int fuse) {
+  constexpr int N1 = 1 << LOG2N1, T = 64;                 // tile: all N1 rows x 64 columns k2
+  __shared__ float tile[N1][T + 1];
+  const int k2b = blockIdx.x * T;
+  for (int i = threadIdx.x; i < N1 * T; i += 256) {
+    const int k1 = i / T, c = i % T;
+    float* q = s + (long long)k1 * kRowN + k2b + c;
+    tile[k1][c] = *q;
+    *q = 0.f;
+  }
+  __syncthreads();
+  constexpr long long half = (long long)N1 * kRowN / 2;
+  for (int i = threadIdx.x; i < N1 * T; i += 256) {
+    const int c = i / N1, k1 = i % N1;
+    const long long k = (long long)(k2b + c) * N1 + k1;
+    const long long ks = k ^ half;
+    const double x = double(tile[k1][c]);
+    const double sum = add ? dst[ks] + x : x;
+    dst[ks] = sum;
+    if (fuse) big_finish_bin(fin, ks, sum);
+  }
 }
 
 // ---- DC of long frames: exact sums (integers for byte formats), tracker in double ---------------------------
@@ -193,8 +207,8 @@ static hipError_t cols_launch(const BigColsParams& p, int n_seg, hipStream_t s) 
   return hipGetLastError();
 }
 template <int L>
-static hipError_t gather_launch(const float* src, double* dst, int add, hipStream_t s) {
-  hipLaunchKernelGGL(big_gather_kernel<L>, dim3(kRowN / 64), dim3(256), 0, s, src, dst, add);
+static hipError_t gather_launch(float* src, double* dst, int add, const BigFinishParams& fin, int fuse, hipStream_t s) {
+  hipLaunchKernelGGL(big_gather_kernel<L>, dim3(kRowN / 64), dim3(256), 0, s, src, dst, add, fin, fuse);
   return hipGetLastError();
 }
 
@@ -214,16 +228,31 @@ hipError_t launch_big_cols(int log2n, const void* in, int in_c64, long long seg_
   }
 }
 
-hipError_t launch_big_gather(int log2n, const float* s_rows, double* dst, int add, hipStream_t s) {
+static hipError_t gather_dispatch(int log2n, float* s_rows, double* dst, int add, const BigFinishParams& fin, int fuse,
+                                  hipStream_t s) {
   switch (log2n - kRowLog2) {
-    case 1: return gather_launch<1>(s_rows, dst, add, s);
-    case 2: return gather_launch<2>(s_rows, dst, add, s);
-    case 3: return gather_launch<3>(s_rows, dst, add, s);
-    case 4: return gather_launch<4>(s_rows, dst, add, s);
-    case 5: return gather_launch<5>(s_rows, dst, add, s);
-    case 6: return gather_launch<6>(s_rows, dst, add, s);
+    case 1: return gather_launch<1>(s_rows, dst, add, fin, fuse, s);
+    case 2: return gather_launch<2>(s_rows, dst, add, fin, fuse, s);
+    case 3: return gather_launch<3>(s_rows, dst, add, fin, fuse, s);
+    case 4: return gather_launch<4>(s_rows, dst, add, fin, fuse, s);
+    case 5: return gather_launch<5>(s_rows, dst, add, fin, fuse, s);
+    case 6: return gather_launch<6>(s_rows, dst, add, fin, fuse, s);
     default: return hipErrorInvalidValue;
   }
+}
+
+hipError_t launch_big_gather(int log2n, float* s_rows, double* dst, int add, hipStream_t s) {
+  return gather_dispatch(log2n, s_rows, dst, add, BigFinishParams{}, 0, s);
+}
+
+// gather + finish in one launch: dst (+)= S, then mean = dst / count -> dB row, hold (Welch and plain frames)
+hipError_t launch_big_gather_finish(int log2n, float* s_rows, double* dst, int add, double* mean_out, int count,
+                                    int db_mode, float pscale, float log_floor, float cal_db, const float* tare,
+                                    float* out_db, float* hold_max, float* hold_min, int max_first, int min_first,
+                                    hipStream_t s) {
+  const BigFinishParams fin{dst, mean_out, count, db_mode, pscale, log_floor, cal_db, tare, out_db, hold_max, hold_min,
+                            max_first, min_first};
+  return gather_dispatch(log2n, s_rows, dst, add, fin, 1, s);
 }
 
 hipError_t launch_big_finish(const double* src, long long n, double* mean_out, int count, int db_mode, float pscale,

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -92,7 +93,7 @@ struct tdsa_plan_s {
   float2* d_tw_lo = nullptr;             // W_N^m, m < 1024
   float2* d_tw_row = nullptr;            // W_16384^m : the row pass's twiddle table
   float* d_ones = nullptr;               // [16384] unit window for the row pass
-  int big_group = 8;                     // segments per column-pass / row-pass round (Z stays cache resident)
+  int big_group = 32;                    // segments per column-pass / row-pass round (Z stays cache resident)
   bool profiling = false;
   std::vector<hipEvent_t> prof_events;   // pairs (begin, end) around frame-kernel launches
   size_t prof_used = 0;
@@ -201,7 +202,7 @@ int process_big(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n_f
                          double(in_off), double(in_scale), p->d_sums64, p->d_dc_state, p->d_dc_sub, p->stream));
     dc_sub = p->d_dc_sub;
   }
-  HIPCHK(hipMemsetAsync(p->d_acc, 0, N * sizeof(float), p->stream));
+  // (d_acc is all zero here: cleared at plan creation and by every gather)
   // column pass and row pass alternate over groups of segments: the 8N-byte rows of a group are consumed
   // right after they are produced, out of the Infinity Cache rather than HBM
   for (int s0 = 0; s0 < n_frames; s0 += group) {
@@ -242,28 +243,26 @@ int process_big(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n_f
   }
   const bool hmax = (m.hold_flags & TDSA_HOLD_MAX) != 0, hmin = (m.hold_flags & TDSA_HOLD_MIN) != 0;
   const float pscale = m.db_mode == TDSA_DB_POW ? m.power_scale : 1.0f;
-  const double* src = nullptr;
-  double* mean_out = nullptr;
-  int count = 1;
+  float* const tare = p->tare_active ? p->d_tare_base : nullptr;
+  float* const hold_max = hmax ? p->d_hold_max : nullptr;
+  float* const hold_min = hmin ? p->d_hold_min : nullptr;
   if (welch) {
-    HIPCHK(launch_big_gather(p->log2n, p->d_acc, p->d_sum, p->avg_count > 0, p->stream));
+    HIPCHK(launch_big_gather_finish(p->log2n, p->d_acc, p->d_sum, p->avg_count > 0, p->d_avg, p->avg_count + n_frames,
+                                    m.db_mode, pscale, m.log_floor, m.cal_offset_db, tare, out_db_dev, hold_max, hold_min,
+                                    p->held_max == 0, p->held_min == 0, p->stream));
     p->avg_count += n_frames;
-    src = p->d_sum;
-    mean_out = p->d_avg;
-    count = p->avg_count;
   } else if (averaging) {    // TraceAverager exp / capped lin, one frame (signal_processing.py:35-61)
     HIPCHK(launch_big_gather(p->log2n, p->d_acc, p->d_lin64, 0, p->stream));
     HIPCHK(launch_avg_host_frame(p->d_lin64, p->nfft, p->d_avg, p->avg_count, m.avg_mode, m.avg_n, p->stream));
     if (p->avg_count == 0) p->avg_count = 1;
     else if (m.avg_mode == TDSA_AVG_LIN && p->avg_count < m.avg_n) p->avg_count += 1;
-    src = p->d_avg;
+    HIPCHK(launch_big_finish(p->d_avg, (long long)N, nullptr, 1, m.db_mode, pscale, m.log_floor, m.cal_offset_db, tare,
+                             out_db_dev, hold_max, hold_min, p->held_max == 0, p->held_min == 0, p->stream));
   } else {
-    HIPCHK(launch_big_gather(p->log2n, p->d_acc, p->d_lin64, 0, p->stream));
-    src = p->d_lin64;
+    HIPCHK(launch_big_gather_finish(p->log2n, p->d_acc, p->d_lin64, 0, nullptr, 1, m.db_mode, pscale, m.log_floor,
+                                    m.cal_offset_db, tare, out_db_dev, hold_max, hold_min, p->held_max == 0,
+                                    p->held_min == 0, p->stream));
   }
-  HIPCHK(launch_big_finish(src, (long long)N, mean_out, count, m.db_mode, pscale, m.log_floor, m.cal_offset_db,
-                           p->tare_active ? p->d_tare_base : nullptr, out_db_dev, hmax ? p->d_hold_max : nullptr,
-                           hmin ? p->d_hold_min : nullptr, p->held_max == 0, p->held_min == 0, p->stream));
   if (hmax) p->held_max += 1;
   if (hmin) p->held_min += 1;
   p->frames_seen += n_frames;
@@ -345,9 +344,14 @@ static int plan_init(tdsa_plan p) {
   }
   HIPCHK(hipMemcpy(p->d_tw, tw.data(), size_t(nfft) * sizeof(float2), hipMemcpyHostToDevice));
   if (big) {
+    if (const char* g = getenv("TDSA_BIG_GROUP")) {     // developer knob: segments per column/row round
+      const int v = atoi(g);
+      if (v >= 1 && v <= 64) p->big_group = v;
+    }
     HIPCHK(hipMalloc(&p->d_sum, size_t(nfft) * sizeof(double)));
     HIPCHK(hipMalloc(&p->d_lin64, size_t(nfft) * sizeof(double)));
     HIPCHK(hipMalloc(&p->d_acc, size_t(nfft) * sizeof(float)));
+    HIPCHK(hipMemsetAsync(p->d_acc, 0, size_t(nfft) * sizeof(float), p->stream));
     const int nhi = nfft / 1024, nrow = 1 << kMaxLog2N;
     HIPCHK(hipMalloc(&p->d_tw_hi, size_t(nhi) * sizeof(float2)));
     HIPCHK(hipMalloc(&p->d_tw_lo, 1024 * sizeof(float2)));

@@ -138,8 +138,13 @@ hipError_t launch_big_dc(const void* in, int in_c64, unsigned xor_mask, long lon
                          hipStream_t s);
 // row pass: the 16384-point frame kernel on complex64 rows, power summed per group into p.acc
 hipError_t launch_spectrum_acc(const SpecParams& p, const LaunchGeom& g, hipStream_t s);
-// S[k1][k2] float -> dst[(k1 + N1*k2) ^ N/2] double (overwrite or accumulate)
-hipError_t launch_big_gather(int log2n, const float* s_rows, double* dst, int add, hipStream_t s);
+// S[k1][k2] float (cleared for the next call) -> dst[(k1 + N1*k2) ^ N/2] double (overwrite or accumulate)
+hipError_t launch_big_gather(int log2n, float* s_rows, double* dst, int add, hipStream_t s);
+// the same + mean = dst / count -> dB (+cal, -tare) row and hold traces, one launch
+hipError_t launch_big_gather_finish(int log2n, float* s_rows, double* dst, int add, double* mean_out, int count,
+                                    int db_mode, float pscale, float log_floor, float cal_db, const float* tare,
+                                    float* out_db, float* hold_max, float* hold_min, int max_first, int min_first,
+                                    hipStream_t s);
 hipError_t launch_big_finish(const double* src, long long n, double* mean_out, int count, int db_mode, float pscale,
                              float log_floor, float cal_db, const float* tare, float* out_db, float* hold_max,
                              float* hold_min, int max_first, int min_first, hipStream_t s);

@@ -355,7 +355,24 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     }
   };
   if (u0 < u1) load_frame_raw(u0 * FPW + slot);
-  if constexpr (!C::WIN_LDS) load_window();
+  if constexpr (!C::WIN_LDS && !ACC) load_window();
+  // ACC (row pass of the long-frame path): no window, no raw bytes, no hold traces - the registers they
+  // would take hold the NEXT frame's complex64 samples instead, fetched while this frame is transformed
+  c32 vnext[ACC ? 16 : 1];
+  auto load_frame_c64 = [&](int frame) {
+    if constexpr (ACC) {
+      const int fg = frame / p.group;
+      const unsigned char* fb = static_cast<const unsigned char*>(p.in) + (long long)(frame - fg * p.group) * p.frame_stride +
+                                (long long)fg * p.group_stride;
+      static_for<0, 16>([&](auto ic) {
+        constexpr int idx = decltype(ic)::value;
+        constexpr int jj = idx / H, i = idx % H;
+        const c32* row = reinterpret_cast<const c32*>(fb + 2 * i * (N / A) * 8 + lane_in_off);
+        vnext[idx] = row[jj];
+      });
+    }
+  };
+  if constexpr (ACC) { if (u0 < u1) load_frame_c64(u0 * FPW + slot); }
 
   for (int unit = u0; unit < u1; ++unit) {
     const int frame = unit * FPW + slot;
@@ -365,13 +382,10 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     c32 v[16];                                              // pass 1: v[jj*H + i] = sample a = 2i + h of butterfly jj
     float sub_re = p.in_off, sub_im = p.in_off;
     // ---- frame sums for DC removal ---------------------------------------------------------------
-    if constexpr (IN_C64) {
+    if constexpr (ACC) {
+      static_for<0, 16>([&](auto ic) { constexpr int idx = decltype(ic)::value; v[idx] = vnext[idx]; });
+    } else if constexpr (IN_C64) {
       const unsigned char* fb = static_cast<const unsigned char*>(p.in) + (long long)frame * p.frame_stride;
-      if constexpr (ACC) {
-        const int fg = frame / p.group;
-        fb = static_cast<const unsigned char*>(p.in) + (long long)(frame - fg * p.group) * p.frame_stride +
-             (long long)fg * p.group_stride;
-      }
       static_for<0, 16>([&](auto ic) {
         constexpr int idx = decltype(ic)::value;
         constexpr int jj = idx / H, i = idx % H;
@@ -492,7 +506,9 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     if constexpr (C::WIN_LDS) load_window();
 
     // ---- unpack + DC removal + window ------------------------------------------------------------
-    if constexpr (IN_C64) {
+    if constexpr (ACC) {
+      // rows arrive windowed, DC-free and pre-twiddled from the column pass
+    } else if constexpr (IN_C64) {
       static_for<0, 16>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         v[i] = c32{(v[i].x - sub_re) * win[i], (v[i].y - sub_im) * win[i]};
@@ -532,6 +548,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       if constexpr ((TDSA_ABLATE & 2) == 0) { lds_st(&buf[wr1_base + li], v[re]); lds_st(&buf[wr1_base + li + H], v[ro]); }
     });
     TDSA_STAMP(4);
+    if constexpr (ACC) { if (unit + 1 < u1) load_frame_c64((unit + 1) * FPW + slot); }
     TDSA_SYNC();
     TDSA_STAMP(5);
 
@@ -627,7 +644,6 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
           });
         }
       }
-      if constexpr (!C::WIN_LDS) load_window();
     } else
     if (active) {
       if (p.out_cplx != nullptr) {            // real-input path: hand the complex bins to the fold kernel
