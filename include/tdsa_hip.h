@@ -90,7 +90,11 @@ int tdsa_device_count(int* count);
 /* One plan = (device, FFT size, batch capacity).  Replaces _allocate_fft_resources
  * (datasources/hackrf_samples.py:311-324) + the per-source TraceAverager (datasources/base.py:59)
  * + the hold buffers mw.max_power_levels / mw.min_power_levels (main.py:70-105).
- * nfft: power of two, 64 .. 16384 (single-pass-in-LDS kernel) or 2^20 (four-step kernel). */
+ * nfft: any power of two from 64 to 2^20 (HackrfSamplesDataSource.set_num_samples is unbounded,
+ * hackrf_samples.py:392-405): 64 .. 16384 run as ONE LDS-resident kernel; 2^15 .. 2^20 as N1 x 16384 in two
+ * passes (in-register column DFT kernel + the same frame kernel as row pass).  A long-frame plan takes one
+ * frame per call, or - with avg_mode lin and avg_n >= the frames seen since the last reset - a batch of K
+ * segments whose Welch average comes back as ONE dB row. */
 int tdsa_create(int device_id, int nfft, int max_frames, tdsa_plan* out);
 int tdsa_destroy(tdsa_plan p);
 int tdsa_get_info(tdsa_plan p, tdsa_info* out);

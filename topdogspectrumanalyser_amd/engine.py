@@ -105,7 +105,7 @@ class SpectrumEngine:
             raise TypeError(f"unsupported IQ dtype {iq.dtype}; need int8, uint8 or complex64")
         if n_frames is None:
             n_frames = 0 if n_samples < self.nfft else (n_samples - self.nfft) // hop + 1
-        rows = n_frames if self.nfft <= 16384 else min(n_frames, 1)   # 2^20-point plans return the Welch row
+        rows = n_frames if self.nfft <= 16384 else min(n_frames, 1)   # long-frame plans return ONE row (Welch)
         out = np.empty((rows, self.nfft), dtype=np.float32) if want_db else None
         nat.check(fn(self._h, _ptr(iq), n_samples, hop, n_frames, _ptr(out)))
         return out
