@@ -1,0 +1,54 @@
+"""bench.py launch conventions (no GPU): `python bench.py --gpus N` spawns its own workers, ranks meet over
+gloo on 127.0.0.1, rank 0 prints ONE well-formed JSON line; the same under torch.distributed.run.  The
+stand-in engine of --dry-run does no arithmetic: only the plumbing of the multi-GPU leg is exercised."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _run(cmd):
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None), env.pop("LOCAL_RANK", None)
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def _check_line(d, n):
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "value_serial", "per_gpu_frames_per_s"):
+        assert key in d, key
+    assert d["n_gpus"] == n and len(d["per_gpu_frames_per_s"]) == n and d["scaling"] == "weak"
+    assert d["metric"].startswith("PSD frames/sec at 16384-pt FFT") and d["unit"] == "frames/s"
+    assert d["steps"] == 40 and d["warmup"] == 3 and d["value"] > 0 and d["ms_per_step"] > 0
+    assert "dry-run" in d["data"] and d["roofline"]["frac"] is None
+    assert d["timing"]["repetitions"] == 3 and d["timing"]["steps_per_region"] == 40 * d["timing"]["inner_repeats"]
+    assert min(d["timing"]["region_ms"]) >= 50.0          # every timed region lasts >= 50 ms
+    assert "no collective" in d["config"]["parallelism"]
+
+
+@pytest.mark.parametrize("n", [1, 2])
+def test_bench_spawns_its_own_workers(n):
+    d = _run([sys.executable, "bench.py", "--gpus", str(n), "--steps", "40", "--warmup", "3", "--reps", "3", "--dry-run"])
+    _check_line(d, n)
+    assert d["config"]["launcher"] == ("self-spawned workers" if n > 1 else "single process")
+
+
+def test_bench_under_torch_distributed_run():
+    d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+              "127.0.0.1", "--master-port", "29517", "bench.py", "--gpus", "2", "--steps", "40", "--warmup", "3",
+              "--reps", "3", "--dry-run"])
+    _check_line(d, 2)
+    assert d["config"]["launcher"] == "torch.distributed.run"
+
+
+def test_bench_has_no_rccl_in_it():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "nccl" not in src.lower() and 'backend="gloo"' in src

@@ -306,7 +306,7 @@ class _Label:
         self.text = s
 
 
-def _make_processor(pkg, src, cal_offset, max_on, min_on):
+def _make_processor(pkg, src, cal_offset, max_on, min_on, **dp_options):
     mw, dm = _NS(), _NS()
     mw.current_source = src
     mw.calibration_manager = _NS()
@@ -325,10 +325,10 @@ def _make_processor(pkg, src, cal_offset, max_on, min_on):
     def _clear():
         mw.tare_active, mw.baseline_power_levels = False, None
     dm._clear_tare = _clear
-    return pkg.DataProcessor(mw, dm), mw, dm
+    return pkg.DataProcessor(mw, dm, **dp_options), mw, dm
 
 
-@pytest.mark.parametrize("holds", ["max", "min", "both"])
+@pytest.mark.parametrize("holds", ["max", "min", "both", "both_as_reference"])
 def test_data_processor_sequence_golden(pkg, golden_dir, holds):
     g = np.load(os.path.join(golden_dir, "processor_1024.npz"))
     n = int(g["nfft"])
@@ -336,12 +336,16 @@ def test_data_processor_sequence_golden(pkg, golden_dir, holds):
     src.num_samples = n
     src.running = True
     src._allocate_fft_resources()
+    as_ref = holds == "both_as_reference"
+    if as_ref:
+        holds = "both"
     dp, mw, dm = _make_processor(pkg, src, float(g["cal_offset"]), holds in ("max", "both"),
-                                 holds in ("min", "both"))
-    # independent max / min traces: what the reference computes with ONE hold enabled, and what the
-    # oracle computes with alias_quirk=False when both are (quirk ii deliberately dropped)
-    ref_max = g["max_hold"]
-    ref_min = g["min_hold"]
+                                 holds in ("min", "both"), reference_hold_alias=as_ref)
+    # default: independent max / min traces - what the reference computes with ONE hold enabled, and what
+    # the oracle computes with alias_quirk=False when both are.  reference_hold_alias=True: the reference's
+    # own both-holds sequence (one shared ndarray: golden max_hold_both / min_hold_both), SURVEY 8(a) quirk ii
+    ref_max = g["max_hold_both"] if as_ref else g["max_hold"]
+    ref_min = g["min_hold_both"] if as_ref else g["min_hold"]
     for k, fr in enumerate(g["frames_c64"]):
         if k == int(g["tare_start"]):
             dm.tare_state = pkg.TareState(collecting=True)
@@ -366,6 +370,8 @@ def test_data_processor_sequence_golden(pkg, golden_dir, holds):
         if holds in ("min", "both"):
             dn_ = np.abs(mw.min_power_levels - ref_min[k])
             assert np.all(dn_ <= allowance(ref_min[k] + base)), (k, float(dn_.max()))
+        if as_ref:
+            assert mw.max_power_levels is mw.min_power_levels        # one buffer, as in the reference
     assert mw.tare_active == bool(g["tare_active_at_end"])
     assert np.abs(mw.baseline_power_levels - g["baseline"]).max() < DB_TOL
     assert dm.tare_state.collecting is False

@@ -11,7 +11,8 @@ from the device after every frame.
 Scope notes
   * The two hold traces are independent buffers.  The reference lets them alias ONE ndarray when both
     are switched on for the same first frame (SURVEY.md 8(a) quirk ii), after which both just follow
-    the live trace; that accident is pinned in the oracle and not reproduced.
+    the live trace; that accident is pinned in the oracle (golden max_hold_both / min_hold_both) and is
+    reproduced only on request: DataProcessor(..., reference_hold_alias=True).
   * The GUI feeds around the spectrum path (sweep traces, constellation + EVM read-out, zero-span with
     its rise / fall trigger, peak-list read-out) behave as the reference's do, on the host: they are
     per-tick scalar work with no GPU side; batch users go through `analytics.py` instead.
@@ -43,10 +44,14 @@ def _plural(n: int, word: str) -> str:
 
 
 class DataProcessor:
-    def __init__(self, main_window, display_manager, gpu_device: int = 0):
+    def __init__(self, main_window, display_manager, gpu_device: int = 0, reference_hold_alias: bool = False):
         self.mw = main_window
         self.dm = display_manager
         self._device = gpu_device
+        # True: reproduce the reference's both-holds accident bit for bit (see _alias_holds); default: two
+        # independent running fmax / fmin traces
+        self.reference_hold_alias = bool(reference_hold_alias)
+        self._holds_share_buffer = False
         self._state: Optional[TraceState] = None          # device-side trace state, sized on first use
         self._sweep_averager = TraceAverager(device=gpu_device)
         self._sweeps_since_axis_refresh = 0
@@ -297,12 +302,38 @@ class DataProcessor:
         setattr(mw, attr, mx if which == "hold_max" else mn)
 
     def _update_max_hold(self, power_levels: np.ndarray) -> None:
+        self._note_adoption(power_levels)
         self._hold(power_levels, attr="max_power_levels", enabled=bool(self.dm.max_peak_search_enabled),
                    reset_bit=nat.RESET_HOLD_MAX, which="hold_max")
 
     def _update_min_hold(self, power_levels: np.ndarray) -> None:
         self._hold(power_levels, attr="min_power_levels", enabled=bool(self.mw.min_hold_enabled),
                    reset_bit=nat.RESET_HOLD_MIN, which="hold_min")
+        self._alias_holds(power_levels)
+
+    # ------------------------------------------------------------------ reference_hold_alias=True only
+    def _note_adoption(self, trace: np.ndarray) -> None:
+        """The reference adopts a frame as hold buffer WITHOUT copying it when it has no NaN
+        (display_data_processor.py:380,393 + _nan_safe :473-480).  If both traces adopt the same frame they
+        are one ndarray from then on: fmax(out=) followed by fmin(out=) on it leaves the live trace, frame
+        after frame, until one of them is cleared."""
+        if not self.reference_hold_alias:
+            return
+        mw = self.mw
+        both_on = bool(self.dm.max_peak_search_enabled) and bool(mw.min_hold_enabled)
+
+        def adopting(held):
+            return held is None or held.shape != trace.shape
+
+        if not both_on or mw.max_power_levels is None or mw.min_power_levels is None:
+            self._holds_share_buffer = False
+        if both_on and adopting(mw.max_power_levels) and adopting(mw.min_power_levels):
+            self._holds_share_buffer = not np.isnan(trace).any()
+
+    def _alias_holds(self, trace: np.ndarray) -> None:
+        if self.reference_hold_alias and self._holds_share_buffer:
+            shared = np.array(trace, copy=True)
+            self.mw.max_power_levels = self.mw.min_power_levels = shared
 
     # ================================================================== per-tick scalars (host side)
     def _update_duty_cycle(self, power_levels: np.ndarray) -> None:

@@ -94,6 +94,8 @@ struct tdsa_plan_s {
   float2* d_tw_row = nullptr;            // W_16384^m : the row pass's twiddle table
   float* d_ones = nullptr;               // [16384] unit window for the row pass
   int big_group = 32;                    // segments per column-pass / row-pass round (Z stays cache resident)
+  void* d_scratch = nullptr;             // grows on demand: results of tdsa_rows_stats / tdsa_rows_top_peaks
+  size_t scratch_bytes = 0;
   bool profiling = false;
   std::vector<hipEvent_t> prof_events;   // pairs (begin, end) around frame-kernel launches
   size_t prof_used = 0;
@@ -400,7 +402,7 @@ int tdsa_destroy(tdsa_plan p) {
   void* bufs[] = {p->d_window[0], p->d_window[1], p->d_window[2], p->d_tw, p->d_hold_max, p->d_hold_min,
                   p->d_avg, p->d_lin, p->d_carry, p->d_cplx, p->d_lin1, p->d_db1, p->d_dc_state, p->d_sums, p->d_dc_sub,
                   p->d_tare_base, p->d_tare_acc, p->d_in_stage, p->d_out_stage, p->d_trace_in,
-                  p->d_trace_live, p->d_z, p->d_acc, p->d_sum, p->d_lin64, p->d_sums64, p->d_tw_hi, p->d_tw_lo, p->d_tw_row, p->d_ones,
+                  p->d_trace_live, p->d_scratch, p->d_z, p->d_acc, p->d_sum, p->d_lin64, p->d_sums64, p->d_tw_hi, p->d_tw_lo, p->d_tw_row, p->d_ones,
                   p->d_dbg};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -704,6 +706,8 @@ int tdsa_process_real2(tdsa_plan p, const float* lr_host, size_t n_samples, int 
   if (!p->window_set) return fail(TDSA_ERR_STATE, "tdsa_set_window has not been called");
   const tdsa_mode& m = p->mode;
   if (m.db_mode != TDSA_DB_POW) return fail(TDSA_ERR_ARG, "real-input path computes power dB: set TDSA_DB_POW");
+  if (avg_active(m) && channel == TDSA_CH_STEREO)
+    return fail(TDSA_ERR_ARG, "stereo with averaging: process frame by frame (left is averaged, right is not)");
   HIPCHK(hipSetDevice(p->device));
   JOIN(p);
   const int n = p->nfft, nb = n / 2 + 1;
@@ -737,8 +741,6 @@ int tdsa_process_real2(tdsa_plan p, const float* lr_host, size_t n_samples, int 
   HIPCHK(launch_real_fold(p->d_cplx, n, n_frames, channel, m.power_scale, p->d_lin1, p->stream));
   const int rows = channel == TDSA_CH_STEREO ? 2 * n_frames : n_frames;
   if (avg_active(m)) {
-    if (channel == TDSA_CH_STEREO)
-      return fail(TDSA_ERR_ARG, "stereo with averaging: process frame by frame (left is averaged, right is not)");
     AvgParams ap{};
     ap.lin = p->d_lin1;
     ap.n_frames = n_frames;
@@ -1091,13 +1093,13 @@ int tdsa_pipe_create(tdsa_plan p, int in_format, size_t slot_samples, int n_slot
   if (in_format < TDSA_IN_I8 || in_format > TDSA_IN_C64) return fail(TDSA_ERR_ARG, "in_format %d", in_format);
   if (n_slots < 1 || n_slots > 16) return fail(TDSA_ERR_ARG, "n_slots=%d outside [1, 16]", n_slots);
   if (slot_samples < size_t(p->nfft)) return fail(TDSA_ERR_ARG, "slot_samples=%zu < nfft", slot_samples);
+  if (want_rows < 0 || want_rows > 2) return fail(TDSA_ERR_ARG, "want_rows=%d (0 none, 1 host, 2 device)", want_rows);
   HIPCHK(hipSetDevice(p->device));
   tdsa_pipe q = new (std::nothrow) tdsa_pipe_s();
   if (!q) return fail(TDSA_ERR_NOMEM, "out of host memory");
   q->plan = p;
   q->fmt = in_format;
   q->slot_samples = slot_samples;
-  if (want_rows < 0 || want_rows > 2) return fail(TDSA_ERR_ARG, "want_rows=%d (0 none, 1 host, 2 device)", want_rows);
   q->rows = want_rows != 0;
   q->rows_host = want_rows == 1;
   q->slots.resize(size_t(n_slots));
@@ -1225,26 +1227,17 @@ int tdsa_pipe_pending(tdsa_pipe q, int* pending) {
 // ================================================================================================
 namespace {
 
-// scratch that grows on demand, owned by the plan's device context (freed with the object that holds it)
-struct DevScratch {
-  void* ptr = nullptr;
-  size_t bytes = 0;
-  int ensure(size_t need) {
-    if (need <= bytes) return TDSA_OK;
-    if (ptr) HIPCHK(hipFree(ptr));
-    ptr = nullptr;
-    bytes = 0;
-    HIPCHK(hipMalloc(&ptr, need));
-    bytes = need;
-    return TDSA_OK;
-  }
-  void release() {
-    if (ptr) (void)hipFree(ptr);
-    ptr = nullptr;
-    bytes = 0;
-  }
-};
-thread_local DevScratch g_scratch[16];   // per device, per host thread
+// scratch that grows on demand, owned by the plan (freed by tdsa_destroy; one plan = one thread at a time)
+int plan_scratch(tdsa_plan p, size_t need) {
+  if (need <= p->scratch_bytes) return TDSA_OK;
+  HIPCHK(hipStreamSynchronize(p->stream));
+  if (p->d_scratch) HIPCHK(hipFree(p->d_scratch));
+  p->d_scratch = nullptr;
+  p->scratch_bytes = 0;
+  HIPCHK(hipMalloc(&p->d_scratch, need));
+  p->scratch_bytes = need;
+  return TDSA_OK;
+}
 
 }  // namespace
 
@@ -1257,11 +1250,10 @@ int tdsa_rows_stats(tdsa_plan p, const float* rows_dev, int n_rows, int n_bins, 
     return fail(TDSA_ERR_ARG, "band [%d, %d] outside [0, %d)", band_lo, band_hi, n_bins);
   HIPCHK(hipSetDevice(p->device));
   JOIN(p);
-  DevScratch& sc = g_scratch[p->device & 15];
   const size_t per = sizeof(float) + sizeof(int) + sizeof(double);
-  int rc = sc.ensure(size_t(n_rows) * per);
+  int rc = plan_scratch(p, size_t(n_rows) * per);
   if (rc != TDSA_OK) return rc;
-  double* d_band = static_cast<double*>(sc.ptr);
+  double* d_band = static_cast<double*>(p->d_scratch);
   float* d_peak = reinterpret_cast<float*>(d_band + n_rows);
   int* d_bin = reinterpret_cast<int*>(d_peak + n_rows);
   HIPCHK(launch_rows_stats(rows_dev, n_rows, n_bins, band_lo, band_hi, bin_width, d_peak, d_bin,
@@ -1282,11 +1274,10 @@ int tdsa_rows_top_peaks(tdsa_plan p, const float* rows_dev, int n_rows, int n_bi
   if (n_bins < 1 || n_bins > 16384) return fail(TDSA_ERR_ARG, "n_bins=%d outside [1, 16384] (row must fit the LDS)", n_bins);
   HIPCHK(hipSetDevice(p->device));
   JOIN(p);
-  DevScratch& sc = g_scratch[p->device & 15];
   const size_t cnt = size_t(n_rows) * n_peaks;
-  int rc = sc.ensure(cnt * (sizeof(int) + sizeof(float)));
+  int rc = plan_scratch(p, cnt * (sizeof(int) + sizeof(float)));
   if (rc != TDSA_OK) return rc;
-  int* d_bins = static_cast<int*>(sc.ptr);
+  int* d_bins = static_cast<int*>(p->d_scratch);
   float* d_db = reinterpret_cast<float*>(d_bins + cnt);
   HIPCHK(launch_top_peaks(rows_dev, n_rows, n_bins, n_peaks, min_sep_bins, min_excursion_db, d_bins, d_db, p->stream));
   HIPCHK(hipMemcpyAsync(peak_bins_host, d_bins, cnt * sizeof(int), hipMemcpyDeviceToHost, p->stream));

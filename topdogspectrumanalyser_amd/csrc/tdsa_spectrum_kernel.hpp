@@ -101,10 +101,11 @@ __device__ __forceinline__ float hw_min(float a, float b) { float r; asm("v_min_
 
 // wave64 integer sum with DPP adds (no LDS round trips); the total is valid in lanes 48..63
 __device__ __forceinline__ int dpp_wave_sum(int x) {
-  x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
-  x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
-  x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, false);   // row_half_mirror
-  x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, false);   // row_mirror: every lane = row sum
+  // bound_ctrl: every source lane of these four steps exists and the masks are full, so `old` is never read
+  x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
+  x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+  x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, true);    // row_half_mirror
+  x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, true);    // row_mirror: every lane = row sum
   x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
   x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
   return x;
@@ -678,6 +679,11 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
             constexpr int q = decltype(ic)::value;
             const float mag = __builtin_amdgcn_sqrtf(db[q]);
             db[q] = fmaf(2.0f * k10Log10_2, __builtin_amdgcn_logf(mag + p.log_floor), cal_v);
+          });
+        } else if (mag_mode) {          // 10*log10(|X|^2): no power scale, no floor (wave-uniform branch)
+          static_for<0, 16>([&](auto ic) {
+            constexpr int q = decltype(ic)::value;
+            db[q] = fmaf(k10Log10_2, __builtin_amdgcn_logf(db[q]), cal_v);
           });
         } else {
           static_for<0, 16>([&](auto ic) {

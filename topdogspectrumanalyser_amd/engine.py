@@ -28,9 +28,12 @@ class SpectrumEngine:
         self._h = C.c_void_p()
         nat.check(nat.lib.tdsa_create(self.device, self.nfft, self.max_frames, C.byref(self._h)))
         self._mode = nat.Mode(nat.DB_MAG, 1.0, 1e-12, nat.AVG_OFF, 1, 1.0, 0.0, 0)
+        self._pipes = []                  # live HostPipe objects: they hold slots the plan's streams write to
 
     # ------------------------------------------------------------------ lifetime
     def close(self) -> None:
+        for q in list(getattr(self, "_pipes", [])):
+            q.close()                     # a pipe must go before its plan (tdsa_pipe_destroy syncs the plan)
         if getattr(self, "_h", None) is not None and self._h:
             nat.lib.tdsa_destroy(self._h)
             self._h = C.c_void_p()
@@ -285,11 +288,15 @@ class HostPipe:
         self._q = C.c_void_p()
         nat.check(nat.lib.tdsa_pipe_create(engine._h, self.in_format, self.slot_samples, int(n_slots),
                                             self.rows_mode, C.byref(self._q)))
+        engine._pipes.append(self)
 
     def close(self) -> None:
         if getattr(self, "_q", None) is not None and self._q:
-            nat.lib.tdsa_pipe_destroy(self._q)
+            if self._eng._h:              # (the engine closes its pipes before it destroys the plan)
+                nat.lib.tdsa_pipe_destroy(self._q)
             self._q = C.c_void_p()
+            if self in self._eng._pipes:
+                self._eng._pipes.remove(self)
 
     def __del__(self):
         try:
