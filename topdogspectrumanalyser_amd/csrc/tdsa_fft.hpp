@@ -108,6 +108,69 @@ __device__ __forceinline__ void dif(c32 (&v)[TOT]) {
   }
 }
 
+// ---- decimation-in-time butterflies with the twiddle folded into FMAs ---------------------------
+// (e, o) -> (e + w o, e - w o), w = exp(-2 pi i K / R) a compile-time constant.  A general twiddle costs
+// 6 instructions (4 literal-operand FMAs for e + w o, then 2 e - that) against 8 for "multiply, add, subtract".
+// EXACT: the difference output is formed as e - w o with its own two FMAs instead of 2 e - (e + w o) - one
+// rounding less where the two operands cancel (used in the last stage of a frame, where the 31 other bins
+// of a strong tone's butterfly must come out near zero).
+template <int K, int R, bool EXACT = false>
+__device__ __forceinline__ void bf_w(c32& e, c32& o) {
+  constexpr int k = ((K % R) + R) % R;
+  constexpr float s8 = 0.70710678118654752440f;
+  if constexpr (k == 0) {
+    const c32 a = e, b = o;
+    e = cadd(a, b); o = csub(a, b);
+  } else if constexpr (4 * k == R) {            // w = -i : w o = (o.y, -o.x)
+    const c32 a = e, b = o;
+    e = c32{a.x + b.y, a.y - b.x}; o = c32{a.x - b.y, a.y + b.x};
+  } else if constexpr (2 * k == R) {            // w = -1
+    const c32 a = e, b = o;
+    e = csub(a, b); o = cadd(a, b);
+  } else if constexpr (4 * k == 3 * R) {        // w = +i : w o = (-o.y, o.x)
+    const c32 a = e, b = o;
+    e = c32{a.x - b.y, a.y + b.x}; o = c32{a.x + b.y, a.y - b.x};
+  } else if constexpr ((8 * k) % R == 0) {      // odd multiples of R/8: w = (+-1 +- i)/sqrt2
+    const float p = o.x + o.y, m = o.y - o.x;   // (1 - i)/sqrt2 * o = s8 (p + i m)
+    float tr, ti;                                // t = w o / s8
+    if constexpr (8 * k == R) { tr = p; ti = m; }
+    else if constexpr (8 * k == 3 * R) { tr = m; ti = -p; }
+    else if constexpr (8 * k == 5 * R) { tr = -p; ti = -m; }
+    else { tr = -m; ti = p; }
+    const c32 x1 = c32{fmaf(s8, tr, e.x), fmaf(s8, ti, e.y)};
+    if constexpr (EXACT) o = c32{fmaf(-s8, tr, e.x), fmaf(-s8, ti, e.y)};
+    else o = c32{fmaf(2.0f, e.x, -x1.x), fmaf(2.0f, e.y, -x1.y)};
+    e = x1;
+  } else {
+    constexpr float c = float(cx_cos(cx_angle(k, R)));
+    constexpr float s = float(cx_sin(cx_angle(k, R)));   // w = c - i s :  w o = (o.x c + o.y s) + i (o.y c - o.x s)
+    const c32 x1 = c32{fmaf(o.y, s, fmaf(o.x, c, e.x)), fmaf(-o.x, s, fmaf(o.y, c, e.y))};
+    if constexpr (EXACT) o = c32{fmaf(-o.y, s, fmaf(-o.x, c, e.x)), fmaf(o.x, s, fmaf(-o.y, c, e.y))};
+    else o = c32{fmaf(2.0f, e.x, -x1.x), fmaf(2.0f, e.y, -x1.y)};
+    e = x1;
+  }
+}
+
+// In-place radix-R DIT on the registers v[BASE + i*STRIDE], i < R (natural input order): afterwards
+// X[k] = v[BASE + STRIDE * bitrev(k, log2 R)] - the same output convention as dif<>.
+template <int R, int BASE, int STRIDE, int TOT>
+__device__ __forceinline__ void dit_s(c32 (&v)[TOT]) {
+  if constexpr (R == 2) {
+    bf_w<0, 2>(v[BASE], v[BASE + STRIDE]);
+  } else if constexpr (R > 2) {
+    constexpr int h = R / 2, L1 = ilog2(h);
+    dit_s<h, BASE, 2 * STRIDE, TOT>(v);              // E = DFT of the even samples
+    dit_s<h, BASE + STRIDE, 2 * STRIDE, TOT>(v);     // O = DFT of the odd samples
+    static_for<0, h>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      constexpr int slot = BASE + 2 * STRIDE * bitrev(k, L1);       // E[k]; O[k] sits STRIDE above
+      bf_w<k, R>(v[slot], v[slot + STRIDE]);
+    });
+  }
+}
+template <int R, int BASE, int TOT>
+__device__ __forceinline__ void dit(c32 (&v)[TOT]) { dit_s<R, BASE, 1, TOT>(v); }
+
 // Same butterfly network, depth first, calling emit(integral_constant<register index>) as soon as a
 // register holds a final output: the LDS stores of the first outputs then issue while the rest of the
 // butterfly is still being computed (X[k] sits in register BASE + bitrev(k)).

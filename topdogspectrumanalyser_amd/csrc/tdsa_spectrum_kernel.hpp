@@ -201,6 +201,17 @@ __device__ __forceinline__ void swap_halves(c32& a, c32& b) {
   a.y = __uint_as_float(ry[0]); b.y = __uint_as_float(ry[1]);
 }
 
+// In-register radix network of the passes: decimation in time with the twiddles folded into FMAs
+// (tdsa_fft.hpp: 6 instructions per general butterfly instead of 8); -DTDSA_DIF restores the DIF network.
+template <int R, int BASE, int TOT>
+__device__ __forceinline__ void radix(c32 (&v)[TOT]) {
+#ifdef TDSA_DIF
+  dif<R, BASE, TOT>(v);
+#else
+  dit<R, BASE, TOT>(v);
+#endif
+}
+
 // radix-2 combine  (E, O) -> (E + w O, E - w O)  in six FMAs (second output as 2E - first)
 __device__ __forceinline__ void combine(c32& e, c32& o, c32 w) {
   const float x1 = fmaf(w.x, o.x, fmaf(-w.y, o.y, e.x));
@@ -210,18 +221,27 @@ __device__ __forceinline__ void combine(c32& e, c32& o, c32 w) {
 }
 // radix-32 combine for unit u + 8h: the lower half-wave uses W_32^u, the upper W_32^(u+8) = -i W_32^u.
 // The -i is applied to O with two selects (-i (x + iy) = y - ix), the rest is compile-time constants.
-template <int U>
+template <int U, bool EXACT = false>
 __device__ __forceinline__ void combine32(c32& e, c32& o, bool odd_half) {
   const c32 orot = c32{odd_half ? o.y : o.x, odd_half ? -o.x : o.y};
+#ifdef TDSA_DIF
   const c32 t = mul_w<U, 32>(orot);
   o = csub(e, t);
   e = cadd(e, t);
+#else
+  o = orot;
+  bf_w<U, 32, EXACT>(e, o);
+#endif
 }
 template <int K, int R>   // compile-time twiddle W_R^K
 __device__ __forceinline__ void combine_const(c32& e, c32& o) {
+#ifdef TDSA_DIF
   const c32 t = mul_w<K, R>(o);
   o = csub(e, t);
   e = cadd(e, t);
+#else
+  bf_w<K, R>(e, o);
+#endif
 }
 
 // Thread layout: a wave owns 32 consecutive butterfly rows; lane l < 32 is the EVEN half-thread of row
@@ -537,7 +557,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     if (unit + 1 < u1) load_frame_raw((unit + 1) * FPW + slot);
 
     // ---- pass 1: per lane M radix-H DFTs on the even (odd) rows, then the cross-lane combine ------
-    static_for<0, M>([&](auto jc) { dif<H, decltype(jc)::value * H, 16>(v); });
+    static_for<0, M>([&](auto jc) { radix<H, decltype(jc)::value * H, 16>(v); });
     static_for<0, 8>([&](auto uc) {
       constexpr int u = decltype(uc)::value;
       constexpr int jj0 = u / H, k0 = u % H, jj1 = (u + 8) / H, k1 = (u + 8) % H;
@@ -568,7 +588,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
         c32 tw8[8];
         static_for<0, 8>([&](auto ic) {
           constexpr int i = b0 + decltype(ic)::value;
-          if constexpr ((TDSA_ABLATE & 16) == 0) tw8[i - b0] = twm[tw_o + i * 2 * A];
+          if constexpr ((TDSA_ABLATE & 16) == 0) tw8[i - b0] = lds_ld(&twm[tw_o + i * 2 * A]);   // unpaired, like the data
           else tw8[i - b0] = twf_hi[i & 3];
         });
         __builtin_amdgcn_sched_barrier(0);
@@ -579,7 +599,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
         __builtin_amdgcn_sched_barrier(0);
       });
       TDSA_STAMP(6);
-      dif<16, 0, 16>(v);
+      radix<16, 0, 16>(v);
       static_for<0, 8>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
         constexpr int re = bitrev(u, 4), ro = bitrev(u + 8, 4);
@@ -614,12 +634,12 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       else if constexpr (j == 0) v[i] = cmul(v[i], twf_hi[a]);
       else v[i] = cmul(v[i], cmul(twf_hi[a], twf_lo[j - 1]));
     });
-    if constexpr ((TDSA_ABLATE & 512) == 0) dif<16, 0, 16>(v);
+    if constexpr ((TDSA_ABLATE & 512) == 0) radix<16, 0, 16>(v);
     static_for<0, 8>([&](auto uc) {
       constexpr int u = decltype(uc)::value;
       constexpr int re = bitrev(u, 4), ro = bitrev(u + 8, 4);
       if constexpr ((TDSA_ABLATE & 32) == 0) swap_halves(v[re], v[ro]);
-      combine32<u>(v[re], v[ro], odd_half);                  // bins kc = u + 8h (v[re]) and kc + 16 (v[ro])
+      combine32<u, true>(v[re], v[ro], odd_half);            // bins kc = u + 8h (v[re]) and kc + 16 (v[ro])
     });
     TDSA_STAMP(10);
 
