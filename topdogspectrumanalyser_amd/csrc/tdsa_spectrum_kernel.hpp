@@ -588,7 +588,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
         c32 tw8[8];
         static_for<0, 8>([&](auto ic) {
           constexpr int i = b0 + decltype(ic)::value;
-          if constexpr ((TDSA_ABLATE & 16) == 0) tw8[i - b0] = lds_ld(&twm[tw_o + i * 2 * A]);   // unpaired, like the data
+          if constexpr ((TDSA_ABLATE & 16) == 0) tw8[i - b0] = twm[tw_o + i * 2 * A];
           else tw8[i - b0] = twf_hi[i & 3];
         });
         __builtin_amdgcn_sched_barrier(0);
@@ -725,6 +725,15 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
           float* orow = p.out_db + (long long)frame * N;
           if constexpr (FPW == 1) {
             const rsrc_t r = make_rsrc(orow, N * 4u);
+            if constexpr ((TDSA_ABLATE & 1024) != 0) {
+              // timing experiment only (wrong layout): the same 64 KiB as four 16-byte stores per lane
+              static_for<0, 4>([&](auto gc) {
+                constexpr int g4 = decltype(gc)::value;
+                const u32x4 pk = {__float_as_uint(db[4 * g4]), __float_as_uint(db[4 * g4 + 1]),
+                                  __float_as_uint(db[4 * g4 + 2]), __float_as_uint(db[4 * g4 + 3])};
+                __builtin_amdgcn_raw_buffer_store_b128(pk, r, unsigned(tid) * 16u, g4 * 16384u, 0);
+              });
+            } else
             static_for<0, 16>([&](auto ic) {
               constexpr int q = decltype(ic)::value;
               constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
