@@ -713,11 +713,17 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
           });
         }
         if (p.tare != nullptr) {
-          const float* trow = p.tare + t + 8 * h * SG;
+          // SGPR descriptor + the store offsets: no per-thread 64-bit pointers (hoisted out of the frame loop
+          // they cost 19 dwords of scratch per lane - 20 MB of spill writes per C3 launch)
+          const rsrc_t tr = make_rsrc(p.tare, N * 4u);
           static_for<0, 16>([&](auto ic) {
             constexpr int q = decltype(ic)::value;
             constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
-            db[q] -= trow[kcs * SG];
+            if constexpr (FPW == 1) {
+              db[q] -= __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(tr, out_voff, kcs * SG * 4u, 0));
+            } else {
+              db[q] -= p.tare[t + 8 * h * SG + kcs * SG];
+            }
           });
         }
         if constexpr (!C::WIN_LDS) load_window();     // next frame's window, ahead of this frame's stores
