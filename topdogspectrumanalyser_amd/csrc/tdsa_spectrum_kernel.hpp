@@ -719,11 +719,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
           static_for<0, 16>([&](auto ic) {
             constexpr int q = decltype(ic)::value;
             constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
-            if constexpr (FPW == 1) {
-              db[q] -= __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(tr, out_voff, kcs * SG * 4u, 0));
-            } else {
-              db[q] -= p.tare[t + 8 * h * SG + kcs * SG];
-            }
+            db[q] -= __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(tr, out_voff, kcs * SG * 4u, 0));
           });
         }
         if constexpr (!C::WIN_LDS) load_window();     // next frame's window, ahead of this frame's stores
