@@ -605,6 +605,59 @@ def test_c5_million_point_welch(pkg):
         assert int(np.argmax(out[0])) == nfft // 2 + nfft // 8
 
 
+def test_c5_reference_fixture(pkg, golden_dir):
+    """C5 against vectors from the imported reference (tests/golden/c5_million.npz): 2^20 points, RTL branch,
+    Welch mean of 8 segments + the calibration offset of calibration.json; comb of every 257th bin and the 64
+    strongest bins, after the first segment and after the eighth."""
+    g = np.load(os.path.join(golden_dir, "c5_million.npz"))
+    n, k, cal = int(g["nfft"]), int(g["k"]), -0.8087054556396822
+    iq = so.synth_iq_int8(n * k, n, seed=int(g["seed"]))
+    with pkg.SpectrumEngine(n, max_frames=k) as e:
+        e.set_window(so.rtl_window("hanning", n).astype(np.float32))
+        e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=-1.0,
+                    avg=("lin", k), cal_offset_db=cal)
+        first = e.process(iq[: 2 * n], hop=n)[0]
+        mean = e.process(iq[2 * n:], hop=n)[0]               # the other seven: state carried like TraceAverager
+    for tag, got in (("first", first), ("mean", mean)):
+        for kind in ("comb", "top"):
+            bins, want = g[f"{tag}_{kind}_bins"], g[f"{tag}_{kind}_db"] + cal
+            top = g[f"{tag}_top_db"].max() + cal
+            allow = np.maximum(DB_TOL, (20.0 / np.log(10.0)) * 2 * so.AMP_FLOOR * 10.0 ** ((top - want) / 20.0))
+            d = np.abs(got[bins] - want)
+            assert np.all(d[want >= top - 100.0] <= allow[want >= top - 100.0]), (tag, kind, float(d.max()))
+        assert np.array_equal(np.sort(np.argsort(got)[-64:]), g[f"{tag}_top_bins"]) or tag == "first"
+    assert int(np.argmax(mean)) == n // 2 + n // 8
+
+
+def test_c5_full_size_properties(pkg):
+    """K = 64 segments of 2^20 points (the BASELINE.json size) through properties that do not need a CPU FFT of
+    the whole batch: Parseval against the time-domain energy, state carried across calls, tone position, hold."""
+    n, k = 1 << 20, 64
+    iq = so.synth_iq_int8(n * k, n, seed=11)
+    w = so.rtl_window("hanning", n)
+    with pkg.SpectrumEngine(n, max_frames=k) as e:
+        e.set_window(w.astype(np.float32))
+        e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=-1.0, avg=("lin", k),
+                    hold_max=True)
+        one = e.process(iq, hop=n)[0]
+        mean, cnt = e.averaged()
+        mx, _ = e.hold()
+        assert cnt == k and np.array_equal(mx, one)
+        e.reset()
+        e.process(iq[: 2 * n * 24], hop=n)                                   # 24 + 40 segments, two calls
+        two = e.process(iq[2 * n * 24:], hop=n)[0]
+        assert e.averaged()[1] == k
+    assert np.max(np.abs(two - one)) < 1e-4
+    assert int(np.argmax(one)) == n // 2 + n // 8
+    # Parseval: sum_k |X[k]|^2 = N sum_n |w x|^2, averaged over the segments
+    x = so.unpack_iq_int8(iq).astype(np.complex128).reshape(k, n)
+    energy = float(np.mean(np.sum(np.abs(x * w) ** 2, axis=1))) * n
+    assert abs(float(mean.sum()) - energy) <= 2e-6 * energy
+    # the strongest tone (40 LSB at bin N/8 exactly): |X|^2 = (A/128 * sum(w))^2 plus noise far below
+    peak = 10 * np.log10((40.0 / 128.0 * w.sum()) ** 2)
+    assert abs(one[n // 2 + n // 8] - peak) < 0.05
+
+
 def test_c5_single_frame_with_dc_removal(pkg):
     nfft = 1 << 20
     iq = so.synth_iq_int8(nfft, nfft, seed=6)

@@ -186,3 +186,24 @@ def test_rbw_examples():
     for fs, n, rbw in ((20e6, 1024, 19531.25), (2e6, 1024, 1953.125), (44100, 1024, 43.06640625)):
         fb = so.shifted_freq_bins(n, fs, 0.0)
         assert abs((fb[1] - fb[0]) - rbw) < 1e-9
+
+
+def test_c5_million_point_fixture(golden_dir):
+    """Long-frame (C5) vectors from the imported reference (tests/golden/make_golden_c5.py): RTL branch at 2^20
+    points, TraceAverager lin over 8 segments.  The restatement reproduces the comb of the first frame and of
+    the Welch mean bit for bit (input regenerated from the stored seed)."""
+    g = _load(golden_dir, "c5_million.npz")
+    n, k = int(g["nfft"]), int(g["k"])
+    x = so.unpack_iq_int8(so.synth_iq_int8(n * k, n, seed=int(g["seed"])))
+    br = so.RtlBranchOracle(n, float(g["sample_rate"]), precision="ref")
+    br.averager.set_mode("lin", k)
+    for seg in range(k):
+        p = np.asarray(br.power_levels(x[seg * n:(seg + 1) * n]), dtype=np.float64)
+        tag = {0: "first", k - 1: "mean"}.get(seg)
+        if tag:
+            assert np.array_equal(p[g[f"{tag}_comb_bins"]], g[f"{tag}_comb_db"]), tag
+            assert np.array_equal(p[g[f"{tag}_top_bins"]], g[f"{tag}_top_db"]), tag
+            assert np.array_equal(np.sort(np.argsort(p)[-64:]), g[f"{tag}_top_bins"])
+            assert p.sum() == float(g[f"{tag}_sum_db"])
+    fb = so.shifted_freq_bins(n, float(g["sample_rate"]), float(g["centre_freq"]))
+    assert fb[0] == float(g["freq_first"]) and fb[-1] == float(g["freq_last"])
