@@ -158,7 +158,18 @@ def main() -> None:
 
     if world > 1:                                    # host-side rendezvous only: barrier + gather of scalars
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo")
+        # gloo announces its connections on stdout; the contract is ONE JSON line there: park fd 1 meanwhile
+        sys.stdout.flush()
+        saved_fd, null_fd = os.dup(1), os.open(os.devnull, os.O_WRONLY)
+        os.dup2(null_fd, 1)
+        try:
+            dist.init_process_group(backend="gloo")
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
+            os.close(null_fd)
 
     def host_barrier() -> None:
         if world > 1:
@@ -234,14 +245,20 @@ def main() -> None:
         host_barrier()
         dev_sync()
 
+    rank_times = []                                   # per timed region: every rank's own seconds
+
     def timed_loop(n_steps: int) -> float:
-        """one timed region: fence, n_steps steps, fence; seconds of the slowest rank"""
+        """one timed region: fence, n_steps steps, device synchronize, fence; seconds of the slowest rank"""
         fence()
         t0 = time.perf_counter()
         for i in range(n_steps):
             step(i)
+        dev_sync()
+        own = time.perf_counter() - t0                # this rank's own work, before it waits for the others
         fence()
-        return max(gather(time.perf_counter() - t0))
+        every = gather(own)
+        rank_times.append(every)
+        return max(every)
 
     def measure(n_streams: int):
         """-> (median seconds per region, all region times, inner)"""
@@ -253,11 +270,13 @@ def main() -> None:
         inner = max(1, int(np.ceil(1.2 * MIN_REGION_S / max(est * args.steps, 1e-9))))
         for _ in range(4):                                         # a region that came out short is re-timed longer
             inner = max(gather(inner))                             # same loop count on every rank
+            del rank_times[:]
             times = [timed_loop(args.steps * inner) for _ in range(max(1, args.reps))]
             if min(times) >= MIN_REGION_S:
                 break
             inner = int(np.ceil(inner * 1.3 * MIN_REGION_S / max(min(times), 1e-9)))
-        return statistics.median(times), times, inner
+        per_rank = [statistics.median(t[r] for t in rank_times) for r in range(world)]
+        return statistics.median(times), times, inner, per_rank
 
     # clocks: an idle MI355X needs a few hundred ms of load before shader/fabric clocks settle; this
     # untimed pre-roll keeps short --steps/--warmup runs from measuring the ramp
@@ -269,13 +288,13 @@ def main() -> None:
             i_pre += 1
         dev_sync()
 
-    med, times, inner = measure(streams)
+    med, times, inner, per_rank_s = measure(streams)
     if streams > 1:
-        med_serial, times_serial, inner_serial = measure(1)
+        med_serial, times_serial, inner_serial, _ = measure(1)
     else:
         med_serial, times_serial, inner_serial = med, times, inner
     steps_timed = args.steps * inner
-    per_rank_fps = gather(frames * steps_timed / med)              # (every rank reports the max-over-ranks time)
+    per_rank_fps = [frames * steps_timed / t for t in per_rank_s]  # each rank's own rate (median region)
 
     # ---- dominant kernel alone: HIP events on the plan's stream around every frame-kernel launch,
     #      launches strictly serial so that one kernel owns the GPU while it is timed ---------------

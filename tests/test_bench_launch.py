@@ -16,8 +16,8 @@ def _run(cmd):
     env.pop("RANK", None), env.pop("WORLD_SIZE", None), env.pop("LOCAL_RANK", None)
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
-    assert len(lines) == 1, out.stdout
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout      # ONE JSON line on stdout, nothing else
     return json.loads(lines[0])
 
 
