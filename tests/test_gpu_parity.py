@@ -1110,6 +1110,25 @@ def test_random_configuration_sweep(pkg, case_id):
     _check(mn, gmin, what + " min hold", floor_units=units)
 
 
+def test_engine_closes_its_pipes_first(pkg):
+    """A pipe holds slots the plan's streams write to: closing the engine first (or leaving `with` blocks out
+    of order) closes its live pipes before the plan goes, and a later pipe.close() is a no-op."""
+    nfft, nf = 1024, 8
+    iq = so.synth_iq_int8(nfft * nf, nfft, seed=23)
+    e = _hackrf_engine(pkg, nfft, nf)
+    q = e.pipe(nfft * nf, n_slots=2, rows=True)
+    q.acquire()[: iq.size] = iq
+    q.submit(nfft * nf, nfft, nf)
+    rows = np.array(q.collect(), copy=True)
+    q.acquire()[: iq.size] = iq
+    q.submit(nfft * nf, nfft, nf)                     # one slot still in flight when the engine goes away
+    e.close()
+    assert not q._q and q not in e._pipes
+    q.close()                                         # nothing left to free, must not touch the dead plan
+    gold, _, _ = so.hackrf_batch(iq, nfft, nfft, 20e6, precision="gold", hold=False)
+    _check(rows, gold, "pipe rows before the engine closed")
+
+
 def test_host_pipe_device_rows_feed_analytics(pkg):
     """rows="device": the dB rows of every slot stay on the GPU and are handed to the analytics as a device
     pointer; results equal those computed from rows read back the ordinary way."""
