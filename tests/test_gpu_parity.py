@@ -439,6 +439,39 @@ def test_c4_shape_independence_and_parseval(pkg):
     assert np.max(np.abs(energy_freq / energy_time - 1.0)) < 1e-5
 
 
+def test_c4_full_share_properties(pkg):
+    """C4 at the size one GPU gets: 64k frames / 8 GPUs = 8192 frames x 8192 points (hop = N), one launch.
+    Parseval on every frame, frame independence, max hold == column max, sampled rows against the gold oracle."""
+    nfft, nf, chunk = 8192, 8192, 1024
+    iq = np.concatenate([so.synth_iq_int8(nfft * chunk, nfft, seed=40 + c) for c in range(nf // chunk)])
+    w = so.hackrf_window(nfft)
+    with pkg.SpectrumEngine(nfft, max_frames=nf) as e:
+        e.set_window(w)
+        e.configure(db_mode="pow", power_scale=1.0, log_floor=0.0, dc_alpha=1.0, hold_max=True)
+        out = e.process(iq, hop=nfft)
+        mx, _ = e.hold()
+        assert out.shape == (nf, nfft)
+        assert np.array_equal(mx, out.max(axis=0))
+        e.reset()
+        for k in (0, 1023, 1024, 4777, nf - 1):
+            alone = e.process(iq[2 * k * nfft: 2 * (k + 1) * nfft], hop=nfft, n_frames=1)
+            assert np.array_equal(alone[0], out[k]), k
+    w64 = w.astype(np.float64)
+    worst = 0.0
+    for c in range(nf // chunk):                      # sum_k |X_k|^2 = N sum_n |w_n (x_n - mean)|^2, frame by frame
+        x = so.unpack_iq_int8(iq[2 * c * chunk * nfft: 2 * (c + 1) * chunk * nfft]).astype(np.complex128).reshape(chunk, nfft)
+        xw = (x - x.mean(axis=1, keepdims=True)) * w64
+        energy_time = nfft * (xw.real ** 2 + xw.imag ** 2).sum(axis=1)
+        energy_freq = (10.0 ** (out[c * chunk:(c + 1) * chunk].astype(np.float64) / 10.0)).sum(axis=1)
+        worst = max(worst, float(np.max(np.abs(energy_freq / energy_time - 1.0))))
+    assert worst < 1e-5, worst
+    br = so.HackrfBranchOracle(nfft, 20e6, precision="gold")
+    for k in (0, 2048, 5000, nf - 1):
+        x = so.unpack_iq_int8(iq[2 * k * nfft: 2 * (k + 1) * nfft])
+        gold = br.power_levels(x)                     # 20 log10(|X| + 1e-12) == 10 log10 |X|^2 at these levels
+        _check(out[k], gold, f"C4 frame {k}")
+
+
 def test_linearity_in_db(pkg):
     """Scaling the input by 2 moves every dB value by 20*log10(2) (DC removal and window are linear)."""
     nfft, nf = 4096, 4

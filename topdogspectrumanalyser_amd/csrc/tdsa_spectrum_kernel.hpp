@@ -149,7 +149,8 @@ constexpr float kMagExactBelow = 1e-8f;                  // |X|^2 below this: th
 
 // developer ablation builds (-DTDSA_ABLATE=mask): 1 no barriers, 2 no LDS exchange, 4 no dB stores,
 // 16 no middle-pass table reads, 32 no half-wave swaps, 64 no log, 128 no last pre-twiddle, 256 no
-// middle pre-twiddle, 512 no last radix-16.  Results are wrong by construction; timing only.
+// middle pre-twiddle, 512 no last radix-16, 4096 / 8192 / 16384 only 1 / 2 / 3 waves per SIMD stay.  Results are
+// wrong by construction; timing only.
 #ifndef TDSA_ABLATE
 #define TDSA_ABLATE 0
 #endif
@@ -271,6 +272,10 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
+  // timing-only developer ablations (with 1|2|4: no barriers, no LDS exchange, no stores): k waves per SIMD
+  if constexpr ((TDSA_ABLATE & 4096) != 0) { if (wave >= 4) return; }
+  if constexpr ((TDSA_ABLATE & 8192) != 0) { if (wave >= 8) return; }
+  if constexpr ((TDSA_ABLATE & 16384) != 0) { if (wave >= 12) return; }
   const int h = (tid >> 5) & 1;                              // 0: even half-thread, 1: odd half-thread
   const int g = wave * 32 + (tid & 31);                      // row inside the workgroup
   const int slot = (FPW == 1) ? 0 : g / SG;
