@@ -319,6 +319,10 @@ static int plan_init(tdsa_plan p) {
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, device_id));
   p->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (const char* c = getenv("TDSA_NUM_CU")) {          // developer knob: persistent grids sized for fewer CUs
+    const int v = atoi(c);
+    if (v >= 1 && v <= p->num_cu) p->num_cu = v;
+  }
   HIPCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreate(&p->ev0));
   HIPCHK(hipEventCreate(&p->ev1));
