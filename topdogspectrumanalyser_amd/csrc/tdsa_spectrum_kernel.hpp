@@ -144,6 +144,11 @@ __device__ __forceinline__ void buf_load(rsrc_t r, unsigned voff, unsigned soff,
   }
 }
 
+// cache policy of the dB row stores: non-temporal (gfx940+ "nt" bit).  The rows are written once and not read again
+// by this kernel; streaming them keeps the input's shared halves in L2 and the Infinity Cache free of 160 MB of
+// write-once data per launch: -4 % per launch at C3, -11 % at C2 once the working set exceeds the 256 MiB cache
+// (bench.py's ring of 8 buffers), no change when everything fits (profiles/r02_c3_experiments.txt)
+constexpr int kRowStorePolicy = 2;
 constexpr float k10Log10_2 = 3.01029995663981195214f;   // 10*log10(2)
 constexpr float kMagExactBelow = 1e-8f;                  // |X|^2 below this: the 1e-12 floor is visible
 
@@ -744,14 +749,14 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
             static_for<0, 16>([&](auto ic) {
               constexpr int q = decltype(ic)::value;
               constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
-              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(db[q]), r, out_voff, kcs * SG * 4u, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(db[q]), r, out_voff, kcs * SG * 4u, kRowStorePolicy);
             });
           } else {
             float* orow_t = orow + t + 8 * h * SG;
             static_for<0, 16>([&](auto ic) {
               constexpr int q = decltype(ic)::value;
               constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
-              orow_t[kcs * SG] = db[q];
+              __builtin_nontemporal_store(db[q], &orow_t[kcs * SG]);
             });
           }
         }
