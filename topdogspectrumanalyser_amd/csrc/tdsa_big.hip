@@ -65,7 +65,8 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
     const unsigned xm = p.xor_mask & 0xffffu;
     static_for<0, N1>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      const unsigned u = unsigned(*reinterpret_cast<const uint16_t*>(src + 2ll * i * kRowN)) ^ xm;
+      // read once: non-temporal, so that the raw bytes do not displace Z from the Infinity Cache
+      const unsigned u = unsigned(__builtin_nontemporal_load(reinterpret_cast<const uint16_t*>(src + 2ll * i * kRowN))) ^ xm;
       const float ww = w[(long long)i * kRowN];
       v[i] = c32{((float(u & 0xffu) - off) - sub_re) * ww, ((float(u >> 8) - off) - sub_im) * ww};
     });
