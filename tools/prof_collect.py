@@ -18,7 +18,8 @@ ALGO = {"c3": 2440 * 81920, "c2": 4096 * 24576, "c4": 8192 * 49152, "c5": 64 * 2
 def counters(name):
     """-> ({kernel short name: {counter: mean per dispatch}}, {kernel: dispatches})"""
     acc = defaultdict(lambda: defaultdict(list))
-    for f in glob.glob(os.path.join(SRC, f"pmc_{name}", "**", "*counter_collection.csv"), recursive=True):
+    files = glob.glob(os.path.join(SRC, f"pmc_{name}", "**", "*counter_collection.csv"), recursive=True)
+    for f in sorted(files, key=os.path.getmtime)[-1:]:       # the newest pass only (gpurun merges old ones back in)
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"]
             short = "frame" if "spectrum_kernel" in k else ("cols" if "big_cols" in k else ("gather" if "big_gather" in k else None))
@@ -33,7 +34,7 @@ def main():
     for c in ("c2", "c3", "c4", "c5"):
         shutil.copy(os.path.join(SRC, f"bench_{c}.json"), os.path.join(DST, f"r02_{c}_bench.json"))
     for c in ("c3", "c5"):
-        f = glob.glob(os.path.join(SRC, f"stats_{c}", "**", "*kernel_stats.csv"), recursive=True)[0]
+        f = max(glob.glob(os.path.join(SRC, f"stats_{c}", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
         shutil.copy(f, os.path.join(DST, f"r02_{c}_kernel_stats.csv"))
     lines = ["# rocprofv3 --pmc passes, round 2 (tools/prof_round.sh; FETCH_SIZE and WRITE_SIZE in separate passes)",
              "# FETCH_SIZE is reported in KB and counts 64 B per 128-B request on gfx950 for wide coalesced reads",

@@ -4,7 +4,7 @@
 # --pmc passes: FETCH_SIZE and WRITE_SIZE do not fit one pass), SQ wait/issue counters for the C3 kernel.
 set -x
 OUT=gpurun_out/prof_r02
-mkdir -p $OUT && export TMPDIR=/tmp
+rm -rf $OUT && mkdir -p $OUT && export TMPDIR=/tmp
 python bench.py > $OUT/bench_c3.json 2> $OUT/bench.err
 for c in c2 c4 c5; do python bench.py --config $c > $OUT/bench_$c.json 2>> $OUT/bench.err; done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3 -- python bench.py --streams 1 --steps 300 --warmup 50 --reps 3 --no-cpu-baseline > $OUT/stats_c3.log 2>&1
