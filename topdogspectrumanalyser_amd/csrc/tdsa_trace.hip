@@ -89,18 +89,61 @@ __device__ __forceinline__ double avg_step(const AvgParams& p, int f, double s, 
 }
 
 constexpr int kAvgChunk = 64;
-__global__ void __launch_bounds__(64) avg_chunk_local_kernel(const AvgParams p, double* carry) {
-  const int k = blockIdx.x * 64 + threadIdx.x, c = blockIdx.y;
-  if (k >= p.n) return;
-  const int f0 = c * kAvgChunk, f1 = f0 + kAvgChunk < p.n_frames ? f0 + kAvgChunk : p.n_frames;
-  double s = 0.0;
-  for (int f = f0; f < f1; ++f) {
+typedef float avg_f4 __attribute__((ext_vector_type(4)));
+
+// per-frame coefficients of one chunk, computed once per workgroup (one frame per thread; they hold float64
+// divisions) and read back as LDS broadcasts
+struct AvgChunkCoeff { double a[kAvgChunk], b[kAvgChunk]; int b_in_float[kAvgChunk]; };
+__device__ __forceinline__ void avg_chunk_coeff(const AvgParams& p, int f0, int f1, AvgChunkCoeff& cc) {
+  const int tid = threadIdx.x;
+  if (f0 + tid < f1) {
     double a, bs; bool bf;
-    avg_coeff(p, f, a, bs, bf);
-    const float lin = p.lin[(size_t)f * p.n + k];
-    s = a * s + (bf ? double(float(bs) * lin) : bs * double(lin));
+    avg_coeff(p, f0 + tid, a, bs, bf);
+    cc.a[tid] = a; cc.b[tid] = bs; cc.b_in_float[tid] = bf ? 1 : 0;
   }
-  carry[(size_t)c * p.n + k] = s;                  // chunk result from a zero carry-in
+  __syncthreads();
+}
+template <int V>
+__device__ __forceinline__ void avg_load_row(const float* row, float (&x)[V]) {
+  if constexpr (V == 4) {
+    const avg_f4 q = *reinterpret_cast<const avg_f4*>(row);
+    x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
+  } else {
+    x[0] = row[0];
+  }
+}
+
+// V bins per thread (4 when the rows allow 16-byte accesses), eight frames fetched ahead of the dependent chain
+template <int V>
+__global__ void __launch_bounds__(64) avg_chunk_local_kernel(const AvgParams p, double* carry) {
+  __shared__ AvgChunkCoeff cc;
+  const int c = blockIdx.y;
+  const int f0 = c * kAvgChunk, f1 = f0 + kAvgChunk < p.n_frames ? f0 + kAvgChunk : p.n_frames;
+  avg_chunk_coeff(p, f0, f1, cc);
+  const int k = (blockIdx.x * 64 + threadIdx.x) * V;
+  if (k >= p.n) return;
+  double s[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) s[v] = 0.0;
+  constexpr int U = 8;
+  for (int fb = f0; fb < f1; fb += U) {
+    float x[U][V];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (fb + u < f1) avg_load_row<V>(p.lin + (size_t)(fb + u) * p.n + k, x[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (fb + u < f1) {
+        const double a = cc.a[fb + u - f0], bs = cc.b[fb + u - f0];
+        const bool bf = cc.b_in_float[fb + u - f0] != 0;
+#pragma unroll
+        for (int v = 0; v < V; ++v) s[v] = a * s[v] + (bf ? double(float(bs) * x[u][v]) : bs * double(x[u][v]));
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < V; ++v) carry[(size_t)c * p.n + k + v] = s[v];   // chunk result from a zero carry-in
 }
 // One thread per bin chains the chunk results in order.  The chunk's state multiplier A_c = prod a_f is the same for
 // every bin: the 64 threads of a workgroup compute 64 chunks' worth of it cooperatively (one chunk each) into LDS
@@ -141,22 +184,50 @@ __global__ void __launch_bounds__(64) avg_chunk_chain_kernel(const AvgParams p, 
   }
   if (live) p.state[k] = s;
 }
+template <int V>
 __global__ void __launch_bounds__(64) avg_chunk_final_kernel(const AvgParams p, const double* carry) {
-  const int k = blockIdx.x * 64 + threadIdx.x, c = blockIdx.y;
+  const int k = (blockIdx.x * 64 + threadIdx.x) * V, c = blockIdx.y;
   if (k >= p.n) return;
   const int f0 = c * kAvgChunk, f1 = f0 + kAvgChunk < p.n_frames ? f0 + kAvgChunk : p.n_frames;
-  double s = carry[(size_t)c * p.n + k];
-  const float tare = p.tare != nullptr ? p.tare[k] : 0.f;
-  float hmax = -INFINITY, hmin = INFINITY;
-  for (int f = f0; f < f1; ++f) {
-    s = avg_step(p, f, s, p.lin[(size_t)f * p.n + k]);
-    const float db = fmaf(k10Log10_2f, __builtin_amdgcn_logf(float(s + double(p.log_floor))), p.cal_db) - tare;
-    if (p.out_db != nullptr) p.out_db[(size_t)f * p.n + k] = db;
-    hmax = fmaxf(hmax, db);
-    hmin = fminf(hmin, db);
+  double s[V];
+  float tare[V], hmax[V], hmin[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    s[v] = carry[(size_t)c * p.n + k + v];
+    tare[v] = p.tare != nullptr ? p.tare[k + v] : 0.f;
+    hmax[v] = -INFINITY; hmin[v] = INFINITY;
   }
-  if (p.state_max != nullptr) atomic_fmax(p.state_max + k, hmax);
-  if (p.state_min != nullptr) atomic_fmin(p.state_min + k, hmin);
+  constexpr int U = 4;
+  for (int fb = f0; fb < f1; fb += U) {
+    float x[U][V];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (fb + u < f1) avg_load_row<V>(p.lin + (size_t)(fb + u) * p.n + k, x[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (fb + u < f1) {
+        float db[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          s[v] = avg_step(p, fb + u, s[v], x[u][v]);
+          db[v] = fmaf(k10Log10_2f, __builtin_amdgcn_logf(float(s[v] + double(p.log_floor))), p.cal_db) - tare[v];
+          hmax[v] = fmaxf(hmax[v], db[v]);
+          hmin[v] = fminf(hmin[v], db[v]);
+        }
+        if (p.out_db != nullptr) {          // rows are written once and not read again here: non-temporal
+          float* o = p.out_db + (size_t)(fb + u) * p.n + k;
+          if constexpr (V == 4) __builtin_nontemporal_store(avg_f4{db[0], db[1], db[2], db[3]}, reinterpret_cast<avg_f4*>(o));
+          else __builtin_nontemporal_store(db[0], o);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    if (p.state_max != nullptr) atomic_fmax(p.state_max + k + v, hmax[v]);
+    if (p.state_min != nullptr) atomic_fmin(p.state_min + k + v, hmin[v]);
+  }
 }
 
 int avg_scan_chunks(int n_frames) { return (n_frames + kAvgChunk - 1) / kAvgChunk; }
@@ -164,10 +235,20 @@ int avg_scan_chunks(int n_frames) { return (n_frames + kAvgChunk - 1) / kAvgChun
 hipError_t launch_avg_scan(const AvgParams& p, hipStream_t s, double* carry) {
   if (carry != nullptr && p.n_frames > 2 * kAvgChunk) {
     const int n_chunks = (p.n_frames + kAvgChunk - 1) / kAvgChunk;
-    const dim3 grid((p.n + 63) / 64, n_chunks);
-    hipLaunchKernelGGL(avg_chunk_local_kernel, grid, dim3(64), 0, s, p, carry);
-    hipLaunchKernelGGL(avg_chunk_chain_kernel, dim3((p.n + 63) / 64), dim3(64), 0, s, p, carry, n_chunks);
-    hipLaunchKernelGGL(avg_chunk_final_kernel, grid, dim3(64), 0, s, p, carry);
+    // four bins per thread when every row starts on a 16-byte boundary (not the N/2+1-bin rows of the audio path)
+    const bool vec = (p.n % 4 == 0) && (reinterpret_cast<uintptr_t>(p.lin) % 16 == 0) &&
+                     (p.out_db == nullptr || reinterpret_cast<uintptr_t>(p.out_db) % 16 == 0);
+    if (vec) {
+      const dim3 grid((p.n / 4 + 63) / 64, n_chunks);
+      hipLaunchKernelGGL(avg_chunk_local_kernel<4>, grid, dim3(64), 0, s, p, carry);
+      hipLaunchKernelGGL(avg_chunk_chain_kernel, dim3((p.n + 63) / 64), dim3(64), 0, s, p, carry, n_chunks);
+      hipLaunchKernelGGL(avg_chunk_final_kernel<4>, grid, dim3(64), 0, s, p, carry);
+    } else {
+      const dim3 grid((p.n + 63) / 64, n_chunks);
+      hipLaunchKernelGGL(avg_chunk_local_kernel<1>, grid, dim3(64), 0, s, p, carry);
+      hipLaunchKernelGGL(avg_chunk_chain_kernel, dim3((p.n + 63) / 64), dim3(64), 0, s, p, carry, n_chunks);
+      hipLaunchKernelGGL(avg_chunk_final_kernel<1>, grid, dim3(64), 0, s, p, carry);
+    }
     return hipGetLastError();
   }
   hipLaunchKernelGGL(avg_scan_kernel, dim3((p.n + 63) / 64), dim3(64), 0, s, p);
