@@ -320,24 +320,60 @@ hipError_t launch_frame_sums(const void* in, int in_c64, unsigned xor_mask, long
   return hipGetLastError();
 }
 
-__global__ void dc_track_kernel(const float2* sums, int n, int n_frames, float alpha, float in_off,
-                                float in_scale, float2* dc_state, float2* dc_sub) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  float2 dc = *dc_state;                       // units of x
+// dc_f = (1 - alpha) dc_(f-1) + alpha mean_f  (hackrf_samples.py:361-364) over the frames of a batch.  The recurrence is
+// linear with a constant multiplier, so one workgroup scans it in three steps: every thread scans its own run of
+// consecutive frames from a zero state, thread 0 chains the 256 run results, every thread re-scans its run from its
+// true carry-in and writes the per-frame subtract values.  (The first version walked all frames on one thread with a
+// dependent global load per frame: 470 us for the 2440 frames of a C3 batch, six times the frame kernel.)  The scan
+// runs in float64 on the float32 frame means; the state handed from call to call stays float32 like the reference's.
+__global__ void __launch_bounds__(256) dc_track_kernel(const float2* sums, int n, int n_frames, float alpha, float in_off,
+                                                        float in_scale, float2* dc_state, float2* dc_sub) {
+  __shared__ double run_re[256], run_im[256], run_a[256];
+  const int tid = threadIdx.x;
+  const int per = (n_frames + 255) / 256;
+  const int f0 = tid * per < n_frames ? tid * per : n_frames;
+  const int f1 = f0 + per < n_frames ? f0 + per : n_frames;
+  const double a = double(1.0f - alpha), b = double(alpha);
   const float inv_n = 1.0f / float(n);
-  for (int f = 0; f < n_frames; ++f) {
-    const float mr = (sums[f].x * inv_n - in_off) * in_scale;
-    const float mi = (sums[f].y * inv_n - in_off) * in_scale;
-    dc.x = (1.0f - alpha) * dc.x + alpha * mr;   // hackrf_samples.py:361-364
-    dc.y = (1.0f - alpha) * dc.y + alpha * mi;
-    dc_sub[f] = float2{in_off + dc.x / in_scale, in_off + dc.y / in_scale};
+  auto mean_of = [&](int f, double& mr, double& mi) {
+    const float2 q = sums[f];
+    mr = double((q.x * inv_n - in_off) * in_scale);
+    mi = double((q.y * inv_n - in_off) * in_scale);
+  };
+  double sr = 0.0, si = 0.0, A = 1.0;
+  for (int f = f0; f < f1; ++f) {
+    double mr, mi;
+    mean_of(f, mr, mi);
+    sr = a * sr + b * mr;
+    si = a * si + b * mi;
+    A *= a;
   }
-  *dc_state = dc;
+  run_re[tid] = sr; run_im[tid] = si; run_a[tid] = A;
+  __syncthreads();
+  if (tid == 0) {
+    double cr = double(dc_state->x), ci = double(dc_state->y);      // units of x
+    for (int t = 0; t < 256; ++t) {
+      const double lr = run_re[t], li = run_im[t], At = run_a[t];
+      run_re[t] = cr; run_im[t] = ci;                                // carry-in of run t
+      cr = lr + At * cr;
+      ci = li + At * ci;
+    }
+    *dc_state = float2{float(cr), float(ci)};
+  }
+  __syncthreads();
+  sr = run_re[tid]; si = run_im[tid];
+  for (int f = f0; f < f1; ++f) {
+    double mr, mi;
+    mean_of(f, mr, mi);
+    sr = a * sr + b * mr;
+    si = a * si + b * mi;
+    dc_sub[f] = float2{in_off + float(sr) / in_scale, in_off + float(si) / in_scale};
+  }
 }
 
 hipError_t launch_dc_track(const float2* sums, int n, int n_frames, float alpha, float in_off, float in_scale,
                            float2* dc_state, float2* dc_sub, hipStream_t s) {
-  hipLaunchKernelGGL(dc_track_kernel, dim3(1), dim3(64), 0, s, sums, n, n_frames, alpha, in_off, in_scale,
+  hipLaunchKernelGGL(dc_track_kernel, dim3(1), dim3(256), 0, s, sums, n, n_frames, alpha, in_off, in_scale,
                      dc_state, dc_sub);
   return hipGetLastError();
 }
