@@ -207,34 +207,70 @@ constexpr float kAmpMin = -200.0f, kAmpRng = 300.0f;
 
 constexpr int kDensRows = kAmpBins / kDensFreq;   // rows whose bin indices one pass of the workgroup forms
 
+// Cost is VALU: every cell takes one multiply per row whatever happens, the question is what finding the ONE cell per
+// (row, frequency bin) that also gets +1 costs.  The first version had every thread compare its amplitude bin with
+// all 16 indices of every row (16 LDS reads + 16 compares + 16 selects per row: 2.1 ms per second of C3 spectra).
+// Now the 512 threads of the workgroup scatter the 512 indices of a 32-row chunk into a bit table in LDS -
+// word [row][a / 2] holds, for amplitude bins a and a + 1, one bit per frequency bin that hit them - and a thread
+// reads ONE word per row; only waves in which some lane was hit (the few whose 64 amplitude bins cover the trace)
+// run the 16 adds, the others do their 16 multiplies and move on.
 __global__ void __launch_bounds__(kAmpBins) density_kernel(const float* __restrict__ rows, int n_rows, int n,
                                                            float decay, float* hist) {
-  __shared__ int s_idx[kDensRows][kDensFreq];
+  __shared__ unsigned s_hit[kDensRows][kAmpBins / 2];
   const int f0 = blockIdx.x * kDensFreq;
   const int a = threadIdx.x;
   const int rr = a / kDensFreq, jj = a % kDensFreq;     // this thread forms the index of (row r0 + rr, bin f0 + jj)
+  const int sh = 16 * (a & 1);
   float h[kDensFreq];
 #pragma unroll
   for (int j = 0; j < kDensFreq; ++j) h[j] = (f0 + j < n) ? hist[(size_t)(f0 + j) * kAmpBins + a] : 0.0f;
+  for (int i = a; i < kDensRows * (kAmpBins / 2); i += kAmpBins) (&s_hit[0][0])[i] = 0u;
   const bool do_decay = decay < 1.0f;
+  float decay_v = decay;
+  asm volatile("" : "+v"(decay_v));      // a VALU op with an SGPR source issues at half rate on gfx950
+  const bool col_ok = f0 + jj < n;
+  float v_next = (rr < n_rows && col_ok) ? rows[(size_t)rr * n + f0 + jj] : NAN;
   for (int r0 = 0; r0 < n_rows; r0 += kDensRows) {
     int idx = -1;
-    if (r0 + rr < n_rows && f0 + jj < n) {
-      const float v = rows[(size_t)(r0 + rr) * n + f0 + jj];
+    const float v = v_next;                       // fetched while the previous chunk was applied
+    v_next = (r0 + kDensRows + rr < n_rows && col_ok) ? rows[(size_t)(r0 + kDensRows + rr) * n + f0 + jj] : NAN;
+    if (r0 + rr < n_rows && col_ok) {
       const float x = (v - kAmpMin) / kAmpRng * float(kAmpBins);
       // astype(int32) truncates toward zero; NaN and anything outside [0, AMP_BINS) is dropped
       if (v == v && x > -1.0f && x < float(kAmpBins)) idx = int(x);
     }
-    __syncthreads();                 // previous chunk fully consumed
-    s_idx[rr][jj] = idx;
+    __syncthreads();                 // previous chunk fully consumed (every word read and cleared by its owners)
+    if (idx >= 0) atomicOr(&s_hit[rr][idx >> 1], 1u << (jj + 16 * (idx & 1)));
     __syncthreads();
     const int lim = n_rows - r0 < kDensRows ? n_rows - r0 : kDensRows;
-    for (int r = 0; r < lim; ++r) {
+    constexpr int RB = 4;                                   // rows whose words are fetched together
+    for (int rb = 0; rb < kDensRows; rb += RB) {
+      if (rb >= lim) break;
+      unsigned w[RB];
 #pragma unroll
-      for (int j = 0; j < kDensFreq; ++j) {
-        float t = do_decay ? __fmul_rn(h[j], decay) : h[j];      // two roundings, like `hist *= d; hist[..] += 1`
-        if (s_idx[r][j] == a) t = __fadd_rn(t, 1.0f);
-        h[j] = t;
+      for (int u = 0; u < RB; ++u) {
+        // lanes a and a ^ 1 share a word and a wave: both have read it before either clears it
+        w[u] = s_hit[rb + u][a >> 1];
+        s_hit[rb + u][a >> 1] = 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        if (rb + u < lim) {
+          const unsigned m = (w[u] >> sh) & 0xffffu;
+          if (do_decay) {
+#pragma unroll
+            for (int j = 0; j < kDensFreq; ++j) h[j] = __fmul_rn(h[j], decay_v);   // `hist *= d`
+          }
+          if (__builtin_amdgcn_ballot_w64(m != 0u) != 0) {                        // `hist[f, idx] += 1`, its own rounding
+            // bit j of m -> 0.0f or 1.0f without a select (v_cndmask with an implicit vcc mask is the slowest
+            // VALU instruction of the chip); h + 0.0f leaves h as it is (h >= 0)
+#pragma unroll
+            for (int j = 0; j < kDensFreq; ++j) {
+              const unsigned all = unsigned(__builtin_amdgcn_sbfe(int(m), j, 1));   // 0 or 0xffffffff
+              h[j] = __fadd_rn(h[j], __uint_as_float(all & 0x3f800000u));
+            }
+          }
+        }
       }
     }
   }
