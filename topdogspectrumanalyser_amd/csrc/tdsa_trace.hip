@@ -293,11 +293,17 @@ __global__ void __launch_bounds__(256) frame_sums_kernel(const void* in, unsigne
     const float2* x = reinterpret_cast<const float2*>(fb);
     for (int i = threadIdx.x; i < n; i += 256) { sr += x[i].x; si += x[i].y; }
   } else {
-    const uint16_t* x = reinterpret_cast<const uint16_t*>(fb);
+    // four samples (8 bytes) per lane and load; frame starts are only sample (2-byte) aligned
+    struct __attribute__((packed, aligned(2))) U2 { unsigned x, y; };
+    const U2* x = reinterpret_cast<const U2*>(fb);
     unsigned ui = 0, uq = 0;
-    for (int i = threadIdx.x; i < n; i += 256) {
-      const unsigned u = (unsigned(x[i]) ^ xor_mask) & 0xffffu;
-      ui += u & 0xffu; uq += u >> 8;
+    for (int i = threadIdx.x; i < n / 4; i += 256) {
+      const U2 q = x[i];
+      const unsigned a = q.x ^ xor_mask, b = q.y ^ xor_mask;
+      ui = __builtin_amdgcn_udot4(a, 0x00010001u, ui, false);
+      uq = __builtin_amdgcn_udot4(a, 0x01000100u, uq, false);
+      ui = __builtin_amdgcn_udot4(b, 0x00010001u, ui, false);
+      uq = __builtin_amdgcn_udot4(b, 0x01000100u, uq, false);
     }
     sr = float(ui); si = float(uq);
   }
