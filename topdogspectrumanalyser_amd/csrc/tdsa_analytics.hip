@@ -45,6 +45,38 @@ __device__ __forceinline__ float wave_min(float x) {
   for (int o = 32; o >= 1; o >>= 1) x = fminf(x, __shfl_xor(x, o));
   return x;
 }
+// the same reductions with DPP moves (no LDS round trip per step as with ds_bpermute); the result is valid in
+// lane 63 only.  Lanes without a source lane keep their own value, which is the identity of min / "better".
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float x) {
+  return __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(x), __float_as_uint(x), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int x) {
+  return __builtin_amdgcn_update_dpp(x, x, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ float wave_min_to_lane63(float x) {
+  x = fminf(x, dpp_f<0xB1, 0xf>(x));     // quad_perm [1,0,3,2]
+  x = fminf(x, dpp_f<0x4E, 0xf>(x));     // quad_perm [2,3,0,1]
+  x = fminf(x, dpp_f<0x141, 0xf>(x));    // row_half_mirror
+  x = fminf(x, dpp_f<0x140, 0xf>(x));    // row_mirror: every lane = row minimum
+  x = fminf(x, dpp_f<0x142, 0xa>(x));    // row_bcast:15 -> rows 1, 3
+  x = fminf(x, dpp_f<0x143, 0xc>(x));    // row_bcast:31 -> rows 2, 3
+  return x;
+}
+// strongest candidate of the wave, equal values: larger index (the order of the reference's reversed ascending sort)
+__device__ __forceinline__ PeakPair wave_strongest_to_lane63(PeakPair p) {
+  auto step = [&](float qv, int qi) {
+    if (qv > p.v || (qv == p.v && qi > p.i)) p = PeakPair{qv, qi};
+  };
+  step(dpp_f<0xB1, 0xf>(p.v), dpp_i<0xB1, 0xf>(p.i));
+  step(dpp_f<0x4E, 0xf>(p.v), dpp_i<0x4E, 0xf>(p.i));
+  step(dpp_f<0x141, 0xf>(p.v), dpp_i<0x141, 0xf>(p.i));
+  step(dpp_f<0x140, 0xf>(p.v), dpp_i<0x140, 0xf>(p.i));
+  step(dpp_f<0x142, 0xa>(p.v), dpp_i<0x142, 0xa>(p.i));
+  step(dpp_f<0x143, 0xc>(p.v), dpp_i<0x143, 0xc>(p.i));
+  return p;
+}
 
 // ---- per-row peak / argmax / band power ------------------------------------------------------------
 __global__ void __launch_bounds__(256) rows_stats_kernel(const float* __restrict__ rows, int n, int band_lo,
@@ -102,8 +134,7 @@ __global__ void __launch_bounds__(kPeakThreads) top_peaks_kernel(const float* __
   __shared__ float s_min[kMaxPeaks][kPeakThreads / 64];
   __shared__ int s_sel[kMaxPeaks];
   __shared__ float s_selv[kMaxPeaks];
-  __shared__ int s_nsel, s_cur;
-  __shared__ float s_curv;
+  __shared__ int s_nsel;
 
   const float* src = rows + (size_t)blockIdx.x * n;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -123,72 +154,91 @@ __global__ void __launch_bounds__(kPeakThreads) top_peaks_kernel(const float* __
       const float v = cand[i];
       if (v > best.v || (v == best.v && v != -INFINITY && i > best.i)) best = PeakPair{v, i};
     }
+    best = wave_strongest_to_lane63(best);
+    if (lane == 63) s_best[w] = best;
+    __syncthreads();
+    // every thread folds the 16 wave results itself (LDS broadcasts): no serial section, one barrier less
+    PeakPair gb = s_best[0];
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-      const PeakPair q{__shfl_xor(best.v, o), __shfl_xor(best.i, o)};
-      if (q.v > best.v || (q.v == best.v && q.i > best.i)) best = q;
+    for (int k = 1; k < kPeakThreads / 64; ++k) {
+      const PeakPair q = s_best[k];
+      if (q.v > gb.v || (q.v == gb.v && q.i > gb.i)) gb = q;
     }
-    if (lane == 0) s_best[w] = best;
-    __syncthreads();
-    if (tid == 0) {
-      PeakPair b = s_best[0];
-      for (int k = 1; k < kPeakThreads / 64; ++k)
-        if (s_best[k].v > b.v || (s_best[k].v == b.v && s_best[k].i > b.i)) b = s_best[k];
-      s_cur = b.v == -INFINITY ? -1 : b.i;
-      s_curv = b.v;
-    }
-    __syncthreads();
-    const int cur = s_cur;
+    const int cur = gb.v == -INFINITY ? -1 : gb.i;
     if (cur < 0) break;
-    const float curv = s_curv;
+    const float curv = gb.v;
     const int nsel = s_nsel;
-    // valley minimum between the candidate and every accepted peak, one pass over the row
+    // the separation test needs no valley: a candidate too close to an accepted peak is dropped right away
+    bool too_close = false;
+#pragma unroll
+    for (int k = 0; k < kMaxPeaks; ++k) {
+      if (k < nsel) {
+        const int sk = s_sel[k];
+        const int d = cur > sk ? cur - sk : sk - cur;
+        too_close |= d < min_sep;
+      }
+    }
+    if (too_close) {
+      if (tid == 0) cand[cur] = -INFINITY;   // (every thread is past this round's scan of cand)
+      __syncthreads();
+      continue;
+    }
+    // valley minimum between the candidate and every accepted peak, one pass over the row; the ranges are formed
+    // once per round (registers), peaks beyond nsel are skipped by uniform branches
+    int lo[kMaxPeaks], hi[kMaxPeaks];
     float vmin[kMaxPeaks];
 #pragma unroll
-    for (int k = 0; k < kMaxPeaks; ++k) vmin[k] = INFINITY;
+    for (int k = 0; k < kMaxPeaks; ++k) {
+      const int sk = k < nsel ? s_sel[k] : cur;
+      lo[k] = cur < sk ? cur : sk;
+      hi[k] = cur < sk ? sk : cur;
+      vmin[k] = INFINITY;
+    }
     for (int i = tid; i < n; i += kPeakThreads) {
       const float v = row[i];
 #pragma unroll
       for (int k = 0; k < kMaxPeaks; ++k) {
         if (k < nsel) {
-          const int s = s_sel[k];
-          const int lo = cur < s ? cur : s, hi = cur < s ? s : cur;
-          if (i >= lo && i <= hi) vmin[k] = fminf(vmin[k], v);   // (a NaN in the range would make np.min NaN and
-        }                                                         //  never reject; rows of this path carry none)
+          if (i >= lo[k] && i <= hi[k]) vmin[k] = fminf(vmin[k], v);   // (a NaN in the range would make np.min NaN
+        }                                                               //  and never reject; rows here carry none)
       }
     }
 #pragma unroll
     for (int k = 0; k < kMaxPeaks; ++k) {
       if (k < nsel) {
-        const float m = wave_min(vmin[k]);
-        if (lane == 0) s_min[k][w] = m;
+        const float m = wave_min_to_lane63(vmin[k]);
+        if (lane == 63) s_min[k][w] = m;
       }
     }
     __syncthreads();
-    if (tid == 0) {
+    if (w == 0) {
+      // wave 0: lane l folds the 16 wave minima of every accepted peak (one LDS read + shuffles per peak)
       bool reject = false;
-      for (int k = 0; k < nsel && !reject; ++k) {
-        const int s = s_sel[k];
-        const int d = cur > s ? cur - s : s - cur;
-        if (d < min_sep) {
-          reject = true;
-          break;
-        }
-        float valley = s_min[k][0];
-        for (int j = 1; j < kPeakThreads / 64; ++j) valley = fminf(valley, s_min[k][j]);
+      for (int k = 0; k < nsel; ++k) {
+        const float valley = __shfl(wave_min_to_lane63(lane < kPeakThreads / 64 ? s_min[k][lane] : INFINITY), 63);
         // reference arithmetic: power[idx] - valley is float32 - Python float (float32 under numpy >= 2),
         // sel_pwr - valley is Python float - Python float (double)
         if (curv - valley < excursion || (double)s_selv[k] - (double)valley < (double)excursion) reject = true;
       }
-      if (!reject) {
-        s_sel[nsel] = cur;
-        s_selv[nsel] = curv;
-        s_nsel = nsel + 1;
+      if (lane == 0) {
+        if (!reject) {
+          s_sel[nsel] = cur;
+          s_selv[nsel] = curv;
+          s_nsel = nsel + 1;
+        }
+        cand[cur] = -INFINITY;
       }
-      cand[cur] = -INFINITY;
     }
     __syncthreads();
-    if (s_nsel >= n_peaks) break;
+    const int nsel_now = s_nsel;
+    if (nsel_now >= n_peaks) break;
+    if (nsel_now != nsel && min_sep > 1) {
+      // accepted: every candidate closer than min_sep would be turned down when its turn came (the accepted set
+      // only grows and a rejected candidate leaves no trace), so they go now instead of costing a round each
+      for (int i = cur - min_sep + 1 + tid; i < cur + min_sep; i += kPeakThreads)
+        if (i >= 0 && i < n) cand[i] = -INFINITY;
+      __syncthreads();
+    }
   }
   if (tid < n_peaks) {
     const bool have = tid < s_nsel;
