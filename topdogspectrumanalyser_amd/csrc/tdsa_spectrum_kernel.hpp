@@ -10,21 +10,23 @@
 // algorithmic minimum: the raw samples are read once, the dB row is written once.
 //
 // Work decomposition (N = A * 32 * 32 for N >= 2048, N = A * 32 below):
-//   * SG = N/32 threads own one frame; each thread holds 32 complex points in VGPRs in every pass.
-//   * pass 1: M = 32/A adjacent radix-A butterflies per thread, inputs straight from global memory
-//             (thread t reads samples a*(N/A) + t*M .. +M-1 : 2M contiguous bytes per load), no twiddles.
-//             The raw registers are refilled with the NEXT frame's samples as soon as they have been
-//             unpacked, so the HBM read of frame f+1 overlaps the FFT of frame f at no register cost.
-//   * pass 2 (3-pass sizes): radix-32 IN PLACE (a thread stores output kb into the LDS slot input b = kb
-//             came from, so no barrier separates its gather from its scatter), twiddles W_(32A)^(ka*b)
-//             read from a 4 KiB LDS table.  Outputs are stored depth-first, as soon as they are final,
-//             so the slow LDS write path (~80 B/clk/CU) drains underneath the remaining butterflies.
-//   * last pass: radix-32, twiddles W_N^(t*c) rebuilt from 10 exact per-thread table values
-//             (every factor is at most one rounded product away from the table).
-//   * the thread -> bin mapping of the last pass is frame invariant, so the window, the twiddle seeds
-//     and the max/min hold traces live in registers across the persistent frame loop.
-//   * a workgroup processes a CONTIGUOUS range of frames (overlapping frames re-read their shared
-//     half from the same XCD's L2, not from HBM).
+//   * 2 * N/32 threads own one frame: N/32 butterfly rows, each shared by two half-threads (lanes l and l + 32 of a
+//     wave) that hold 16 complex points apiece in every pass - 128 VGPRs, 4 waves per SIMD.  A radix-R pass is two
+//     radix-R/2 DFTs (one per half-thread) plus one combine stage across the lane pair (v_permlane32_swap).
+//   * pass 1: M = 32/A adjacent radix-A butterflies per row, inputs straight from global memory (row t reads samples
+//             a*(N/A) + t*M .. +M-1 : 2M contiguous bytes per load), no twiddles.  The raw registers are refilled
+//             with the NEXT frame's samples as soon as they have been unpacked, so the HBM read of frame f+1
+//             overlaps the FFT of frame f at no register cost.
+//   * pass 2 (3-pass sizes): radix-32 IN PLACE (a row stores output kb into the LDS slot input b = kb came from, so
+//             no barrier separates its gather from its scatter), twiddles W_(32A)^(ka*b) read from a 4 KiB LDS
+//             table.  Outputs are stored depth-first, as soon as they are final, so the slow LDS write path
+//             (~93 B/clk/CU) drains underneath the remaining butterflies.
+//   * last pass: radix-32, twiddles W_N^(t*c) rebuilt from 7 exact per-thread table values (every factor is at most
+//             one rounded product away from the table).
+//   * the thread -> bin mapping of the last pass is frame invariant, so the window slice, the twiddle seeds and the
+//     max/min hold traces live in registers across the persistent frame loop.
+//   * a workgroup processes a CONTIGUOUS range of frames (overlapping frames re-read their shared half from the
+//     same XCD's L2, not from HBM); the dB rows leave with non-temporal stores.
 #pragma once
 #include "tdsa_fft.hpp"
 #include "tdsa_kernels.hpp"
