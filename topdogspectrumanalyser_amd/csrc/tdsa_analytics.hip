@@ -128,8 +128,7 @@ __global__ void __launch_bounds__(kPeakThreads) top_peaks_kernel(const float* __
                                                                  int min_sep, float excursion, int* out_bins,
                                                                  float* out_db) {
   extern __shared__ float smem[];
-  float* row = smem;             // [n]
-  float* cand = smem + n;        // [n]: value of a live candidate, -inf otherwise
+  float* row = smem;             // [n]; the only large LDS array, so two rows are in flight per CU
   __shared__ PeakPair s_best[kPeakThreads / 64];
   __shared__ float s_min[kMaxPeaks][kPeakThreads / 64];
   __shared__ int s_sel[kMaxPeaks];
@@ -141,20 +140,27 @@ __global__ void __launch_bounds__(kPeakThreads) top_peaks_kernel(const float* __
   for (int i = tid; i < n; i += kPeakThreads) row[i] = src[i];
   if (tid == 0) s_nsel = 0;
   __syncthreads();
-  for (int i = tid; i < n; i += kPeakThreads) {
+  // live candidates (strict interior local maxima) of this thread's elements i = tid + 1024 k: bit k of a register
+  unsigned live = 0u;
+  for (int i = tid, k = 0; i < n; i += kPeakThreads, ++k) {
     const bool is_max = i > 0 && i < n - 1 && row[i] > row[i - 1] && row[i] > row[i + 1];
-    cand[i] = is_max ? row[i] : -INFINITY;
+    live |= is_max ? (1u << k) : 0u;
   }
-  __syncthreads();
+  // strongest live candidate of this thread; equal values: larger index first (reversed ascending sort).  Only a
+  // thread whose mask changed looks at the row again.
+  PeakPair mine{-INFINITY, -1};
+  auto rescan = [&] {
+    mine = PeakPair{-INFINITY, -1};
+    for (unsigned m = live; m != 0u; m &= m - 1u) {
+      const int i = tid + kPeakThreads * __builtin_ctz(m);
+      const float v = row[i];
+      if (v > mine.v || (v == mine.v && i > mine.i)) mine = PeakPair{v, i};
+    }
+  };
+  rescan();
 
   for (;;) {
-    // strongest live candidate; equal values: larger index first (reversed ascending sort)
-    PeakPair best{-INFINITY, -1};
-    for (int i = tid; i < n; i += kPeakThreads) {
-      const float v = cand[i];
-      if (v > best.v || (v == best.v && v != -INFINITY && i > best.i)) best = PeakPair{v, i};
-    }
-    best = wave_strongest_to_lane63(best);
+    PeakPair best = wave_strongest_to_lane63(mine);
     if (lane == 63) s_best[w] = best;
     __syncthreads();
     // every thread folds the 16 wave results itself (LDS broadcasts): no serial section, one barrier less
@@ -166,6 +172,10 @@ __global__ void __launch_bounds__(kPeakThreads) top_peaks_kernel(const float* __
     }
     const int cur = gb.v == -INFINITY ? -1 : gb.i;
     if (cur < 0) break;
+    if (tid == (cur & (kPeakThreads - 1))) {      // the candidate leaves the list whatever happens to it
+      live &= ~(1u << (cur / kPeakThreads));
+      rescan();
+    }
     const float curv = gb.v;
     const int nsel = s_nsel;
     // the separation test needs no valley: a candidate too close to an accepted peak is dropped right away
@@ -179,8 +189,7 @@ __global__ void __launch_bounds__(kPeakThreads) top_peaks_kernel(const float* __
       }
     }
     if (too_close) {
-      if (tid == 0) cand[cur] = -INFINITY;   // (every thread is past this round's scan of cand)
-      __syncthreads();
+      __syncthreads();                       // s_best is rewritten next round
       continue;
     }
     // valley minimum between the candidate and every accepted peak, one pass over the row; the ranges are formed
@@ -226,7 +235,6 @@ __global__ void __launch_bounds__(kPeakThreads) top_peaks_kernel(const float* __
           s_selv[nsel] = curv;
           s_nsel = nsel + 1;
         }
-        cand[cur] = -INFINITY;
       }
     }
     __syncthreads();
@@ -235,9 +243,12 @@ __global__ void __launch_bounds__(kPeakThreads) top_peaks_kernel(const float* __
     if (nsel_now != nsel && min_sep > 1) {
       // accepted: every candidate closer than min_sep would be turned down when its turn came (the accepted set
       // only grows and a rejected candidate leaves no trace), so they go now instead of costing a round each
-      for (int i = cur - min_sep + 1 + tid; i < cur + min_sep; i += kPeakThreads)
-        if (i >= 0 && i < n) cand[i] = -INFINITY;
-      __syncthreads();
+      const unsigned before = live;
+      for (unsigned m = live; m != 0u; m &= m - 1u) {
+        const int k = __builtin_ctz(m), i = tid + kPeakThreads * k;
+        if (i > cur - min_sep && i < cur + min_sep) live &= ~(1u << k);
+      }
+      if (live != before) rescan();
     }
   }
   if (tid < n_peaks) {
@@ -375,9 +386,9 @@ hipError_t launch_rows_stats(const float* rows, int n_rows, int n, int band_lo, 
 hipError_t launch_top_peaks(const float* rows, int n_rows, int n, int n_peaks, int min_sep, float excursion,
                             int* out_bins, float* out_db, hipStream_t s) {
   if (n_rows <= 0) return hipSuccess;
-  const size_t lds = size_t(2) * n * sizeof(float);
+  const size_t lds = size_t(n) * sizeof(float);
   static std::atomic<unsigned long long> attr_done{0};
-  const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(top_peaks_kernel), 140 * 1024, attr_done);
+  const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(top_peaks_kernel), 72 * 1024, attr_done);
   if (e != hipSuccess) return e;
   top_peaks_kernel<<<n_rows, kPeakThreads, lds, s>>>(rows, n, n_peaks, min_sep, excursion, out_bins, out_db);
   return hipGetLastError();
