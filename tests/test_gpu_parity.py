@@ -959,6 +959,39 @@ def test_overlapped_launches_match_serial(pkg, streams):
             nat.lib.tdsa_dev_free(0, b)
 
 
+def test_averager_scan_row_alignment(pkg):
+    """Chunked averager scan (> 128 frames): the 4-bins-per-thread kernels need 16-byte aligned rows; an output
+    pointer that is only float aligned must fall back to the one-bin kernels with identical rows."""
+    import ctypes as C
+    nat = pkg._native
+    nfft, hop, nf = 1024, 512, 300
+    ns = hop * (nf - 1) + nfft
+    iq = so.synth_iq_int8(ns, nfft, seed=77)
+    d_in, d_out = C.c_void_p(), C.c_void_p()
+    nat.check(nat.lib.tdsa_dev_alloc(0, iq.nbytes, C.byref(d_in)))
+    nat.check(nat.lib.tdsa_dev_alloc(0, nf * nfft * 4 + 64, C.byref(d_out)))
+    nat.check(nat.lib.tdsa_memcpy_h2d(0, d_in, iq.ctypes.data_as(C.c_void_p), iq.nbytes))
+    try:
+        rows = {}
+        for off in (0, 4):
+            with pkg.SpectrumEngine(nfft, max_frames=nf) as e:
+                e.set_window(so.hackrf_window(nfft))
+                e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=1.0, avg=("exp", 8),
+                            hold_max=True)
+                e.process_device(nat.IN_I8, d_in.value, ns, hop, nf, d_out.value + off)
+                e.synchronize()
+                got = np.empty((nf, nfft), dtype=np.float32)
+                nat.check(nat.lib.tdsa_memcpy_d2h(0, got.ctypes.data_as(C.c_void_p), C.c_void_p(d_out.value + off),
+                                                  got.nbytes))
+                rows[off] = (got, e.hold()[0])
+        assert np.array_equal(rows[0][0], rows[4][0]) and np.array_equal(rows[0][1], rows[4][1])
+        gold, _, _ = so.hackrf_batch(iq, nfft, hop, 20e6, precision="gold", avg=("exp", 8))
+        _check(rows[4][0], gold, "chunked exp scan, unaligned rows")
+    finally:
+        nat.lib.tdsa_dev_free(0, d_in)
+        nat.lib.tdsa_dev_free(0, d_out)
+
+
 @pytest.mark.parametrize("streams", [2, 3, 4])
 def test_host_entry_points_stay_consistent_with_overlap(pkg, streams):
     """tdsa_process_i8 after tdsa_set_overlap(n > 1): the frame kernel may run on an auxiliary stream, the
