@@ -400,8 +400,8 @@ def parity_metrics(db_gpu: np.ndarray, db_gold: np.ndarray, floor_rel_db: float 
     in units of one rounding unit the worst bin of a case sits at a median of 0.14, 99 % of the cases stay below 0.9,
     the worst seen is 1.38 - always the one bin N/2 away from a full-scale tone that falls exactly on a bin, where
     the last radix-2 stage cancels two half-amplitude terms; long frames (two FFT kernels) worst 1.03; the tracked
-    DC remover (its estimate reaches the frame kernel as one float32 in raw sample units) worst 3.8.  The tests
-    therefore bound with TWO units (2^-23 A_max) and with four for the tracked DC remover."""
+    DC remover worst 1.19 (3.8 while its estimate still reached the frame kernel folded into one float32
+    "128 + dc").  The tests therefore bound with TWO units (2^-23 A_max)."""
     db_gpu = np.asarray(db_gpu, dtype=np.float64)
     db_gold = np.asarray(db_gold, dtype=np.float64)
     p_gpu = 10.0 ** (db_gpu / 10.0)

@@ -1166,13 +1166,9 @@ def test_random_configuration_sweep(pkg, case_id):
         out = np.concatenate(parts)
         mx, mn = e.hold()
     what = f"case {case_id}: {c}"
-    # the tracked DC remover (0 <= alpha < 1) hands the frame kernel its estimate as ONE float32 in raw
-    # sample units (128 + dc): 2^-17 LSB of resolution, the same for every sample of the frame, so up to
-    # 2e-7 * A_max of it adds up coherently in the DC bin (the reference keeps the estimate in complex128)
-    units = 4 if 0.0 <= dc < 1.0 else None
-    _check(out, gold, what, floor_units=units)
-    _check(mx, gmax, what + " max hold", floor_units=units)
-    _check(mn, gmin, what + " min hold", floor_units=units)
+    _check(out, gold, what)
+    _check(mx, gmax, what + " max hold")
+    _check(mn, gmin, what + " min hold")
 
 
 def test_engine_closes_its_pipes_first(pkg):

@@ -38,7 +38,7 @@ struct SpecParams {
   float* out_db;             // [F][N] fftshift-ed dB, or null
   float* out_lin;            // [F][N] fftshift-ed linear power * pscale (averaging modes), or null
   float2* out_cplx;          // [F][N] complex spectrum X[k] in natural bin order (real-input path), or null
-  const float2* dc_sub;      // [F] per-frame subtract value in raw-sample units (DC_TRACKED), or null
+  const float2* dc_sub;      // [F] per-frame DC estimate in raw-sample units, WITHOUT in_off (DC_TRACKED), or null
   float2* dc_state;          // last frame's mean in units of x is stored here (DC_FRAME_MEAN), or null
   float* part_max;           // [N] the plan's max-hold trace (merged into with float atomics), or null
   float* part_min;           // [N] the plan's min-hold trace

@@ -416,6 +416,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
 
     c32 v[16];                                              // pass 1: v[jj*H + i] = sample a = 2i + h of butterfly jj
     float sub_re = p.in_off, sub_im = p.in_off;
+    float res_re = 0.f, res_im = 0.f;     // DC_TRACKED: the estimate as a small residual on top of in_off (see below)
     // ---- frame sums for DC removal ---------------------------------------------------------------
     if constexpr (ACC) {
       static_for<0, 16>([&](auto ic) { constexpr int idx = decltype(ic)::value; v[idx] = vnext[idx]; });
@@ -473,7 +474,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
         if (p.dc_state != nullptr && frame == p.n_frames - 1 && t == 0 && h == 0)
           *p.dc_state = c32{(sub_re - p.in_off) * p.in_scale, (sub_im - p.in_off) * p.in_scale};
       } else if (p.dc_mode == DC_TRACKED && active) {
-        const c32 sv = p.dc_sub[frame]; sub_re = sv.x; sub_im = sv.y;
+        const c32 sv = p.dc_sub[frame]; res_re = sv.x; res_im = sv.y;
       }
     } else if (!IN_C64 && p.dc_mode == DC_FRAME_MEAN) {
       // byte formats, several frames per wave (N < 1024): exact integer sums again, reduced over the
@@ -534,7 +535,11 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
         *p.dc_state = c32{(sub_re - p.in_off) * p.in_scale, (sub_im - p.in_off) * p.in_scale};
     } else {
       TDSA_SYNC();
-      if (p.dc_mode == DC_TRACKED && active) { const c32 s = p.dc_sub[frame]; sub_re = s.x; sub_im = s.y; }
+      if (p.dc_mode == DC_TRACKED && active) {
+        const c32 s = p.dc_sub[frame];
+        if constexpr (IN_C64) { sub_re = s.x; sub_im = s.y; }    // in_off = 0: the estimate IS the subtract value
+        else { res_re = s.x; res_im = s.y; }
+      }
     }
     sub_re = in_vgpr(sub_re);
     sub_im = in_vgpr(sub_im);
@@ -565,6 +570,17 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
           v[i1] = c32{(float((u >> 16) & 0xffu) - sub_re) * win[i1], (float(u >> 24) - sub_im) * win[i1]};
         });
       });
+    }
+    if constexpr (!ACC && !IN_C64) {
+      // Tracked DC remover: x - in_off above is exact (small integers / halves), the estimate follows as its own
+      // term, v -= dc * w, instead of one float32 "128 + dc" whose 2^-17 LSB of resolution would add up coherently
+      // in the DC bin (it was worth up to 3.8 rounding units of A_max there).  Wave-uniform branch, this mode only.
+      if (p.dc_mode == DC_TRACKED) {
+        static_for<0, 16>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          v[i] = c32{fmaf(-res_re, win[i], v[i].x), fmaf(-res_im, win[i], v[i].y)};
+        });
+      }
     }
     TDSA_STAMP(3);
     // raw registers are free again: start the next frame's HBM read now, it lands during the FFT

@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(256) dc_track_kernel(const float2* sums, int n
     mean_of(f, mr, mi);
     sr = a * sr + b * mr;
     si = a * si + b * mi;
-    dc_sub[f] = float2{in_off + float(sr) / in_scale, in_off + float(si) / in_scale};
+    dc_sub[f] = float2{float(sr) / in_scale, float(si) / in_scale};      // residual on top of in_off, raw units
   }
 }
 
