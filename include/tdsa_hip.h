@@ -64,7 +64,7 @@ typedef struct tdsa_mode {
   int32_t db_mode;       /* TDSA_DB_MAG | TDSA_DB_POW                                                */
   float power_scale;     /* POW only: 1 or 1/(fs*N) for PSD (hackrf_samples.py:375, rtl_samples.py:177) */
   float log_floor;       /* 1e-12 (LOG_FLOOR) or 1e-10 (POWER_LOG_FLOOR)                               */
-  int32_t avg_mode;      /* TDSA_AVG_*  ; set_mode semantics of TraceAverager.set_mode (:19-28)        */
+  int32_t avg_mode;      /* TDSA_AVG_*  ; a CHANGE of avg_mode / avg_n restarts the average (see below) */
   int32_t avg_n;         /* clamped to >= 1; n <= 1 means pass-through                                 */
   float dc_alpha;        /* < 0: no DC removal (RTL branch); 1: per-frame mean removal; (0,1): tracker
                             dc <- (1-a)*dc + a*mean(x)  (hackrf_samples.py:360-365, :32, :654-657)     */
@@ -106,7 +106,9 @@ int tdsa_set_window(tdsa_plan p, const float* w_host, int n);
 
 /* Replaces set_psd_mode / set_averaging / set_dc_alpha / CalibrationManager.get_offset / hold toggles
  * (datasources/base.py:148-165, hackrf_samples.py:654-657, core/calibration_manager.py:29-31).
- * Changing avg_mode/avg_n resets the averager (TraceAverager.set_mode :19-28). */
+ * Changing avg_mode/avg_n resets the averager (TraceAverager.set_mode :19-28); setting the same values again does
+ * not (the whole mode is one struct: a new calibration offset must not restart an average) - callers that want the
+ * reference's unconditional restart follow up with tdsa_reset_state(TDSA_RESET_AVG), as the Python sources do. */
 int tdsa_set_mode(tdsa_plan p, const tdsa_mode* m);
 
 /* reset_averaging (base.py:167), hold clears (core/display_manager.py:139-185), _flush_buffers DC

@@ -1171,6 +1171,86 @@ def test_random_configuration_sweep(pkg, case_id):
     _check(mn, gmin, what + " min hold")
 
 
+# ------------------------------------------------------------------------------------------------
+# random CALL SEQUENCES on one plan: process in pieces, averaging changes, resets, calibration offset, tare
+# baseline - checked call by call against the float64 oracle driven through the same sequence
+# ------------------------------------------------------------------------------------------------
+def _mode_for(psd, averaging, fs, nfft):
+    if psd:
+        return dict(db_mode="pow", power_scale=1.0 / (fs * nfft), log_floor=so.LOG_FLOOR)
+    if averaging:
+        return dict(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR)
+    return dict(db_mode="mag", power_scale=1.0, log_floor=so.LOG_FLOOR)
+
+
+def call_sequence_trial(pkg, trial, report=None):
+    """-> (worst dB error in allowance units of ONE rounding unit, worst relative power error, process calls)"""
+    nat = pkg._native
+    rng = np.random.default_rng(9000 + trial)
+    nfft = int(2 ** rng.integers(6, 14))
+    hop = int(rng.choice([nfft, nfft // 2, int(rng.integers(1, 2 * nfft))]))
+    fs, psd = 20e6, bool(rng.integers(0, 2))
+    dc_alpha = float(rng.choice([1.0, 1.0, 0.3]))
+    max_call, total = 12, 90
+    iq = so.synth_iq_int8(hop * (total - 1) + nfft, nfft, seed=int(rng.integers(1, 1 << 30)))
+    x = so.unpack_iq_int8(iq)
+    br = so.HackrfBranchOracle(nfft, fs, dc_alpha, psd, "gold")
+    hold = so.HoldOracle(True, True)
+    cal, tare = 0.0, None
+    worst_units, worst_rel, calls = 0.0, 0.0, 0
+    with pkg.SpectrumEngine(nfft, max_frames=max_call) as e:
+        e.set_window(so.hackrf_window(nfft))
+        e.configure(dc_alpha=dc_alpha, avg=("off", 1), cal_offset_db=0.0, hold_max=True, hold_min=True,
+                    **_mode_for(psd, False, fs, nfft))
+        pos = 0
+        while pos < total:
+            op = int(rng.integers(0, 10))
+            if op == 0:
+                avg = [("off", 1), ("exp", int(rng.integers(2, 9))), ("lin", int(rng.integers(2, 20)))][int(rng.integers(0, 3))]
+                # tdsa_set_mode restarts the average when mode or length CHANGE (include/tdsa_hip.h)
+                if (avg[0], max(1, avg[1])) != (br.averager.mode, br.averager.n):
+                    br.averager.set_mode(*avg)
+                e.configure(avg=avg, **_mode_for(psd, br.averager.is_active, fs, nfft))
+            elif op == 1:
+                br.averager.reset()
+                e.reset(nat.RESET_AVG)
+            elif op == 2:
+                hold = so.HoldOracle(True, True)
+                e.reset(nat.RESET_HOLD_MAX | nat.RESET_HOLD_MIN)
+            elif op == 3:
+                cal = float(rng.choice([0.0, -0.8087, 3.5]))
+                e.configure(cal_offset_db=cal)
+            elif op == 4:
+                tare = None if rng.integers(0, 2) else rng.uniform(-3, 3, nfft).astype(np.float32)
+                e.set_tare_baseline(tare)
+            else:
+                k = int(min(rng.integers(1, max_call + 1), total - pos))
+                out = e.process(iq[2 * hop * pos: 2 * (hop * (pos + k - 1) + nfft)], hop=hop, n_frames=k)
+                gold = np.empty((k, nfft))
+                for j in range(k):
+                    g = np.asarray(br.power_levels(so.frame(x, nfft, hop, pos + j)), dtype=np.float64) + cal
+                    if tare is not None:
+                        g = g - tare.astype(np.float64)
+                    gold[j] = g
+                    hold.update(g)
+                mx, mn = e.hold()
+                pairs = (so.parity_metrics(out, gold), so.parity_metrics(mx, hold.max), so.parity_metrics(mn, hold.min))
+                units = max(p[1] for p in pairs) / 1e-3
+                rel = max(p[0] for p in pairs)
+                if report is not None and (units > 2.0 or rel > REL_TOL):
+                    report(f"trial {trial} pos {pos} k {k}: nfft {nfft} hop {hop} psd {psd} dc {dc_alpha} avg "
+                           f"{br.averager.mode},{br.averager.n} cal {cal} tare {tare is not None}: {units:.2f} units, rel {rel:.1e}")
+                worst_units, worst_rel, calls = max(worst_units, units), max(worst_rel, rel), calls + 1
+                pos += k
+    return worst_units, worst_rel, calls
+
+
+@pytest.mark.parametrize("trial", range(int(os.environ.get("TDSA_SEQUENCE_TRIALS", "24"))))
+def test_random_call_sequences(pkg, trial):
+    units, rel, calls = call_sequence_trial(pkg, trial)
+    assert calls > 0 and rel <= REL_TOL and units <= 2.0, f"trial {trial}: {units:.2f} units, rel {rel:.2e}"
+
+
 def test_engine_closes_its_pipes_first(pkg):
     """A pipe holds slots the plan's streams write to: closing the engine first (or leaving `with` blocks out
     of order) closes its live pipes before the plan goes, and a later pipe.close() is a no-op."""
