@@ -159,6 +159,32 @@ def test_density_histogram_matches_restatement(pkg, an, decay):
         one.close()
 
 
+@pytest.mark.filterwarnings("ignore:invalid value encountered in cast")     # the restated astype(int32) of +-inf
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TDSA_DENSITY_CASES", "8"))))
+def test_density_histogram_random(pkg, an, seed):
+    """Seeded random row sets (sizes off the 16-bin tile, row counts off the 32-row chunk, clustered and spread
+    amplitudes, NaN / inf / edge values, several calls in a row): bit for bit the restated float32 sequence."""
+    rng = np.random.default_rng(500 + seed)
+    n = int(rng.choice([16, 17, 100, 1000, 1024, 4096, 5000]))
+    decay = float(rng.choice([0.96, 0.5, 1.0, 0.999]))
+    ref = ao.DensityOracle(decay)
+    with an.DensityHistogram(n, decay) as dh:
+        for _call in range(int(rng.integers(1, 4))):
+            nf = int(rng.integers(1, 100))
+            centre, spread = rng.uniform(-150, 50), float(rng.choice([0.2, 3.0, 25.0, 120.0]))
+            rows = rng.normal(centre, spread, size=(nf, n)).astype(np.float32)
+            for _ in range(int(rng.integers(0, 6))):
+                rows[rng.integers(0, nf), rng.integers(0, n)] = rng.choice(
+                    np.array([np.nan, np.inf, -np.inf, -200.0, 100.0, 99.999, -200.3, -201.0], dtype=np.float32))
+            if rng.integers(0, 2):
+                rows = np.round(rows * 512 / 300) * np.float32(300 / 512) - np.float32(200.0) + np.float32(200.0)   # near bin edges
+            for r in rows:
+                ref.update(r)
+            with DevRows(pkg, rows) as d:
+                dh.update_rows(None, d, nf)
+            assert np.array_equal(dh.hist(), ref.hist), (seed, n, decay, nf)
+
+
 def test_density_from_engine_rows(pkg, an):
     nfft, nf = 2048, 50
     iq = so.synth_iq_int8(nfft * nf, nfft, seed=9)
