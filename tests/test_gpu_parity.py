@@ -1056,6 +1056,56 @@ def test_host_pipe_matches_synchronous_calls(pkg, rows, streams):
             assert np.array_equal(mx, ref_max)
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TDSA_PIPE_CASES", "8"))))
+def test_host_pipe_random(pkg, seed):
+    """Seeded random pipelines (size incl. a long frame, slots, frames per submit, overlap streams, averaging, tracked
+    DC, holds): every slot's rows and the plan state bit for bit what synchronous tdsa_process_i8 calls give."""
+    rng = np.random.default_rng(3000 + seed)
+    nfft = int(2 ** rng.choice([6, 8, 10, 11, 12, 13, 14, 15]))
+    long_frame = nfft > 16384
+    hop = nfft if long_frame else int(rng.choice([nfft, nfft // 2, int(rng.integers(1, nfft + 1))]))
+    max_nf = 1 if long_frame else int(rng.integers(1, 40))
+    n_slots = int(rng.integers(1, 5))
+    streams = int(rng.integers(1, 4))
+    avg = [("off", 1), ("exp", 4), ("lin", 7)][int(rng.integers(0, 3))]
+    dc_alpha = float(rng.choice([1.0, 0.3, -1.0]))
+    averaging = avg[0] != "off"
+    mode = dict(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR) if averaging else \
+        dict(db_mode="mag", log_floor=so.LOG_FLOOR)
+    slot_samples = hop * (max_nf - 1) + nfft
+    chunks = []
+    for i in range(int(rng.integers(3, 10))):
+        nf = int(rng.integers(1, max_nf + 1))
+        chunks.append((nf, so.synth_iq_int8(hop * (nf - 1) + nfft, nfft, seed=int(rng.integers(1, 1 << 30)))))
+
+    def engine():
+        e = pkg.SpectrumEngine(nfft, max_frames=max_nf)
+        e.set_window(so.hackrf_window(nfft))
+        e.configure(dc_alpha=dc_alpha, avg=avg, cal_offset_db=-0.8087, hold_max=True, hold_min=True, **mode)
+        return e
+
+    with engine() as e:
+        ref = [e.process(iq, hop=hop, n_frames=nf) for nf, iq in chunks]
+        ref_hold = e.hold()
+    with engine() as e:
+        e.set_overlap(streams)
+        with e.pipe(slot_samples, n_slots=n_slots, rows=True) as q:
+            got = []
+            for nf, iq in chunks:
+                if q.pending == n_slots:
+                    got.append(q.collect().copy())
+                q.acquire()[: iq.size] = iq
+                q.submit(iq.size // 2, hop, nf)
+            while q.pending:
+                got.append(q.collect().copy())
+        hold = e.hold()
+    assert len(got) == len(ref)
+    for i, (g, r) in enumerate(zip(got, ref)):
+        assert g.shape == r.shape and np.array_equal(g, r), (seed, i, nfft, hop, avg, dc_alpha, streams, n_slots)
+    for a, b in zip(hold, ref_hold):
+        assert (a is None and b is None) or np.array_equal(a, b)
+
+
 def test_host_pipe_state_modes_and_errors(pkg):
     nfft, hop, nf = 1024, 1024, 16
     ns = nfft * nf
