@@ -783,6 +783,71 @@ def test_long_frame_welch_groups_and_overlap(pkg):
         assert cnt == k and np.max(np.abs(mean - acc / k) / (acc / k).max()) < 1e-5
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TDSA_LONG_CASES", "6"))))
+def test_long_frames_random(pkg, seed):
+    """Seeded random long-frame cases (2^15 .. 2^18 points; int8 / uint8 / complex64; DC off, per frame or tracked;
+    plain frames, TraceAverager exp / capped lin, or a Welch mean fed in random portions with 0-75 % overlap; calibration
+    offset, hold traces) against the float64 arithmetic of the reference."""
+    rng = np.random.default_rng(7000 + seed)
+    log2n = int(rng.integers(15, 19))
+    nfft = 1 << log2n
+    fmt = str(rng.choice(["i8", "u8", "c64"]))
+    dc_alpha = float(rng.choice([-1.0, 1.0, 0.3]))
+    kind = str(rng.choice(["plain", "exp", "lin", "welch"]))
+    cal = float(rng.choice([0.0, -0.8087]))
+    k = int(rng.integers(2, 9))
+    hop = nfft if kind != "welch" else int(nfft * float(rng.choice([1.0, 0.5, 0.25])))
+    win = so.rtl_window(str(rng.choice(["hanning", "hamming", "rectangle"])), nfft)
+    i8 = so.synth_iq_int8(hop * (k - 1) + nfft, nfft, seed=int(rng.integers(1, 1 << 30)))
+    if fmt == "i8":
+        raw, x = i8, so.unpack_iq_int8(i8).astype(np.complex128)
+    elif fmt == "u8":
+        raw = (i8.astype(np.int16) + 128).astype(np.uint8)
+        x = so.unpack_iq_uint8_rtl(raw).astype(np.complex128)
+    else:
+        raw = so.unpack_iq_int8(i8)
+        x = raw.astype(np.complex128)
+    per = 2 if fmt != "c64" else 1
+    avg = {"plain": ("off", 1), "exp": ("exp", int(rng.integers(2, 6))), "lin": ("lin", int(rng.integers(2, 5))),
+           "welch": ("lin", 64)}[kind]
+    # float64 restatement: per segment (x - dc) * w -> |fftshift(fft)|^2, then the averager, then dB + offset
+    dc = 0.0 + 0.0j
+    powers = []
+    for s_ in range(k):
+        seg = x[s_ * hop: s_ * hop + nfft]
+        if dc_alpha >= 0.0:
+            dc = (1.0 - dc_alpha) * dc + dc_alpha * seg.mean()
+            seg = seg - dc
+        powers.append(np.abs(np.fft.fftshift(np.fft.fft(seg * win))) ** 2)
+    av = so.TraceAveragerOracle()
+    av.set_mode(*avg)
+    with pkg.SpectrumEngine(nfft, max_frames=k) as e:
+        e.set_window(win.astype(np.float32))
+        e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=dc_alpha, avg=avg,
+                    cal_offset_db=cal, hold_max=True, hold_min=True)
+        what = f"seed {seed}: 2^{log2n} {fmt} dc {dc_alpha} {kind} {avg} hop {hop} k {k}"
+        rows = []
+        if kind == "welch":
+            done = 0
+            while done < k:
+                take = int(rng.integers(1, k - done + 1))
+                part = raw[per * hop * done: per * (hop * (done + take - 1) + nfft)]
+                out = e.process(part, hop=hop, n_frames=take)
+                assert out.shape == (1, nfft)
+                done += take
+                gold = 10 * np.log10(np.mean(powers[:done], axis=0) + so.POWER_LOG_FLOOR) + cal
+                _check(out[0], gold, what + f" after {done} segments")
+                rows.append(out[0])
+        else:
+            for s_ in range(k):
+                out = e.process(raw[per * hop * s_: per * (hop * s_ + nfft)], hop=nfft, n_frames=1)
+                gold = 10 * np.log10(np.asarray(av.process(powers[s_]), dtype=np.float64) + so.POWER_LOG_FLOOR) + cal
+                _check(out[0], gold, what + f" frame {s_}")
+                rows.append(out[0])
+        mx, mn = e.hold()
+        assert np.array_equal(mx, np.max(rows, axis=0)) and np.array_equal(mn, np.min(rows, axis=0)), what
+
+
 def test_hackrf_source_long_fft_size(pkg):
     """set_num_samples above 16384 (unbounded in the reference, hackrf_samples.py:392-405) runs on the GPU."""
     from topdogspectrumanalyser_amd.datasources.replay import ReplayHackRF
