@@ -377,6 +377,115 @@ def test_data_processor_sequence_golden(pkg, golden_dir, holds):
     src.running = False
 
 
+class _TraceSource:
+    """stands in for a sample source: hands out prepared dB traces"""
+
+    def __init__(self, pkg):
+        self.base = pkg.SampleDataSource
+        self.trace, self.axis = None, None
+        self.last_data_time = 0.0
+
+    def get_power_levels(self):
+        return self.trace, self.axis
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TDSA_PROCESSOR_CASES", "6"))))
+def test_data_processor_random_events(pkg, seed):
+    """Random GUI histories through DataProcessor._process_sample_data - holds switched on and off, tare runs
+    started and cleared, calibration offset changes, trace length changes, NaN bins - against a float64 model of
+    display_data_processor.py:317-395 of the reference (cal offset, tare, max / min hold)."""
+    rng = np.random.default_rng(8000 + seed)
+    src = _TraceSource(pkg)
+    cal = {"v": 0.0}
+    mw, dm = _NS(), _NS()
+    mw.current_source = src
+    mw.calibration_manager = _NS()
+    mw.calibration_manager.get_offset = lambda source_type: cal["v"]
+    mw.source_manager = _NS()
+    mw.source_manager.last_source_type = "hackrf_samples"
+    mw.status_label = _Label()
+    mw.tare_active, mw.baseline_power_levels = False, None
+    mw.live_power_levels = mw.max_power_levels = mw.min_power_levels = mw.frequency_bins = None
+    mw.min_hold_enabled = bool(rng.integers(0, 2))
+    dm.tare_state = pkg.TareState()
+    dm.max_peak_search_enabled = bool(rng.integers(0, 2))
+    dm.duty_cycle_enabled = dm.peak_list_enabled = False
+    dm._update_tare_button_label = lambda s: None
+
+    def _clear():
+        mw.tare_active, mw.baseline_power_levels = False, None
+        dm.tare_state = pkg.TareState()
+    dm._clear_tare = _clear
+    dp = pkg.DataProcessor(mw, dm)
+
+    # float64 model of the reference's three steps
+    m_collect, m_buf, m_cnt, m_active, m_base = False, None, 0, False, None
+    m_max = m_min = None
+    n = int(rng.choice([128, 256]))
+    for tick in range(150):
+        ev = rng.random()
+        if ev < 0.05:
+            dm.max_peak_search_enabled = not dm.max_peak_search_enabled
+        elif ev < 0.10:
+            mw.min_hold_enabled = not mw.min_hold_enabled
+        elif ev < 0.14:
+            dm.tare_state = pkg.TareState(collecting=True)
+            m_collect, m_buf, m_cnt = True, None, 0
+        elif ev < 0.17:
+            dm._clear_tare()
+            m_collect, m_buf, m_cnt, m_active, m_base = False, None, 0, False, None
+        elif ev < 0.22:
+            cal["v"] = float(rng.choice([0.0, -0.8087, 3.5]))
+        elif ev < 0.25:
+            n = int(rng.choice([128, 256, 512]))
+        x = rng.normal(-70.0, 10.0, n).astype(np.float32)
+        if rng.random() < 0.1:
+            x[rng.integers(0, n)] = np.nan
+        src.trace, src.axis = x, np.arange(n, dtype=np.float64)
+        dp._process_sample_data()
+        # ---- model ----
+        lv = x.astype(np.float64) + (cal["v"] if cal["v"] != 0.0 else 0.0)
+        if m_collect:
+            lin = 10.0 ** (lv / 10.0)
+            if m_buf is None or m_buf.shape != lin.shape:
+                m_buf, m_cnt = lin.copy(), 1
+            else:
+                m_buf += lin
+                m_cnt += 1
+            if m_cnt >= 32:
+                m_base = 10.0 * np.log10(np.maximum(m_buf / m_cnt, 1e-30))
+                m_active, m_collect, m_buf, m_cnt = True, False, None, 0
+        if m_active and m_base is not None:
+            if lv.shape != m_base.shape:
+                m_active, m_base = False, None
+            else:
+                lv = lv - m_base
+        for which in ("max", "min"):
+            on = dm.max_peak_search_enabled if which == "max" else mw.min_hold_enabled
+            cur = m_max if which == "max" else m_min
+            if not on:
+                if cur is not None and cur.shape != lv.shape:
+                    cur = None
+            elif cur is None or cur.shape != lv.shape:
+                cur = np.where(np.isnan(lv), -500.0 if which == "max" else 500.0, lv)
+            else:
+                cur = np.fmax(cur, lv) if which == "max" else np.fmin(cur, lv)
+            if which == "max":
+                m_max = cur
+            else:
+                m_min = cur
+        what = f"seed {seed} tick {tick}"
+        assert mw.tare_active == m_active, what
+        dlive = np.abs(np.asarray(mw.live_power_levels, dtype=np.float64) - lv)
+        bad = int(np.nanargmax(np.where(np.isnan(dlive), -1.0, dlive)))
+        assert np.allclose(mw.live_power_levels, lv, rtol=0, atol=2e-4, equal_nan=True), \
+            f"{what}: bin {bad} got {mw.live_power_levels[bad]} want {lv[bad]} x {x[bad]} base {None if m_base is None else m_base[bad]} nan mismatch {int((np.isnan(mw.live_power_levels) != np.isnan(lv)).sum())}"
+        for got, want, name in ((mw.max_power_levels, m_max, "max"), (mw.min_power_levels, m_min, "min")):
+            assert (got is None) == (want is None), f"{what}: {name} hold present {got is not None} vs {want is not None}"
+            if want is not None:
+                assert np.allclose(got, want, rtol=0, atol=2e-4, equal_nan=True), f"{what}: {name} hold"
+
+
 def test_trace_averager_golden(pkg, golden_dir):
     g = np.load(os.path.join(golden_dir, "averager.npz"))
     for name, (mode, n) in {"off": ("off", 1), "exp8": ("exp", 8), "lin4": ("lin", 4), "lin64": ("lin", 64),

@@ -394,7 +394,12 @@ __global__ void __launch_bounds__(256) trace_update_kernel(const TraceParams p) 
     const float acc = p.tare_first ? lin : p.tare_acc[k] + lin;
     p.tare_acc[k] = acc;
     if (p.tare_finish)                                      // (:351-356)
-      p.tare_base[k] = k10Log10_2f * __builtin_amdgcn_logf(fmaxf(acc / float(p.tare_count), 1e-30f));
+    {
+      // np.maximum(avg, 1e-30) PROPAGATES a NaN (fmaxf would drop it): a bin that saw a NaN during the run keeps a
+      // NaN baseline, as in the reference
+      const float avg = acc / float(p.tare_count);
+      p.tare_base[k] = k10Log10_2f * __builtin_amdgcn_logf(avg < 1e-30f ? 1e-30f : avg);
+    }
   }
   if (p.tare_active) db -= p.tare_base[k];                  // (:361-367)
   if (p.live != nullptr) p.live[k] = db;
