@@ -164,6 +164,9 @@ int tdsa_get_avg(tdsa_plan p, double* avg_linear_host, int* count);
 
 /* HackrfSamplesDataSource._dc_estimate (complex, units of x). */
 int tdsa_get_dc(tdsa_plan p, float* re, float* im);
+/* ... and its assignment: the estimate belongs to the source, not to an FFT size - the reference keeps it across
+ * set_num_samples (datasources/hackrf_samples.py:392-405), which is a new plan here. */
+int tdsa_set_dc(tdsa_plan p, float re, float im);
 
 int tdsa_synchronize(tdsa_plan p);
 

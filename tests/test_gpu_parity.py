@@ -183,6 +183,54 @@ def test_hackrf_source_class_golden(pkg, golden_dir, mode):
     src.running = False
 
 
+def test_hackrf_source_dc_estimate_across_resize_and_retune(pkg):
+    """The tracked DC estimate belongs to the source: the reference keeps self._dc_estimate across set_num_samples
+    (hackrf_samples.py:392-405).  Here a size change means a new plan: the estimate has to move with it.  A retune,
+    on the other hand, ends in _flush_buffers in the reference too (its saved_dc is overwritten by the flush in
+    _start_internal, :615): the estimate restarts from zero."""
+    from topdogspectrumanalyser_amd.datasources.replay import ReplayHackRF
+    iq = so.synth_iq_int8(1 << 18, 1024, seed=31)
+    x = so.unpack_iq_int8(iq)
+    src = pkg.HackrfSamplesDataSource(sample_rate=20_000_000, centre_freq=100_000_000)
+    src.num_samples = 1024
+    src.running = True
+    src._allocate_fft_resources()
+    src.set_dc_alpha(0.25)
+    br = so.HackrfBranchOracle(1024, 20e6, dc_alpha=0.25, precision="gold")
+    pos = 0
+    for k in range(4):
+        fr = x[pos: pos + 1024]
+        pos += 1024
+        src._reservoir = np.array(fr, copy=True)
+        p, _ = src.get_power_levels()
+        _check(p, br.power_levels(fr), f"1024 frame {k}")
+    assert abs(src._dc_estimate - complex(br.dc_estimate)) < 1e-6
+    src.set_num_samples(4096)                                   # new FFT size: a new plan on the GPU
+    br2 = so.HackrfBranchOracle(4096, 20e6, dc_alpha=0.25, precision="gold")
+    br2.dc_estimate = br.dc_estimate
+    for k in range(3):
+        fr = x[pos: pos + 4096]
+        pos += 4096
+        src._reservoir = np.array(fr, copy=True)
+        p, _ = src.get_power_levels()
+        _check(p, br2.power_levels(fr), f"4096 frame {k} after the size change")
+    assert abs(src._dc_estimate - complex(br2.dc_estimate)) < 1e-6
+    src.running = False
+    # retune of a running source (injected replay device): buffers are flushed, the estimate is not
+    live = pkg.HackrfSamplesDataSource(sample_rate=20_000_000, centre_freq=100_000_000,
+                                       device_factory=lambda: ReplayHackRF(iq))
+    live.set_dc_alpha(0.25)
+    live.start()
+    try:
+        for _ in range(5):
+            live.get_power_levels()
+        assert abs(live._dc_estimate) > 1e-4
+        live.update_centre_frequency(101_000_000)
+        assert live._dc_estimate == 0j
+    finally:
+        live.stop()
+
+
 def test_hackrf_source_streaming_front_end(pkg):
     """start() with an injected device: reader thread + freshest-chunk framing + hold-last-good."""
     from topdogspectrumanalyser_amd.datasources.replay import ReplayHackRF

@@ -55,6 +55,7 @@ _SIGNATURES = {
     "tdsa_get_hold": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int64)]),
     "tdsa_get_avg": (C.c_int, [_P, _P, C.POINTER(C.c_int)]),
     "tdsa_get_dc": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "tdsa_set_dc": (C.c_int, [_P, C.c_float, C.c_float]),
     "tdsa_synchronize": (C.c_int, [_P]),
     "tdsa_set_overlap": (C.c_int, [_P, C.c_int]),
     "tdsa_rows_stats": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _P, _P, _P]),

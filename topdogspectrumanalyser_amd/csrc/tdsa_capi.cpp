@@ -806,6 +806,16 @@ int tdsa_get_dc(tdsa_plan p, float* re, float* im) {
   return TDSA_OK;
 }
 
+int tdsa_set_dc(tdsa_plan p, float re, float im) {
+  if (!p) return fail(TDSA_ERR_ARG, "null plan");
+  HIPCHK(hipSetDevice(p->device));
+  JOIN(p);
+  HIPCHK(hipStreamSynchronize(p->stream));
+  const float2 dc{re, im};
+  HIPCHK(hipMemcpy(p->d_dc_state, &dc, sizeof(dc), hipMemcpyHostToDevice));
+  return TDSA_OK;
+}
+
 int tdsa_synchronize(tdsa_plan p) {
   if (!p) return fail(TDSA_ERR_ARG, "null plan");
   HIPCHK(hipSetDevice(p->device));

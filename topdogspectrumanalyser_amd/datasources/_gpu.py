@@ -26,10 +26,15 @@ class GpuSpectrumMixin:
         if nfft < GPU_MIN_FFT or nfft > GPU_MAX_FFT or nfft & (nfft - 1):
             raise ValueError(f"FFT size {nfft} is not a power of two in [{GPU_MIN_FFT}, {GPU_MAX_FFT}]")
         if self._engine is None or self._engine_n != nfft:
+            # the DC estimate is a property of the source, not of an FFT size (the reference keeps
+            # self._dc_estimate across set_num_samples): it moves to the new plan
+            carried = self._engine.dc_estimate if self._engine is not None else None
             self._gpu_release()
             self._engine = SpectrumEngine(nfft, max_frames=1, device=self._gpu_device)
             self._engine_n = nfft
             self._engine_dirty = True
+            if carried:
+                self._engine.dc_estimate = carried
         return self._engine
 
     def _gpu_configure(self, nfft: int, window: np.ndarray, *, branch: str, use_psd: bool,

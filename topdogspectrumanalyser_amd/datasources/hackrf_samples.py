@@ -425,7 +425,9 @@ class HackrfSamplesDataSource(GpuSpectrumMixin, SampleDataSource):
             self.running = False
             self._halt.set()
             self._park_reader(0.5, yank_device=False)
-            self._flush_buffers()
+            self._flush_buffers()     # also drops the DC estimate: the reference saves and restores it around the
+            #                           restart (hackrf_samples.py:473-482) but its _start_internal flushes again
+            #                           (:615), so the estimate does start from zero after a retune there too
         if sample_rate is not None:
             self.sample_rate = self.last_sample_rate = sample_rate
         if centre_freq is not None:

@@ -173,6 +173,11 @@ class SpectrumEngine:
         nat.check(nat.lib.tdsa_get_dc(self._h, C.byref(re), C.byref(im)))
         return complex(re.value, im.value)
 
+    @dc_estimate.setter
+    def dc_estimate(self, value: complex) -> None:
+        value = complex(value)
+        nat.check(nat.lib.tdsa_set_dc(self._h, float(value.real), float(value.imag)))
+
     def info(self) -> nat.Info:
         inf = nat.Info()
         nat.check(nat.lib.tdsa_get_info(self._h, C.byref(inf)))
