@@ -231,6 +231,59 @@ def test_hackrf_source_dc_estimate_across_resize_and_retune(pkg):
         live.stop()
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TDSA_SOURCE_CASES", "6"))))
+def test_hackrf_source_random_knob_histories(pkg, seed):
+    """Random histories of the HackRF source's DSP knobs between frames - FFT size, averaging mode / length / reset,
+    PSD, DC alpha - against the float64 oracle of get_power_levels put through the same history."""
+    rng = np.random.default_rng(6000 + seed)
+    iq = so.synth_iq_int8(1 << 19, 1024, seed=int(rng.integers(1, 1 << 30)))
+    x = so.unpack_iq_int8(iq)
+    fs = 20_000_000
+    n = 1024
+    src = pkg.HackrfSamplesDataSource(sample_rate=fs, centre_freq=100_000_000)
+    src.num_samples = n
+    src.running = True
+    src._allocate_fft_resources()
+    br = so.HackrfBranchOracle(n, float(fs), dc_alpha=1.0, precision="gold")
+    pos = 0
+    for step in range(120):
+        ev = rng.random()
+        if ev < 0.08:
+            new_n = int(rng.choice([256, 1024, 2048, 8192]))
+            if new_n != n:
+                n = new_n
+                src.set_num_samples(n)
+                nb = so.HackrfBranchOracle(n, float(fs), dc_alpha=br.dc_alpha, use_psd=br.use_psd, precision="gold")
+                nb.dc_estimate = br.dc_estimate                  # survives the size change (hackrf_samples.py:392-405)
+                nb.averager.set_mode(br.averager.mode, br.averager.n)   # set_num_samples resets the averager
+                br = nb
+        elif ev < 0.16:
+            mode = [("off", 1), ("exp", int(rng.integers(2, 9))), ("lin", int(rng.integers(2, 12)))][int(rng.integers(0, 3))]
+            src.set_averaging(*mode)
+            br.averager.set_mode(*mode)
+        elif ev < 0.20:
+            src.reset_averaging()
+            br.averager.reset()
+        elif ev < 0.26:
+            psd = bool(rng.integers(0, 2))
+            src.set_psd_mode(psd)
+            br.use_psd = psd
+        elif ev < 0.32:
+            a = float(rng.choice([1.0, 0.25, 0.05]))
+            src.set_dc_alpha(a)
+            br.dc_alpha = a
+        if pos + n > len(x):
+            pos = 0
+        fr = x[pos: pos + n]
+        pos += n
+        src._reservoir = np.array(fr, copy=True)
+        p, fb = src.get_power_levels()
+        gold = np.asarray(br.power_levels(fr), dtype=np.float64)
+        _check(p, gold, f"seed {seed} step {step}: n {n} avg {br.averager.mode},{br.averager.n} psd {br.use_psd} alpha {br.dc_alpha}")
+        assert p.shape == (n,) and fb.shape == (n,)
+    src.running = False
+
+
 def test_hackrf_source_streaming_front_end(pkg):
     """start() with an injected device: reader thread + freshest-chunk framing + hold-last-good."""
     from topdogspectrumanalyser_amd.datasources.replay import ReplayHackRF
@@ -337,6 +390,54 @@ def test_rtl_source_class_golden(pkg, golden_dir, mode):
         _check(p, g[mode][k], f"rtl {mode} frame {k}")
         assert np.array_equal(fb, g["freq_bins"])
     src.stop()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TDSA_SOURCE_CASES", "6"))))
+def test_rtl_source_random_knob_histories(pkg, seed):
+    """Random histories of the RTL source's knobs between frames - FFT size (which silently reverts the window to
+    Hanning, rtl_samples.py:213), window type, PSD, averaging - against the float64 oracle through the same history."""
+    from topdogspectrumanalyser_amd.datasources.replay import ReplayRtlSdr
+    rng = np.random.default_rng(6500 + seed)
+    iq = so.synth_iq_int8(1 << 18, 1024, seed=int(rng.integers(1, 1 << 30)))
+    x = so.unpack_iq_int8(iq)
+    fs, fc = 2_048_000.0, 100e6
+    src = pkg.RtlSamplesDataSource(sample_rate=int(fs), centre_freq=int(fc), device_factory=lambda: ReplayRtlSdr(iq, fs, fc))
+    src.start()
+    n = 1024
+    src.set_fft_size(n)
+    br = so.RtlBranchOracle(n, fs, "hanning", precision="gold")
+    pos = 0
+    try:
+        for step in range(100):
+            ev = rng.random()
+            if ev < 0.08:
+                new_n = int(rng.choice([256, 1024, 4096]))
+                if new_n != n:
+                    n = new_n
+                    src.set_fft_size(n)
+                    nb = so.RtlBranchOracle(n, fs, "hanning", use_psd=br.use_psd, precision="gold")   # (sic) Hanning again
+                    nb.averager.set_mode(br.averager.mode, br.averager.n)
+                    br = nb
+            elif ev < 0.16:
+                w = str(rng.choice(["hanning", "hamming", "rectangle"]))
+                src.set_window_type(w)
+                br.window = so.rtl_window(w, n)
+            elif ev < 0.24:
+                mode = [("off", 1), ("exp", int(rng.integers(2, 9))), ("lin", int(rng.integers(2, 12)))][int(rng.integers(0, 3))]
+                src.set_averaging(*mode)
+                br.averager.set_mode(*mode)
+            elif ev < 0.30:
+                psd = bool(rng.integers(0, 2))
+                src.set_psd_mode(psd)
+                br.use_psd = psd
+            idx = (pos + np.arange(n)) % len(x)
+            pos = (pos + n) % len(x)
+            p, fb = src.get_power_levels()
+            gold = np.asarray(br.power_levels(x[idx]), dtype=np.float64)
+            _check(p, gold, f"seed {seed} step {step}: n {n} avg {br.averager.mode},{br.averager.n} psd {br.use_psd}")
+            assert p.dtype == np.float64 and fb.shape == (n,)
+    finally:
+        src.stop()
 
 
 # ------------------------------------------------------------------------------------------------
