@@ -141,8 +141,9 @@ int tdsa_process_dev(tdsa_plan p, int in_format, const void* iq_dev, size_t n_sa
                      int n_frames, float* out_db_dev);
 
 /* Real-input path of MicrophoneSamplesDataSource (datasources/audio_samples.py:121-184): frames of
- * stereo float32 samples [L0,R0,L1,R1,...]; both channels ride ONE complex FFT (z = L + iR) and are
- * separated afterwards.  Per frame: mean removal, window, N-point FFT, one-sided power with the
+ * stereo float32 samples [L0,R0,L1,R1,...]; every real signal of a frame (the mono mix, left, right - both for
+ * stereo) is transformed on its own as signal + 0i, so a loud channel leaves nothing in a quiet one, as in the
+ * reference.  Per frame: mean removal, window, N-point FFT, one-sided power with the
  * non-DC / non-Nyquist bins doubled (:131), PSD scale, TraceAverager, 10*log10(. + floor).
  * channel: TDSA_CH_MONO ((L+R)/2), _LEFT, _RIGHT -> out [n_frames][N/2+1];
  *          TDSA_CH_STEREO -> out [n_frames][2][N/2+1] (left averaged, right not, as :158-171).

@@ -1214,6 +1214,98 @@ def test_audio_stereo_and_averaging(pkg, golden_dir):
     src.stop()
 
 
+def test_audio_quiet_channel_is_not_polluted(pkg):
+    """Each channel is transformed on its own (as the reference does): a channel 80 dB below the other, or silent,
+    keeps the same parity as a loud one.  (A packed z = L + iR transform leaves ~1e-7 of the louder channel's
+    amplitude in the quieter one: 5.7 dB of error at -80 dB.)"""
+    n, fs = 4096, 48000
+    rng = np.random.default_rng(1)
+    t = np.arange(n)
+    win = so.rtl_window("hanning", n)
+    for ratio in (1.0, 1e-2, 1e-4, 0.0):
+        left = 0.5 * np.sin(2 * np.pi * 1000.3 * t / fs)
+        right = ratio * 0.5 * np.sin(2 * np.pi * 3333.1 * t / fs) + 1e-6 * rng.standard_normal(n)
+        st = np.stack([left, right], axis=1).astype(np.float32)
+        with pkg.SpectrumEngine(n, max_frames=1) as e:
+            e.set_window(win.astype(np.float32))
+            e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=1.0)
+            gold_r = so.audio_db(so.audio_compute_power(st[:, 1].astype(np.float64), win, n, fs, False, precision="gold"), False)
+            gold_l = so.audio_db(so.audio_compute_power(st[:, 0].astype(np.float64), win, n, fs, False, precision="gold"), False)
+            _check(e.process_real2(st, "right")[0], gold_r, f"right alone, level ratio {ratio}")
+            both = e.process_real2(st, "stereo")[0]
+            _check(both[1], gold_r, f"stereo right, level ratio {ratio}")
+            _check(both[0], gold_l, f"stereo left, level ratio {ratio}")
+
+
+class _EndlessStream:
+    """a stereo float32 stream that hands out consecutive blocks of whatever length is asked for"""
+
+    def __init__(self, data):
+        self._d, self._pos = data, 0
+
+    def start(self): pass
+    def stop(self): pass
+    def close(self): pass
+
+    def read(self, n):
+        idx = (self._pos + np.arange(n)) % len(self._d)
+        self._pos = (self._pos + n) % len(self._d)
+        return np.array(self._d[idx], copy=True), False
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TDSA_SOURCE_CASES", "6"))))
+def test_audio_source_random_histories(pkg, seed):
+    """Microphone source with short blocks and the rolling window of audio_samples.py:149-156 (low sample rate: a
+    30 ms read is shorter than the FFT), channel mode / PSD / averaging changed between ticks: against the float64
+    restatement fed the same rolling buffer."""
+    rng = np.random.default_rng(6800 + seed)
+    fs = int(rng.choice([8000, 16000, 48000]))
+    n = int(rng.choice([256, 1024, 2048]))
+    t = np.arange(1 << 16)
+    data = np.stack([0.3 * np.sin(2 * np.pi * 440.0 * t / fs) + 0.01 * rng.standard_normal(len(t)) + 0.02,
+                     0.1 * np.sin(2 * np.pi * 1234.5 * t / fs) + 0.02 * rng.standard_normal(len(t))], axis=1).astype(np.float32)
+    src = pkg.MicrophoneSamplesDataSource(sample_rate=fs, stream_factory=lambda rate, block: _EndlessStream(data))
+    src.set_fft_size(n)
+    src.start(None)
+    block = src._audio_block
+    assert block == min(n, max(64, int(fs * 30 / 1000)))
+    win = so.rtl_window("hanning", n)
+    av = so.TraceAveragerOracle()
+    chan, psd = "mono", False
+    buf = np.zeros((n, 2), dtype=np.float64)
+    pos = 0
+    try:
+        for step in range(60):
+            ev = rng.random()
+            if ev < 0.12:
+                chan = str(rng.choice(["mono", "left", "right", "stereo"]))
+                src.set_channel_mode(chan)
+            elif ev < 0.20:
+                psd = bool(rng.integers(0, 2))
+                src.set_psd_mode(psd)
+            elif ev < 0.30:
+                mode = [("off", 1), ("exp", int(rng.integers(2, 7))), ("lin", int(rng.integers(2, 9)))][int(rng.integers(0, 3))]
+                src.set_averaging(*mode)
+                av.set_mode(*mode)
+            idx = (pos + np.arange(block)) % len(data)
+            pos = (pos + block) % len(data)
+            raw = data[idx].astype(np.float64)
+            buf = np.concatenate([buf[block:], raw]) if block < n else raw
+            res, axis = src.get_power_levels()
+            sig = {"mono": (buf[:, 0] + buf[:, 1]) * 0.5, "left": buf[:, 0], "right": buf[:, 1], "stereo": buf[:, 0]}[chan]
+            gold = so.audio_db(np.asarray(av.process(so.audio_compute_power(sig, win, n, fs, psd, precision="gold"))), psd)
+            what = f"seed {seed} step {step}: fs {fs} n {n} block {block} {chan} psd {psd} avg {av.mode},{av.n}"
+            if chan == "stereo":
+                left, right = res
+                _check(left, gold, what + " left")
+                _check(right, so.audio_db(so.audio_compute_power(buf[:, 1], win, n, fs, psd, precision="gold"), psd), what + " right")
+            else:
+                _check(res, gold, what)
+            assert axis.shape == (n // 2 + 1,)
+    finally:
+        src.stop()
+
+
 def test_real2_batch_matches_per_frame(pkg):
     n, nf = 2048, 6
     rng = np.random.default_rng(3)

@@ -66,6 +66,8 @@ struct tdsa_plan_s {
   float* d_lin = nullptr;                // [max_frames][N] linear power scratch (averaging modes)
   double* d_carry = nullptr;             // [ceil(max_frames/64)][N] chunk carries of the averager scan
   float2* d_cplx = nullptr;              // [max_frames][N] complex spectra (real-input path)
+  float2* d_real = nullptr;              // real-input path: the selected signal(s) as complex streams (two for stereo)
+  size_t real_bytes = 0;
   float* d_lin1 = nullptr;               // [max_frames][2][N/2+1] one-sided linear power (real-input path)
   float* d_db1 = nullptr;                // same shape, dB
   float2* d_dc_state = nullptr;
@@ -404,7 +406,7 @@ int tdsa_destroy(tdsa_plan p) {
     if (a) (void)hipStreamSynchronize(a);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   void* bufs[] = {p->d_window[0], p->d_window[1], p->d_window[2], p->d_tw, p->d_hold_max, p->d_hold_min,
-                  p->d_avg, p->d_lin, p->d_carry, p->d_cplx, p->d_lin1, p->d_db1, p->d_dc_state, p->d_sums, p->d_dc_sub,
+                  p->d_avg, p->d_lin, p->d_carry, p->d_cplx, p->d_real, p->d_lin1, p->d_db1, p->d_dc_state, p->d_sums, p->d_dc_sub,
                   p->d_tare_base, p->d_tare_acc, p->d_in_stage, p->d_out_stage, p->d_trace_in,
                   p->d_trace_live, p->d_scratch, p->d_z, p->d_acc, p->d_sum, p->d_lin64, p->d_sums64, p->d_tw_hi, p->d_tw_lo, p->d_tw_row, p->d_ones,
                   p->d_dbg};
@@ -727,22 +729,37 @@ int tdsa_process_real2(tdsa_plan p, const float* lr_host, size_t n_samples, int 
   if (!p->d_cplx) HIPCHK(hipMalloc(&p->d_cplx, size_t(p->max_frames) * n * sizeof(float2)));
   if (!p->d_lin1) HIPCHK(hipMalloc(&p->d_lin1, size_t(p->max_frames) * 2 * nb * sizeof(float)));
   if (!p->d_db1) HIPCHK(hipMalloc(&p->d_db1, size_t(p->max_frames) * 2 * nb * sizeof(float)));
+  const int n_sig = channel == TDSA_CH_STEREO ? 2 : 1;
+  if (in_bytes * n_sig > p->real_bytes) {
+    HIPCHK(hipStreamSynchronize(p->stream));
+    if (p->d_real) HIPCHK(hipFree(p->d_real));
+    p->d_real = nullptr;
+    p->real_bytes = 0;
+    HIPCHK(hipMalloc(&p->d_real, in_bytes * n_sig));
+    p->real_bytes = in_bytes * n_sig;
+  }
   HIPCHK(hipMemcpyAsync(p->d_in_stage, lr_host, in_bytes, hipMemcpyHostToDevice, p->stream));
-  SpecParams sp{};
-  sp.in = p->d_in_stage;
-  sp.frame_stride = (long long)hop * sizeof(float2);
-  sp.n_frames = n_frames;
-  sp.first_frame_index = 1;
-  sp.window = p->d_window[TDSA_IN_C64];
-  sp.tw = p->d_tw;
-  sp.out_cplx = p->d_cplx;
-  sp.in_scale = 1.0f;
-  sp.dc_mode = DC_FRAME_MEAN;                       // signal - signal.mean()  (audio_samples.py:123)
-  sp.db_mode = TDSA_DB_POW;
-  sp.pscale = 1.0f;
-  const LaunchGeom g = spectrum_geometry(p->log2n, n_frames, p->num_cu);
-  HIPCHK(launch_spectrum(p->log2n, 1, sp, g, p->stream));
-  HIPCHK(launch_real_fold(p->d_cplx, n, n_frames, channel, m.power_scale, p->d_lin1, p->stream));
+  // one transform per real signal (no left / right packing: see real_select_kernel)
+  float2* const za = p->d_real;
+  float2* const zb = p->d_real + need;
+  HIPCHK(launch_real_select(static_cast<const float2*>(p->d_in_stage), need, channel, za, zb, p->stream));
+  for (int sig = 0; sig < n_sig; ++sig) {
+    SpecParams sp{};
+    sp.in = sig == 0 ? za : zb;
+    sp.frame_stride = (long long)hop * sizeof(float2);
+    sp.n_frames = n_frames;
+    sp.first_frame_index = 1;
+    sp.window = p->d_window[TDSA_IN_C64];
+    sp.tw = p->d_tw;
+    sp.out_cplx = p->d_cplx;
+    sp.in_scale = 1.0f;
+    sp.dc_mode = DC_FRAME_MEAN;                     // signal - signal.mean()  (audio_samples.py:123)
+    sp.db_mode = TDSA_DB_POW;
+    sp.pscale = 1.0f;
+    const LaunchGeom g = spectrum_geometry(p->log2n, n_frames, p->num_cu);
+    HIPCHK(launch_spectrum(p->log2n, 1, sp, g, p->stream));
+    HIPCHK(launch_real_fold(p->d_cplx, n, n_frames, n_sig, sig, m.power_scale, p->d_lin1, p->stream));
+  }
   const int rows = channel == TDSA_CH_STEREO ? 2 * n_frames : n_frames;
   if (avg_active(m)) {
     AvgParams ap{};

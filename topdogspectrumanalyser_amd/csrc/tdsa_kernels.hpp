@@ -121,8 +121,9 @@ hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s);
 
 // ---- real-input (audio) path: two real channels ride one complex FFT (z = left + i*right) ----
 // channel: 0 mono ((L+R)/2), 1 left, 2 right, 3 stereo (rows 2f = left, 2f+1 = right)
-hipError_t launch_real_fold(const float2* spec, int n, int n_frames, int channel, float pscale, float* lin,
-                            hipStream_t s);
+hipError_t launch_real_select(const float2* lr, size_t count, int channel, float2* za, float2* zb, hipStream_t s);
+hipError_t launch_real_fold(const float2* spec, int n, int n_frames, int rows_per_frame, int row, float pscale,
+                            float* lin, hipStream_t s);
 hipError_t launch_lin_to_db(const float* lin, size_t count, float log_floor, float cal_db, float* out_db,
                             hipStream_t s);
 

@@ -8,8 +8,9 @@ Nyquist doubled, `10*log10(P + 1e-10)` or PSD `10*log10(P/(fs*N) + 1e-12)`; chan
 mono / left / right / stereo, where stereo returns a (left, right) pair and only the LEFT trace goes
 through the averager; a source that is not running, or a block that fails, yields a flat -120 dB row.
 
-On the GPU both channels ride ONE complex FFT (z = left + i*right) and are pulled apart afterwards
-(`real_fold_kernel`, `tdsa_process_real2` in include/tdsa_hip.h).  The stream object comes from
+On the GPU every real signal a tick needs (mono mix, left, right) is transformed on its own as signal + 0i
+(`real_select_kernel` / `real_fold_kernel`, `tdsa_process_real2` in include/tdsa_hip.h): a loud channel leaves
+nothing in a quiet one.  The stream object comes from
 `sounddevice` when it is installed, else from `stream_factory(sample_rate, blocksize)` - anything with
 start / stop / close / read(n) -> (frames, overflowed).
 """
