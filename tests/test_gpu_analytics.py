@@ -233,6 +233,61 @@ def test_waterfall_ring_matches_restatement(pkg, an):
             wf.push(base[0][:10])
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TDSA_WATERFALL_CASES", "8"))))
+def test_waterfall_ring_random(pkg, an, seed):
+    """Seeded random update streams (repeated rows, NaN rows, batches shorter and longer than the history, host and
+    device entry points mixed): pointer, number of new rows and the displayed view against the restatement."""
+    rng = np.random.default_rng(700 + seed)
+    H, W = int(rng.integers(1, 40)), int(rng.choice([16, 100, 1000, 1024]))
+    pool = rng.normal(-90, 5, size=(12, W)).astype(np.float32)
+    pool[3, rng.integers(0, W)] = np.nan
+    ref = ao.WaterfallOracle(H, W, -120.0)
+    with an.WaterfallRing(H, W, -120.0) as wf:
+        for _call in range(int(rng.integers(2, 12))):
+            k = int(rng.integers(1, 3 * H + 4))
+            picks = rng.integers(0, len(pool), k)
+            picks = np.repeat(picks, rng.integers(1, 3, k))[:k]          # runs of identical rows
+            rows = np.ascontiguousarray(pool[picks])
+            if rng.integers(0, 3) == 0:
+                for r in rows:
+                    assert wf.push(r) == ref.update(r)
+            else:
+                want = sum(ref.update(r) for r in rows)
+                with DevRows(pkg, rows) as d:
+                    assert wf.push_rows(None, d, len(rows)) == want
+            assert wf.ptr == ref.ptr
+            assert np.array_equal(wf.view(), ref.view(), equal_nan=True), (seed, H, W)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TDSA_STATS_CASES", "8"))))
+def test_rows_stats_random(pkg, an, seed):
+    """Seeded random rows (ties at the maximum, NaNs, -inf, bands of every width incl. empty and out of range):
+    peak value, argmax (numpy's first-index / first-NaN rules) and band power against numpy."""
+    rng = np.random.default_rng(800 + seed)
+    n = int(2 ** rng.integers(6, 15))
+    nr = int(rng.integers(1, 20))
+    rows = rng.normal(-80, 10, size=(nr, n)).astype(np.float32)
+    if rng.integers(0, 2):
+        rows = np.round(rows)                                   # ties
+    for _ in range(int(rng.integers(0, 5))):
+        rows[rng.integers(0, nr), rng.integers(0, n)] = rng.choice(np.array([np.nan, -np.inf, 30.0], dtype=np.float32))
+    bins = np.linspace(100e6, 120e6, n)
+    a, b = sorted(rng.uniform(95e6, 125e6, 2))
+    if rng.integers(0, 6) == 0:
+        a, b = 130e6, 140e6                                     # no bin inside
+    with pkg.SpectrumEngine(max(n, 64), max_frames=1) as e, DevRows(pkg, rows) as d:
+        peak, pbin, bdb = an.rows_stats(e, d, nr, n_bins=n, freq_bins=bins, band=(a, b))
+    for r in range(nr):
+        want_bin = int(np.argmax(rows[r]))
+        assert pbin[r] == want_bin, (seed, r)
+        assert (np.isnan(peak[r]) and np.isnan(rows[r][want_bin])) or peak[r] == rows[r][want_bin]
+        ref = ao.band_power_db(bins, rows[r], a, b)
+        if ref is None:
+            assert np.isnan(bdb[r])
+        else:
+            assert (np.isnan(ref) and np.isnan(bdb[r])) or abs(bdb[r] - ref) <= 1e-4, (seed, r, bdb[r], ref)
+
+
 @pytest.mark.parametrize("mode", ["medium", "fast", "off"])
 def test_density_histogram_matches_reference_fixture(pkg, an, golden_dir, mode):
     """density_kernel against DensityDisplay._update_hist of the imported reference (displays.npz): NaN,

@@ -111,7 +111,8 @@ __global__ void __launch_bounds__(256) rows_stats_kernel(const float* __restrict
     if (peak_bin) peak_bin[blockIdx.x] = best.i;
     if (band_db) {
       const double total = bsum * bin_width;
-      band_db[blockIdx.x] = band_lo > band_hi ? NAN : 10.0 * log10(total > 1e-30 ? total : 1e-30);
+      // Python's max(total, 1e-30) keeps a NaN total (1e-30 > nan is False): so does `total < 1e-30 ? ... : total`
+      band_db[blockIdx.x] = band_lo > band_hi ? NAN : 10.0 * log10(total < 1e-30 ? 1e-30 : total);
     }
   }
 }
