@@ -1796,3 +1796,29 @@ def test_process_sharded_threads(pkg, world):
         process_sharded(iq, nfft, hop, [0], w, avg=("exp", 4))
     short, _, _ = process_sharded(iq[: 2 * 100], nfft, hop, [0, 0], w)
     assert short.shape == (0, nfft)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TDSA_SHARD_CASES", "6"))))
+def test_process_sharded_random(pkg, seed):
+    """Seeded random captures split over 1 .. 9 shards (more shards than frames included; int8 and complex64; any
+    hop; DC per frame or off): rows and hold traces bit for bit the unsharded result."""
+    from topdogspectrumanalyser_amd.sharding import process_sharded
+    rng = np.random.default_rng(9500 + seed)
+    nfft = int(2 ** rng.integers(6, 14))
+    hop = int(rng.choice([nfft, nfft // 2, int(rng.integers(1, 2 * nfft))]))
+    nf = int(rng.integers(1, 60))
+    world = int(rng.integers(1, 10))
+    dc_alpha = float(rng.choice([1.0, -1.0]))
+    iq = so.synth_iq_int8(hop * (nf - 1) + nfft + int(rng.integers(0, hop)), nfft, seed=int(rng.integers(1, 1 << 30)))
+    data = iq if rng.integers(0, 2) else so.unpack_iq_int8(iq)
+    w = so.hackrf_window(nfft)
+    with pkg.SpectrumEngine(nfft, max_frames=nf) as e:
+        e.set_window(w)
+        e.configure(db_mode="mag", log_floor=so.LOG_FLOOR, dc_alpha=dc_alpha, hold_max=True, hold_min=True)
+        ref = e.process(data, hop=hop, n_frames=nf)
+        rmx, rmn = e.hold()
+    rows, mx, mn = process_sharded(data, nfft, hop, [0] * world, w, hold="maxmin", db_mode="mag",
+                                   log_floor=so.LOG_FLOOR, dc_alpha=dc_alpha)
+    assert rows.shape == ref.shape and np.array_equal(rows, ref), (seed, nfft, hop, nf, world)
+    assert np.array_equal(mx, rmx) and np.array_equal(mn, rmn)
+
