@@ -648,6 +648,35 @@ def test_trace_averager_golden(pkg, golden_dir):
         assert np.allclose(av.process(g["frames"][3]), g["frames"][3])   # first frame after reset == input
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TDSA_AVERAGER_CASES", "8"))))
+def test_trace_averager_random_histories(pkg, seed):
+    """TraceAverager (host-array API of utils/signal_processing.py:5-73) through random histories - mode / length
+    changes, resets, shape changes, 2-D inputs, huge and tiny values, NaN bins - against the reference's arithmetic
+    restated in float64 numpy."""
+    rng = np.random.default_rng(4400 + seed)
+    av, ref = pkg.TraceAverager(), so.TraceAveragerOracle()
+    shape = (256,)
+    for step in range(80):
+        ev = rng.random()
+        if ev < 0.10:
+            mode = [("off", 1), ("exp", int(rng.integers(1, 10))), ("lin", int(rng.integers(1, 12)))][int(rng.integers(0, 3))]
+            av.set_mode(*mode)
+            ref.set_mode(*mode)
+        elif ev < 0.15:
+            av.reset()
+            ref.reset()
+        elif ev < 0.20:
+            shape = [(256,), (1000,), (3, 64), (1,)][int(rng.integers(0, 4))]
+        x = (10.0 ** rng.uniform(-12, 3, size=shape)).astype(np.float32)
+        if rng.random() < 0.05:
+            x.flat[int(rng.integers(0, x.size))] = np.nan
+        got = av.process(x)
+        want = ref.process(x)
+        assert np.shape(got) == np.shape(want), (seed, step)
+        assert av.is_active == ref.is_active
+        assert np.allclose(got, want, rtol=1e-6, atol=0, equal_nan=True), (seed, step, ref.mode, ref.n)
+
+
 # ------------------------------------------------------------------------------------------------
 # size-independent properties at BASELINE.json's full shapes
 # ------------------------------------------------------------------------------------------------
