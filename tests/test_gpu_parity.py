@@ -1687,7 +1687,15 @@ def call_sequence_trial(pkg, trial, report=None):
     dc_alpha = float(rng.choice([1.0, 1.0, 0.3]))
     max_call, total = 12, 90
     iq = so.synth_iq_int8(hop * (total - 1) + nfft, nfft, seed=int(rng.integers(1, 1 << 30)))
-    x = so.unpack_iq_int8(iq)
+    fmt = str(rng.choice(["i8", "u8", "c64"]))           # the three input formats of the C-ABI
+    if fmt == "i8":
+        raw, x, per = iq, so.unpack_iq_int8(iq), 2
+    elif fmt == "u8":
+        raw = (iq.astype(np.int16) + 128).astype(np.uint8)
+        x, per = so.unpack_iq_uint8_rtl(raw), 2
+    else:
+        raw = so.unpack_iq_int8(iq)
+        x, per = raw, 1
     br = so.HackrfBranchOracle(nfft, fs, dc_alpha, psd, "gold")
     hold = so.HoldOracle(True, True)
     cal, tare = 0.0, None
@@ -1719,7 +1727,7 @@ def call_sequence_trial(pkg, trial, report=None):
                 e.set_tare_baseline(tare)
             else:
                 k = int(min(rng.integers(1, max_call + 1), total - pos))
-                out = e.process(iq[2 * hop * pos: 2 * (hop * (pos + k - 1) + nfft)], hop=hop, n_frames=k)
+                out = e.process(raw[per * hop * pos: per * (hop * (pos + k - 1) + nfft)], hop=hop, n_frames=k)
                 gold = np.empty((k, nfft))
                 for j in range(k):
                     g = np.asarray(br.power_levels(so.frame(x, nfft, hop, pos + j)), dtype=np.float64) + cal
