@@ -326,6 +326,59 @@ class _ScriptedHackRF:
         return getattr(self._inner, name)
 
 
+def test_hackrf_source_concurrent_setters_and_reads(pkg):
+    """The GUI thread turns knobs (FFT size incl. a long frame, averaging, PSD, DC alpha, retune) while the display
+    timer keeps asking for frames and the reader thread keeps feeding: nothing raises, nothing hangs, every answer
+    has the size that was current when it was produced."""
+    import threading
+    from topdogspectrumanalyser_amd.datasources.replay import ReplayHackRF
+    iq = so.synth_iq_int8(1 << 18, 1024, seed=23)
+    src = pkg.HackrfSamplesDataSource(sample_rate=20_000_000, centre_freq=100_000_000,
+                                      device_factory=lambda: ReplayHackRF(iq))
+    src.CONSUME_TIMEOUT = 0.2
+    src.start()
+    stop = threading.Event()
+    problems, answers = [], [0]
+
+    def timer():
+        try:
+            while not stop.is_set():
+                p, fb = src.get_power_levels()
+                if p.shape != fb.shape or p.ndim != 1:
+                    problems.append(("shape", p.shape, fb.shape))
+                answers[0] += 1
+        except Exception as exc:                      # get_power_levels never raises
+            problems.append(exc)
+
+    th = threading.Thread(target=timer, daemon=True)
+    th.start()
+    rng = np.random.default_rng(5)
+    t_end = time.time() + 2.0
+    try:
+        while time.time() < t_end:
+            op = int(rng.integers(0, 6))
+            if op == 0:
+                src.set_num_samples(int(rng.choice([256, 1024, 4096, 16384, 32768])))
+            elif op == 1:
+                src.set_averaging(str(rng.choice(["off", "exp", "lin"])), int(rng.integers(1, 9)))
+            elif op == 2:
+                src.set_psd_mode(bool(rng.integers(0, 2)))
+            elif op == 3:
+                src.set_dc_alpha(float(rng.choice([1.0, 0.25])))
+            elif op == 4:
+                src.update_centre_frequency(int(100_000_000 + rng.integers(0, 5) * 1_000_000))
+            else:
+                src.reset_averaging()
+            time.sleep(0.01)
+    finally:
+        stop.set()
+        th.join(timeout=5.0)
+        src.stop()
+    assert not th.is_alive(), "display-timer thread hung"
+    assert not problems, problems[:3]
+    assert answers[0] > 10
+
+
 def test_hackrf_source_holds_last_good_frame(pkg):
     """a3 (hackrf_samples.py:351-355): a silent frame and an underrun both return the PREVIOUS trace
     object; before any good frame they return zeros; a good frame afterwards replaces it."""
