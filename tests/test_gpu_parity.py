@@ -1912,3 +1912,49 @@ def test_process_sharded_random(pkg, seed):
     assert rows.shape == ref.shape and np.array_equal(rows, ref), (seed, nfft, hop, nf, world)
     assert np.array_equal(mx, rmx) and np.array_equal(mn, rmn)
 
+
+def test_no_device_memory_left_behind(pkg):
+    """Plans, pipes, trace objects and display accumulators created, used through their lazily allocating paths
+    (averaging, real input, long frames, analytics scratch) and closed, many times: the free device memory comes back."""
+    import torch
+    from topdogspectrumanalyser_amd import analytics as an
+
+    def cycle(i):
+        rng = np.random.default_rng(i)
+        nfft = int(2 ** rng.integers(6, 17))
+        nf = 1 if nfft > 16384 else int(rng.integers(1, 40))
+        iq = so.synth_iq_int8(nfft * nf, nfft, seed=i)
+        with pkg.SpectrumEngine(nfft, max_frames=max(nf, 130)) as e:
+            e.set_window(so.hackrf_window(nfft))
+            e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=0.5, avg=("exp", 4),
+                        hold_max=True)
+            e.process(iq, hop=nfft, n_frames=nf if nfft <= 16384 else 1)
+            if nfft <= 16384:
+                e.configure(avg=("off", 1), dc_alpha=1.0)
+                st = rng.standard_normal((nfft * 2, 2)).astype(np.float32)
+                e.process_real2(st, "stereo")
+                with e.pipe(nfft * nf, n_slots=2) as q:
+                    q.acquire()[: iq.size] = iq
+                    q.submit(nfft * nf, nfft, nf)
+                    rows = q.collect()
+                    assert rows.shape == (nf, nfft)
+                e.set_overlap(3)
+        with an.DensityHistogram(256, 0.9) as dh, an.WaterfallRing(10, 256, -120.0) as wf:
+            dh.update(np.zeros(256, dtype=np.float32))
+            wf.push(np.zeros(256, dtype=np.float32))
+        av = pkg.TraceAverager()
+        av.set_mode("exp", 4)
+        av.process(np.ones(512, dtype=np.float32))
+
+    for i in range(3):
+        cycle(i)                                   # first-use allocations of the runtime itself
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for i in range(40):
+        cycle(100 + i)
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, f"{(free0 - free1) / 2**20:.1f} MiB of device memory not returned"
+
