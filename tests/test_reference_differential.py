@@ -1,0 +1,160 @@
+"""Live differential tests against the IMPORTED reference, for the host-side pieces of DataProcessor that carry no GPU
+work (peak search, NaN clean-up, zero-span view with its trigger, peak-list read-out).  They run where
+/root/reference exists (the build container) and are skipped elsewhere (the GPU box has no reference); the committed
+fixtures of tests/golden/ pin the same functions there.  Nothing is copied: both implementations are driven with
+the same seeded random inputs through plain stub objects and must agree exactly."""
+import os
+import sys
+import types
+from unittest.mock import MagicMock
+
+import numpy as np
+import pytest
+
+REF = os.environ.get("TDSA_REFERENCE", "/root/reference")
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "core")), reason="reference tree not present")
+
+
+@pytest.fixture(scope="module")
+def ref_dp():
+    sys.dont_write_bytecode = True                       # never leave __pycache__ in the reference tree
+    before = set(sys.modules)
+    mocked = [m for m in ("hackrf", "rtlsdr", "sounddevice") if m not in sys.modules]
+    for m in mocked:
+        sys.modules[m] = MagicMock()
+    sys.path.insert(0, REF)
+    try:
+        from core.display_data_processor import DataProcessor as RefDP
+    finally:
+        sys.path.remove(REF)
+        # leave no trace for the other test modules: neither the hardware stand-ins nor the reference's
+        # top-level packages (core, utils, datasources ...) stay importable by name
+        for m in set(sys.modules) - before:
+            del sys.modules[m]
+        for m in mocked:
+            sys.modules.pop(m, None)
+    return RefDP
+
+
+@pytest.fixture(scope="module")
+def our_dp():
+    from topdogspectrumanalyser_amd.core.display_data_processor import DataProcessor
+    return DataProcessor
+
+
+class _Label:
+    text = None
+
+    def setText(self, s):
+        self.text = s
+
+
+def _bare(cls, mw, dm):
+    dp = cls.__new__(cls)
+    dp.mw, dp.dm = mw, dm
+    for k, v in dict(_fused=None, _sweeps_since_axis_refresh=0, reference_hold_alias=False,
+                     _holds_share_buffer=False).items():
+        setattr(dp, k, v)
+    return dp
+
+
+def test_find_top_peaks_random(ref_dp, our_dp):
+    rng = np.random.default_rng(11)
+    for case in range(400):
+        n = int(rng.integers(3, 3000))
+        p = rng.exponential(1.0, n) * 10.0 ** rng.uniform(-12, -6)
+        k = np.arange(n)
+        for _ in range(int(rng.integers(0, 6))):
+            p += 10.0 ** rng.uniform(-9, -2) * np.sinc((k - rng.integers(0, n)) / rng.uniform(0.6, 4.0)) ** 2
+        tr = (10 * np.log10(p + 1e-15)).astype(np.float32 if rng.integers(0, 2) else np.float64)
+        bins = np.linspace(88e6, 108e6, n)
+        kw = dict(n=int(rng.integers(1, 9)), min_sep_bins=int(rng.integers(1, 60)), min_excursion_db=float(rng.choice([3.0, 6.0, 10.0])))
+        want = ref_dp._find_top_peaks(bins, tr, **kw)
+        got = our_dp._find_top_peaks(bins, tr, **kw)
+        assert got == want, (case, kw)
+
+
+def test_nan_safe_random(ref_dp, our_dp):
+    rng = np.random.default_rng(12)
+    for case in range(200):
+        a = rng.normal(-70, 10, int(rng.integers(1, 500))).astype(np.float32 if rng.integers(0, 2) else np.float64)
+        if rng.integers(0, 2):
+            a[rng.integers(0, a.size, int(rng.integers(1, 4)))] = np.nan
+        fill = float(rng.choice([-500.0, 500.0]))
+        want, got = ref_dp._nan_safe(a, fill), our_dp._nan_safe(a, fill)
+        assert np.array_equal(got, want) and got.dtype == want.dtype
+        assert (got is a) == (want is a)                 # a clean array comes back as the same object in both
+
+
+def test_zero_span_random_histories(ref_dp, our_dp):
+    class W:
+        t = y = None
+
+        def update_zero_span_data(self, t, y):
+            self.t, self.y = np.array(t), np.array(y)
+
+    rng = np.random.default_rng(13)
+    for trial in range(30):
+        rate = float(rng.choice([8000.0, 44100.0, 2_000_000.0]))
+        pair = []
+        for cls in (ref_dp, our_dp):
+            src = types.SimpleNamespace(sample_rate=rate, block=None)
+            src.read_samples_only = (lambda s=src: s.block)
+            mw = types.SimpleNamespace(current_source=src, zero_span_widget=W())
+            dm = types.SimpleNamespace(zero_span_buffer=None, zero_span_time_window=0.01,
+                                       zero_span_trigger_mode="free_run", zero_span_trigger_level=0.0)
+            pair.append((_bare(cls, mw, dm), src, mw, dm))
+        for step in range(60):
+            ev = rng.random()
+            if ev < 0.2:
+                mode, level = str(rng.choice(["free_run", "rise", "fall"])), float(rng.uniform(-0.8, 0.8))
+                for _, _, _, dm in pair:
+                    dm.zero_span_trigger_mode, dm.zero_span_trigger_level = mode, level
+            elif ev < 0.3:
+                win = float(rng.choice([0.001, 0.01, 0.05, 0.5]))
+                for _, _, _, dm in pair:
+                    dm.zero_span_time_window = win
+            kind = int(rng.integers(0, 6))
+            m = int(rng.integers(1, 5000))
+            if kind == 0:
+                block = None
+            elif kind == 1:
+                block = np.zeros(0, dtype=np.complex64)
+            elif kind == 2:
+                block = (rng.standard_normal((m, 2)) * 0.5).astype(np.float32)          # stereo audio block
+            else:
+                t = np.arange(m)
+                block = (np.sin(2 * np.pi * rng.uniform(0.001, 0.2) * t + rng.uniform(0, 6)) * rng.uniform(0.1, 1.0)
+                         + 0.05 * rng.standard_normal(m) + 1j * rng.standard_normal(m)).astype(np.complex64)
+            for dp, src, _, _ in pair:
+                src.block = None if block is None else block.copy()
+                dp._process_zero_span_data()
+            (rw, ow) = (pair[0][2].zero_span_widget, pair[1][2].zero_span_widget)
+            assert (rw.y is None) == (ow.y is None), (trial, step)
+            if rw.y is not None:
+                assert np.array_equal(ow.y, rw.y) and np.array_equal(ow.t, rw.t), (trial, step)
+            rb, ob = pair[0][3].zero_span_buffer, pair[1][3].zero_span_buffer
+            assert (rb is None) == (ob is None) and (rb is None or np.array_equal(ob, rb)), (trial, step)
+
+
+def test_peak_list_readout_random(ref_dp, our_dp):
+    class TwoD:
+        peaks = None
+
+        def set_peak_list(self, peaks):
+            self.peaks = peaks
+
+    rng = np.random.default_rng(14)
+    for case in range(100):
+        n = int(rng.integers(16, 4096))
+        tr = (rng.normal(-90, 4, n) + 40 * (rng.random(n) < 0.01)).astype(np.float32)
+        bins = np.linspace(2.4e9, 2.5e9, n)
+        exc = float(rng.choice([3.0, 6.0, 8.0, 10.0]))
+        out = []
+        for cls in (ref_dp, our_dp):
+            mw = types.SimpleNamespace(two_d_widget=TwoD(), marker_readout_label=_Label(), peak_excursion=exc)
+            dp = _bare(cls, mw, types.SimpleNamespace(peak_list_enabled=True))
+            dp._update_peak_list(bins, tr)
+            out.append((mw.marker_readout_label.text, mw.two_d_widget.peaks))
+        assert out[0][0] == out[1][0], case
+        assert out[0][1] == out[1][1], case
