@@ -158,3 +158,138 @@ def test_peak_list_readout_random(ref_dp, our_dp):
             out.append((mw.marker_readout_label.text, mw.two_d_widget.peaks))
         assert out[0][0] == out[1][0], case
         assert out[0][1] == out[1][1], case
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# the ORACLE against the imported reference on random inputs: oracle/spectrum_oracle.py (precision="ref") has to be
+# np.array_equal to what the reference's own source classes return, frame by frame, through random knob histories -
+# the committed fixtures pin the same thing at fixed inputs, this pins it at thousands more
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def ref_sources():
+    sys.dont_write_bytecode = True
+    before = set(sys.modules)
+    mocked = [m for m in ("hackrf", "rtlsdr", "sounddevice") if m not in sys.modules]
+    for m in mocked:
+        sys.modules[m] = MagicMock()
+    sys.path.insert(0, REF)
+    try:
+        from datasources.hackrf_samples import HackrfSamplesDataSource
+        from datasources.rtl_samples import RtlSamplesDataSource
+        from datasources.audio_samples import MicrophoneSamplesDataSource
+        from utils.signal_processing import TraceAverager
+    finally:
+        sys.path.remove(REF)
+        for m in set(sys.modules) - before:
+            del sys.modules[m]
+        for m in mocked:
+            sys.modules.pop(m, None)
+    return types.SimpleNamespace(hackrf=HackrfSamplesDataSource, rtl=RtlSamplesDataSource,
+                                 audio=MicrophoneSamplesDataSource, averager=TraceAverager)
+
+
+def test_oracle_hackrf_branch_random_histories(ref_sources):
+    from oracle import spectrum_oracle as so
+    rng = np.random.default_rng(21)
+    for trial in range(12):
+        n = int(2 ** rng.integers(6, 13))
+        fs = 20_000_000
+        src = ref_sources.hackrf(sample_rate=fs, centre_freq=2_450_000_000)
+        src.num_samples = n
+        src.running = True
+        src._allocate_fft_resources()
+        br = so.HackrfBranchOracle(n, float(fs), precision="ref")
+        x = so.unpack_iq_int8(so.synth_iq_int8(n * 40, n, seed=int(rng.integers(1, 1 << 30))))
+        for k in range(40):
+            ev = rng.random()
+            if ev < 0.12:
+                mode = [("off", 1), ("exp", int(rng.integers(1, 9))), ("lin", int(rng.integers(1, 12)))][int(rng.integers(0, 3))]
+                src.set_averaging(*mode)
+                br.averager.set_mode(*mode)
+            elif ev < 0.18:
+                src.reset_averaging()
+                br.averager.reset()
+            elif ev < 0.26:
+                psd = bool(rng.integers(0, 2))
+                src.set_psd_mode(psd)
+                br.use_psd = psd
+            elif ev < 0.34:
+                a = float(rng.choice([1.0, 0.25, 0.05, 0.0]))
+                src.set_dc_alpha(a)
+                br.dc_alpha = a
+            fr = x[k * n:(k + 1) * n]
+            src._reservoir = np.array(fr, dtype=np.complex64, copy=True)
+            want, _ = src.get_power_levels()
+            got = br.power_levels(np.array(fr, copy=True))
+            assert np.asarray(got).dtype == np.asarray(want).dtype, (trial, k)
+            assert np.array_equal(got, want), (trial, k, n, br.averager.mode, br.use_psd, br.dc_alpha)
+        assert complex(br.dc_estimate) == complex(src._dc_estimate)
+
+
+def test_oracle_rtl_branch_random_histories(ref_sources):
+    from oracle import spectrum_oracle as so
+
+    class Sdr:
+        def __init__(self, x, fs, fc):
+            self.x, self.pos, self.fs, self.fc = x, 0, fs, fc
+
+        def read_samples(self, n):
+            out = self.x[self.pos: self.pos + n]
+            self.pos += n
+            return np.array(out, copy=True)
+
+        def get_sample_rate(self): return self.fs
+        def get_center_freq(self): return self.fc
+
+    rng = np.random.default_rng(22)
+    for trial in range(12):
+        n = int(2 ** rng.integers(6, 13))
+        fs, fc = 2_000_000.0, 100_300_000.0
+        x = so.unpack_iq_int8(so.synth_iq_int8(n * 40, n, seed=int(rng.integers(1, 1 << 30)))).astype(np.complex128)
+        src = ref_sources.rtl(sample_rate=int(fs), centre_freq=int(fc))
+        src.set_fft_size(n)
+        src.sdr = Sdr(x, fs, fc)
+        src.running = True
+        br = so.RtlBranchOracle(n, fs, "hanning", precision="ref")
+        for k in range(40):
+            ev = rng.random()
+            if ev < 0.12:
+                w = str(rng.choice(["hanning", "hamming", "rectangle"]))
+                src.set_window_type(w)
+                br.window = so.rtl_window(w, n)
+            elif ev < 0.24:
+                mode = [("off", 1), ("exp", int(rng.integers(1, 9))), ("lin", int(rng.integers(1, 12)))][int(rng.integers(0, 3))]
+                src.set_averaging(*mode)
+                br.averager.set_mode(*mode)
+            elif ev < 0.32:
+                psd = bool(rng.integers(0, 2))
+                src.set_psd_mode(psd)
+                br.use_psd = psd
+            want, _ = src.get_power_levels()
+            got = br.power_levels(x[k * n:(k + 1) * n])
+            assert np.array_equal(got, want), (trial, k, n, br.averager.mode, br.use_psd)
+
+
+def test_oracle_trace_averager_random_histories(ref_sources):
+    from oracle import spectrum_oracle as so
+    rng = np.random.default_rng(23)
+    for trial in range(40):
+        ref, ora = ref_sources.averager(), so.TraceAveragerOracle()
+        shape = (64,)
+        for step in range(60):
+            ev = rng.random()
+            if ev < 0.12:
+                mode = [("off", 1), ("exp", int(rng.integers(1, 10))), ("lin", int(rng.integers(1, 12)))][int(rng.integers(0, 3))]
+                ref.set_mode(*mode)
+                ora.set_mode(*mode)
+            elif ev < 0.18:
+                ref.reset()
+                ora.reset()
+            elif ev < 0.24:
+                shape = [(64,), (100,), (2, 32)][int(rng.integers(0, 3))]
+            xin = (10.0 ** rng.uniform(-12, 3, size=shape)).astype(np.float32 if rng.integers(0, 2) else np.float64)
+            want = np.array(ref.process(xin.copy()), copy=True)
+            got = np.array(ora.process(xin.copy()), copy=True)
+            assert got.dtype == want.dtype and np.array_equal(got, want), (trial, step)
+            assert ora.is_active == ref.is_active
+
