@@ -579,6 +579,86 @@ def test_data_processor_sequence_golden(pkg, golden_dir, holds):
     src.running = False
 
 
+class ProcessorModel:
+    """float64 model of display_data_processor.py:317-395 of the reference: + calibration offset, tare collect /
+    subtract (32 frames, cleared on a length change), fmax / fmin hold with the first frame adopted (NaN -> -500 /
+    +500) and a disabled hold dropped when the trace length changes.  Validated against the imported reference in
+    tests/test_reference_differential.py."""
+
+    def __init__(self, alias_quirk=False):
+        # alias_quirk: like the reference, a hold ADOPTS the frame object itself when it holds no NaN (_nan_safe
+        # returns its argument), so two holds adopting on the same frame share one array and from then on both
+        # just follow the live trace (SURVEY 8(a) quirk ii); False: independent running fmax / fmin (product default)
+        self.alias_quirk = alias_quirk
+        self.collect, self.buf, self.cnt, self.active, self.base = False, None, 0, False, None
+        self.max = self.min = None
+
+    def start_tare(self):
+        self.collect, self.buf, self.cnt = True, None, 0
+
+    def clear_tare(self):
+        self.collect, self.buf, self.cnt, self.active, self.base = False, None, 0, False, None
+
+    def frame(self, x, cal, max_on, min_on):
+        lv = np.asarray(x, dtype=np.float64) + (cal if cal != 0.0 else 0.0)
+        if self.collect:
+            lin = 10.0 ** (lv / 10.0)
+            if self.buf is None or self.buf.shape != lin.shape:
+                self.buf, self.cnt = lin.copy(), 1
+            else:
+                self.buf += lin
+                self.cnt += 1
+            if self.cnt >= 32:
+                self.base = 10.0 * np.log10(np.maximum(self.buf / self.cnt, 1e-30))
+                self.active, self.collect, self.buf, self.cnt = True, False, None, 0
+        if self.active and self.base is not None:
+            if lv.shape != self.base.shape:
+                self.active, self.base = False, None
+            else:
+                lv = lv - self.base
+        for which, on in (("max", max_on), ("min", min_on)):
+            cur = getattr(self, which)
+            if not on:
+                if cur is not None and cur.shape != lv.shape:
+                    cur = None
+            elif cur is None or cur.shape != lv.shape:
+                if self.alias_quirk and not np.isnan(lv).any():
+                    cur = lv                                  # the very object (and the other hold's, if it adopts too)
+                else:
+                    cur = np.where(np.isnan(lv), -500.0 if which == "max" else 500.0, lv)
+            elif which == "max":
+                np.fmax(cur, lv, out=cur)                     # in place, like the reference: an aliased partner sees it
+            else:
+                np.fmin(cur, lv, out=cur)
+            setattr(self, which, cur)
+        return lv
+
+
+def processor_history(rng, ticks=150):
+    """seeded random GUI history: yields (event, trace) per tick; events are ('max',), ('min',), ('tare',), ('clear',),
+    ('cal', value) or None"""
+    n = int(rng.choice([128, 256]))
+    for _ in range(ticks):
+        ev = rng.random()
+        event = None
+        if ev < 0.05:
+            event = ("max",)
+        elif ev < 0.10:
+            event = ("min",)
+        elif ev < 0.14:
+            event = ("tare",)
+        elif ev < 0.17:
+            event = ("clear",)
+        elif ev < 0.22:
+            event = ("cal", float(rng.choice([0.0, -0.8087, 3.5])))
+        elif ev < 0.25:
+            n = int(rng.choice([128, 256, 512]))
+        x = rng.normal(-70.0, 10.0, n).astype(np.float32)
+        if rng.random() < 0.1:
+            x[rng.integers(0, n)] = np.nan
+        yield event, x
+
+
 class _TraceSource:
     """stands in for a sample source: hands out prepared dB traces"""
 
@@ -591,8 +671,9 @@ class _TraceSource:
         return self.trace, self.axis
 
 
+@pytest.mark.parametrize("as_reference", [False, True])
 @pytest.mark.parametrize("seed", range(int(os.environ.get("TDSA_PROCESSOR_CASES", "6"))))
-def test_data_processor_random_events(pkg, seed):
+def test_data_processor_random_events(pkg, seed, as_reference):
     """Random GUI histories through DataProcessor._process_sample_data - holds switched on and off, tare runs
     started and cleared, calibration offset changes, trace length changes, NaN bins - against a float64 model of
     display_data_processor.py:317-395 of the reference (cal offset, tare, max / min hold)."""
@@ -618,64 +699,27 @@ def test_data_processor_random_events(pkg, seed):
         mw.tare_active, mw.baseline_power_levels = False, None
         dm.tare_state = pkg.TareState()
     dm._clear_tare = _clear
-    dp = pkg.DataProcessor(mw, dm)
+    dp = pkg.DataProcessor(mw, dm, reference_hold_alias=as_reference)      # True: quirk ii reproduced on request
 
-    # float64 model of the reference's three steps
-    m_collect, m_buf, m_cnt, m_active, m_base = False, None, 0, False, None
-    m_max = m_min = None
-    n = int(rng.choice([128, 256]))
-    for tick in range(150):
-        ev = rng.random()
-        if ev < 0.05:
+    model = ProcessorModel(alias_quirk=as_reference)
+    for tick, (event, x) in enumerate(processor_history(rng)):
+        if event == ("max",):
             dm.max_peak_search_enabled = not dm.max_peak_search_enabled
-        elif ev < 0.10:
+        elif event == ("min",):
             mw.min_hold_enabled = not mw.min_hold_enabled
-        elif ev < 0.14:
+        elif event == ("tare",):
             dm.tare_state = pkg.TareState(collecting=True)
-            m_collect, m_buf, m_cnt = True, None, 0
-        elif ev < 0.17:
+            model.start_tare()
+        elif event == ("clear",):
             dm._clear_tare()
-            m_collect, m_buf, m_cnt, m_active, m_base = False, None, 0, False, None
-        elif ev < 0.22:
-            cal["v"] = float(rng.choice([0.0, -0.8087, 3.5]))
-        elif ev < 0.25:
-            n = int(rng.choice([128, 256, 512]))
-        x = rng.normal(-70.0, 10.0, n).astype(np.float32)
-        if rng.random() < 0.1:
-            x[rng.integers(0, n)] = np.nan
+            model.clear_tare()
+        elif event is not None:
+            cal["v"] = event[1]
+        n = len(x)
         src.trace, src.axis = x, np.arange(n, dtype=np.float64)
         dp._process_sample_data()
-        # ---- model ----
-        lv = x.astype(np.float64) + (cal["v"] if cal["v"] != 0.0 else 0.0)
-        if m_collect:
-            lin = 10.0 ** (lv / 10.0)
-            if m_buf is None or m_buf.shape != lin.shape:
-                m_buf, m_cnt = lin.copy(), 1
-            else:
-                m_buf += lin
-                m_cnt += 1
-            if m_cnt >= 32:
-                m_base = 10.0 * np.log10(np.maximum(m_buf / m_cnt, 1e-30))
-                m_active, m_collect, m_buf, m_cnt = True, False, None, 0
-        if m_active and m_base is not None:
-            if lv.shape != m_base.shape:
-                m_active, m_base = False, None
-            else:
-                lv = lv - m_base
-        for which in ("max", "min"):
-            on = dm.max_peak_search_enabled if which == "max" else mw.min_hold_enabled
-            cur = m_max if which == "max" else m_min
-            if not on:
-                if cur is not None and cur.shape != lv.shape:
-                    cur = None
-            elif cur is None or cur.shape != lv.shape:
-                cur = np.where(np.isnan(lv), -500.0 if which == "max" else 500.0, lv)
-            else:
-                cur = np.fmax(cur, lv) if which == "max" else np.fmin(cur, lv)
-            if which == "max":
-                m_max = cur
-            else:
-                m_min = cur
+        lv = model.frame(x, cal["v"], dm.max_peak_search_enabled, mw.min_hold_enabled)
+        m_active, m_base, m_max, m_min = model.active, model.base, model.max, model.min
         what = f"seed {seed} tick {tick}"
         assert mw.tare_active == m_active, what
         dlive = np.abs(np.asarray(mw.live_power_levels, dtype=np.float64) - lv)

@@ -22,7 +22,7 @@ def _bare(mw, dm):
     dp.mw, dp.dm = mw, dm
     dp._fused = None
     dp._sweeps_since_axis_refresh = 0
-    dp.reference_hold_alias, dp._holds_share_buffer = False, False
+    dp.reference_hold_alias = False
     return dp
 
 

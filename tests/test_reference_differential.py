@@ -52,8 +52,7 @@ class _Label:
 def _bare(cls, mw, dm):
     dp = cls.__new__(cls)
     dp.mw, dp.dm = mw, dm
-    for k, v in dict(_fused=None, _sweeps_since_axis_refresh=0, reference_hold_alias=False,
-                     _holds_share_buffer=False).items():
+    for k, v in dict(_fused=None, _sweeps_since_axis_refresh=0, reference_hold_alias=False).items():
         setattr(dp, k, v)
     return dp
 
@@ -292,4 +291,62 @@ def test_oracle_trace_averager_random_histories(ref_sources):
             got = np.array(ora.process(xin.copy()), copy=True)
             assert got.dtype == want.dtype and np.array_equal(got, want), (trial, step)
             assert ora.is_active == ref.is_active
+
+
+def test_processor_model_against_reference(ref_dp):
+    """The float64 model the GPU suite checks DataProcessor against (tests/test_gpu_parity.py::ProcessorModel) is
+    itself checked here against the reference's DataProcessor._process_sample_data, through the same seeded random
+    GUI histories (holds switched, tare runs, offset and trace-length changes, NaN bins)."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_gpu_parity as T
+    sys.path.insert(0, REF)
+    try:
+        from core.tare_state import TareState
+    finally:
+        sys.path.remove(REF)
+        for m in [k for k in sys.modules if k == "core" or k.startswith("core.")]:
+            del sys.modules[m]
+    for seed in range(40):
+        rng = np.random.default_rng(8000 + seed)
+        cal = {"v": 0.0}
+        src = types.SimpleNamespace(trace=None, axis=None, last_data_time=0.0)
+        src.get_power_levels = lambda s=src: (s.trace, s.axis)
+        mw = types.SimpleNamespace(current_source=src, status_label=_Label(), tare_active=False, baseline_power_levels=None,
+                                   live_power_levels=None, max_power_levels=None, min_power_levels=None,
+                                   frequency_bins=None, min_hold_enabled=bool(rng.integers(0, 2)))
+        mw.calibration_manager = types.SimpleNamespace(get_offset=lambda source_type: cal["v"])
+        mw.source_manager = types.SimpleNamespace(last_source_type="hackrf_samples")
+        dm = types.SimpleNamespace(tare_state=TareState(), max_peak_search_enabled=bool(rng.integers(0, 2)),
+                                   duty_cycle_enabled=False, peak_list_enabled=False,
+                                   _update_tare_button_label=lambda s: None)
+
+        def _clear():
+            mw.tare_active, mw.baseline_power_levels = False, None
+            dm.tare_state = TareState()
+        dm._clear_tare = _clear
+        dp = ref_dp(mw, dm)
+        model = T.ProcessorModel(alias_quirk=True)           # the reference's own behaviour incl. quirk ii
+        for tick, (event, x) in enumerate(T.processor_history(rng)):
+            if event == ("max",):
+                dm.max_peak_search_enabled = not dm.max_peak_search_enabled
+            elif event == ("min",):
+                mw.min_hold_enabled = not mw.min_hold_enabled
+            elif event == ("tare",):
+                dm.tare_state = TareState(collecting=True)
+                model.start_tare()
+            elif event == ("clear",):
+                dm._clear_tare()
+                model.clear_tare()
+            elif event is not None:
+                cal["v"] = event[1]
+            src.trace, src.axis = x.copy(), np.arange(len(x), dtype=np.float64)
+            dp._process_sample_data()
+            lv = model.frame(x, cal["v"], dm.max_peak_search_enabled, mw.min_hold_enabled)
+            what = (seed, tick)
+            assert mw.tare_active == model.active, what
+            assert np.allclose(mw.live_power_levels, lv, rtol=0, atol=2e-4, equal_nan=True), what
+            for got, want in ((mw.max_power_levels, model.max), (mw.min_power_levels, model.min)):
+                assert (got is None) == (want is None), what
+                if want is not None:
+                    assert np.allclose(got, want, rtol=0, atol=2e-4, equal_nan=True), what
 

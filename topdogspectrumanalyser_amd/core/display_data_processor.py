@@ -48,10 +48,9 @@ class DataProcessor:
         self.mw = main_window
         self.dm = display_manager
         self._device = gpu_device
-        # True: reproduce the reference's both-holds accident bit for bit (see _alias_holds); default: two
+        # True: hold traces kept the reference's way, object identity included (see _hold); default: two
         # independent running fmax / fmin traces
         self.reference_hold_alias = bool(reference_hold_alias)
-        self._holds_share_buffer = False
         self._state: Optional[TraceState] = None          # device-side trace state, sized on first use
         self._sweep_averager = TraceAverager(device=gpu_device)
         self._sweeps_since_axis_refresh = 0
@@ -219,6 +218,8 @@ class DataProcessor:
             gpu.set_tare_baseline(baseline)               # baseline restored from a preset, not collected here
         want_max, reset_max = self._hold_plan(n, "max_power_levels", dm.max_peak_search_enabled)
         want_min, reset_min = self._hold_plan(n, "min_power_levels", mw.min_hold_enabled)
+        if self.reference_hold_alias:                     # that mode keeps its hold traces on the host (_hold)
+            want_max = want_min = reset_max = reset_min = False
         if reset_max or reset_min:                        # first frame is adopted (NaN -> -500 / +500)
             gpu.reset((nat.RESET_HOLD_MAX if reset_max else 0) | (nat.RESET_HOLD_MIN if reset_min else 0))
         offset_db = self._cal_offset_value()
@@ -291,6 +292,15 @@ class DataProcessor:
             if held is not None and not fits:
                 setattr(mw, attr, None)                   # a stale trace of another length is dropped
             return
+        if self.reference_hold_alias:
+            # the reference's own bookkeeping, object identity included: a clean first frame is adopted as the very
+            # array (so two holds adopting on one frame share it, and it is the live trace of that frame), later
+            # frames are folded in place (display_data_processor.py:371-395 + _nan_safe :473-480, SURVEY quirk ii)
+            if not fits:
+                setattr(mw, attr, self._nan_safe(trace, -500.0 if which == "hold_max" else 500.0))
+            else:
+                (np.fmax if which == "hold_max" else np.fmin)(held, trace, out=held)
+            return
         fused = getattr(self, "_fused", None)
         if fused is not None and trace is fused["live"]:
             setattr(mw, attr, fused["max" if which == "hold_max" else "min"])
@@ -302,38 +312,12 @@ class DataProcessor:
         setattr(mw, attr, mx if which == "hold_max" else mn)
 
     def _update_max_hold(self, power_levels: np.ndarray) -> None:
-        self._note_adoption(power_levels)
         self._hold(power_levels, attr="max_power_levels", enabled=bool(self.dm.max_peak_search_enabled),
                    reset_bit=nat.RESET_HOLD_MAX, which="hold_max")
 
     def _update_min_hold(self, power_levels: np.ndarray) -> None:
         self._hold(power_levels, attr="min_power_levels", enabled=bool(self.mw.min_hold_enabled),
                    reset_bit=nat.RESET_HOLD_MIN, which="hold_min")
-        self._alias_holds(power_levels)
-
-    # ------------------------------------------------------------------ reference_hold_alias=True only
-    def _note_adoption(self, trace: np.ndarray) -> None:
-        """The reference adopts a frame as hold buffer WITHOUT copying it when it has no NaN
-        (display_data_processor.py:380,393 + _nan_safe :473-480).  If both traces adopt the same frame they
-        are one ndarray from then on: fmax(out=) followed by fmin(out=) on it leaves the live trace, frame
-        after frame, until one of them is cleared."""
-        if not self.reference_hold_alias:
-            return
-        mw = self.mw
-        both_on = bool(self.dm.max_peak_search_enabled) and bool(mw.min_hold_enabled)
-
-        def adopting(held):
-            return held is None or held.shape != trace.shape
-
-        if not both_on or mw.max_power_levels is None or mw.min_power_levels is None:
-            self._holds_share_buffer = False
-        if both_on and adopting(mw.max_power_levels) and adopting(mw.min_power_levels):
-            self._holds_share_buffer = not np.isnan(trace).any()
-
-    def _alias_holds(self, trace: np.ndarray) -> None:
-        if self.reference_hold_alias and self._holds_share_buffer:
-            shared = np.array(trace, copy=True)
-            self.mw.max_power_levels = self.mw.min_power_levels = shared
 
     # ================================================================== per-tick scalars (host side)
     def _update_duty_cycle(self, power_levels: np.ndarray) -> None:
