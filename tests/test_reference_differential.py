@@ -350,3 +350,101 @@ def test_processor_model_against_reference(ref_dp):
                 if want is not None:
                     assert np.allclose(got, want, rtol=0, atol=2e-4, equal_nan=True), what
 
+
+# ----------------------------------------------------------------------------------------------------------------
+# the display accumulators of the reference (density histogram, waterfall ring) against oracle/analytics_oracle.py
+# on random streams; PyQt6 / pyqtgraph are absent, so the reference classes are imported against stub modules made of
+# plain do-nothing classes (as tests/golden/make_golden_displays.py does) and run their own numpy code
+# ----------------------------------------------------------------------------------------------------------------
+class _Stub:
+    def __init__(self, *a, **k):
+        pass
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return lambda *a, **k: _Stub()
+
+    def __call__(self, *a, **k):
+        return _Stub()
+
+
+@pytest.fixture(scope="module")
+def ref_displays():
+    sys.dont_write_bytecode = True
+    before = set(sys.modules)
+
+    def module(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class Qt:
+        class PenStyle:
+            DashLine, SolidLine = 2, 1
+
+        class AlignmentFlag:
+            AlignCenter = 0
+
+    qtcore = module("PyQt6.QtCore", Qt=Qt, QRectF=type("QRectF", (_Stub,), {}), QTimer=_Stub, pyqtSignal=_Stub)
+    qtwidgets = module("PyQt6.QtWidgets", QWidget=type("QWidget", (_Stub,), {}),
+                       QVBoxLayout=type("QVBoxLayout", (_Stub,), {}), QLabel=_Stub)
+    qtgui = module("PyQt6.QtGui", QColor=_Stub, QFont=_Stub)
+    module("PyQt6", QtCore=qtcore, QtWidgets=qtwidgets, QtGui=qtgui)
+    module("pyqtgraph", AxisItem=type("AxisItem", (_Stub,), {}), PlotWidget=_Stub, ImageItem=_Stub, PlotCurveItem=_Stub,
+           InfiniteLine=_Stub, GraphicsLayoutWidget=_Stub, ColorMap=_Stub, colormap=_Stub(), mkPen=_Stub(),
+           mkBrush=_Stub(), TextItem=_Stub, ScatterPlotItem=_Stub)
+    sys.path.insert(0, REF)
+    try:
+        from displays.density_display import DensityDisplay
+        from displays.waterfall import Waterfall
+    finally:
+        sys.path.remove(REF)
+        for m in set(sys.modules) - before:
+            del sys.modules[m]
+    return types.SimpleNamespace(density=DensityDisplay, waterfall=Waterfall)
+
+
+@pytest.mark.filterwarnings("ignore:invalid value encountered in cast")
+def test_density_oracle_random_streams(ref_displays):
+    from oracle import analytics_oracle as ao
+    rng = np.random.default_rng(31)
+    for trial in range(30):
+        n = int(rng.choice([16, 100, 256, 1000]))
+        mode = str(rng.choice(["medium", "fast", "off"]))
+        d = ref_displays.density()
+        d.set_decay(mode)
+        ora = ao.DensityOracle(float(d._decay))
+        fb = np.linspace(99e6, 101e6, n)
+        for r in range(int(rng.integers(1, 80))):
+            row = rng.normal(rng.uniform(-150, 50), float(rng.choice([0.3, 5.0, 40.0, 150.0])), n).astype(np.float32)
+            for _ in range(int(rng.integers(0, 4))):
+                row[rng.integers(0, n)] = rng.choice(np.array([np.nan, np.inf, -np.inf, -200.0, 100.0, -200.3, 99.99], dtype=np.float32))
+            with np.errstate(invalid="ignore"):
+                d._update_hist(row, fb)
+            ora.update(row)
+            assert np.array_equal(ora.hist, d._hist), (trial, r, mode)
+
+
+def test_waterfall_oracle_random_streams(ref_displays):
+    from oracle import analytics_oracle as ao
+    rng = np.random.default_rng(32)
+    for trial in range(30):
+        w = ref_displays.waterfall()
+        w.wf_time_span, w.seconds_per_row = float(rng.uniform(0.3, 3.0)), 0.1
+        nb = int(rng.choice([16, 64, 300]))
+        fb = np.linspace(2.40e9, 2.48e9, nb)
+        pool = rng.normal(-90, 5, size=(10, nb)).astype(np.float32)
+        ora = None
+        for step in range(int(rng.integers(5, 80))):
+            row = pool[int(rng.integers(0, len(pool)))] if rng.integers(0, 3) else pool[0]
+            before = None if w._last_row is None else w._last_row.copy()
+            w.update_widget_data(row, None, fb)
+            if ora is None:
+                ora = ao.WaterfallOracle(int(w.history_lines), nb, float(w.wf_min_db))
+            new = ora.update(row)
+            assert new == (before is None or not np.array_equal(before, row)), (trial, step)
+            assert ora.ptr == w._ptr, (trial, step)
+            assert np.array_equal(ora.view(), w._display_view()), (trial, step)
+
