@@ -448,3 +448,93 @@ def test_waterfall_oracle_random_streams(ref_displays):
             assert ora.ptr == w._ptr, (trial, step)
             assert np.array_equal(ora.view(), w._display_view()), (trial, step)
 
+
+@pytest.fixture(scope="module")
+def ref_analytics():
+    sys.dont_write_bytecode = True
+    before = set(sys.modules)
+    mocked = [m for m in ("hackrf", "rtlsdr", "sounddevice") if m not in sys.modules]
+    for m in mocked:
+        sys.modules[m] = MagicMock()
+    sys.path.insert(0, REF)
+    try:
+        from core.duty_cycle import DutyCycleAnalyser
+        from core.marker_manager import MarkerManager
+        from datasources.audio_samples import MicrophoneSamplesDataSource
+    finally:
+        sys.path.remove(REF)
+        for m in set(sys.modules) - before:
+            del sys.modules[m]
+        for m in mocked:
+            sys.modules.pop(m, None)
+    return types.SimpleNamespace(duty=DutyCycleAnalyser, markers=MarkerManager, audio=MicrophoneSamplesDataSource)
+
+
+def test_band_power_oracle_random(ref_analytics):
+    from oracle import analytics_oracle as ao
+    rng = np.random.default_rng(41)
+    for case in range(300):
+        n = int(rng.integers(8, 5000))
+        fb = np.linspace(99e6, 101e6, n)
+        tr = rng.normal(-80, 10, n).astype(np.float32 if rng.integers(0, 2) else np.float64)
+        if rng.integers(0, 4) == 0:
+            tr[rng.integers(0, n)] = np.nan
+        a, b = rng.uniform(98e6, 102e6, 2)
+        want = ref_analytics.markers._band_power(types.SimpleNamespace(_data=lambda: (fb, tr)), a, b)
+        got = ao.band_power_db(fb, tr, a, b)
+        assert (want is None) == (got is None), case
+        if want is not None:
+            assert (np.isnan(want) and np.isnan(got)) or want == got, (case, want, got)
+
+
+def test_duty_cycle_oracle_random(ref_analytics):
+    from oracle import analytics_oracle as ao
+    rng = np.random.default_rng(42)
+    for trial in range(20):
+        ref, ora = ref_analytics.duty(), ao.DutyCycleOracle()
+        for i in range(int(rng.integers(5, 300))):
+            fr = rng.normal(-70, 6, 256).astype(np.float32) + (0.0 if rng.integers(0, 3) else 40.0)
+            thr = float(rng.choice([-60.0, -45.0, -30.0]))
+            ref.update_from_power(fr, threshold_dbm=thr)
+            ora.update_from_power(fr, threshold_dbm=thr)
+            assert ora.duty_pct == ref.duty_pct, (trial, i)
+            for name in ("on_power_dbm", "off_power_dbm"):
+                a, b = getattr(ref, name), getattr(ora, name)
+                assert (a is None) == (b is None) and (a is None or a == b), (trial, i, name)
+
+
+def test_audio_oracle_random(ref_analytics):
+    from oracle import spectrum_oracle as so
+
+    class Stream:
+        def __init__(self, data):
+            self.d, self.pos = data, 0
+
+        def read(self, n):
+            out = self.d[self.pos: self.pos + n]
+            self.pos += n
+            return np.array(out, copy=True), False
+
+    rng = np.random.default_rng(43)
+    for trial in range(16):
+        n = int(2 ** rng.integers(6, 13))
+        fs = 44100
+        nf = 12
+        data = (0.3 * rng.standard_normal((n * nf, 2))).astype(np.float32)
+        data[:, 0] += (0.5 * np.sin(2 * np.pi * 997.0 * np.arange(n * nf) / fs)).astype(np.float32)
+        chan, psd = str(rng.choice(["mono", "left", "right"])), bool(rng.integers(0, 2))
+        src = ref_analytics.audio(sample_rate=fs, centre_freq=0)
+        src.set_fft_size(n)
+        src.set_channel_mode(chan)
+        src.set_psd_mode(psd)
+        src.stream = Stream(data)
+        src.running = True
+        src._audio_block = n
+        win = np.array(src.window, copy=True)
+        for k in range(nf):
+            want, _ = src.get_power_levels()
+            blk = data[k * n:(k + 1) * n]
+            sig = {"mono": (blk[:, 0] + blk[:, 1]) * 0.5, "left": blk[:, 0], "right": blk[:, 1]}[chan]
+            got = so.audio_db(so.audio_compute_power(np.array(sig, copy=True), win, n, fs, psd, precision="ref"), psd)
+            assert np.array_equal(got, want), (trial, k, chan, psd)
+
