@@ -538,3 +538,76 @@ def test_audio_oracle_random(ref_analytics):
             got = so.audio_db(so.audio_compute_power(np.array(sig, copy=True), win, n, fs, psd, precision="ref"), psd)
             assert np.array_equal(got, want), (trial, k, chan, psd)
 
+
+# ----------------------------------------------------------------------------------------------------------------
+# the product's source classes against the reference's, on everything that needs no samples: constructor state,
+# property round trips, setter validation (exception types), what a source that is not running answers
+# ----------------------------------------------------------------------------------------------------------------
+def _outcome(fn):
+    try:
+        return ("ok", fn())
+    except Exception as exc:                                        # compare the exception TYPE, as callers do
+        return ("raised", type(exc).__name__)
+
+
+def _same(a, b):
+    if isinstance(a, tuple) and isinstance(b, tuple) and len(a) == len(b):
+        return all(_same(x, y) for x, y in zip(a, b))
+    if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
+        return isinstance(a, np.ndarray) and isinstance(b, np.ndarray) and a.shape == b.shape and \
+            np.array_equal(a, b, equal_nan=True)
+    return a == b
+
+
+def test_sources_idle_behaviour_matches_reference(ref_sources, ref_analytics):
+    import topdogspectrumanalyser_amd as pkg
+    pairs = [("hackrf", ref_sources.hackrf, pkg.HackrfSamplesDataSource, dict(sample_rate=20_000_000, centre_freq=2_450_000_000)),
+             ("rtl", ref_sources.rtl, pkg.RtlSamplesDataSource, dict(sample_rate=2_048_000, centre_freq=100_000_000)),
+             ("audio", ref_analytics.audio, pkg.MicrophoneSamplesDataSource, dict(sample_rate=44100, centre_freq=0))]
+    for name, RefCls, OurCls, kw in pairs:
+        ref, our = RefCls(**kw), OurCls(**kw)
+        probes = [
+            ("sample_rate", lambda s: s.sample_rate), ("centre_freq", lambda s: s.centre_freq),
+            ("sample_count", lambda s: s.sample_count), ("last_data_time", lambda s: s.last_data_time),
+            ("idle frame", lambda s: s.get_power_levels()),
+            ("raw samples", lambda s: s.get_raw_samples()),
+            ("read_samples_only", lambda s: s.read_samples_only()),
+            ("averaging is_active", lambda s: (s.set_averaging("exp", 4), s._averager.is_active)[1]),
+            ("averaging n<1", lambda s: (s.set_averaging("lin", 0), s._averager.is_active)[1]),
+            ("reset_averaging", lambda s: s.reset_averaging()),
+            ("psd mode", lambda s: s.set_psd_mode(True)),
+            ("idle frame after psd", lambda s: s.get_power_levels()),
+            ("sample_count = 2048", lambda s: (setattr(s, "sample_count", 2048), s.sample_count)[1]),
+            ("idle frame at 2048", lambda s: s.get_power_levels()),
+            ("stop when idle", lambda s: s.stop()),
+        ]
+        if name == "hackrf":
+            probes += [
+                ("set_num_samples(0)", lambda s: s.set_num_samples(0)),
+                ("set_num_samples(-5)", lambda s: s.set_num_samples(-5)),
+                ("set_gains ok", lambda s: (s.set_gains(lna_gain=16, vga_gain=20), s.lna_gain, s.vga_gain)[1:]),
+                ("set_gains lna too high", lambda s: s.set_gains(lna_gain=100)),
+                ("set_gains vga negative", lambda s: s.set_gains(vga_gain=-2)),
+                ("set_dc_alpha clamps", lambda s: (s.set_dc_alpha(7.0), s._DC_ALPHA, s.set_dc_alpha(-1.0), s._DC_ALPHA)[1::2]),
+                ("stats keys", lambda s: sorted(s.get_stats().keys())),
+                ("update_centre_frequency idle", lambda s: (s.update_centre_frequency(2_400_000_000), s.centre_freq)[1]),
+            ]
+        if name == "rtl":
+            probes += [
+                ("window type", lambda s: (s.set_window_type("hamming"), np.array(s.window))[1]),
+                ("unknown window type", lambda s: (s.set_window_type("kaiser"), np.array(s.window))[1]),
+                ("fft size resets window", lambda s: (s.set_fft_size(512), np.array(s.window))[1]),
+                ("idle frame at 512", lambda s: s.get_power_levels()),
+            ]
+        if name == "audio":
+            probes += [
+                ("channel mode", lambda s: (s.set_channel_mode("left"), s.channel_mode)[1]),
+                ("bad channel mode ignored", lambda s: (s.set_channel_mode("quad"), s.channel_mode)[1]),
+                ("fft size", lambda s: (s.set_fft_size(4096), s.sample_count, np.array(s.window))[1:]),
+                ("idle frame at 4096", lambda s: s.get_power_levels()),
+            ]
+        for what, probe in probes:
+            want, got = _outcome(lambda: probe(ref)), _outcome(lambda: probe(our))
+            assert want[0] == got[0], (name, what, want, got)
+            assert _same(want[1], got[1]), (name, what, want[1], got[1])
+
