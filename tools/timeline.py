@@ -39,7 +39,19 @@ def main():
     e.process_device(nat.IN_I8, dev_in.value, ns, hop, F, dev_out.value)
     out = np.zeros(2048, dtype=np.uint64)
     nat.check(dbg(e._h, out.ctypes.data_as(C.c_void_p)))
-    t = out.reshape(8, 16, 16)[:, :, :12].astype(np.int64)   # [frame][wave][stamp]
+    raw = out.reshape(8, 16, 16).astype(np.int64)
+    t = raw[:, :, :12]                                        # [frame][wave][stamp]
+    entry, ready, left, end = (raw[2, :, k] for k in (12, 13, 14, 15))
+    if entry.min() > 0:
+        e0 = entry.min()
+        print("launch level, workgroup 0 (cycles since its first wave started):")
+        print(f"  waves start        {int((entry - e0).min()):8d} .. {int((entry - e0).max())}")
+        print(f"  prologue done      {int((ready - e0).min()):8d} .. {int((ready - e0).max())}   (twiddle table + seeds + first frame's bytes fetched)")
+        print(f"  third frame top    {int((raw[2, :, 0] - e0).min()):8d} .. {int((raw[2, :, 0] - e0).max())}")
+        print(f"  frame loop left    {int((left - e0).min()):8d} .. {int((left - e0).max())}")
+        print(f"  wave ends          {int((end - e0).min()):8d} .. {int((end - e0).max())}   (hold traces merged)")
+        per = np.diff(raw[:, 0, 0])
+        print(f"  frame periods of wave 0: {per.tolist()}")
     t0 = t[0, :, 0].min()
     print("frame-to-frame period (wave 0, cycles):", np.diff(t[:, 0, 0]))
     for f in (2, 3):

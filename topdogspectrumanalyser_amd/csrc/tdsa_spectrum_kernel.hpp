@@ -279,6 +279,9 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6;
+#ifdef TDSA_TIMELINE
+  const unsigned long long tl_entry = __builtin_amdgcn_s_memtime();     // launch-level stamps of workgroup 0
+#endif
   // timing-only developer ablations (with 1|2|4: no barriers, no LDS exchange, no stores): k waves per SIMD
   if constexpr ((TDSA_ABLATE & 4096) != 0) { if (wave >= 4) return; }
   if constexpr ((TDSA_ABLATE & 8192) != 0) { if (wave >= 8) return; }
@@ -302,15 +305,6 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   }
   const unsigned win_voff = unsigned(h) * (N / A) * 4u + unsigned(t) * (M * 4u);
   const bool odd_half = h != 0;   // upper half-wave: its radix-32 combine twiddle is W_32^(u+8) = -i * W_32^u
-  c32 twf_lo[3], twf_hi[4];   // last pass: W_N^(t*(2i+h)), i = 4a + j  ->  hi[a] = W^(t(8a+h)), lo[j-1] = W^(2tj)
-  static_for<0, 3>([&](auto ic) { constexpr int j = decltype(ic)::value; twf_lo[j] = p.tw[t * 2 * (j + 1)]; });
-  static_for<0, 4>([&](auto ic) { constexpr int a = decltype(ic)::value; twf_hi[a] = p.tw[t * (8 * a + h)]; });
-  if constexpr (C::NPASS == 3) {   // middle pass table twm[b*A + ka] = W_(32A)^(ka*b)
-    if (tid < C::TWM) {
-      const int b = tid / A, ka = tid % A;
-      twm[tid] = p.tw[ka * b * (N / (32 * A))];
-    }
-  }
   float pacc[ACC ? 16 : 1];                 // ACC: linear power summed over the frames of one group
   static_for<0, (ACC ? 16 : 1)>([&](auto ic) { pacc[decltype(ic)::value] = 0.f; });
   float hmax[(HOLD & 1) ? 16 : 1], hmin[(HOLD & 2) ? 16 : 1];
@@ -388,7 +382,6 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     }
   };
   if (u0 < u1) load_frame_raw(u0 * FPW + slot);
-  if constexpr (!C::WIN_LDS && !ACC) load_window();
   // ACC (row pass of the long-frame path): no window, no raw bytes, no hold traces - the registers they
   // would take hold the NEXT frame's complex64 samples instead, fetched while this frame is transformed
   c32 vnext[ACC ? 16 : 1];
@@ -408,7 +401,26 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     }
   };
   if constexpr (ACC) { if (u0 < u1) load_frame_c64(u0 * FPW + slot); }
+  // order of the cold fetches: the first frame's bytes (the DC sums need them first), the twiddles (the
+  // middle-pass table goes through registers into LDS, which waits for everything issued before it), the
+  // window slice last (64 KiB per workgroup, not needed before the first barrier has been passed)
+  c32 twf_lo[3], twf_hi[4];   // last pass: W_N^(t*(2i+h)), i = 4a + j  ->  hi[a] = W^(t(8a+h)), lo[j-1] = W^(2tj)
+  static_for<0, 3>([&](auto ic) { constexpr int j = decltype(ic)::value; twf_lo[j] = p.tw[t * 2 * (j + 1)]; });
+  static_for<0, 4>([&](auto ic) { constexpr int a = decltype(ic)::value; twf_hi[a] = p.tw[t * (8 * a + h)]; });
+  if constexpr (C::NPASS == 3) {   // middle pass table twm[b*A + ka] = W_(32A)^(ka*b)
+    if (tid < C::TWM) {
+      const int b = tid / A, ka = tid % A;
+      twm[tid] = p.tw[ka * b * (N / (32 * A))];
+    }
+  }
+  if constexpr (!C::WIN_LDS && !ACC) load_window();
 
+#ifdef TDSA_TIMELINE
+  if (p.dbg != nullptr && blockIdx.x == 0 && (tid & 63) == 0) {
+    tl[(2 * 16 + wave) * 16 + 12] = tl_entry;
+    tl[(2 * 16 + wave) * 16 + 13] = __builtin_amdgcn_s_memtime();         // prologue done (loads waited for)
+  }
+#endif
   for (int unit = u0; unit < u1; ++unit) {
     const int frame = unit * FPW + slot;
     const bool active = frame < p.n_frames;
@@ -799,6 +811,8 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   }
 
 #ifdef TDSA_TIMELINE
+  if (p.dbg != nullptr && blockIdx.x == 0 && (tid & 63) == 0)
+    tl[(2 * 16 + wave) * 16 + 14] = __builtin_amdgcn_s_memtime();         // frame loop left
   __syncthreads();
   if (p.dbg != nullptr && blockIdx.x == 0)
     for (int i = tid; i < 8 * 16 * 16; i += C::WGT) p.dbg[i] = tl[i];
@@ -806,7 +820,9 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   // fold this workgroup's register-resident hold traces straight into the plan's traces with
   // integer-punned float atomics (max/min are associative; the traces start at -inf / +inf).
   // (Issuing the bulk of them before the last frame to hide the tail was tried: the extra live state
-  //  pushed the kernel into 39 scratch spills and cost more than the ~6 us tail it removed.)
+  //  pushed the kernel into 39 scratch spills and cost more than the ~6 us tail it removed.  Fetching the
+  //  current trace into the window registers during the last frame, to save the round trip below: 16 bytes
+  //  of scratch inside the frame loop, 75.3 instead of 73.9 us per C3 launch.)
   if constexpr (HOLD != 0) {
     const int prow = t + 8 * h * SG;
     const bool any = (u1 > u0) && (FPW == 1 || u0 * FPW + slot < p.n_frames);
@@ -866,6 +882,10 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       }
     }
   }
+#ifdef TDSA_TIMELINE
+  if (p.dbg != nullptr && blockIdx.x == 0 && (tid & 63) == 0)
+    p.dbg[(2 * 16 + wave) * 16 + 15] = __builtin_amdgcn_s_memtime();      // hold traces merged: the wave ends here
+#endif
 }
 
 template <int LOG2N>
