@@ -293,8 +293,13 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   c32* buf = lds + slot * NPAD;
 
   const int n_units = (p.n_frames + FPW - 1) / FPW;
-  const int u0 = int((long long)blockIdx.x * n_units / gridDim.x);
-  const int u1 = int((long long)(blockIdx.x + 1) * n_units / gridDim.x);
+  // unit range of this workgroup: [floor(b n / g), floor((b + 1) n / g)) with n = q g + r evaluated as
+  // b q + floor(b r / g) - 32-bit divisions (the 64-bit form cost two emulated 64-bit divisions at the head of
+  // every launch, ahead of the first load).  The workgroups that take one unit more stay spread over the grid:
+  // handing them out as one contiguous block instead measured +0.6 us per serial C3 launch.
+  const unsigned upw = unsigned(n_units) / gridDim.x, urem = unsigned(n_units) - upw * gridDim.x;
+  const int u0 = int(blockIdx.x * upw + blockIdx.x * urem / gridDim.x);
+  const int u1 = int((blockIdx.x + 1) * upw + (blockIdx.x + 1) * urem / gridDim.x);
 
   // ---- frame-invariant per-thread state ---------------------------------------------------------
   const rsrc_t win_rsrc = make_rsrc(p.window, N * 4u);
