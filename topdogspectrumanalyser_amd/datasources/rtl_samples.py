@@ -136,7 +136,9 @@ class RtlSamplesDataSource(GpuSpectrumMixin, SampleDataSource):
         self.running = False
 
     def resume(self):
-        self.running = self.sdr is not None
+        if self.sdr is None:      # rtl_samples.py:65-71: nothing to resume, the flag stays as it is
+            return
+        self.running = True
 
     # ------------------------------------------------------------------ retune
     def update_frequency(self, sample_rate: float, centre_freq: float):
