@@ -745,6 +745,28 @@ def test_trace_averager_golden(pkg, golden_dir):
         assert np.allclose(av.process(g["frames"][3]), g["frames"][3])   # first frame after reset == input
 
 
+def test_trace_averager_as_the_reference_smoke_checks_it(pkg):
+    """The three TraceAverager checks of the reference's test_smoke.py:137-175 (passthrough when inactive, first
+    frame == input and the second blends towards it, reset clears a NaN buffer), on the device-backed class.
+    (tests/test_reference_own_tests.py runs the reference's file itself for everything that needs no GPU.)"""
+    ta = pkg.TraceAverager()
+    ones = np.ones(128, dtype=np.float64)
+    assert ta.is_active is False
+    assert np.allclose(ta.process(ones), ones)
+    ta = pkg.TraceAverager()
+    ta.set_mode("exp", 4)
+    assert ta.is_active
+    low = ta.process(np.ones(64) * 10.0).copy()[0]
+    assert low == 10.0
+    high = ta.process(np.ones(64) * 20.0).copy()[0]
+    assert high > low and high == 10.0 * 0.75 + 20.0 / 4
+    ta = pkg.TraceAverager()
+    ta.set_mode("exp", 4)
+    ta.process(np.full(64, np.nan))
+    ta.reset()
+    assert not np.any(np.isnan(ta.process(np.ones(64) * 5.0)))
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("TDSA_AVERAGER_CASES", "8"))))
 def test_trace_averager_random_histories(pkg, seed):
     """TraceAverager (host-array API of utils/signal_processing.py:5-73) through random histories - mode / length

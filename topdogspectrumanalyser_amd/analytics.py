@@ -74,47 +74,11 @@ def peaks_as_reference(freq_bins: np.ndarray, bins_row: np.ndarray, db_row: np.n
     return [(float(freq_bins[b]), float(p)) for b, p in zip(bins_row, db_row) if b >= 0]
 
 
-class DutyCycle:
-    """DutyCycleAnalyser (core/duty_cycle.py:10-80) whose envelope is fed with per-frame peaks computed on
-    the device; update_from_power() keeps the reference's host-array entry point."""
-    BUFFER_FRAMES = 100
+from .core.duty_cycle import DutyCycleAnalyser  # noqa: E402
 
-    def __init__(self):
-        self._envelope = deque(maxlen=self.BUFFER_FRAMES)
-        self.duty_pct = 0.0
-        self.on_power_dbm: Optional[float] = None
-        self.off_power_dbm: Optional[float] = None
-        self.threshold_dbm = -60.0
 
-    def update_from_power(self, power_levels_db, threshold_dbm=None) -> None:
-        if power_levels_db is None or len(power_levels_db) == 0:
-            return
-        if threshold_dbm is not None:
-            self.threshold_dbm = threshold_dbm
-        self._push(float(np.max(power_levels_db)))
-
-    def update_from_rows(self, engine: SpectrumEngine, rows_dev: int, n_rows: int, threshold_dbm=None) -> None:
-        """Same as calling update_from_power once per row, without reading the rows back."""
-        if threshold_dbm is not None:
-            self.threshold_dbm = threshold_dbm
-        peaks, _, _ = rows_stats(engine, rows_dev, n_rows)
-        for p in peaks:
-            self._push(float(p))
-
-    def _push(self, peak: float) -> None:
-        self._envelope.append(peak)
-        arr = np.array(self._envelope)
-        on = arr >= self.threshold_dbm
-        cnt = int(np.sum(on))
-        self.duty_pct = 100.0 * cnt / len(arr)
-        self.on_power_dbm = float(np.mean(arr[on])) if cnt > 0 else None
-        self.off_power_dbm = float(np.mean(arr[~on])) if cnt < len(arr) else None
-
-    def reset(self) -> None:
-        self._envelope.clear()
-        self.duty_pct = 0.0
-        self.on_power_dbm = None
-        self.off_power_dbm = None
+class DutyCycle(DutyCycleAnalyser):
+    """The analyser of core/duty_cycle.py under the name earlier callers of this module use."""
 
 
 class _Handle:
