@@ -503,6 +503,39 @@ def test_duty_cycle_oracle_random(ref_analytics):
                 assert (a is None) == (b is None) and (a is None or a == b), (trial, i, name)
 
 
+def test_duty_cycle_analyser_of_the_product_random(ref_analytics):
+    """The product's DutyCycleAnalyser (host class; its device feed is checked in the GPU suite) against the
+    reference's through random histories of all three entry points: raw complex / real samples, dB spectra with
+    and without a threshold, resets - every attribute and the readout string identical."""
+    from topdogspectrumanalyser_amd.core.duty_cycle import DutyCycleAnalyser
+    rng = np.random.default_rng(420)
+    for trial in range(10):
+        ref, got = ref_analytics.duty(), DutyCycleAnalyser()
+        assert ref.get_readout() == got.get_readout() == ""
+        for i in range(int(rng.integers(50, 400))):
+            k = int(rng.integers(0, 10))
+            thr = float(rng.uniform(-80, -20))
+            if k < 3:
+                x = ((rng.normal(size=64) + 1j * rng.normal(size=64)) * 10 ** rng.uniform(-6, 0)).astype(np.complex64)
+                ref.update(x, thr), got.update(x, thr)
+            elif k < 5:
+                x = (rng.normal(size=(32, 2)) * 10 ** rng.uniform(-6, 0)).astype(np.float32)
+                ref.update(x, thr), got.update(x, thr)
+            elif k < 9:
+                d = rng.uniform(-120, 0, size=128)
+                t = None if rng.random() < 0.5 else thr
+                ref.update_from_power(d, t), got.update_from_power(d, t)
+            elif rng.random() < 0.3:
+                ref.reset(), got.reset()
+            else:
+                ref.update(None, thr), got.update(None, thr)
+                ref.update_from_power(np.empty(0)), got.update_from_power(np.empty(0))
+            for name in ("duty_pct", "on_power_dbm", "off_power_dbm", "threshold_dbm"):
+                assert getattr(ref, name) == getattr(got, name), (trial, i, name)
+            assert ref.get_readout() == got.get_readout(), (trial, i)
+            assert list(ref._envelope) == list(got._envelope)
+
+
 def test_audio_oracle_random(ref_analytics):
     from oracle import spectrum_oracle as so
 
