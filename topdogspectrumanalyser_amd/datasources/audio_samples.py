@@ -72,6 +72,10 @@ class MicrophoneSamplesDataSource(GpuSpectrumMixin, SampleDataSource):
     def _axis(self) -> np.ndarray:
         return np.linspace(0, self.sample_rate / 2, self._n_out)
 
+    # the reference's names for the two (audio_samples.py:113-119), for code that reaches for them
+    _rfft_bins = _n_out
+    _freq_bins = _axis
+
     def _reset_history(self) -> None:
         self._audio_buffer = np.zeros((self.fft_size, 2), dtype=np.float32)
         self._audio_block = self.fft_size
