@@ -273,8 +273,10 @@ def main():
     gen_hackrf(1024, 6, 1024, seed=1)
     gen_hackrf(4096, 4, 2048, seed=2)
     gen_hackrf(16384, 3, 8192, seed=3)
+    gen_hackrf(1000, 5, 500, seed=4)          # sizes that are not a power of two: np.fft.fft takes any N
     gen_rtl(1024, 5, seed=11)
     gen_rtl(4096, 4, seed=12)
+    gen_rtl(1500, 4, seed=13)
     gen_audio(1024, 4, seed=21)
     gen_averager(seed=31)
     gen_processor(1024, 40, seed=41)

@@ -64,6 +64,25 @@ def test_hackrf_plain_int8_all_sizes(pkg, nfft):
     assert np.array_equal(mx, out.max(axis=0)) and np.array_equal(mn, out.min(axis=0))
 
 
+@pytest.mark.parametrize("nfft", [3, 7, 12, 32, 33, 65, 100, 1000, 1009, 1536, 3000, 4095, 4097, 6000, 8000, 8191])
+def test_hackrf_plain_int8_sizes_that_are_not_a_power_of_two(pkg, nfft):
+    """HackrfSamplesDataSource.set_num_samples takes any positive size and np.fft.fft any N
+    (hackrf_samples.py:392-405, :370): every size up to 8192 has a device path (chirp-z on the frame kernel)."""
+    nf = 5
+    hop = max(1, nfft // 2)
+    iq = so.synth_iq_int8(hop * (nf - 1) + nfft, nfft, seed=nfft)
+    gold, gmax, gmin = so.hackrf_batch(iq, nfft, hop, 20e6, precision="gold")
+    with _hackrf_engine(pkg, nfft, nf, hold_max=True, hold_min=True) as e:
+        out = e.process(iq, hop=hop)
+        mx, mn = e.hold()
+        assert e.info().nfft == nfft
+    assert out.shape == gold.shape and out.dtype == np.float32
+    _check(out, gold, f"N={nfft}")
+    _check(mx, gmax, "max hold")
+    _check(mn, gmin, "min hold")
+    assert np.array_equal(mx, out.max(axis=0)) and np.array_equal(mn, out.min(axis=0))
+
+
 @pytest.mark.parametrize("nfft", [64, 1024, 4096, 16384])
 def test_hackrf_plain_c64(pkg, nfft):
     nf = 3
@@ -103,7 +122,7 @@ HACKRF_MODES = {
 }
 
 
-@pytest.mark.parametrize("nfft", [1024, 4096, 16384])
+@pytest.mark.parametrize("nfft", [1000, 1024, 4096, 16384])
 @pytest.mark.parametrize("mode", sorted(HACKRF_MODES))
 def test_hackrf_golden_batch(pkg, golden_dir, nfft, mode):
     g = np.load(os.path.join(golden_dir, f"hackrf_{nfft}.npz"))
@@ -137,7 +156,7 @@ RTL_MODES = {
 }
 
 
-@pytest.mark.parametrize("nfft", [1024, 4096])
+@pytest.mark.parametrize("nfft", [1024, 1500, 4096])
 @pytest.mark.parametrize("mode", sorted(RTL_MODES))
 def test_rtl_golden_batch(pkg, golden_dir, nfft, mode):
     g = np.load(os.path.join(golden_dir, f"rtl_{nfft}.npz"))
@@ -156,9 +175,10 @@ def test_rtl_golden_batch(pkg, golden_dir, nfft, mode):
 # ------------------------------------------------------------------------------------------------
 # the reference's own source classes' API, frame by frame (drop-in boundary)
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nfft", [4096, 1000])                      # 1000: a size that is not a power of two
 @pytest.mark.parametrize("mode", ["plain", "psd", "exp4", "lin3", "dc_alpha_0p25"])
-def test_hackrf_source_class_golden(pkg, golden_dir, mode):
-    g = np.load(os.path.join(golden_dir, "hackrf_4096.npz"))
+def test_hackrf_source_class_golden(pkg, golden_dir, mode, nfft):
+    g = np.load(os.path.join(golden_dir, f"hackrf_{nfft}.npz"))
     n, hop, nf = int(g["nfft"]), int(g["hop"]), int(g["n_frames"])
     x = so.unpack_iq_int8(g["iq_i8"])
     src = pkg.HackrfSamplesDataSource(sample_rate=int(g["sample_rate"]), centre_freq=int(g["centre_freq"]))
@@ -422,10 +442,11 @@ def test_hackrf_source_holds_last_good_frame(pkg):
         src.stop()
 
 
+@pytest.mark.parametrize("nfft", [1024, 1500])                      # 1500: a size that is not a power of two
 @pytest.mark.parametrize("mode", ["hanning", "hamming", "rectangle", "psd", "lin3"])
-def test_rtl_source_class_golden(pkg, golden_dir, mode):
+def test_rtl_source_class_golden(pkg, golden_dir, mode, nfft):
     from topdogspectrumanalyser_amd.datasources.replay import ReplayRtlSdr
-    g = np.load(os.path.join(golden_dir, "rtl_1024.npz"))
+    g = np.load(os.path.join(golden_dir, f"rtl_{nfft}.npz"))
     n, nf, fs, fc = int(g["nfft"]), int(g["n_frames"]), float(g["sample_rate"]), float(g["centre_freq"])
     src = pkg.RtlSamplesDataSource(sample_rate=int(fs), centre_freq=int(fc),
                                    device_factory=lambda: ReplayRtlSdr(g["iq_i8"], fs, fc))
@@ -943,11 +964,13 @@ def test_empty_and_error_paths(pkg):
         with pytest.raises(TypeError):
             e.process(np.zeros(2048, dtype=np.float64))
     with pytest.raises(nat.TdsaError):
-        pkg.SpectrumEngine(1000)                                                 # not a power of two
+        pkg.SpectrumEngine(12000)                                                # not a power of two AND above 8192
     with pytest.raises(nat.TdsaError):
         pkg.SpectrumEngine(1 << 21)                                              # beyond the largest plan (2^20)
     with pytest.raises(nat.TdsaError):
-        pkg.SpectrumEngine(32)                                                   # below the smallest (64)
+        pkg.SpectrumEngine(1)                                                    # below the smallest (2)
+    with pytest.raises(nat.TdsaError):
+        pkg.SpectrumEngine(0)
     e = pkg.SpectrumEngine(1024)
     with pytest.raises(nat.TdsaError):
         e.process(np.zeros(2048, dtype=np.int8))                                 # window never set
@@ -1735,8 +1758,19 @@ def test_stream_spectra_helper(pkg):
 # ------------------------------------------------------------------------------------------------
 # seeded random sweep over sizes x formats x hops x modes: a wider net than the hand-picked cases
 # ------------------------------------------------------------------------------------------------
-def _random_case(rng):
-    nfft = int(2 ** rng.integers(6, 15))
+def _any_size(rng):
+    """A frame length the native kernels do not cover: anything in [3, 8192] that is not a power of two >= 64
+    (small, prime, highly composite and just-below-the-limit sizes all get their share)."""
+    while True:
+        kind = int(rng.integers(0, 4))
+        n = int([rng.integers(3, 64), rng.integers(64, 1025), rng.integers(1025, 8193),
+                 rng.choice([1000, 1009, 1536, 3000, 4095, 4097, 6000, 8000, 8191])][kind])
+        if n < 64 or n & (n - 1):
+            return n
+
+
+def _random_case(rng, any_size=False):
+    nfft = _any_size(rng) if any_size else int(2 ** rng.integers(6, 15))
     nf = int(rng.integers(1, 24))
     hop = int(rng.choice([nfft, nfft // 2, nfft // 4 + 1, int(rng.integers(1, 2 * nfft))]))
     branch = str(rng.choice(["hackrf", "rtl"]))
@@ -1748,7 +1782,10 @@ def _random_case(rng):
 
 @pytest.mark.parametrize("case_id", range(int(os.environ.get("TDSA_SWEEP_CASES", "48"))))
 def test_random_configuration_sweep(pkg, case_id):
-    c = _random_case(np.random.default_rng(4242 + case_id))
+    _run_sweep_case(pkg, case_id, _random_case(np.random.default_rng(4242 + case_id)))
+
+
+def _run_sweep_case(pkg, case_id, c):
     nfft, nf, hop = c["nfft"], c["nf"], c["hop"]
     iq = so.synth_iq_int8(hop * (nf - 1) + nfft, nfft, seed=c["seed"])
     fs = 20e6 if c["branch"] == "hackrf" else 2e6
@@ -1784,6 +1821,13 @@ def test_random_configuration_sweep(pkg, case_id):
     _check(mn, gmin, what + " min hold")
 
 
+@pytest.mark.parametrize("case_id", range(int(os.environ.get("TDSA_ANYSIZE_CASES", "24"))))
+def test_random_configuration_sweep_any_size(pkg, case_id):
+    """The same sweep over frame lengths that are NOT a power of two (np.fft.fft / scipy.fft.fft take any N,
+    hackrf_samples.py:370, rtl_samples.py:170): chirp-z path of tdsa_chirp.hip, same bounds."""
+    _run_sweep_case(pkg, case_id, _random_case(np.random.default_rng(777 + case_id), any_size=True))
+
+
 # ------------------------------------------------------------------------------------------------
 # random CALL SEQUENCES on one plan: process in pieces, averaging changes, resets, calibration offset, tare
 # baseline - checked call by call against the float64 oracle driven through the same sequence
@@ -1796,11 +1840,11 @@ def _mode_for(psd, averaging, fs, nfft):
     return dict(db_mode="mag", power_scale=1.0, log_floor=so.LOG_FLOOR)
 
 
-def call_sequence_trial(pkg, trial, report=None):
+def call_sequence_trial(pkg, trial, report=None, any_size=False):
     """-> (worst dB error in allowance units of ONE rounding unit, worst relative power error, process calls)"""
     nat = pkg._native
-    rng = np.random.default_rng(9000 + trial)
-    nfft = int(2 ** rng.integers(6, 14))
+    rng = np.random.default_rng((9000 if not any_size else 19000) + trial)
+    nfft = _any_size(rng) if any_size else int(2 ** rng.integers(6, 14))
     hop = int(rng.choice([nfft, nfft // 2, int(rng.integers(1, 2 * nfft))]))
     fs, psd = 20e6, bool(rng.integers(0, 2))
     dc_alpha = float(rng.choice([1.0, 1.0, 0.3]))
@@ -1869,6 +1913,12 @@ def call_sequence_trial(pkg, trial, report=None):
 @pytest.mark.parametrize("trial", range(int(os.environ.get("TDSA_SEQUENCE_TRIALS", "24"))))
 def test_random_call_sequences(pkg, trial):
     units, rel, calls = call_sequence_trial(pkg, trial)
+    assert calls > 0 and rel <= REL_TOL and units <= 2.0, f"trial {trial}: {units:.2f} units, rel {rel:.2e}"
+
+
+@pytest.mark.parametrize("trial", range(int(os.environ.get("TDSA_ANYSIZE_TRIALS", "12"))))
+def test_random_call_sequences_any_size(pkg, trial):
+    units, rel, calls = call_sequence_trial(pkg, trial, any_size=True)
     assert calls > 0 and rel <= REL_TOL and units <= 2.0, f"trial {trial}: {units:.2f} units, rel {rel:.2e}"
 
 

@@ -33,7 +33,7 @@ HACKRF_MODES = {
 }
 
 
-@pytest.mark.parametrize("nfft", [1024, 4096, 16384])
+@pytest.mark.parametrize("nfft", [1000, 1024, 4096, 16384])
 @pytest.mark.parametrize("mode", sorted(HACKRF_MODES))
 def test_hackrf_branch_bit_identical(golden_dir, nfft, mode):
     g = _load(golden_dir, f"hackrf_{nfft}.npz")
@@ -71,7 +71,7 @@ RTL_MODES = {
 }
 
 
-@pytest.mark.parametrize("nfft", [1024, 4096])
+@pytest.mark.parametrize("nfft", [1024, 1500, 4096])
 @pytest.mark.parametrize("mode", sorted(RTL_MODES))
 def test_rtl_branch_bit_identical(golden_dir, nfft, mode):
     g = _load(golden_dir, f"rtl_{nfft}.npz")

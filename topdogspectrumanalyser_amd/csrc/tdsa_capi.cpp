@@ -96,6 +96,13 @@ struct tdsa_plan_s {
   float2* d_tw_row = nullptr;            // W_16384^m : the row pass's twiddle table
   float* d_ones = nullptr;               // [16384] unit window for the row pass
   int big_group = 32;                    // segments per column-pass / row-pass round (Z stays cache resident)
+  // frame lengths that are not a power of two (tdsa_chirp.hip): chirp-z on the m_fft-point frame kernel
+  bool chirp = false;
+  int m_fft = 0, log2m = 0;              // M = 2^log2m >= 2 nfft - 1
+  float2* d_chirp_a = nullptr;           // [nfft] a[n] = exp(-i pi n^2 / nfft)
+  float2* d_chirp_b = nullptr;           // [M]    FFT_M of conj(a) wrapped around M
+  float2* d_u0 = nullptr;                // [max_frames][M] work rows (allocated on first use)
+  float2* d_u1 = nullptr;
   void* d_scratch = nullptr;             // grows on demand: results of tdsa_rows_stats / tdsa_rows_top_peaks
   size_t scratch_bytes = 0;
   bool profiling = false;
@@ -273,6 +280,92 @@ int process_big(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n_f
   return TDSA_OK;
 }
 
+// Plans whose frame length is not a power of two (tdsa_chirp.hip): same modes, same state, same outputs as the
+// native sizes - every stage on the plan's main stream.
+int process_chirp(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n_frames, float* out_db_dev) {
+  const tdsa_mode& m = p->mode;
+  const bool averaging = avg_active(m);
+  const int N = p->nfft, M = p->m_fft;
+  const int in_c64 = in_format == TDSA_IN_C64;
+  const unsigned xor_mask = in_format == TDSA_IN_I8 ? 0x80808080u : 0u;
+  const float in_off = in_format == TDSA_IN_I8 ? 128.0f : (in_c64 ? 0.0f : 127.5f);
+  const float in_scale = in_format == TDSA_IN_I8 ? 1.0f / 128.0f : (in_c64 ? 1.0f : 1.0f / 127.5f);
+  const long long stride = (long long)hop * bytes_per_sample(in_format);
+  hipStream_t s = p->stream;
+  if (!p->d_u0) HIPCHK(hipMalloc(&p->d_u0, size_t(p->max_frames) * M * sizeof(float2)));
+  if (!p->d_u1) HIPCHK(hipMalloc(&p->d_u1, size_t(p->max_frames) * M * sizeof(float2)));
+  const float2* dc_sub = nullptr;
+  if (m.dc_alpha >= 0.0f) {
+    // frame means as residuals (exact sums), then the tracker of the native path fed with them directly
+    // (n = 1, zero level 0): alpha >= 1 makes it the plain per-frame mean
+    HIPCHK(launch_chirp_sums(iq_dev, in_c64, xor_mask, stride, N, n_frames,
+                             in_format == TDSA_IN_I8 ? 256 : (in_c64 ? 0 : 255), p->d_sums, s));
+    HIPCHK(launch_dc_track(p->d_sums, 1, n_frames, m.dc_alpha > 1.0f ? 1.0f : m.dc_alpha, 0.0f, in_scale, p->d_dc_state,
+                           p->d_dc_sub, s));
+    dc_sub = p->d_dc_sub;
+  }
+  HIPCHK(launch_chirp_pre(iq_dev, in_c64, stride, N, M, n_frames, p->d_window[in_format], p->d_chirp_a, dc_sub, xor_mask,
+                          in_off, p->d_u0, s));
+  SpecParams sp{};
+  sp.frame_stride = (long long)M * sizeof(float2);
+  sp.n_frames = n_frames;
+  sp.first_frame_index = 1;
+  sp.window = p->d_ones;
+  sp.tw = p->d_tw;
+  sp.in_scale = 1.0f;
+  sp.dc_mode = DC_NONE;
+  sp.db_mode = TDSA_DB_POW;
+  sp.pscale = 1.0f;
+  const LaunchGeom g = spectrum_geometry(p->log2m, n_frames, p->num_cu);
+  sp.in = p->d_u0;
+  sp.out_cplx = p->d_u1;
+  { const int rc = launch_spectrum_profiled(p, 1, sp, g); if (rc != TDSA_OK) return rc; }
+  HIPCHK(launch_chirp_mul(p->d_u1, p->d_chirp_b, M, n_frames, s));
+  sp.in = p->d_u1;
+  sp.out_cplx = p->d_u0;
+  { const int rc = launch_spectrum_profiled(p, 1, sp, g); if (rc != TDSA_OK) return rc; }
+  const float pscale = m.db_mode == TDSA_DB_POW ? m.power_scale : 1.0f;
+  float* const tare = p->tare_active ? p->d_tare_base : nullptr;
+  const int first = p->frames_seen > 0 ? 1 : 0;
+  if (averaging) {
+    if (!p->d_lin) HIPCHK(hipMalloc(&p->d_lin, size_t(p->max_frames) * N * sizeof(float)));
+    if (!p->d_carry && p->max_frames > 128)
+      HIPCHK(hipMalloc(&p->d_carry, size_t(avg_scan_chunks(p->max_frames)) * N * sizeof(double)));
+    HIPCHK(launch_chirp_post(p->d_u0, p->d_chirp_a, N, M, n_frames, first, m.db_mode, pscale, m.log_floor,
+                             m.cal_offset_db, nullptr, nullptr, p->d_lin, nullptr, nullptr, s));
+    AvgParams ap{};
+    ap.lin = p->d_lin;
+    ap.n_frames = n_frames;
+    ap.n = N;
+    ap.state = p->d_avg;
+    ap.count_in = p->avg_count;
+    ap.mode = m.avg_mode;
+    ap.avg_n = m.avg_n;
+    ap.log_floor = m.log_floor;
+    ap.cal_db = m.cal_offset_db;
+    ap.tare = tare;
+    ap.out_db = out_db_dev;
+    ap.state_max = (m.hold_flags & TDSA_HOLD_MAX) ? p->d_hold_max : nullptr;
+    ap.state_min = (m.hold_flags & TDSA_HOLD_MIN) ? p->d_hold_min : nullptr;
+    HIPCHK(launch_avg_scan(ap, s, p->d_carry));
+    if (m.avg_mode == TDSA_AVG_LIN) {
+      const long long c = (long long)p->avg_count + n_frames;
+      p->avg_count = int(c < m.avg_n ? c : m.avg_n);
+    } else {
+      p->avg_count = 1;
+    }
+  } else {
+    HIPCHK(launch_chirp_post(p->d_u0, p->d_chirp_a, N, M, n_frames, first, m.db_mode, pscale, m.log_floor,
+                             m.cal_offset_db, tare, out_db_dev, nullptr,
+                             (m.hold_flags & TDSA_HOLD_MAX) ? p->d_hold_max : nullptr,
+                             (m.hold_flags & TDSA_HOLD_MIN) ? p->d_hold_min : nullptr, s));
+  }
+  if (m.hold_flags & TDSA_HOLD_MAX) p->held_max += n_frames;
+  if (m.hold_flags & TDSA_HOLD_MIN) p->held_min += n_frames;
+  p->frames_seen += n_frames;
+  return TDSA_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -291,9 +384,12 @@ static int plan_init(tdsa_plan p);
 int tdsa_create(int device_id, int nfft, int max_frames, tdsa_plan* out) {
   if (!out) return fail(TDSA_ERR_ARG, "out is null");
   *out = nullptr;
-  if (nfft < (1 << kMinLog2N) || nfft > (1 << kBigMaxLog2N) || (nfft & (nfft - 1)))
-    return fail(TDSA_ERR_ARG, "nfft=%d: need a power of two in [%d, %d]", nfft, 1 << kMinLog2N, 1 << kBigMaxLog2N);
-  const bool big = nfft > (1 << kMaxLog2N);
+  const bool native = nfft >= (1 << kMinLog2N) && nfft <= (1 << kBigMaxLog2N) && (nfft & (nfft - 1)) == 0;
+  const bool chirp = !native && nfft >= 2 && nfft <= kChirpMaxN;
+  if (!native && !chirp)
+    return fail(TDSA_ERR_ARG, "nfft=%d: need a power of two in [%d, %d] or any size in [2, %d]", nfft, 1 << kMinLog2N,
+                1 << kBigMaxLog2N, kChirpMaxN);
+  const bool big = native && nfft > (1 << kMaxLog2N);
   if (max_frames < 1) return fail(TDSA_ERR_ARG, "max_frames=%d must be >= 1", max_frames);
   int ndev = 0;
   HIPCHK(hipGetDeviceCount(&ndev));
@@ -306,6 +402,14 @@ int tdsa_create(int device_id, int nfft, int max_frames, tdsa_plan* out) {
   p->log2n = ilog2i(nfft);
   p->max_frames = max_frames;
   p->big = big;
+  p->chirp = chirp;
+  if (chirp) {
+    int m = 1 << kMinLog2N;
+    while (m < 2 * nfft - 1) m <<= 1;
+    p->m_fft = m;
+    p->log2m = ilog2i(m);
+    p->log2n = p->log2m;      // what the frame kernel of this plan transforms
+  }
   const int rc_init = plan_init(p);          // a failure half way leaves nothing behind
   if (rc_init != TDSA_OK) {
     (void)tdsa_destroy(p);
@@ -331,7 +435,8 @@ static int plan_init(tdsa_plan p) {
   HIPCHK(hipEventCreateWithFlags(&p->ev_state, hipEventDisableTiming));
   const size_t nb = size_t(nfft) * sizeof(float);
   for (int f = 0; f < 3; ++f) HIPCHK(hipMalloc(&p->d_window[f], nb));
-  HIPCHK(hipMalloc(&p->d_tw, size_t(nfft) * sizeof(float2)));
+  const int tw_n = p->chirp ? p->m_fft : nfft;       // the size the frame kernel transforms
+  HIPCHK(hipMalloc(&p->d_tw, size_t(tw_n) * sizeof(float2)));
   HIPCHK(hipMalloc(&p->d_hold_max, nb));
   HIPCHK(hipMalloc(&p->d_hold_min, nb));
   HIPCHK(hipMalloc(&p->d_avg, size_t(nfft) * sizeof(double)));
@@ -345,12 +450,57 @@ static int plan_init(tdsa_plan p) {
   HIPCHK(hipMemsetAsync(p->d_dc_state, 0, sizeof(float2), p->stream));
   HIPCHK(hipMemsetAsync(p->d_avg, 0, size_t(nfft) * sizeof(double), p->stream));
   // twiddle table exp(-2 pi i m / N), evaluated in double, rounded once
-  std::vector<float2> tw(nfft);
-  for (int m = 0; m < nfft; ++m) {
-    const double ang = -2.0 * M_PI * double(m) / double(nfft);
+  std::vector<float2> tw(tw_n);
+  for (int m = 0; m < tw_n; ++m) {
+    const double ang = -2.0 * M_PI * double(m) / double(tw_n);
     tw[m] = float2{float(std::cos(ang)), float(std::sin(ang))};
   }
-  HIPCHK(hipMemcpy(p->d_tw, tw.data(), size_t(nfft) * sizeof(float2), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(p->d_tw, tw.data(), size_t(tw_n) * sizeof(float2), hipMemcpyHostToDevice));
+  if (p->chirp) {
+    // a[n] = exp(-i pi n^2 / N): the phase from n^2 mod 2N in integers, so that it is exact for every n;
+    // B = FFT_M(b), b[n] = b[M - n] = conj(a[n]) for n < N, 0 elsewhere - in double (plain radix-2), rounded once
+    const int M = p->m_fft;
+    std::vector<double> ar(nfft), ai(nfft), br(M, 0.0), bi(M, 0.0);
+    for (int n = 0; n < nfft; ++n) {
+      const long long q = ((long long)n * n) % (2ll * nfft);
+      const double ang = -M_PI * double(q) / double(nfft);
+      ar[n] = std::cos(ang);
+      ai[n] = std::sin(ang);
+      br[n] = ar[n];
+      bi[n] = -ai[n];
+      if (n > 0) { br[M - n] = ar[n]; bi[M - n] = -ai[n]; }
+    }
+    for (int i = 1, j = 0; i < M; ++i) {        // bit reversal
+      int bit = M >> 1;
+      for (; j & bit; bit >>= 1) j ^= bit;
+      j ^= bit;
+      if (i < j) { std::swap(br[i], br[j]); std::swap(bi[i], bi[j]); }
+    }
+    for (int len = 2; len <= M; len <<= 1) {
+      for (int i = 0; i < M; i += len) {
+        for (int k = 0; k < len / 2; ++k) {
+          const double ang = -2.0 * M_PI * double(k) / double(len);
+          const double wr = std::cos(ang), wi = std::sin(ang);
+          const double xr = br[i + k + len / 2] * wr - bi[i + k + len / 2] * wi;
+          const double xi = br[i + k + len / 2] * wi + bi[i + k + len / 2] * wr;
+          br[i + k + len / 2] = br[i + k] - xr;
+          bi[i + k + len / 2] = bi[i + k] - xi;
+          br[i + k] += xr;
+          bi[i + k] += xi;
+        }
+      }
+    }
+    std::vector<float2> a32(nfft), b32(M);
+    for (int n = 0; n < nfft; ++n) a32[n] = float2{float(ar[n]), float(ai[n])};
+    for (int k = 0; k < M; ++k) b32[k] = float2{float(br[k]), float(bi[k])};
+    HIPCHK(hipMalloc(&p->d_chirp_a, size_t(nfft) * sizeof(float2)));
+    HIPCHK(hipMalloc(&p->d_chirp_b, size_t(M) * sizeof(float2)));
+    HIPCHK(hipMalloc(&p->d_ones, size_t(M) * sizeof(float)));
+    std::vector<float> ones(M, 1.0f);
+    HIPCHK(hipMemcpy(p->d_chirp_a, a32.data(), size_t(nfft) * sizeof(float2), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->d_chirp_b, b32.data(), size_t(M) * sizeof(float2), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->d_ones, ones.data(), size_t(M) * sizeof(float), hipMemcpyHostToDevice));
+  }
   if (big) {
     if (const char* g = getenv("TDSA_BIG_GROUP")) {     // developer knob: segments per column/row round
       const int v = atoi(g);
@@ -408,7 +558,7 @@ int tdsa_destroy(tdsa_plan p) {
   void* bufs[] = {p->d_window[0], p->d_window[1], p->d_window[2], p->d_tw, p->d_hold_max, p->d_hold_min,
                   p->d_avg, p->d_lin, p->d_carry, p->d_cplx, p->d_real, p->d_lin1, p->d_db1, p->d_dc_state, p->d_sums, p->d_dc_sub,
                   p->d_tare_base, p->d_tare_acc, p->d_in_stage, p->d_out_stage, p->d_trace_in,
-                  p->d_trace_live, p->d_scratch, p->d_z, p->d_acc, p->d_sum, p->d_lin64, p->d_sums64, p->d_tw_hi, p->d_tw_lo, p->d_tw_row, p->d_ones,
+                  p->d_trace_live, p->d_scratch, p->d_z, p->d_chirp_a, p->d_chirp_b, p->d_u0, p->d_u1, p->d_acc, p->d_sum, p->d_lin64, p->d_sums64, p->d_tw_hi, p->d_tw_lo, p->d_tw_row, p->d_ones,
                   p->d_dbg};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -540,6 +690,13 @@ static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size
   if ((reinterpret_cast<uintptr_t>(iq_dev) % (bps == 8 ? 8 : 2)) != 0)
     return fail(TDSA_ERR_ARG, "iq pointer must be aligned to one sample (%d bytes)", bps);
   HIPCHK(hipSetDevice(p->device));
+  if (p->chirp) {
+    JOIN(p);
+    if (before) HIPCHK(hipStreamWaitEvent(p->stream, before, 0));
+    const int rc_chirp = process_chirp(p, in_format, iq_dev, hop, n_frames, out_db_dev);
+    if (rc_chirp == TDSA_OK && after) HIPCHK(hipEventRecord(after, p->stream));
+    return rc_chirp;
+  }
   if (p->big) {
     JOIN(p);
     if (before) HIPCHK(hipStreamWaitEvent(p->stream, before, 0));
@@ -700,7 +857,7 @@ int tdsa_process_c64(tdsa_plan p, const float* iq_host, size_t n_samples, int ho
 int tdsa_process_real2(tdsa_plan p, const float* lr_host, size_t n_samples, int hop, int n_frames, int channel,
                        float* out_db_host) {
   if (!p) return fail(TDSA_ERR_ARG, "null plan");
-  if (p->big) return fail(TDSA_ERR_ARG, "real-input path needs an LDS-resident FFT size");
+  if (p->big || p->chirp) return fail(TDSA_ERR_ARG, "real-input path needs a power-of-two FFT size of at most 16384");
   if (channel < TDSA_CH_MONO || channel > TDSA_CH_STEREO) return fail(TDSA_ERR_ARG, "channel %d", channel);
   if (n_frames == 0) return TDSA_OK;
   if (!lr_host || !out_db_host) return fail(TDSA_ERR_ARG, "null buffer");

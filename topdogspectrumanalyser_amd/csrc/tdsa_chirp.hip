@@ -1,0 +1,214 @@
+// tdsa_chirp.hip - frames whose length is NOT a power of two (and the powers of two below 64): 2 <= N <= 8192.
+//
+// np.fft.fft / scipy.fft.fft take any N (hackrf_samples.py:370, rtl_samples.py:170) and
+// HackrfSamplesDataSource.set_num_samples / RtlSamplesDataSource.set_fft_size accept any positive size
+// (hackrf_samples.py:392-405, rtl_samples.py:208-214).  Such a frame is transformed as a chirp-z (Bluestein)
+// convolution on the power-of-two frame kernel:
+//
+//   X[k] = a[k] * sum_n (x[n] w[n] a[n]) * conj(a)[k - n],     a[n] = exp(-i pi n^2 / N)
+//
+//   (0) chirp_sums   : exact per-frame I / Q sums -> the frame mean as a small residual on top of the format's
+//                      zero level (then the ordinary DC tracker of tdsa_trace.hip)
+//   (1) chirp_pre    : unpack + DC + window, times a[n], zero-padded to M = 2^ceil(log2(2N-1)) -> U[f][M] complex64
+//   (2) frame kernel : FFT_M(U)                                   (complex64 in, complex spectrum out)
+//   (3) chirp_mul    : conj(FFT_M(U) * B),  B = FFT_M(conj(a) wrapped) - a plan-time table made in double
+//   (4) frame kernel : FFT_M of that = M * conj(convolution)      (inverse transform through conjugation)
+//   (5) chirp_post   : X[k] = a[k] * conj(.)/M for k < N -> |X|^2 -> fftshift by N/2 (np.fft.fftshift for any N)
+//                      -> dB (+cal, -tare) rows and hold traces, or linear power rows for the averager scan
+//
+// Cost: two M-point transforms + 8 B/point of intermediate traffic per pass - about 6x the bytes of a native
+// size; the point of this path is that every size the reference accepts has a device path, not its speed.
+#include "tdsa_fft.hpp"
+#include "tdsa_kernels.hpp"
+
+namespace tdsa {
+
+namespace {
+
+constexpr float kTenLog10Of2 = 3.01029995663981195214f;   // 10*log10(2): dB = kTenLog10Of2 * log2(power)
+
+// float max/min through integer atomics (IEEE-754 order trick); NaN candidates are skipped (np.fmax / np.fmin)
+__device__ __forceinline__ void chirp_atomic_fmax(float* addr, float v) {
+  if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else if (v < 0.f) atomicMin(reinterpret_cast<unsigned*>(addr), __float_as_uint(v));
+}
+__device__ __forceinline__ void chirp_atomic_fmin(float* addr, float v) {
+  if (v >= 0.f) atomicMin(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else if (v < 0.f) atomicMax(reinterpret_cast<unsigned*>(addr), __float_as_uint(v));
+}
+
+}  // namespace
+
+// ---- (0) frame means ------------------------------------------------------------------------------------
+// res[f] = mean of the frame's raw samples MINUS the format's zero level (128 / 127.5 / 0), raw units.  Byte
+// formats: integer sums (exact), the small numerator sum - zero * n formed in integers, one division in double -
+// a float32 "sum / n - 128" would cancel to ~1e-5 LSB, visible in the DC bin.
+template <bool IN_C64>
+__global__ void __launch_bounds__(256) chirp_sums_kernel(const void* in, unsigned xor_mask, long long frame_stride, int n,
+                                                         int twice_zero, float2* res) {
+  __shared__ double red[8];
+  const int f = blockIdx.x;
+  const unsigned char* fb = static_cast<const unsigned char*>(in) + (long long)f * frame_stride;
+  double sr = 0.0, si = 0.0;
+  if constexpr (IN_C64) {
+    const float2* x = reinterpret_cast<const float2*>(fb);
+    for (int i = threadIdx.x; i < n; i += 256) { sr += double(x[i].x); si += double(x[i].y); }
+  } else {
+    const uint16_t* x = reinterpret_cast<const uint16_t*>(fb);
+    const unsigned xm = xor_mask & 0xffffu;
+    long long ui = 0, uq = 0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const unsigned u = unsigned(x[i]) ^ xm;
+      ui += u & 0xffu;
+      uq += u >> 8;
+    }
+    sr = double(ui); si = double(uq);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { sr += __shfl_xor(sr, off); si += __shfl_xor(si, off); }
+  if ((threadIdx.x & 63) == 0) { red[(threadIdx.x >> 6) * 2] = sr; red[(threadIdx.x >> 6) * 2 + 1] = si; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double tr = red[0] + red[2] + red[4] + red[6], ti = red[1] + red[3] + red[5] + red[7];
+    // (2 sum - twice_zero n) / (2 n): integer-valued numerator for the byte formats
+    const double dn = double(n), tz = double(twice_zero);
+    res[f] = float2{float((2.0 * tr - tz * dn) / (2.0 * dn)), float((2.0 * ti - tz * dn) / (2.0 * dn))};
+  }
+}
+
+hipError_t launch_chirp_sums(const void* in, int in_c64, unsigned xor_mask, long long frame_stride, int n, int n_frames,
+                             int twice_zero, float2* res, hipStream_t s) {
+  if (in_c64)
+    hipLaunchKernelGGL(chirp_sums_kernel<true>, dim3(n_frames), dim3(256), 0, s, in, xor_mask, frame_stride, n, twice_zero, res);
+  else
+    hipLaunchKernelGGL(chirp_sums_kernel<false>, dim3(n_frames), dim3(256), 0, s, in, xor_mask, frame_stride, n, twice_zero, res);
+  return hipGetLastError();
+}
+
+// ---- (1) unpack, DC, window, chirp, zero padding ------------------------------------------------------------
+struct ChirpPreParams {
+  const void* in;
+  int in_c64;
+  long long frame_stride;    // bytes
+  int n, m, n_frames;
+  const float* window;       // [n] window * input scale
+  const float2* chirp;       // [n] a[n]
+  const float2* dc_sub;      // [F] DC estimate minus the zero level, raw units, or null
+  unsigned xor_mask;
+  float in_off;
+  float2* u;                 // [F][m]
+};
+
+__global__ void __launch_bounds__(256) chirp_pre_kernel(const ChirpPreParams p) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.m) return;
+  const unsigned xm = p.xor_mask & 0xffffu;
+  for (int f = blockIdx.y; f < p.n_frames; f += gridDim.y) {
+    c32 out = c32{0.f, 0.f};
+    if (i < p.n) {
+      const unsigned char* fb = static_cast<const unsigned char*>(p.in) + (long long)f * p.frame_stride;
+      float re, im;
+      if (p.in_c64) {
+        const float2 x = reinterpret_cast<const float2*>(fb)[i];
+        re = x.x; im = x.y;
+      } else {
+        const unsigned v = unsigned(reinterpret_cast<const uint16_t*>(fb)[i]) ^ xm;
+        re = float(v & 0xffu) - p.in_off;      // exact: small integers / halves
+        im = float(v >> 8) - p.in_off;
+      }
+      if (p.dc_sub != nullptr) { const float2 d = p.dc_sub[f]; re -= d.x; im -= d.y; }
+      const float w = p.window[i];
+      out = cmul(c32{re * w, im * w}, p.chirp[i]);
+    }
+    p.u[(long long)f * p.m + i] = out;
+  }
+}
+
+hipError_t launch_chirp_pre(const void* in, int in_c64, long long frame_stride, int n, int m, int n_frames,
+                            const float* window, const float2* chirp, const float2* dc_sub, unsigned xor_mask,
+                            float in_off, float2* u, hipStream_t s) {
+  ChirpPreParams p{in, in_c64, frame_stride, n, m, n_frames, window, chirp, dc_sub, xor_mask, in_off, u};
+  const int gy = n_frames < 4096 ? n_frames : 4096;
+  hipLaunchKernelGGL(chirp_pre_kernel, dim3((m + 255) / 256, gy), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+// ---- (3) spectrum of the convolution, conjugated for the inverse transform ------------------------------------
+__global__ void __launch_bounds__(256) chirp_mul_kernel(float2* y, const float2* b, long long count, int m_mask) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
+    const c32 v = cmul(y[i], b[int(i) & m_mask]);
+    y[i] = c32{v.x, -v.y};
+  }
+}
+
+hipError_t launch_chirp_mul(float2* y, const float2* b, int m, int n_frames, hipStream_t s) {
+  const long long count = (long long)m * n_frames;
+  long long blocks = (count + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(chirp_mul_kernel, dim3(unsigned(blocks)), dim3(256), 0, s, y, b, count, m - 1);
+  return hipGetLastError();
+}
+
+// ---- (5) back to N bins: chirp, power, fftshift, dB / linear rows, hold traces --------------------------------
+struct ChirpPostParams {
+  const float2* y;           // [F][m]  M * conj(convolution)
+  const float2* chirp;       // [n]
+  int n, m, n_frames, first_frame_index;
+  float inv_m;
+  int db_mode;               // 0: 20 log10(|X| + floor), 1: 10 log10(|X|^2 * pscale + floor)
+  float pscale, log_floor, cal_db;
+  const float* tare;         // [n] or null
+  float* out_db;             // [F][n] or null
+  float* out_lin;            // [F][n] linear power * pscale (averaging modes) or null
+  float* hold_max;           // [n] or null
+  float* hold_min;
+};
+
+constexpr int kChirpFramesPerBlock = 32;   // one hold atomic per bin and this many frames
+
+__global__ void __launch_bounds__(256) chirp_post_kernel(const ChirpPostParams p) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= p.n) return;
+  const c32 a = p.chirp[k];
+  int j = k + p.n / 2;                       // np.fft.fftshift: bin k lands at (k + N/2) mod N, any N
+  if (j >= p.n) j -= p.n;
+  const float tare = p.tare != nullptr ? p.tare[j] : 0.f;
+  float hmax = -INFINITY, hmin = INFINITY;
+  const int f0 = blockIdx.y * kChirpFramesPerBlock;
+  const int f1 = f0 + kChirpFramesPerBlock < p.n_frames ? f0 + kChirpFramesPerBlock : p.n_frames;
+  for (int f = f0; f < f1; ++f) {
+    const c32 w = p.y[(long long)f * p.m + k];
+    const c32 X = cmul(c32{w.x * p.inv_m, -w.y * p.inv_m}, a);
+    const float pw = X.x * X.x + X.y * X.y;
+    if (p.out_lin != nullptr) {
+      p.out_lin[(long long)f * p.n + j] = pw * p.pscale;
+      continue;
+    }
+    float db;
+    if (p.db_mode == 0) db = fmaf(2.0f * kTenLog10Of2, __builtin_amdgcn_logf(__builtin_amdgcn_sqrtf(pw) + p.log_floor), p.cal_db);
+    else db = fmaf(kTenLog10Of2, __builtin_amdgcn_logf(fmaf(pw, p.pscale, p.log_floor)), p.cal_db);
+    db -= tare;
+    if (p.out_db != nullptr) p.out_db[(long long)f * p.n + j] = db;
+    float dmx = db, dmn = db;
+    if (p.first_frame_index + f == 0 && db != db) { dmx = -500.f; dmn = 500.f; }     // _nan_safe, first frame ever
+    hmax = fmaxf(hmax, dmx);                 // a NaN operand is ignored, as by np.fmax
+    hmin = fminf(hmin, dmn);
+  }
+  if (p.out_lin == nullptr) {
+    if (p.hold_max != nullptr && hmax > p.hold_max[j]) chirp_atomic_fmax(p.hold_max + j, hmax);
+    if (p.hold_min != nullptr && hmin < p.hold_min[j]) chirp_atomic_fmin(p.hold_min + j, hmin);
+  }
+}
+
+hipError_t launch_chirp_post(const float2* y, const float2* chirp, int n, int m, int n_frames, int first_frame_index,
+                             int db_mode, float pscale, float log_floor, float cal_db, const float* tare, float* out_db,
+                             float* out_lin, float* hold_max, float* hold_min, hipStream_t s) {
+  ChirpPostParams p{y, chirp, n, m, n_frames, first_frame_index, 1.0f / float(m), db_mode, pscale, log_floor, cal_db,
+                    tare, out_db, out_lin, hold_max, hold_min};
+  const int gy = (n_frames + kChirpFramesPerBlock - 1) / kChirpFramesPerBlock;
+  hipLaunchKernelGGL(chirp_post_kernel, dim3((n + 255) / 256, gy), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+}  // namespace tdsa

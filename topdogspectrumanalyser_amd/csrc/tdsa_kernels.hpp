@@ -151,6 +151,19 @@ hipError_t launch_big_finish(const double* src, long long n, double* mean_out, i
                              float* hold_min, int max_first, int min_first, hipStream_t s);
 
 
+// ---- frame lengths that are not a power of two, 2 <= N <= 8192 (tdsa_chirp.hip): chirp-z on the frame kernel ----
+constexpr int kChirpMaxN = 8192;
+// res[f] = frame mean minus the format's zero level, raw units (twice_zero: 256 int8 after the xor, 255 uint8, 0 c64)
+hipError_t launch_chirp_sums(const void* in, int in_c64, unsigned xor_mask, long long frame_stride, int n, int n_frames,
+                             int twice_zero, float2* res, hipStream_t s);
+hipError_t launch_chirp_pre(const void* in, int in_c64, long long frame_stride, int n, int m, int n_frames,
+                            const float* window, const float2* chirp, const float2* dc_sub, unsigned xor_mask,
+                            float in_off, float2* u, hipStream_t s);
+hipError_t launch_chirp_mul(float2* y, const float2* b, int m, int n_frames, hipStream_t s);
+hipError_t launch_chirp_post(const float2* y, const float2* chirp, int n, int m, int n_frames, int first_frame_index,
+                             int db_mode, float pscale, float log_floor, float cal_db, const float* tare, float* out_db,
+                             float* out_lin, float* hold_max, float* hold_min, hipStream_t s);
+
 // ---- trace analytics / accumulators (tdsa_analytics.hip) ---------------------------------------------
 hipError_t launch_rows_stats(const float* rows, int n_rows, int n, int band_lo, int band_hi, double bin_width,
                              float* peak_db, int* peak_bin, double* band_db, hipStream_t s);

@@ -5,7 +5,7 @@ import numpy as np
 
 from .. import _native as nat
 from ..engine import SpectrumEngine
-from ..utils.constants import DSPConstants, GPU_MAX_FFT, GPU_MIN_FFT
+from ..utils.constants import DSPConstants, gpu_fft_size_supported
 
 
 class GpuSpectrumMixin:
@@ -23,8 +23,8 @@ class GpuSpectrumMixin:
         self._engine_n = 0
 
     def _gpu_engine(self, nfft: int) -> SpectrumEngine:
-        if nfft < GPU_MIN_FFT or nfft > GPU_MAX_FFT or nfft & (nfft - 1):
-            raise ValueError(f"FFT size {nfft} is not a power of two in [{GPU_MIN_FFT}, {GPU_MAX_FFT}]")
+        if not gpu_fft_size_supported(nfft):
+            raise ValueError(f"FFT size {nfft}: the device library plans any size up to 8192 and powers of two up to 2^20")
         if self._engine is None or self._engine_n != nfft:
             # the DC estimate is a property of the source, not of an FFT size (the reference keeps
             # self._dc_estimate across set_num_samples): it moves to the new plan

@@ -21,8 +21,8 @@ class DisplayMode(IntEnum):
 
 
 class FFTSize(IntEnum):
-    """FFT sizes the reference enumerates (512..8192); the GPU path additionally takes any power of two
-    from 64 to 16384 (see GPU_MIN / GPU_MAX)."""
+    """FFT sizes the reference enumerates (512..8192); the GPU path takes every size up to 8192 and every power
+    of two up to 2^20 (gpu_fft_size_supported)."""
     SIZE_512 = 512
     SIZE_1024 = 1024
     SIZE_2048 = 2048
@@ -44,6 +44,15 @@ class FFTSize(IntEnum):
 
 GPU_MIN_FFT = 64
 GPU_MAX_FFT = 1 << 20      # 64 .. 16384 in one LDS-resident pass, 2^15 .. 2^20 as N1 x 16384 (two passes)
+GPU_MAX_ANY_FFT = 8192     # any size from 2 up to here (chirp-z on the power-of-two kernel), power of two or not
+
+
+def gpu_fft_size_supported(nfft: int) -> bool:
+    """Sizes the device library has a plan for: every N in [2, 8192], every power of two up to 2^20."""
+    nfft = int(nfft)
+    if 2 <= nfft <= GPU_MAX_ANY_FFT:
+        return True
+    return GPU_MIN_FFT <= nfft <= GPU_MAX_FFT and nfft & (nfft - 1) == 0
 
 
 class WindowType(str, Enum):
