@@ -95,7 +95,7 @@ int tdsa_device_count(int* count);
  * LDS-resident kernel; 2^15 .. 2^20 as N1 x 16384 in two passes (in-register column DFT kernel + the same frame
  * kernel as row pass); every other size up to 8192 as a chirp-z convolution on the power-of-two kernel
  * (tdsa_chirp.hip: same modes, state and outputs, about an order of magnitude slower per frame; fftshift by
- * nfft / 2 as np.fft.fftshift does for odd sizes; tdsa_process_real2 is not available on such a plan).  A long-frame plan takes one
+ * nfft / 2 as np.fft.fftshift does for odd sizes).  A long-frame plan takes one
  * frame per call, or - with avg_mode lin and avg_n >= the frames seen since the last reset - a batch of K
  * segments whose Welch average comes back as ONE dB row. */
 int tdsa_create(int device_id, int nfft, int max_frames, tdsa_plan* out);

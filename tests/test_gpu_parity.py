@@ -1431,7 +1431,7 @@ def test_audio_source_random_histories(pkg, seed):
     restatement fed the same rolling buffer."""
     rng = np.random.default_rng(6800 + seed)
     fs = int(rng.choice([8000, 16000, 48000]))
-    n = int(rng.choice([256, 1024, 2048]))
+    n = int(rng.choice([256, 1024, 2048, 300, 1000, 1501]))      # the last three: not powers of two (chirp-z path)
     t = np.arange(1 << 16)
     data = np.stack([0.3 * np.sin(2 * np.pi * 440.0 * t / fs) + 0.01 * rng.standard_normal(len(t)) + 0.02,
                      0.1 * np.sin(2 * np.pi * 1234.5 * t / fs) + 0.02 * rng.standard_normal(len(t))], axis=1).astype(np.float32)

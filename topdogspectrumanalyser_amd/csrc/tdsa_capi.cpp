@@ -280,32 +280,16 @@ int process_big(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n_f
   return TDSA_OK;
 }
 
-// Plans whose frame length is not a power of two (tdsa_chirp.hip): same modes, same state, same outputs as the
-// native sizes - every stage on the plan's main stream.
-int process_chirp(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n_frames, float* out_db_dev) {
-  const tdsa_mode& m = p->mode;
-  const bool averaging = avg_active(m);
+// Chirp-z core of a plan whose frame length is not a power of two: frames at `in` (stride bytes apart) ->
+// p->d_u0[f][k] = M * conj(convolution), k < nfft (tdsa_chirp.hip steps 1-4), on the main stream.
+int chirp_transform(tdsa_plan p, const void* in, int in_format, long long stride, int n_frames, const float2* dc_sub,
+                    unsigned xor_mask, float in_off) {
   const int N = p->nfft, M = p->m_fft;
-  const int in_c64 = in_format == TDSA_IN_C64;
-  const unsigned xor_mask = in_format == TDSA_IN_I8 ? 0x80808080u : 0u;
-  const float in_off = in_format == TDSA_IN_I8 ? 128.0f : (in_c64 ? 0.0f : 127.5f);
-  const float in_scale = in_format == TDSA_IN_I8 ? 1.0f / 128.0f : (in_c64 ? 1.0f : 1.0f / 127.5f);
-  const long long stride = (long long)hop * bytes_per_sample(in_format);
   hipStream_t s = p->stream;
   if (!p->d_u0) HIPCHK(hipMalloc(&p->d_u0, size_t(p->max_frames) * M * sizeof(float2)));
   if (!p->d_u1) HIPCHK(hipMalloc(&p->d_u1, size_t(p->max_frames) * M * sizeof(float2)));
-  const float2* dc_sub = nullptr;
-  if (m.dc_alpha >= 0.0f) {
-    // frame means as residuals (exact sums), then the tracker of the native path fed with them directly
-    // (n = 1, zero level 0): alpha >= 1 makes it the plain per-frame mean
-    HIPCHK(launch_chirp_sums(iq_dev, in_c64, xor_mask, stride, N, n_frames,
-                             in_format == TDSA_IN_I8 ? 256 : (in_c64 ? 0 : 255), p->d_sums, s));
-    HIPCHK(launch_dc_track(p->d_sums, 1, n_frames, m.dc_alpha > 1.0f ? 1.0f : m.dc_alpha, 0.0f, in_scale, p->d_dc_state,
-                           p->d_dc_sub, s));
-    dc_sub = p->d_dc_sub;
-  }
-  HIPCHK(launch_chirp_pre(iq_dev, in_c64, stride, N, M, n_frames, p->d_window[in_format], p->d_chirp_a, dc_sub, xor_mask,
-                          in_off, p->d_u0, s));
+  HIPCHK(launch_chirp_pre(in, in_format == TDSA_IN_C64, stride, N, M, n_frames, p->d_window[in_format], p->d_chirp_a, dc_sub,
+                          xor_mask, in_off, p->d_u0, s));
   SpecParams sp{};
   sp.frame_stride = (long long)M * sizeof(float2);
   sp.n_frames = n_frames;
@@ -324,6 +308,32 @@ int process_chirp(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n
   sp.in = p->d_u1;
   sp.out_cplx = p->d_u0;
   { const int rc = launch_spectrum_profiled(p, 1, sp, g); if (rc != TDSA_OK) return rc; }
+  return TDSA_OK;
+}
+
+// Plans whose frame length is not a power of two (tdsa_chirp.hip): same modes, same state, same outputs as the
+// native sizes - every stage on the plan's main stream.
+int process_chirp(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n_frames, float* out_db_dev) {
+  const tdsa_mode& m = p->mode;
+  const bool averaging = avg_active(m);
+  const int N = p->nfft, M = p->m_fft;
+  const int in_c64 = in_format == TDSA_IN_C64;
+  const unsigned xor_mask = in_format == TDSA_IN_I8 ? 0x80808080u : 0u;
+  const float in_off = in_format == TDSA_IN_I8 ? 128.0f : (in_c64 ? 0.0f : 127.5f);
+  const float in_scale = in_format == TDSA_IN_I8 ? 1.0f / 128.0f : (in_c64 ? 1.0f : 1.0f / 127.5f);
+  const long long stride = (long long)hop * bytes_per_sample(in_format);
+  hipStream_t s = p->stream;
+  const float2* dc_sub = nullptr;
+  if (m.dc_alpha >= 0.0f) {
+    // frame means as residuals (exact sums), then the tracker of the native path fed with them directly
+    // (n = 1, zero level 0): alpha >= 1 makes it the plain per-frame mean
+    HIPCHK(launch_chirp_sums(iq_dev, in_c64, xor_mask, stride, N, n_frames,
+                             in_format == TDSA_IN_I8 ? 256 : (in_c64 ? 0 : 255), p->d_sums, s));
+    HIPCHK(launch_dc_track(p->d_sums, 1, n_frames, m.dc_alpha > 1.0f ? 1.0f : m.dc_alpha, 0.0f, in_scale, p->d_dc_state,
+                           p->d_dc_sub, s));
+    dc_sub = p->d_dc_sub;
+  }
+  { const int rc = chirp_transform(p, iq_dev, in_format, stride, n_frames, dc_sub, xor_mask, in_off); if (rc != TDSA_OK) return rc; }
   const float pscale = m.db_mode == TDSA_DB_POW ? m.power_scale : 1.0f;
   float* const tare = p->tare_active ? p->d_tare_base : nullptr;
   const int first = p->frames_seen > 0 ? 1 : 0;
@@ -331,7 +341,7 @@ int process_chirp(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n
     if (!p->d_lin) HIPCHK(hipMalloc(&p->d_lin, size_t(p->max_frames) * N * sizeof(float)));
     if (!p->d_carry && p->max_frames > 128)
       HIPCHK(hipMalloc(&p->d_carry, size_t(avg_scan_chunks(p->max_frames)) * N * sizeof(double)));
-    HIPCHK(launch_chirp_post(p->d_u0, p->d_chirp_a, N, M, n_frames, first, m.db_mode, pscale, m.log_floor,
+    HIPCHK(launch_chirp_post(p->d_u0, N, M, n_frames, first, m.db_mode, pscale, m.log_floor,
                              m.cal_offset_db, nullptr, nullptr, p->d_lin, nullptr, nullptr, s));
     AvgParams ap{};
     ap.lin = p->d_lin;
@@ -355,7 +365,7 @@ int process_chirp(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n
       p->avg_count = 1;
     }
   } else {
-    HIPCHK(launch_chirp_post(p->d_u0, p->d_chirp_a, N, M, n_frames, first, m.db_mode, pscale, m.log_floor,
+    HIPCHK(launch_chirp_post(p->d_u0, N, M, n_frames, first, m.db_mode, pscale, m.log_floor,
                              m.cal_offset_db, tare, out_db_dev, nullptr,
                              (m.hold_flags & TDSA_HOLD_MAX) ? p->d_hold_max : nullptr,
                              (m.hold_flags & TDSA_HOLD_MIN) ? p->d_hold_min : nullptr, s));
@@ -857,7 +867,7 @@ int tdsa_process_c64(tdsa_plan p, const float* iq_host, size_t n_samples, int ho
 int tdsa_process_real2(tdsa_plan p, const float* lr_host, size_t n_samples, int hop, int n_frames, int channel,
                        float* out_db_host) {
   if (!p) return fail(TDSA_ERR_ARG, "null plan");
-  if (p->big || p->chirp) return fail(TDSA_ERR_ARG, "real-input path needs a power-of-two FFT size of at most 16384");
+  if (p->big) return fail(TDSA_ERR_ARG, "real-input path needs an FFT size of at most 16384");
   if (channel < TDSA_CH_MONO || channel > TDSA_CH_STEREO) return fail(TDSA_ERR_ARG, "channel %d", channel);
   if (n_frames == 0) return TDSA_OK;
   if (!lr_host || !out_db_host) return fail(TDSA_ERR_ARG, "null buffer");
@@ -901,6 +911,16 @@ int tdsa_process_real2(tdsa_plan p, const float* lr_host, size_t n_samples, int 
   float2* const zb = p->d_real + need;
   HIPCHK(launch_real_select(static_cast<const float2*>(p->d_in_stage), need, channel, za, zb, p->stream));
   for (int sig = 0; sig < n_sig; ++sig) {
+    if (p->chirp) {
+      // a size that is not a power of two: signal + 0i through the chirp-z core, mean removed (exact sums), and
+      // the one-sided power straight from the full spectrum
+      const float2* zin = sig == 0 ? za : zb;
+      const long long stride = (long long)hop * sizeof(float2);
+      HIPCHK(launch_chirp_sums(zin, 1, 0u, stride, n, n_frames, 0, p->d_sums, p->stream));
+      { const int rc = chirp_transform(p, zin, TDSA_IN_C64, stride, n_frames, p->d_sums, 0u, 0.0f); if (rc != TDSA_OK) return rc; }
+      HIPCHK(launch_chirp_post_real(p->d_u0, n, p->m_fft, n_frames, n_sig, sig, m.power_scale, p->d_lin1, p->stream));
+      continue;
+    }
     SpecParams sp{};
     sp.in = sig == 0 ? za : zb;
     sp.frame_stride = (long long)hop * sizeof(float2);

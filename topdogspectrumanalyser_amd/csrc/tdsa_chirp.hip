@@ -13,7 +13,7 @@
 //   (2) frame kernel : FFT_M(U)                                   (complex64 in, complex spectrum out)
 //   (3) chirp_mul    : conj(FFT_M(U) * B),  B = FFT_M(conj(a) wrapped) - a plan-time table made in double
 //   (4) frame kernel : FFT_M of that = M * conj(convolution)      (inverse transform through conjugation)
-//   (5) chirp_post   : X[k] = a[k] * conj(.)/M for k < N -> |X|^2 -> fftshift by N/2 (np.fft.fftshift for any N)
+//   (5) chirp_post   : |X[k]|^2 = |./M|^2 for k < N (|a[k]| = 1) -> fftshift by N/2 (np.fft.fftshift for any N)
 //                      -> dB (+cal, -tare) rows and hold traces, or linear power rows for the averager scan
 //
 // Cost: two M-point transforms + 8 B/point of intermediate traffic per pass - about 6x the bytes of a native
@@ -150,10 +150,9 @@ hipError_t launch_chirp_mul(float2* y, const float2* b, int m, int n_frames, hip
   return hipGetLastError();
 }
 
-// ---- (5) back to N bins: chirp, power, fftshift, dB / linear rows, hold traces --------------------------------
+// ---- (5) back to N bins: power, fftshift, dB / linear rows, hold traces ---------------------------------------
 struct ChirpPostParams {
   const float2* y;           // [F][m]  M * conj(convolution)
-  const float2* chirp;       // [n]
   int n, m, n_frames, first_frame_index;
   float inv_m;
   int db_mode;               // 0: 20 log10(|X| + floor), 1: 10 log10(|X|^2 * pscale + floor)
@@ -170,7 +169,6 @@ constexpr int kChirpFramesPerBlock = 32;   // one hold atomic per bin and this m
 __global__ void __launch_bounds__(256) chirp_post_kernel(const ChirpPostParams p) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= p.n) return;
-  const c32 a = p.chirp[k];
   int j = k + p.n / 2;                       // np.fft.fftshift: bin k lands at (k + N/2) mod N, any N
   if (j >= p.n) j -= p.n;
   const float tare = p.tare != nullptr ? p.tare[j] : 0.f;
@@ -178,9 +176,10 @@ __global__ void __launch_bounds__(256) chirp_post_kernel(const ChirpPostParams p
   const int f0 = blockIdx.y * kChirpFramesPerBlock;
   const int f1 = f0 + kChirpFramesPerBlock < p.n_frames ? f0 + kChirpFramesPerBlock : p.n_frames;
   for (int f = f0; f < f1; ++f) {
+    // X[k] = a[k] * conj(w) / M with |a[k]| = 1: only |X|^2 is needed, the last chirp factor drops out
     const c32 w = p.y[(long long)f * p.m + k];
-    const c32 X = cmul(c32{w.x * p.inv_m, -w.y * p.inv_m}, a);
-    const float pw = X.x * X.x + X.y * X.y;
+    const float xr = w.x * p.inv_m, xi = w.y * p.inv_m;
+    const float pw = xr * xr + xi * xi;
     if (p.out_lin != nullptr) {
       p.out_lin[(long long)f * p.n + j] = pw * p.pscale;
       continue;
@@ -201,13 +200,38 @@ __global__ void __launch_bounds__(256) chirp_post_kernel(const ChirpPostParams p
   }
 }
 
-hipError_t launch_chirp_post(const float2* y, const float2* chirp, int n, int m, int n_frames, int first_frame_index,
+hipError_t launch_chirp_post(const float2* y, int n, int m, int n_frames, int first_frame_index,
                              int db_mode, float pscale, float log_floor, float cal_db, const float* tare, float* out_db,
                              float* out_lin, float* hold_max, float* hold_min, hipStream_t s) {
-  ChirpPostParams p{y, chirp, n, m, n_frames, first_frame_index, 1.0f / float(m), db_mode, pscale, log_floor, cal_db,
+  ChirpPostParams p{y, n, m, n_frames, first_frame_index, 1.0f / float(m), db_mode, pscale, log_floor, cal_db,
                     tare, out_db, out_lin, hold_max, hold_min};
   const int gy = (n_frames + kChirpFramesPerBlock - 1) / kChirpFramesPerBlock;
   hipLaunchKernelGGL(chirp_post_kernel, dim3((n + 255) / 256, gy), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+// Real-input (audio) frames on a chirp plan: the signal went in as signal + 0i, so X is its full spectrum and the
+// one-sided power is |X[k]|^2 for k = 0 .. N/2, every bin but the first and the last doubled
+// (power[1:-1] *= 2, audio_samples.py:131 - also for odd N, where the last bin is not a Nyquist bin).
+// lin[(f * rows_per_frame + row) * (N/2 + 1) + k]: the layout of real_fold_kernel.
+__global__ void __launch_bounds__(256) chirp_post_real_kernel(const float2* y, int n, int m, int n_frames, int rows_per_frame,
+                                                              int row, float inv_m, float pscale, float* lin) {
+  const int nb = n / 2 + 1;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= nb) return;
+  const float two = (k >= 1 && k <= nb - 2) ? 2.0f : 1.0f;
+  for (int f = blockIdx.y; f < n_frames; f += gridDim.y) {
+    const c32 w = y[(long long)f * m + k];
+    const float xr = w.x * inv_m, xi = w.y * inv_m;
+    lin[((long long)f * rows_per_frame + row) * nb + k] = (xr * xr + xi * xi) * pscale * two;
+  }
+}
+
+hipError_t launch_chirp_post_real(const float2* y, int n, int m, int n_frames, int rows_per_frame, int row, float pscale,
+                                  float* lin, hipStream_t s) {
+  const int gy = n_frames < 4096 ? n_frames : 4096;
+  hipLaunchKernelGGL(chirp_post_real_kernel, dim3((n / 2 + 1 + 255) / 256, gy), dim3(256), 0, s, y, n, m, n_frames,
+                     rows_per_frame, row, 1.0f / float(m), pscale, lin);
   return hipGetLastError();
 }
 

@@ -160,9 +160,12 @@ hipError_t launch_chirp_pre(const void* in, int in_c64, long long frame_stride, 
                             const float* window, const float2* chirp, const float2* dc_sub, unsigned xor_mask,
                             float in_off, float2* u, hipStream_t s);
 hipError_t launch_chirp_mul(float2* y, const float2* b, int m, int n_frames, hipStream_t s);
-hipError_t launch_chirp_post(const float2* y, const float2* chirp, int n, int m, int n_frames, int first_frame_index,
+hipError_t launch_chirp_post(const float2* y, int n, int m, int n_frames, int first_frame_index,
                              int db_mode, float pscale, float log_floor, float cal_db, const float* tare, float* out_db,
                              float* out_lin, float* hold_max, float* hold_min, hipStream_t s);
+// real-input frames: one-sided linear power rows in the layout of launch_real_fold
+hipError_t launch_chirp_post_real(const float2* y, int n, int m, int n_frames, int rows_per_frame, int row, float pscale,
+                                  float* lin, hipStream_t s);
 
 // ---- trace analytics / accumulators (tdsa_analytics.hip) ---------------------------------------------
 hipError_t launch_rows_stats(const float* rows, int n_rows, int n, int band_lo, int band_hi, double bin_width,
