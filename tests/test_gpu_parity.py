@@ -1648,6 +1648,8 @@ def test_host_pipe_random(pkg, seed):
     DC, holds): every slot's rows and the plan state bit for bit what synchronous tdsa_process_i8 calls give."""
     rng = np.random.default_rng(3000 + seed)
     nfft = int(2 ** rng.choice([6, 8, 10, 11, 12, 13, 14, 15]))
+    if rng.integers(0, 4) == 0:
+        nfft = _any_size(rng)                      # one case in four: a size that is not a power of two
     long_frame = nfft > 16384
     hop = nfft if long_frame else int(rng.choice([nfft, nfft // 2, int(rng.integers(1, nfft + 1))]))
     max_nf = 1 if long_frame else int(rng.integers(1, 40))
@@ -2010,8 +2012,8 @@ def test_process_sharded_random(pkg, seed):
     hop; DC per frame or off): rows and hold traces bit for bit the unsharded result."""
     from topdogspectrumanalyser_amd.sharding import process_sharded
     rng = np.random.default_rng(9500 + seed)
-    nfft = int(2 ** rng.integers(6, 14))
-    hop = int(rng.choice([nfft, nfft // 2, int(rng.integers(1, 2 * nfft))]))
+    nfft = int(2 ** rng.integers(6, 14)) if rng.integers(0, 4) else _any_size(rng)
+    hop = int(rng.choice([nfft, max(1, nfft // 2), int(rng.integers(1, 2 * nfft))]))
     nf = int(rng.integers(1, 60))
     world = int(rng.integers(1, 10))
     dc_alpha = float(rng.choice([1.0, -1.0]))
