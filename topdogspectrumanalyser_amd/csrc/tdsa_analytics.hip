@@ -40,11 +40,6 @@ __device__ __forceinline__ double wave_sum(double x) {
   for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o);
   return x;
 }
-__device__ __forceinline__ float wave_min(float x) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) x = fminf(x, __shfl_xor(x, o));
-  return x;
-}
 // the same reductions with DPP moves (no LDS round trip per step as with ds_bpermute); the result is valid in
 // lane 63 only.  Lanes without a source lane keep their own value, which is the identity of min / "better".
 template <int CTRL, int ROW_MASK>
