@@ -281,7 +281,7 @@ int process_big(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n_f
 }
 
 // Chirp-z core of a plan whose frame length is not a power of two: frames at `in` (stride bytes apart) ->
-// p->d_u0[f][k] = M * conj(convolution), k < nfft (tdsa_chirp.hip steps 1-4), on the main stream.
+// p->d_u0[f][k] = M * conj(convolution), k < nfft (tdsa_chirp.hip steps 1-3), on the main stream.
 int chirp_transform(tdsa_plan p, const void* in, int in_format, long long stride, int n_frames, const float2* dc_sub,
                     unsigned xor_mask, float in_off) {
   const int N = p->nfft, M = p->m_fft;
@@ -303,10 +303,11 @@ int chirp_transform(tdsa_plan p, const void* in, int in_format, long long stride
   const LaunchGeom g = spectrum_geometry(p->log2m, n_frames, p->num_cu);
   sp.in = p->d_u0;
   sp.out_cplx = p->d_u1;
+  sp.out_mul = p->d_chirp_b;          // the first transform stores conj(FFT_M(U) * B)
   { const int rc = launch_spectrum_profiled(p, 1, sp, g); if (rc != TDSA_OK) return rc; }
-  HIPCHK(launch_chirp_mul(p->d_u1, p->d_chirp_b, M, n_frames, s));
   sp.in = p->d_u1;
   sp.out_cplx = p->d_u0;
+  sp.out_mul = nullptr;
   { const int rc = launch_spectrum_profiled(p, 1, sp, g); if (rc != TDSA_OK) return rc; }
   return TDSA_OK;
 }
@@ -325,13 +326,17 @@ int process_chirp(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n
   hipStream_t s = p->stream;
   const float2* dc_sub = nullptr;
   if (m.dc_alpha >= 0.0f) {
-    // frame means as residuals (exact sums), then the tracker of the native path fed with them directly
-    // (n = 1, zero level 0): alpha >= 1 makes it the plain per-frame mean
+    // frame means as residuals (exact sums); 0 <= alpha < 1: the tracker of the native path fed with them
+    // directly (n = 1, zero level 0)
+    const bool tracked = m.dc_alpha < 1.0f;
     HIPCHK(launch_chirp_sums(iq_dev, in_c64, xor_mask, stride, N, n_frames,
-                             in_format == TDSA_IN_I8 ? 256 : (in_c64 ? 0 : 255), p->d_sums, s));
-    HIPCHK(launch_dc_track(p->d_sums, 1, n_frames, m.dc_alpha > 1.0f ? 1.0f : m.dc_alpha, 0.0f, in_scale, p->d_dc_state,
-                           p->d_dc_sub, s));
-    dc_sub = p->d_dc_sub;
+                             in_format == TDSA_IN_I8 ? 256 : (in_c64 ? 0 : 255), p->d_sums,
+                             tracked ? nullptr : p->d_dc_state, in_scale, s));
+    dc_sub = p->d_sums;                   // dc_alpha >= 1: the frame's own mean
+    if (tracked) {
+      HIPCHK(launch_dc_track(p->d_sums, 1, n_frames, m.dc_alpha, 0.0f, in_scale, p->d_dc_state, p->d_dc_sub, s));
+      dc_sub = p->d_dc_sub;
+    }
   }
   { const int rc = chirp_transform(p, iq_dev, in_format, stride, n_frames, dc_sub, xor_mask, in_off); if (rc != TDSA_OK) return rc; }
   const float pscale = m.db_mode == TDSA_DB_POW ? m.power_scale : 1.0f;
@@ -916,7 +921,7 @@ int tdsa_process_real2(tdsa_plan p, const float* lr_host, size_t n_samples, int 
       // the one-sided power straight from the full spectrum
       const float2* zin = sig == 0 ? za : zb;
       const long long stride = (long long)hop * sizeof(float2);
-      HIPCHK(launch_chirp_sums(zin, 1, 0u, stride, n, n_frames, 0, p->d_sums, p->stream));
+      HIPCHK(launch_chirp_sums(zin, 1, 0u, stride, n, n_frames, 0, p->d_sums, nullptr, 1.0f, p->stream));
       { const int rc = chirp_transform(p, zin, TDSA_IN_C64, stride, n_frames, p->d_sums, 0u, 0.0f); if (rc != TDSA_OK) return rc; }
       HIPCHK(launch_chirp_post_real(p->d_u0, n, p->m_fft, n_frames, n_sig, sig, m.power_scale, p->d_lin1, p->stream));
       continue;

@@ -8,16 +8,18 @@
 //   X[k] = a[k] * sum_n (x[n] w[n] a[n]) * conj(a)[k - n],     a[n] = exp(-i pi n^2 / N)
 //
 //   (0) chirp_sums   : exact per-frame I / Q sums -> the frame mean as a small residual on top of the format's
-//                      zero level (then the ordinary DC tracker of tdsa_trace.hip)
+//                      zero level (dc_alpha = 1: that IS the subtract value; 0 <= dc_alpha < 1: the ordinary DC
+//                      tracker of tdsa_trace.hip runs on the residuals)
 //   (1) chirp_pre    : unpack + DC + window, times a[n], zero-padded to M = 2^ceil(log2(2N-1)) -> U[f][M] complex64
-//   (2) frame kernel : FFT_M(U)                                   (complex64 in, complex spectrum out)
-//   (3) chirp_mul    : conj(FFT_M(U) * B),  B = FFT_M(conj(a) wrapped) - a plan-time table made in double
-//   (4) frame kernel : FFT_M of that = M * conj(convolution)      (inverse transform through conjugation)
-//   (5) chirp_post   : |X[k]|^2 = |./M|^2 for k < N (|a[k]| = 1) -> fftshift by N/2 (np.fft.fftshift for any N)
+//   (2) frame kernel : FFT_M(U), stored as conj(FFT_M(U) * B) - B = FFT_M(conj(a) wrapped), a plan-time table
+//                      made in double (SpecParams::out_mul: the multiply rides the transform's stores)
+//   (3) frame kernel : FFT_M of that = M * conj(convolution)      (inverse transform through conjugation)
+//   (4) chirp_post   : |X[k]|^2 = |./M|^2 for k < N (|a[k]| = 1) -> fftshift by N/2 (np.fft.fftshift for any N)
 //                      -> dB (+cal, -tare) rows and hold traces, or linear power rows for the averager scan
 //
-// Cost: two M-point transforms + 8 B/point of intermediate traffic per pass - about 6x the bytes of a native
-// size; the point of this path is that every size the reference accepts has a device path, not its speed.
+// Cost: two M-point complex-to-complex transforms and two element-wise passes over [F][M] complex64 rows - about
+// ten times the time of a native size of similar length; the point of this path is that every size the reference
+// accepts has a device path, not its speed.
 #include "tdsa_fft.hpp"
 #include "tdsa_kernels.hpp"
 
@@ -45,7 +47,7 @@ __device__ __forceinline__ void chirp_atomic_fmin(float* addr, float v) {
 // a float32 "sum / n - 128" would cancel to ~1e-5 LSB, visible in the DC bin.
 template <bool IN_C64>
 __global__ void __launch_bounds__(256) chirp_sums_kernel(const void* in, unsigned xor_mask, long long frame_stride, int n,
-                                                         int twice_zero, float2* res) {
+                                                         int twice_zero, float2* res, float2* dc_state, float in_scale) {
   __shared__ double red[8];
   const int f = blockIdx.x;
   const unsigned char* fb = static_cast<const unsigned char*>(in) + (long long)f * frame_stride;
@@ -72,16 +74,21 @@ __global__ void __launch_bounds__(256) chirp_sums_kernel(const void* in, unsigne
     const double tr = red[0] + red[2] + red[4] + red[6], ti = red[1] + red[3] + red[5] + red[7];
     // (2 sum - twice_zero n) / (2 n): integer-valued numerator for the byte formats
     const double dn = double(n), tz = double(twice_zero);
-    res[f] = float2{float((2.0 * tr - tz * dn) / (2.0 * dn)), float((2.0 * ti - tz * dn) / (2.0 * dn))};
+    const float2 r = float2{float((2.0 * tr - tz * dn) / (2.0 * dn)), float((2.0 * ti - tz * dn) / (2.0 * dn))};
+    res[f] = r;
+    // per-frame mean mode (dc_alpha = 1): the estimate the plan carries is the last frame's mean, in units of x
+    if (dc_state != nullptr && f == int(gridDim.x) - 1) *dc_state = float2{r.x * in_scale, r.y * in_scale};
   }
 }
 
 hipError_t launch_chirp_sums(const void* in, int in_c64, unsigned xor_mask, long long frame_stride, int n, int n_frames,
-                             int twice_zero, float2* res, hipStream_t s) {
+                             int twice_zero, float2* res, float2* dc_state, float in_scale, hipStream_t s) {
   if (in_c64)
-    hipLaunchKernelGGL(chirp_sums_kernel<true>, dim3(n_frames), dim3(256), 0, s, in, xor_mask, frame_stride, n, twice_zero, res);
+    hipLaunchKernelGGL(chirp_sums_kernel<true>, dim3(n_frames), dim3(256), 0, s, in, xor_mask, frame_stride, n, twice_zero,
+                       res, dc_state, in_scale);
   else
-    hipLaunchKernelGGL(chirp_sums_kernel<false>, dim3(n_frames), dim3(256), 0, s, in, xor_mask, frame_stride, n, twice_zero, res);
+    hipLaunchKernelGGL(chirp_sums_kernel<false>, dim3(n_frames), dim3(256), 0, s, in, xor_mask, frame_stride, n, twice_zero,
+                       res, dc_state, in_scale);
   return hipGetLastError();
 }
 
@@ -99,28 +106,43 @@ struct ChirpPreParams {
   float2* u;                 // [F][m]
 };
 
+// two consecutive samples per thread: 4 / 16 bytes in (frame starts are only sample aligned: packed loads),
+// one 16-byte store out; m is a power of two >= 64, so a pair never straddles the end of a row
+struct __attribute__((packed, aligned(2))) ChirpRaw2 { uint32_t v; };
+struct __attribute__((packed, aligned(4))) ChirpC64x2 { float a, b, c, d; };
+
 __global__ void __launch_bounds__(256) chirp_pre_kernel(const ChirpPreParams p) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = 2 * (blockIdx.x * 256 + threadIdx.x);
   if (i >= p.m) return;
-  const unsigned xm = p.xor_mask & 0xffffu;
+  const unsigned xm = p.xor_mask;
+  const bool in0 = i < p.n, in1 = i + 1 < p.n;
+  float w0 = 0.f, w1 = 0.f;
+  c32 a0 = c32{0.f, 0.f}, a1 = c32{0.f, 0.f};
+  if (in0) { w0 = p.window[i]; a0 = p.chirp[i]; }
+  if (in1) { w1 = p.window[i + 1]; a1 = p.chirp[i + 1]; }
   for (int f = blockIdx.y; f < p.n_frames; f += gridDim.y) {
-    c32 out = c32{0.f, 0.f};
-    if (i < p.n) {
+    c32 o0 = c32{0.f, 0.f}, o1 = c32{0.f, 0.f};
+    if (in0) {
       const unsigned char* fb = static_cast<const unsigned char*>(p.in) + (long long)f * p.frame_stride;
-      float re, im;
+      float r0, i0, r1 = 0.f, i1 = 0.f;
       if (p.in_c64) {
-        const float2 x = reinterpret_cast<const float2*>(fb)[i];
-        re = x.x; im = x.y;
+        const float* x = reinterpret_cast<const float*>(fb) + 2 * i;
+        if (in1) { const ChirpC64x2 q = *reinterpret_cast<const ChirpC64x2*>(x); r0 = q.a; i0 = q.b; r1 = q.c; i1 = q.d; }
+        else { r0 = x[0]; i0 = x[1]; }
       } else {
-        const unsigned v = unsigned(reinterpret_cast<const uint16_t*>(fb)[i]) ^ xm;
-        re = float(v & 0xffu) - p.in_off;      // exact: small integers / halves
-        im = float(v >> 8) - p.in_off;
+        unsigned v;
+        if (in1) v = reinterpret_cast<const ChirpRaw2*>(fb + 2 * i)->v ^ xm;
+        else v = unsigned(reinterpret_cast<const uint16_t*>(fb)[i]) ^ (xm & 0xffffu);
+        r0 = float(v & 0xffu) - p.in_off;      // exact: small integers / halves
+        i0 = float((v >> 8) & 0xffu) - p.in_off;
+        r1 = float((v >> 16) & 0xffu) - p.in_off;
+        i1 = float(v >> 24) - p.in_off;
       }
-      if (p.dc_sub != nullptr) { const float2 d = p.dc_sub[f]; re -= d.x; im -= d.y; }
-      const float w = p.window[i];
-      out = cmul(c32{re * w, im * w}, p.chirp[i]);
+      if (p.dc_sub != nullptr) { const float2 d = p.dc_sub[f]; r0 -= d.x; i0 -= d.y; r1 -= d.x; i1 -= d.y; }
+      o0 = cmul(c32{r0 * w0, i0 * w0}, a0);
+      if (in1) o1 = cmul(c32{r1 * w1, i1 * w1}, a1);
     }
-    p.u[(long long)f * p.m + i] = out;
+    *reinterpret_cast<float4*>(p.u + (long long)f * p.m + i) = float4{o0.x, o0.y, o1.x, o1.y};
   }
 }
 
@@ -128,29 +150,12 @@ hipError_t launch_chirp_pre(const void* in, int in_c64, long long frame_stride, 
                             const float* window, const float2* chirp, const float2* dc_sub, unsigned xor_mask,
                             float in_off, float2* u, hipStream_t s) {
   ChirpPreParams p{in, in_c64, frame_stride, n, m, n_frames, window, chirp, dc_sub, xor_mask, in_off, u};
-  const int gy = n_frames < 4096 ? n_frames : 4096;
-  hipLaunchKernelGGL(chirp_pre_kernel, dim3((m + 255) / 256, gy), dim3(256), 0, s, p);
+  const int gy = n_frames < 2048 ? n_frames : 2048;
+  hipLaunchKernelGGL(chirp_pre_kernel, dim3((m / 2 + 255) / 256, gy), dim3(256), 0, s, p);
   return hipGetLastError();
 }
 
-// ---- (3) spectrum of the convolution, conjugated for the inverse transform ------------------------------------
-__global__ void __launch_bounds__(256) chirp_mul_kernel(float2* y, const float2* b, long long count, int m_mask) {
-  const long long stride = (long long)gridDim.x * 256;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) {
-    const c32 v = cmul(y[i], b[int(i) & m_mask]);
-    y[i] = c32{v.x, -v.y};
-  }
-}
-
-hipError_t launch_chirp_mul(float2* y, const float2* b, int m, int n_frames, hipStream_t s) {
-  const long long count = (long long)m * n_frames;
-  long long blocks = (count + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(chirp_mul_kernel, dim3(unsigned(blocks)), dim3(256), 0, s, y, b, count, m - 1);
-  return hipGetLastError();
-}
-
-// ---- (5) back to N bins: power, fftshift, dB / linear rows, hold traces ---------------------------------------
+// ---- (4) back to N bins: power, fftshift, dB / linear rows, hold traces ---------------------------------------
 struct ChirpPostParams {
   const float2* y;           // [F][m]  M * conj(convolution)
   int n, m, n_frames, first_frame_index;

@@ -38,6 +38,7 @@ struct SpecParams {
   float* out_db;             // [F][N] fftshift-ed dB, or null
   float* out_lin;            // [F][N] fftshift-ed linear power * pscale (averaging modes), or null
   float2* out_cplx;          // [F][N] complex spectrum X[k] in natural bin order (real-input path), or null
+  const float2* out_mul;     // [N] with out_cplx, complex64 input, no hold: conj(X[k] * out_mul[k]) is stored instead (chirp-z), or null
   const float2* dc_sub;      // [F] per-frame DC estimate in raw-sample units, WITHOUT in_off (DC_TRACKED), or null
   float2* dc_state;          // last frame's mean in units of x is stored here (DC_FRAME_MEAN), or null
   float* part_max;           // [N] the plan's max-hold trace (merged into with float atomics), or null
@@ -154,12 +155,12 @@ hipError_t launch_big_finish(const double* src, long long n, double* mean_out, i
 // ---- frame lengths that are not a power of two, 2 <= N <= 8192 (tdsa_chirp.hip): chirp-z on the frame kernel ----
 constexpr int kChirpMaxN = 8192;
 // res[f] = frame mean minus the format's zero level, raw units (twice_zero: 256 int8 after the xor, 255 uint8, 0 c64)
+// dc_state (or null): receives the last frame's mean in units of x - the per-frame mean mode needs no tracker pass
 hipError_t launch_chirp_sums(const void* in, int in_c64, unsigned xor_mask, long long frame_stride, int n, int n_frames,
-                             int twice_zero, float2* res, hipStream_t s);
+                             int twice_zero, float2* res, float2* dc_state, float in_scale, hipStream_t s);
 hipError_t launch_chirp_pre(const void* in, int in_c64, long long frame_stride, int n, int m, int n_frames,
                             const float* window, const float2* chirp, const float2* dc_sub, unsigned xor_mask,
                             float in_off, float2* u, hipStream_t s);
-hipError_t launch_chirp_mul(float2* y, const float2* b, int m, int n_frames, hipStream_t s);
 hipError_t launch_chirp_post(const float2* y, int n, int m, int n_frames, int first_frame_index,
                              int db_mode, float pscale, float log_floor, float cal_db, const float* tare, float* out_db,
                              float* out_lin, float* hold_max, float* hold_min, hipStream_t s);

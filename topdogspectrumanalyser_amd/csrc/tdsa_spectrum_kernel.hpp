@@ -717,11 +717,28 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       if (p.out_cplx != nullptr) {            // real-input path: hand the complex bins to the fold kernel
         if constexpr (!C::WIN_LDS) load_window();
         c32* crow = p.out_cplx + (long long)frame * N + t + 8 * h * SG;
-        static_for<0, 16>([&](auto ic) {
-          constexpr int q = decltype(ic)::value;
-          constexpr int kc = (q < 8 ? q : q + 8);             // + 8h folded into crow; natural order
-          crow[kc * SG] = v[bitrev(q, 4)];
-        });
+        bool plain = true;
+        if constexpr (IN_C64 && HOLD == 0) {
+          // chirp-z plans (tdsa_chirp.hip): the spectrum leaves multiplied by the chirp filter's spectrum and
+          // conjugated, ready for the inverse transform - one pass over the rows less
+          if (p.out_mul != nullptr) {
+            plain = false;
+            const c32* brow = p.out_mul + t + 8 * h * SG;
+            static_for<0, 16>([&](auto ic) {
+              constexpr int q = decltype(ic)::value;
+              constexpr int kc = (q < 8 ? q : q + 8);
+              const c32 z = cmul(v[bitrev(q, 4)], brow[kc * SG]);
+              crow[kc * SG] = c32{z.x, -z.y};
+            });
+          }
+        }
+        if (plain) {
+          static_for<0, 16>([&](auto ic) {
+            constexpr int q = decltype(ic)::value;
+            constexpr int kc = (q < 8 ? q : q + 8);             // + 8h folded into crow; natural order
+            crow[kc * SG] = v[bitrev(q, 4)];
+          });
+        }
       } else if (p.out_lin != nullptr) {
         if constexpr (!C::WIN_LDS) load_window();
         float* orow = p.out_lin + (long long)frame * N + t + 8 * h * SG;
