@@ -94,7 +94,7 @@ int tdsa_device_count(int* count);
  * is unbounded and np.fft.fft takes any N, hackrf_samples.py:392-405, :370): powers of two 64 .. 16384 run as ONE
  * LDS-resident kernel; 2^15 .. 2^20 as N1 x 16384 in two passes (in-register column DFT kernel + the same frame
  * kernel as row pass); every other size up to 8192 as a chirp-z convolution on the power-of-two kernel
- * (tdsa_chirp.hip: same modes, state and outputs, about an order of magnitude slower per frame; fftshift by
+ * (tdsa_chirp.hip: same modes, state and outputs, 7-8x slower per frame; fftshift by
  * nfft / 2 as np.fft.fftshift does for odd sizes).  A long-frame plan takes one
  * frame per call, or - with avg_mode lin and avg_n >= the frames seen since the last reset - a batch of K
  * segments whose Welch average comes back as ONE dB row. */

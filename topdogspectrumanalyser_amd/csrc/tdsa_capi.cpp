@@ -304,10 +304,13 @@ int chirp_transform(tdsa_plan p, const void* in, int in_format, long long stride
   sp.in = p->d_u0;
   sp.out_cplx = p->d_u1;
   sp.out_mul = p->d_chirp_b;          // the first transform stores conj(FFT_M(U) * B)
+  sp.in_valid = N;                    // rows of U: N samples, the padding up to M is neither written nor read
   { const int rc = launch_spectrum_profiled(p, 1, sp, g); if (rc != TDSA_OK) return rc; }
   sp.in = p->d_u1;
   sp.out_cplx = p->d_u0;
   sp.out_mul = nullptr;
+  sp.in_valid = 0;
+  sp.out_valid = N;                   // only bins k < N of the convolution are needed
   { const int rc = launch_spectrum_profiled(p, 1, sp, g); if (rc != TDSA_OK) return rc; }
   return TDSA_OK;
 }

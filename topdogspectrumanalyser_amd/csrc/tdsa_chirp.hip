@@ -10,7 +10,8 @@
 //   (0) chirp_sums   : exact per-frame I / Q sums -> the frame mean as a small residual on top of the format's
 //                      zero level (dc_alpha = 1: that IS the subtract value; 0 <= dc_alpha < 1: the ordinary DC
 //                      tracker of tdsa_trace.hip runs on the residuals)
-//   (1) chirp_pre    : unpack + DC + window, times a[n], zero-padded to M = 2^ceil(log2(2N-1)) -> U[f][M] complex64
+//   (1) chirp_pre    : unpack + DC + window, times a[n] -> the first N entries of the rows U[f][M] complex64,
+//                      M = 2^ceil(log2(2N-1)); the zero padding is implied (SpecParams::in_valid), not stored
 //   (2) frame kernel : FFT_M(U), stored as conj(FFT_M(U) * B) - B = FFT_M(conj(a) wrapped), a plan-time table
 //                      made in double (SpecParams::out_mul: the multiply rides the transform's stores)
 //   (3) frame kernel : FFT_M of that = M * conj(convolution)      (inverse transform through conjugation)
@@ -113,7 +114,7 @@ struct __attribute__((packed, aligned(4))) ChirpC64x2 { float a, b, c, d; };
 
 __global__ void __launch_bounds__(256) chirp_pre_kernel(const ChirpPreParams p) {
   const int i = 2 * (blockIdx.x * 256 + threadIdx.x);
-  if (i >= p.m) return;
+  if (i >= p.n) return;                  // the padding up to M is never read (SpecParams::in_valid): not written
   const unsigned xm = p.xor_mask;
   const bool in0 = i < p.n, in1 = i + 1 < p.n;
   float w0 = 0.f, w1 = 0.f;
@@ -151,7 +152,7 @@ hipError_t launch_chirp_pre(const void* in, int in_c64, long long frame_stride, 
                             float in_off, float2* u, hipStream_t s) {
   ChirpPreParams p{in, in_c64, frame_stride, n, m, n_frames, window, chirp, dc_sub, xor_mask, in_off, u};
   const int gy = n_frames < 2048 ? n_frames : 2048;
-  hipLaunchKernelGGL(chirp_pre_kernel, dim3((m / 2 + 255) / 256, gy), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(chirp_pre_kernel, dim3(((n + 1) / 2 + 255) / 256, gy), dim3(256), 0, s, p);
   return hipGetLastError();
 }
 

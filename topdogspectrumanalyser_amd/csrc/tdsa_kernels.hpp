@@ -39,6 +39,8 @@ struct SpecParams {
   float* out_lin;            // [F][N] fftshift-ed linear power * pscale (averaging modes), or null
   float2* out_cplx;          // [F][N] complex spectrum X[k] in natural bin order (real-input path), or null
   const float2* out_mul;     // [N] with out_cplx, complex64 input, no hold: conj(X[k] * out_mul[k]) is stored instead (chirp-z), or null
+  int in_valid;              // complex64 input, no hold: samples from this index on are zeros and are not read (0: all N are read)
+  int out_valid;             // with out_cplx, complex64 input, no hold: only bins below this index are stored (0: all N)
   const float2* dc_sub;      // [F] per-frame DC estimate in raw-sample units, WITHOUT in_off (DC_TRACKED), or null
   float2* dc_state;          // last frame's mean in units of x is stored here (DC_FRAME_MEAN), or null
   float* part_max;           // [N] the plan's max-hold trace (merged into with float atomics), or null

@@ -443,7 +443,15 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
         constexpr int idx = decltype(ic)::value;
         constexpr int jj = idx / H, i = idx % H;
         const c32* row = reinterpret_cast<const c32*>(fb + 2 * i * (N / A) * 8 + lane_in_off);
-        v[idx] = active ? row[jj] : c32{0.f, 0.f};
+        if constexpr (HOLD == 0) {
+          // zero-padded rows (chirp-z plans): the padding is not read.  Sample index of this element:
+          // (2 i + h) N/A + t M + jj
+          const int n_idx = (2 * i) * (N / A) + h * (N / A) + t * M + jj;
+          const bool there = active && (p.in_valid == 0 || n_idx < p.in_valid);
+          v[idx] = there ? row[jj] : c32{0.f, 0.f};
+        } else {
+          v[idx] = active ? row[jj] : c32{0.f, 0.f};
+        }
       });
     } else {
       static_for<0, NRAW>([&](auto ic) { raw[decltype(ic)::value] ^= xm_v; });   // int8 -> offset binary
@@ -729,6 +737,14 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
               constexpr int kc = (q < 8 ? q : q + 8);
               const c32 z = cmul(v[bitrev(q, 4)], brow[kc * SG]);
               crow[kc * SG] = c32{z.x, -z.y};
+            });
+          } else if (p.out_valid != 0) {      // only the first out_valid bins are wanted (chirp-z: k < nfft of M)
+            plain = false;
+            const int k0 = t + 8 * h * SG;
+            static_for<0, 16>([&](auto ic) {
+              constexpr int q = decltype(ic)::value;
+              constexpr int kc = (q < 8 ? q : q + 8);
+              if (k0 + kc * SG < p.out_valid) crow[kc * SG] = v[bitrev(q, 4)];
             });
           }
         }
