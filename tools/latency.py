@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Developer tool: what one displayed frame costs through the host entry point (what the live sources do on every
+GUI tick): total per call, and the same frame with the samples already on the device."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from topdogspectrumanalyser_amd import SpectrumEngine, _native as nat  # noqa: E402
+
+
+def main():
+    for n in (1000, 1024, 4096, 16384, 1 << 15, 1 << 17, 1 << 20):
+        iq = np.random.default_rng(0).integers(-100, 100, size=2 * n, dtype=np.int8)
+        x = (iq[0::2] + 1j * iq[1::2]).astype(np.complex64) / 128
+        with SpectrumEngine(n, max_frames=1) as e:
+            e.set_window(np.hanning(n).astype(np.float32))
+            e.configure(db_mode="mag", log_floor=1e-12, dc_alpha=1.0)
+            for name, data in (("int8", iq), ("complex64", x)):
+                for _ in range(200):
+                    e.process(data, hop=n, n_frames=1)
+                t0 = time.perf_counter()
+                for _ in range(2000):
+                    e.process(data, hop=n, n_frames=1)
+                host = (time.perf_counter() - t0) / 2000 * 1e6
+                print(f"N={n:6d} {name:9s}: {host:6.1f} us per host call", end="")
+                if name == "int8":
+                    d_in, d_out = C.c_void_p(), C.c_void_p()
+                    nat.check(nat.lib.tdsa_dev_alloc(0, iq.nbytes, C.byref(d_in)))
+                    nat.check(nat.lib.tdsa_dev_alloc(0, n * 4, C.byref(d_out)))
+                    nat.check(nat.lib.tdsa_memcpy_h2d(0, d_in, iq.ctypes.data_as(C.c_void_p), iq.nbytes))
+                    for _ in range(200):
+                        e.process_device(nat.IN_I8, d_in.value, n, n, 1, d_out.value)
+                    e.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(2000):
+                        e.process_device(nat.IN_I8, d_in.value, n, n, 1, d_out.value)
+                        e.synchronize()
+                    dev = (time.perf_counter() - t0) / 2000 * 1e6
+                    print(f"   device-resident + synchronize: {dev:6.1f} us", end="")
+                print()
+
+
+if __name__ == "__main__":
+    main()

@@ -79,6 +79,11 @@ struct tdsa_plan_s {
   int tare_count = 0;
   void* d_in_stage = nullptr;
   size_t in_stage_bytes = 0;
+  // pinned bounce buffers of the host entry points for small calls (the one-frame-per-GUI-tick case): a copy from / to
+  // pageable memory costs ~10 us each way in the runtime's own staging, a memcpy through pinned memory ~2 us
+  void* h_in_pin = nullptr;
+  void* h_out_pin = nullptr;
+  size_t in_pin_bytes = 0, out_pin_bytes = 0;
   float* d_out_stage = nullptr;
   float* d_trace_in = nullptr;
   float* d_trace_live = nullptr;
@@ -113,6 +118,9 @@ struct tdsa_plan_s {
 namespace {
 
 int bytes_per_sample(int fmt) { return fmt == TDSA_IN_C64 ? 8 : 2; }
+
+constexpr size_t kPinnedBounceMax = size_t(1) << 20;    // host calls up to 1 MiB each way go through pinned bounce buffers
+constexpr size_t kZeroCopyMax = size_t(256) << 10;       // ... and up to 256 KiB in + out are read / written in place by the kernels
 
 bool avg_active(const tdsa_mode& m) { return m.avg_mode != TDSA_AVG_OFF && m.avg_n > 1; }
 
@@ -580,6 +588,8 @@ int tdsa_destroy(tdsa_plan p) {
                   p->d_dbg};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
+  if (p->h_in_pin) (void)hipHostFree(p->h_in_pin);
+  if (p->h_out_pin) (void)hipHostFree(p->h_out_pin);
   for (hipEvent_t e : p->prof_events) (void)hipEventDestroy(e);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
   if (p->ev1) (void)hipEventDestroy(p->ev1);
@@ -846,16 +856,48 @@ static int process_host(tdsa_plan p, int fmt, const void* iq_host, size_t n_samp
   }
   if (out_db_host && !p->d_out_stage)
     HIPCHK(hipMalloc(&p->d_out_stage, size_t(p->big ? 1 : p->max_frames) * p->nfft * sizeof(float)));
-  HIPCHK(hipMemcpyAsync(p->d_in_stage, iq_host, in_bytes, hipMemcpyHostToDevice, p->stream));
+  const size_t out_bytes = out_db_host ? size_t(p->big ? 1 : n_frames) * p->nfft * sizeof(float) : 0;
+  const bool bounce = in_bytes <= kPinnedBounceMax && out_bytes <= kPinnedBounceMax;
+  if (bounce) {
+    if (in_bytes > p->in_pin_bytes) {
+      if (p->h_in_pin) { HIPCHK(hipStreamSynchronize(p->stream)); HIPCHK(hipHostFree(p->h_in_pin)); }
+      p->h_in_pin = nullptr;
+      p->in_pin_bytes = 0;
+      HIPCHK(hipHostMalloc(&p->h_in_pin, in_bytes, hipHostMallocDefault));
+      p->in_pin_bytes = in_bytes;
+    }
+    if (out_bytes > p->out_pin_bytes) {
+      if (p->h_out_pin) { HIPCHK(hipStreamSynchronize(p->stream)); HIPCHK(hipHostFree(p->h_out_pin)); }
+      p->h_out_pin = nullptr;
+      p->out_pin_bytes = 0;
+      HIPCHK(hipHostMalloc(&p->h_out_pin, out_bytes, hipHostMallocDefault));
+      p->out_pin_bytes = out_bytes;
+    }
+    std::memcpy(p->h_in_pin, iq_host, in_bytes);      // the previous call ended with a synchronize: the buffer is free
+  }
+  // the smallest calls (one displayed frame) skip the two DMA operations as well: the kernels read the samples from
+  // and write the row to the pinned buffers directly over the bus (hipHostMalloc memory is device-visible)
+  const bool direct = bounce && in_bytes + out_bytes <= kZeroCopyMax && !p->big;
+  if (direct) {
+    int rc_d = tdsa_process_dev(p, fmt, p->h_in_pin, need, hop, n_frames,
+                                out_db_host ? static_cast<float*>(p->h_out_pin) : nullptr);
+    if (rc_d != TDSA_OK) return rc_d;
+    JOIN(p);
+    HIPCHK(hipStreamSynchronize(p->stream));
+    if (out_db_host) std::memcpy(out_db_host, p->h_out_pin, out_bytes);
+    return TDSA_OK;
+  }
+  HIPCHK(hipMemcpyAsync(p->d_in_stage, bounce ? p->h_in_pin : iq_host, in_bytes, hipMemcpyHostToDevice, p->stream));
   int rc = tdsa_process_dev(p, fmt, p->d_in_stage, need, hop, n_frames, out_db_host ? p->d_out_stage : nullptr);
   if (rc != TDSA_OK) return rc;
   // with tdsa_set_overlap(n > 1) the frame kernel may have gone to an auxiliary stream: order the main
   // stream (read-back + the synchronize below) behind it, so the host call stays sequentially consistent
   JOIN(p);
   if (out_db_host)
-    HIPCHK(hipMemcpyAsync(out_db_host, p->d_out_stage, size_t(p->big ? 1 : n_frames) * p->nfft * sizeof(float),
+    HIPCHK(hipMemcpyAsync(bounce ? p->h_out_pin : static_cast<void*>(out_db_host), p->d_out_stage, out_bytes,
                           hipMemcpyDeviceToHost, p->stream));
   HIPCHK(hipStreamSynchronize(p->stream));
+  if (bounce && out_db_host) std::memcpy(out_db_host, p->h_out_pin, out_bytes);
   return TDSA_OK;
 }
 
