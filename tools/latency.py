@@ -43,6 +43,18 @@ def main():
                     print(f"   device-resident + synchronize: {dev:6.1f} us", end="")
                 print()
 
+    # the display processor's share of a tick: calibration offset, tare, both holds in one launch (TraceState.update)
+    from topdogspectrumanalyser_amd.engine import TraceState
+    for n in (1024, 4096, 16384):
+        row = np.random.default_rng(1).normal(-80, 5, n).astype(np.float32)
+        ts = TraceState(n)
+        for _ in range(200):
+            ts.update(row, cal_offset_db=-0.8, hold_max=True, hold_min=True)
+        t0 = time.perf_counter()
+        for _ in range(2000):
+            ts.update(row, cal_offset_db=-0.8, hold_max=True, hold_min=True)
+        print(f"N={n:6d} trace update (cal + both holds, three rows back): {(time.perf_counter() - t0) / 2000 * 1e6:6.1f} us")
+        ts.close()
 
 if __name__ == "__main__":
     main()

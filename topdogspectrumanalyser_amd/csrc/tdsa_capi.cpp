@@ -1080,6 +1080,7 @@ struct tdsa_trace_s {
   float* d_tare_acc = nullptr;
   double* d_avg = nullptr;
   double* d_avg_in = nullptr;
+  float* h_pin = nullptr;       // pinned, device-visible: [4][n] row in, live / max / min out (one GUI tick, zero-copy)
   long long held_max = 0, held_min = 0;
   bool tare_active = false;
   int tare_count = 0;
@@ -1121,6 +1122,7 @@ int tdsa_trace_destroy(tdsa_trace t) {
                   t->d_avg_in};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
+  if (t->h_pin) (void)hipHostFree(t->h_pin);
   if (t->stream) (void)hipStreamDestroy(t->stream);
   delete t;
   return TDSA_OK;
@@ -1146,9 +1148,16 @@ int tdsa_trace_update(tdsa_trace t, const float* db_in_host, int n, float cal_of
   if (tare_collect && tare_total < 1) return fail(TDSA_ERR_ARG, "tare_total=%d", tare_total);
   HIPCHK(hipSetDevice(t->device));
   const size_t nb = size_t(n) * sizeof(float);
-  HIPCHK(hipMemcpyAsync(t->d_in, db_in_host, nb, hipMemcpyHostToDevice, t->stream));
+  // one displayed frame: the kernel reads the row from and writes its results to pinned, device-visible memory of the
+  // trace object - no DMA operation on the way in or out (each costs ~10 us from / to pageable memory)
+  if (!t->h_pin) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&t->h_pin), 4 * nb, hipHostMallocDefault));
+  float* const h_in = t->h_pin;
+  float* const h_live = t->h_pin + n;
+  float* const h_max = t->h_pin + 2 * size_t(n);
+  float* const h_min = t->h_pin + 3 * size_t(n);
+  std::memcpy(h_in, db_in_host, nb);
   TraceParams tp{};
-  tp.db_in = t->d_in;
+  tp.db_in = h_in;
   tp.n = n;
   tp.cal_db = cal_offset_db;
   tp.tare_acc = t->d_tare_acc;
@@ -1163,9 +1172,11 @@ int tdsa_trace_update(tdsa_trace t, const float* db_in_host, int n, float cal_of
     tp.tare_finish = finish;
   }
   tp.tare_active = ((tare_subtract && t->tare_active) || finish) ? 1 : 0;
-  tp.live = t->d_live;
+  tp.live = live_out ? h_live : nullptr;
   tp.state_max = (hold_flags & TDSA_HOLD_MAX) ? t->d_hold_max : nullptr;
   tp.state_min = (hold_flags & TDSA_HOLD_MIN) ? t->d_hold_min : nullptr;
+  tp.max_copy = (max_out && tp.state_max) ? h_max : nullptr;
+  tp.min_copy = (min_out && tp.state_min) ? h_min : nullptr;
   tp.max_first = t->held_max == 0;
   tp.min_first = t->held_min == 0;
   HIPCHK(launch_trace_update(tp, t->stream));
@@ -1176,12 +1187,10 @@ int tdsa_trace_update(tdsa_trace t, const float* db_in_host, int n, float cal_of
   if (tare_done) *tare_done = finish ? 1 : 0;
   if (hold_flags & TDSA_HOLD_MAX) t->held_max += 1;
   if (hold_flags & TDSA_HOLD_MIN) t->held_min += 1;
-  if (live_out) HIPCHK(hipMemcpyAsync(live_out, t->d_live, nb, hipMemcpyDeviceToHost, t->stream));
-  if (max_out && (hold_flags & TDSA_HOLD_MAX))
-    HIPCHK(hipMemcpyAsync(max_out, t->d_hold_max, nb, hipMemcpyDeviceToHost, t->stream));
-  if (min_out && (hold_flags & TDSA_HOLD_MIN))
-    HIPCHK(hipMemcpyAsync(min_out, t->d_hold_min, nb, hipMemcpyDeviceToHost, t->stream));
   HIPCHK(hipStreamSynchronize(t->stream));
+  if (live_out) std::memcpy(live_out, h_live, nb);
+  if (tp.max_copy) std::memcpy(max_out, h_max, nb);
+  if (tp.min_copy) std::memcpy(min_out, h_min, nb);
   return TDSA_OK;
 }
 

@@ -114,6 +114,8 @@ struct TraceParams {
   float* state_max;     // or null
   float* state_min;
   int max_first, min_first;  // adopt (nan_safe) instead of fmax/fmin
+  float* max_copy;      // [n] second destination of the new max / min trace (a host-visible buffer), or null
+  float* min_copy;
 };
 hipError_t launch_trace_update(const TraceParams& p, hipStream_t s);
 

@@ -406,10 +406,12 @@ __global__ void __launch_bounds__(256) trace_update_kernel(const TraceParams p) 
   if (p.state_max != nullptr) {                             // _update_max_hold (:371-382)
     float m = p.max_first ? ((db != db) ? -500.f : db) : fmaxf(p.state_max[k], db);
     p.state_max[k] = m;
+    if (p.max_copy != nullptr) p.max_copy[k] = m;
   }
   if (p.state_min != nullptr) {                             // _update_min_hold (:384-395)
     float m = p.min_first ? ((db != db) ? 500.f : db) : fminf(p.state_min[k], db);
     p.state_min[k] = m;
+    if (p.min_copy != nullptr) p.min_copy[k] = m;
   }
 }
 
