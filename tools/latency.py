@@ -55,6 +55,19 @@ def main():
             ts.update(row, cal_offset_db=-0.8, hold_max=True, hold_min=True)
         print(f"N={n:6d} trace update (cal + both holds, three rows back): {(time.perf_counter() - t0) / 2000 * 1e6:6.1f} us")
         ts.close()
+    # one tick of the microphone source: stereo float32 block -> one-sided dB trace(s)
+    for n in (1024, 4096):
+        st = np.random.default_rng(2).normal(0, 0.1, (n, 2)).astype(np.float32)
+        with SpectrumEngine(n, max_frames=1) as e:
+            e.set_window(np.hanning(n).astype(np.float32))
+            e.configure(db_mode="pow", log_floor=1e-10, dc_alpha=1.0)
+            for chan in ("mono", "stereo"):
+                for _ in range(200):
+                    e.process_real2(st, chan)
+                t0 = time.perf_counter()
+                for _ in range(2000):
+                    e.process_real2(st, chan)
+                print(f"N={n:6d} audio tick ({chan:6s}): {(time.perf_counter() - t0) / 2000 * 1e6:6.1f} us")
 
 if __name__ == "__main__":
     main()

@@ -831,6 +831,26 @@ int tdsa_process_dev(tdsa_plan p, int in_format, const void* iq_dev, size_t n_sa
   return process_dev_impl(p, in_format, iq_dev, n_samples, hop, n_frames, out_db_dev, nullptr, nullptr);
 }
 
+// pinned, device-visible bounce buffers of the host entry points (grown on demand; every host call ends with a
+// synchronize, so they are free when the next one starts)
+static int ensure_pins(tdsa_plan p, size_t in_bytes, size_t out_bytes) {
+  if (in_bytes > p->in_pin_bytes) {
+    if (p->h_in_pin) { HIPCHK(hipStreamSynchronize(p->stream)); HIPCHK(hipHostFree(p->h_in_pin)); }
+    p->h_in_pin = nullptr;
+    p->in_pin_bytes = 0;
+    HIPCHK(hipHostMalloc(&p->h_in_pin, in_bytes, hipHostMallocDefault));
+    p->in_pin_bytes = in_bytes;
+  }
+  if (out_bytes > p->out_pin_bytes) {
+    if (p->h_out_pin) { HIPCHK(hipStreamSynchronize(p->stream)); HIPCHK(hipHostFree(p->h_out_pin)); }
+    p->h_out_pin = nullptr;
+    p->out_pin_bytes = 0;
+    HIPCHK(hipHostMalloc(&p->h_out_pin, out_bytes, hipHostMallocDefault));
+    p->out_pin_bytes = out_bytes;
+  }
+  return TDSA_OK;
+}
+
 static int process_host(tdsa_plan p, int fmt, const void* iq_host, size_t n_samples, int hop, int n_frames,
                         float* out_db_host) {
   if (!p) return fail(TDSA_ERR_ARG, "null plan");
@@ -859,20 +879,7 @@ static int process_host(tdsa_plan p, int fmt, const void* iq_host, size_t n_samp
   const size_t out_bytes = out_db_host ? size_t(p->big ? 1 : n_frames) * p->nfft * sizeof(float) : 0;
   const bool bounce = in_bytes <= kPinnedBounceMax && out_bytes <= kPinnedBounceMax;
   if (bounce) {
-    if (in_bytes > p->in_pin_bytes) {
-      if (p->h_in_pin) { HIPCHK(hipStreamSynchronize(p->stream)); HIPCHK(hipHostFree(p->h_in_pin)); }
-      p->h_in_pin = nullptr;
-      p->in_pin_bytes = 0;
-      HIPCHK(hipHostMalloc(&p->h_in_pin, in_bytes, hipHostMallocDefault));
-      p->in_pin_bytes = in_bytes;
-    }
-    if (out_bytes > p->out_pin_bytes) {
-      if (p->h_out_pin) { HIPCHK(hipStreamSynchronize(p->stream)); HIPCHK(hipHostFree(p->h_out_pin)); }
-      p->h_out_pin = nullptr;
-      p->out_pin_bytes = 0;
-      HIPCHK(hipHostMalloc(&p->h_out_pin, out_bytes, hipHostMallocDefault));
-      p->out_pin_bytes = out_bytes;
-    }
+    { const int rc_pin = ensure_pins(p, in_bytes, out_bytes); if (rc_pin != TDSA_OK) return rc_pin; }
     std::memcpy(p->h_in_pin, iq_host, in_bytes);      // the previous call ended with a synchronize: the buffer is free
   }
   // the smallest calls (one displayed frame) skip the two DMA operations as well: the kernels read the samples from
@@ -955,11 +962,25 @@ int tdsa_process_real2(tdsa_plan p, const float* lr_host, size_t n_samples, int 
     HIPCHK(hipMalloc(&p->d_real, in_bytes * n_sig));
     p->real_bytes = in_bytes * n_sig;
   }
-  HIPCHK(hipMemcpyAsync(p->d_in_stage, lr_host, in_bytes, hipMemcpyHostToDevice, p->stream));
+  // one tick of audio is small: samples and dB rows go through pinned, device-visible buffers that the kernels read
+  // and write in place (no DMA operation either way); larger batches are copied as before
+  const int rows_out = channel == TDSA_CH_STEREO ? 2 * n_frames : n_frames;
+  const size_t out_bytes = size_t(rows_out) * nb * sizeof(float);
+  const bool direct = in_bytes <= kZeroCopyMax && out_bytes <= kZeroCopyMax;
+  const float2* lr_dev = static_cast<const float2*>(p->d_in_stage);
+  float* db_dst = p->d_db1;
+  if (direct) {
+    { const int rc_pin = ensure_pins(p, in_bytes, out_bytes); if (rc_pin != TDSA_OK) return rc_pin; }
+    std::memcpy(p->h_in_pin, lr_host, in_bytes);
+    lr_dev = static_cast<const float2*>(p->h_in_pin);
+    db_dst = static_cast<float*>(p->h_out_pin);
+  } else {
+    HIPCHK(hipMemcpyAsync(p->d_in_stage, lr_host, in_bytes, hipMemcpyHostToDevice, p->stream));
+  }
   // one transform per real signal (no left / right packing: see real_select_kernel)
   float2* const za = p->d_real;
   float2* const zb = p->d_real + need;
-  HIPCHK(launch_real_select(static_cast<const float2*>(p->d_in_stage), need, channel, za, zb, p->stream));
+  HIPCHK(launch_real_select(lr_dev, need, channel, za, zb, p->stream));
   for (int sig = 0; sig < n_sig; ++sig) {
     if (p->chirp) {
       // a size that is not a power of two: signal + 0i through the chirp-z core, mean removed (exact sums), and
@@ -999,7 +1020,7 @@ int tdsa_process_real2(tdsa_plan p, const float* lr_host, size_t n_samples, int 
     ap.avg_n = m.avg_n;
     ap.log_floor = m.log_floor;
     ap.cal_db = m.cal_offset_db;
-    ap.out_db = p->d_db1;
+    ap.out_db = db_dst;
     HIPCHK(launch_avg_scan(ap, p->stream, nullptr));
     if (m.avg_mode == TDSA_AVG_LIN) {
       long long c = (long long)p->avg_count + n_frames;
@@ -1008,10 +1029,11 @@ int tdsa_process_real2(tdsa_plan p, const float* lr_host, size_t n_samples, int 
       p->avg_count = 1;
     }
   } else {
-    HIPCHK(launch_lin_to_db(p->d_lin1, size_t(rows) * nb, m.log_floor, m.cal_offset_db, p->d_db1, p->stream));
+    HIPCHK(launch_lin_to_db(p->d_lin1, size_t(rows) * nb, m.log_floor, m.cal_offset_db, db_dst, p->stream));
   }
-  HIPCHK(hipMemcpyAsync(out_db_host, p->d_db1, size_t(rows) * nb * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+  if (!direct) HIPCHK(hipMemcpyAsync(out_db_host, p->d_db1, out_bytes, hipMemcpyDeviceToHost, p->stream));
   HIPCHK(hipStreamSynchronize(p->stream));
+  if (direct) std::memcpy(out_db_host, p->h_out_pin, out_bytes);
   return TDSA_OK;
 }
 
