@@ -838,14 +838,14 @@ static int ensure_pins(tdsa_plan p, size_t in_bytes, size_t out_bytes) {
     if (p->h_in_pin) { HIPCHK(hipStreamSynchronize(p->stream)); HIPCHK(hipHostFree(p->h_in_pin)); }
     p->h_in_pin = nullptr;
     p->in_pin_bytes = 0;
-    HIPCHK(hipHostMalloc(&p->h_in_pin, in_bytes, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(&p->h_in_pin, in_bytes, hipHostMallocPortable | hipHostMallocMapped));
     p->in_pin_bytes = in_bytes;
   }
   if (out_bytes > p->out_pin_bytes) {
     if (p->h_out_pin) { HIPCHK(hipStreamSynchronize(p->stream)); HIPCHK(hipHostFree(p->h_out_pin)); }
     p->h_out_pin = nullptr;
     p->out_pin_bytes = 0;
-    HIPCHK(hipHostMalloc(&p->h_out_pin, out_bytes, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(&p->h_out_pin, out_bytes, hipHostMallocPortable | hipHostMallocMapped));
     p->out_pin_bytes = out_bytes;
   }
   return TDSA_OK;
@@ -1172,7 +1172,7 @@ int tdsa_trace_update(tdsa_trace t, const float* db_in_host, int n, float cal_of
   const size_t nb = size_t(n) * sizeof(float);
   // one displayed frame: the kernel reads the row from and writes its results to pinned, device-visible memory of the
   // trace object - no DMA operation on the way in or out (each costs ~10 us from / to pageable memory)
-  if (!t->h_pin) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&t->h_pin), 4 * nb, hipHostMallocDefault));
+  if (!t->h_pin) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&t->h_pin), 4 * nb, hipHostMallocPortable | hipHostMallocMapped));
   float* const h_in = t->h_pin;
   float* const h_live = t->h_pin + n;
   float* const h_max = t->h_pin + 2 * size_t(n);
