@@ -57,11 +57,23 @@ __global__ void __launch_bounds__(256) chirp_sums_kernel(const void* in, unsigne
     const float2* x = reinterpret_cast<const float2*>(fb);
     for (int i = threadIdx.x; i < n; i += 256) { sr += double(x[i].x); si += double(x[i].y); }
   } else {
+    // four samples (8 bytes) per lane and load (frame starts are only sample aligned: packed struct), the tail
+    // sample by sample; sums of bytes: exact in 32-bit integers for any n this path takes
+    struct __attribute__((packed, aligned(2))) Quad { unsigned x, y; };
+    const Quad* xq = reinterpret_cast<const Quad*>(fb);
     const uint16_t* x = reinterpret_cast<const uint16_t*>(fb);
-    const unsigned xm = xor_mask & 0xffffu;
-    long long ui = 0, uq = 0;
-    for (int i = threadIdx.x; i < n; i += 256) {
-      const unsigned u = unsigned(x[i]) ^ xm;
+    unsigned ui = 0, uq = 0;
+    const int nq = n / 4;
+    for (int i = threadIdx.x; i < nq; i += 256) {
+      const Quad q = xq[i];
+      const unsigned a = q.x ^ xor_mask, b = q.y ^ xor_mask;
+      ui = __builtin_amdgcn_udot4(a, 0x00010001u, ui, false);
+      uq = __builtin_amdgcn_udot4(a, 0x01000100u, uq, false);
+      ui = __builtin_amdgcn_udot4(b, 0x00010001u, ui, false);
+      uq = __builtin_amdgcn_udot4(b, 0x01000100u, uq, false);
+    }
+    for (int i = 4 * nq + threadIdx.x; i < n; i += 256) {
+      const unsigned u = unsigned(x[i]) ^ (xor_mask & 0xffffu);
       ui += u & 0xffu;
       uq += u >> 8;
     }
@@ -170,7 +182,7 @@ struct ChirpPostParams {
   float* hold_min;
 };
 
-constexpr int kChirpFramesPerBlock = 32;   // one hold atomic per bin and this many frames
+constexpr int kChirpFramesPerBlock = 8;    // one hold atomic (when the trace moves) per bin and this many frames
 
 __global__ void __launch_bounds__(256) chirp_post_kernel(const ChirpPostParams p) {
   const int k = blockIdx.x * 256 + threadIdx.x;
@@ -181,6 +193,7 @@ __global__ void __launch_bounds__(256) chirp_post_kernel(const ChirpPostParams p
   float hmax = -INFINITY, hmin = INFINITY;
   const int f0 = blockIdx.y * kChirpFramesPerBlock;
   const int f1 = f0 + kChirpFramesPerBlock < p.n_frames ? f0 + kChirpFramesPerBlock : p.n_frames;
+#pragma unroll 4
   for (int f = f0; f < f1; ++f) {
     // X[k] = a[k] * conj(w) / M with |a[k]| = 1: only |X|^2 is needed, the last chirp factor drops out
     const c32 w = p.y[(long long)f * p.m + k];
