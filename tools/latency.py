@@ -55,6 +55,19 @@ def main():
             ts.update(row, cal_offset_db=-0.8, hold_max=True, hold_min=True)
         print(f"N={n:6d} trace update (cal + both holds, three rows back): {(time.perf_counter() - t0) / 2000 * 1e6:6.1f} us")
         ts.close()
+    # TraceAverager.process on a host row (float64 in, float64 state out)
+    from topdogspectrumanalyser_amd import TraceAverager
+    for n in (1024, 16384):
+        ta = TraceAverager()
+        ta.set_mode("exp", 8)
+        row = np.random.default_rng(3).uniform(1e-9, 1e-6, n)
+        for _ in range(200):
+            ta.process(row)
+        t0 = time.perf_counter()
+        for _ in range(2000):
+            ta.process(row)
+        print(f"N={n:6d} TraceAverager.process (host row):                  {(time.perf_counter() - t0) / 2000 * 1e6:6.1f} us")
+
     # one tick of the microphone source: stereo float32 block -> one-sided dB trace(s)
     for n in (1024, 4096):
         st = np.random.default_rng(2).normal(0, 0.1, (n, 2)).astype(np.float32)

@@ -1103,6 +1103,7 @@ struct tdsa_trace_s {
   double* d_avg = nullptr;
   double* d_avg_in = nullptr;
   float* h_pin = nullptr;       // pinned, device-visible: [4][n] row in, live / max / min out (one GUI tick, zero-copy)
+  double* h_pin_avg = nullptr;  // pinned: [2][n] linear row in, averager state out (tdsa_trace_avg_process)
   long long held_max = 0, held_min = 0;
   bool tare_active = false;
   int tare_count = 0;
@@ -1145,6 +1146,7 @@ int tdsa_trace_destroy(tdsa_trace t) {
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (t->h_pin) (void)hipHostFree(t->h_pin);
+  if (t->h_pin_avg) (void)hipHostFree(t->h_pin_avg);
   if (t->stream) (void)hipStreamDestroy(t->stream);
   delete t;
   return TDSA_OK;
@@ -1257,12 +1259,19 @@ int tdsa_trace_avg_process(tdsa_trace t, const double* linear_in_host, int n, do
     return fail(TDSA_ERR_STATE, "averaging is off (pass-through is the caller's job)");
   HIPCHK(hipSetDevice(t->device));
   const size_t nb = size_t(n) * sizeof(double);
-  HIPCHK(hipMemcpyAsync(t->d_avg_in, linear_in_host, nb, hipMemcpyHostToDevice, t->stream));
-  HIPCHK(launch_avg_host_frame(t->d_avg_in, n, t->d_avg, t->avg_count, t->avg_mode, t->avg_n, t->stream));
+  // one row per call: in through pinned, device-visible memory the kernel reads in place, the state back through a
+  // DMA copy into pinned memory (the float64 state itself stays on the device)
+  if (!t->h_pin_avg)
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&t->h_pin_avg), 2 * nb, hipHostMallocPortable | hipHostMallocMapped));
+  double* const h_in = t->h_pin_avg;
+  double* const h_out = t->h_pin_avg + n;
+  std::memcpy(h_in, linear_in_host, nb);
+  HIPCHK(launch_avg_host_frame(h_in, n, t->d_avg, t->avg_count, t->avg_mode, t->avg_n, t->stream));
   if (t->avg_count == 0) t->avg_count = 1;
   else if (t->avg_mode == TDSA_AVG_LIN && t->avg_count < t->avg_n) t->avg_count += 1;
-  if (avg_out_host) HIPCHK(hipMemcpyAsync(avg_out_host, t->d_avg, nb, hipMemcpyDeviceToHost, t->stream));
+  if (avg_out_host) HIPCHK(hipMemcpyAsync(h_out, t->d_avg, nb, hipMemcpyDeviceToHost, t->stream));
   HIPCHK(hipStreamSynchronize(t->stream));
+  if (avg_out_host) std::memcpy(avg_out_host, h_out, nb);
   if (count_out) *count_out = t->avg_count;
   return TDSA_OK;
 }
