@@ -1597,6 +1597,29 @@ def test_host_entry_points_stay_consistent_with_overlap(pkg, streams):
         assert np.array_equal(mx, smax)
 
 
+def test_host_calls_of_every_staging_class_agree(pkg):
+    """The host entry points move small calls through pinned, device-visible buffers (read / written in place),
+    medium ones through the same buffers with DMA copies and large ones straight from the caller's memory
+    (tdsa_capi.cpp: kZeroCopyMax, kPinnedBounceMax): the rows are the same bit for bit whichever way they went."""
+    nfft, hop = 1024, 512
+    total = 700                                            # 700 frames: 1.4 MB of int8 in, 2.8 MB of rows out
+    iq = so.synth_iq_int8(hop * (total - 1) + nfft, nfft, seed=77)
+    with _hackrf_engine(pkg, nfft, total) as e:
+        whole = e.process(iq, hop=hop)                     # large: no staging
+    with _hackrf_engine(pkg, nfft, total) as e:
+        parts, pos = [], 0
+        for k in (1, 3, 40, 1, 200, 7, 448):               # 1..40 frames: in place; 200: bounce; 448: large
+            parts.append(e.process(iq[2 * hop * pos: 2 * (hop * (pos + k - 1) + nfft)], hop=hop, n_frames=k))
+            pos += k
+        assert pos == total
+    assert np.array_equal(np.concatenate(parts), whole)
+    x = so.unpack_iq_int8(iq)
+    with _hackrf_engine(pkg, nfft, total) as e:
+        c = np.concatenate([e.process(x[hop * p: hop * (p + k - 1) + nfft], hop=hop, n_frames=k)
+                            for p, k in ((0, 1), (1, 30), (31, 669))])
+    _check(c, whole.astype(np.float64), "complex64 through the three staging classes", floor_units=2)
+
+
 def test_set_overlap_rejects_bad_counts(pkg):
     with _hackrf_engine(pkg, 1024, 4) as e:
         for bad in (0, -1, 5):
