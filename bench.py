@@ -364,7 +364,9 @@ def main() -> None:
             "timing": {"repetitions": len(times), "inner_repeats": inner, "steps_per_region": steps_timed,
                        "region_ms": [t * 1e3 for t in times], "region_ms_serial": [t * 1e3 for t in times_serial],
                        "statistic": "median over repetitions of (max over ranks)",
-                       "value_is": f"{streams} stream(s) per GPU" if streams > 1 else "strictly serial launches",
+                       "value_is": (f"{streams} stream(s) per GPU" + (", launches sized for half the CUs (two side by side)"
+                                                                         if streams >= 3 else ""))
+                       if streams > 1 else "strictly serial launches",
                        "value_serial_is": "strictly serial launches (1 stream)"},
             "config": {"workload": f"{args.config}: {wl['desc']}", "nfft": nfft, "hop": hop,
                        "frames_per_step_per_gpu": frames, "input": "int8 IQ resident in HBM",

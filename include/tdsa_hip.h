@@ -180,7 +180,9 @@ int tdsa_synchronize(tdsa_plan p);
 /* Let consecutive tdsa_process_dev calls overlap on up to n_streams (1..4) HIP streams owned by the plan.
  * A persistent launch ends ragged (2440 frames over 256 CUs = 9 or 10 frames per workgroup); with more
  * than one stream the next call's workgroups start on the CUs that finish first and the inter-kernel
- * gap disappears (C3: +17 % frames/s with 3 streams).  Only calls whose results do not depend on
+ * gap disappears.  With n_streams >= 3 the overlapped launches are sized for half the CUs, so that two run side by
+ * side and the third queues behind them: a workgroup's fixed costs are spread over twice the frames (C3: 76.4 ->
+ * 74.3 us per step; strictly serial launches keep the whole chip).  Only calls whose results do not depend on
  * execution order rotate over the extra streams: no averaging, dc_alpha < 0 or >= 1 (hold traces are
  * merged with atomics and stay exact).  Every other entry point first orders the plan's main stream
  * after the work in flight, so the API stays sequentially consistent; with overlap on, tdsa_get_dc

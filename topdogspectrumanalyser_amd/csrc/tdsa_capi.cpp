@@ -48,8 +48,8 @@ struct tdsa_plan_s {
   // tdsa_set_overlap: extra streams consecutive order-independent launches rotate over, so the ragged
   // tail of one persistent launch (and the inter-kernel gap) is filled by the head of the next
   static constexpr int kMaxOverlap = 4;
-  hipStream_t aux[kMaxOverlap - 1] = {nullptr, nullptr, nullptr};
-  hipEvent_t ev_aux[kMaxOverlap - 1] = {nullptr, nullptr, nullptr};
+  hipStream_t aux[kMaxOverlap - 1] = {};
+  hipEvent_t ev_aux[kMaxOverlap - 1] = {};
   hipEvent_t ev_state = nullptr;
   int n_overlap = 1, rr = 0;
   bool aux_busy = false, state_dirty = true;
@@ -779,7 +779,13 @@ static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size
     sp.dc_sub = p->d_dc_sub;
   }
 
-  const LaunchGeom g = spectrum_geometry(p->log2n, n_frames, p->num_cu);
+  // With three or more streams the overlapped launches are sized for HALF the CUs: two of them run side by side, the
+  // next one queues behind whichever ends first.  Each workgroup then carries twice the frames - its fixed costs (cold
+  // first fetch, hold merge: ~5 us) count half - and the ragged end of one launch is filled by the next:
+  // C3 76.4 -> 74.3 us per step, C2 26.7 -> 26.0 (profiles/r02_c3_experiments.txt).  More than three streams in flight
+  // measured worse (4: 91 us), and strictly serial launches keep the whole chip.
+  const LaunchGeom g = spectrum_geometry(p->log2n, n_frames,
+                                         (order_free && p->n_overlap >= 3) ? (p->num_cu + 1) / 2 : p->num_cu);
   if (averaging) {
     if (!p->d_lin) HIPCHK(hipMalloc(&p->d_lin, size_t(p->max_frames) * p->nfft * sizeof(float)));
     if (!p->d_carry && p->max_frames > 128)
