@@ -382,6 +382,8 @@ def main() -> None:
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "kernel": "spectrum_kernel" if launches else "column pass + row pass + gather + finish (whole serial step)",
                          "kernel_avg_us": kern_s * 1e6,
+                         "kernel_avg_from": "HIP events on the plan's stream around every launch of a further, strictly "
+                                            "serial pass (one launch on the whole chip at a time)",
                          "algorithmic_bytes_per_frame": bytes_per_frame},
         }
         if args.dry_run:                               # nothing was computed: no performance figures
