@@ -9,17 +9,30 @@ Workload (config C3 of BASELINE.json / SURVEY.md 8(d), the one the metric is quo
 HackRF-shaped 20 Msps int8 IQ, N = 16384, hop = N/2, one second of IQ per step = 20e6 samples
 -> 2440 frames, HackRF-branch semantics (per-frame DC removal, power-normalised Hann,
 20*log10(|X| + 1e-12)), every frame's dB row written + a max-hold trace.  One "step" = one pass of
-the hot path over that second; consecutive steps walk a ring of distinct seconds (320 MB of input,
-larger than the 256 MiB Infinity Cache) so the reads really come from HBM.
+the hot path over that second; consecutive steps walk a ring of distinct seconds (input + output of the ring
+are several times the 256 MiB Infinity Cache) so the traffic really goes to HBM.
+
+Three ways of submitting the same K steps are timed, all in the line:
+  value          `--batch` queued seconds per call (tdsa_process_dev_batch: one persistent launch consumes them;
+                 the per-launch costs - cold fetch of window / twiddles, hold merge, ragged last round of frames
+                 over the CUs - are paid once per launch instead of once per second), calls rotating over
+                 `--streams` plan-owned HIP streams
+  value_streams  one second per launch, launches rotating over the streams (round 2's `value`)
+  value_serial   one second per launch, strictly serial full-chip launches
+Results are bit-identical in all three (tests/test_gpu_parity.py::test_batched_captures_*).
 
 Multi-GPU: frames are independent, every rank processes its own seconds on its own
 GPU with its own plan; there is NO collective in the data path and no RCCL anywhere: ranks meet at a
 host-side (gloo/TCP) barrier around the timed region and the per-GPU hold traces are combined on the
 host with np.fmax.  Aggregate = all ranks' frames / slowest rank's time (weak scaling).
+--config c5 (2^20-point Welch average of K = 64 segments) shards the SEGMENTS of one capture over the ranks
+(strong scaling): every rank averages its share, the float64 partial means + counts are gathered on the host,
+combined with sharding.combine_welch, and rank 0 applies 10*log10(+floor) + calibration offset and checks the
+combined row against the float64 gold.
 
 Timing: after W warm-up steps the step loop of K x `inner` steps is timed `--reps` times, each time
 fenced (device synchronize + host barrier) on both sides; `inner` is chosen so that one timed region
-lasts >= 50 ms whatever K is; the MEDIAN repetition (max over ranks) gives ms_per_step and value.
+lasts >= --min-region-s (0.5 s) whatever K is; the MEDIAN repetition (max over ranks) gives ms_per_step and value.
 
 Prints ONE JSON line on rank 0.
 """
@@ -51,7 +64,7 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
 CAL_DB = -0.8087054556396822
-MIN_REGION_S = 0.050
+WELCH_FLOOR = 1e-10
 
 
 def cpu_all_cores(wl: dict, workers: int, seconds: float) -> dict:
@@ -74,7 +87,7 @@ def cpu_all_cores(wl: dict, workers: int, seconds: float) -> dict:
             n, dt = p.stdout.readline().split()
             frames += int(n)
             slowest = max(slowest, float(dt))
-            p.wait(timeout=30)
+            p.wait(timeout=60)
     finally:
         for p in procs:
             if p.poll() is None:
@@ -82,7 +95,7 @@ def cpu_all_cores(wl: dict, workers: int, seconds: float) -> dict:
     avail = os.cpu_count() or workers
     return {"value": frames / slowest, "unit": "frames/s", "cores": workers, "kind": "port",
             "policy": f"{workers} single-thread worker processes (one per core used) of {avail} host cores; "
-                      f"--cpu-workers 0 = one per host core",
+                      f"--cpu-workers N picks another count",
             "sample": f"{workers} processes x {seconds:.0f} s of the numpy restatement, one synthetic frame stream each",
             "host_cores_available": avail}
 
@@ -92,15 +105,19 @@ class _DryEngine:
     the multi-GPU leg can be exercised in a container without a GPU.  Does no arithmetic; the line it
     produces is marked as a dry run and carries no performance meaning."""
 
-    def __init__(self, nfft):
-        self.nfft, self._n, self._ms = nfft, 0, 0.0
+    def __init__(self, nfft, rank=0):
+        self.nfft, self.rank, self._n = nfft, rank, 0
 
-    def step(self):
-        time.sleep(2e-5)
-        self._n += 1
+    def step(self, captures=1):
+        time.sleep(2e-5 * captures)
+        self._n += captures
 
     def synchronize(self):
         pass
+
+    def averaged_stub(self, count):
+        """a recognisable partial Welch mean: rank r 'measured' the constant r + 1 in every bin (1024 bins)"""
+        return np.full(1024, float(self.rank + 1)), count
 
 
 def _free_port() -> int:
@@ -111,7 +128,8 @@ def _free_port() -> int:
 
 def _spawn_workers(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: one worker process per GPU, rendezvous on 127.0.0.1.
-    Rank 0's stdout (the JSON line) is passed through."""
+    Rank 0's stdout (the JSON line) is passed through.  Every worker is waited for; when one fails the others
+    (who would sit in the gloo barrier for ever) are terminated and the first non-zero exit code is returned."""
     port = _free_port()
     procs = []
     for r in range(n):
@@ -119,10 +137,30 @@ def _spawn_workers(n: int) -> int:
                    MASTER_PORT=str(port), TDSA_BENCH_WORKER="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for p in procs:
-        rc = rc or p.wait()
-    return rc
+    first_bad = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            rc = p.poll()
+            if rc is None:
+                continue
+            pending.remove(p)
+            if rc != 0 and first_bad == 0:
+                first_bad = rc
+                for q in pending:                      # the rest can only hang at the next barrier
+                    q.terminate()
+        if pending:
+            time.sleep(0.05)
+            if first_bad:
+                deadline = time.time() + 5.0
+                for q in pending:
+                    try:
+                        q.wait(timeout=max(0.1, deadline - time.time()))
+                    except subprocess.TimeoutExpired:
+                        q.kill()
+                        q.wait()
+                pending = []
+    return first_bad
 
 
 def main() -> None:
@@ -132,14 +170,18 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--reps", type=int, default=7, help="timed repetitions of the step loop (median reported)")
     ap.add_argument("--config", default="c3", choices=sorted(WORKLOADS))
-    ap.add_argument("--ring", type=int, default=8, help="distinct input/output buffers cycled through")
+    ap.add_argument("--ring", type=int, default=0, help="distinct input/output buffers cycled through "
+                    "(0 = 2 x batch, at least 8)")
     ap.add_argument("--streams", type=int, default=3,
-                    help="HIP streams consecutive steps rotate over (tdsa_set_overlap); 1 = strictly serial")
+                    help="HIP streams consecutive calls rotate over (tdsa_set_overlap); 1 = strictly serial")
+    ap.add_argument("--batch", type=int, default=8,
+                    help="queued steps handed over per call in the `value` leg (tdsa_process_dev_batch); 1 = one launch per step")
+    ap.add_argument("--min-region-s", type=float, default=0.5, help="every timed region lasts at least this long")
     ap.add_argument("--preroll-seconds", type=float, default=0.4, help="untimed load before the warm-up steps")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the single-thread CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-workers", type=int, default=-1,
-                    help="processes of the all-cores CPU leg: -1 = min(32, host cores), 0 = one per host core")
+    ap.add_argument("--cpu-workers", type=int, default=0,
+                    help="processes of the all-cores CPU leg: 0 = one per host core (BASELINE.md 3(ii)), N = N processes")
     ap.add_argument("--no-cpu-pool", action="store_true")
     ap.add_argument("--cpu-pool-seconds", type=float, default=6.0)
     ap.add_argument("--dry-run", action="store_true",
@@ -152,6 +194,9 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
+    if os.environ.get("TDSA_BENCH_FAIL_RANK") == str(rank) and world > 1:     # tests/test_bench_launch.py: a worker dies
+        sys.exit(3)
+    MIN_REGION_S = max(0.05, args.min_region_s)
 
     import torch  # first: one HIP runtime per process (torch's bundled libamdhip64.so.7)
     import torch.distributed as dist
@@ -184,14 +229,26 @@ def main() -> None:
 
     wl = WORKLOADS[args.config]
     nfft, hop, ns = wl["nfft"], wl["hop"], wl["n_samples"]
-    frames = (ns - nfft) // hop + 1
-    ring = max(1, args.ring)
+    frames = (ns - nfft) // hop + 1                   # frames (C5: segments) of one capture
     welch = wl["branch"] == "welch"
+    batch = 1 if welch else max(1, args.batch)
+    ring = args.ring if args.ring > 0 else max(8, 2 * batch)
+    ring = max(batch, (ring // batch) * batch)        # whole batches
+    # C5: the K segments of ONE capture are sharded over the ranks; everything else: every rank
+    # its own captures
+    if welch:
+        from topdogspectrumanalyser_amd.sharding import shard_frames
+        seg0, seg1 = shard_frames(frames, rank, world)
+        my_frames = seg1 - seg0
+    else:
+        seg0, my_frames = 0, frames
+    my_ns = (my_frames - 1) * hop + nfft if my_frames > 0 else 0
 
     if args.dry_run:
-        eng = _DryEngine(nfft)
+        eng = _DryEngine(nfft, rank)
         visible, dev_index = 0, -1
         step = lambda i: eng.step()                   # noqa: E731
+        step_batch = lambda j: eng.step(batch)        # noqa: E731
         dev_sync = lambda: None                       # noqa: E731
         streams = 1
     else:
@@ -206,16 +263,21 @@ def main() -> None:
         from topdogspectrumanalyser_amd.utils.synthetic import synth_iq_int8
 
         # ---- synthetic input, resident in HBM before the timed region ---------------------------
-        base = synth_iq_int8(ns, nfft, seed=3 + rank)
-        ins, outs = [], []
+        # (C5: every rank synthesises the same capture and keeps its own segments)
+        base = synth_iq_int8(ns, nfft, seed=3 + (0 if welch else rank))
+        mine = base[2 * seg0 * hop: 2 * seg0 * hop + 2 * my_ns] if welch else base
         out_rows = 1 if welch else frames
+        # ONE allocation each, constant stride from capture to capture (what tdsa_process_dev_batch takes)
+        in_ring = torch.empty((ring, max(2, 2 * my_ns)), dtype=torch.int8, device=dev)
+        out_ring = torch.empty((ring, out_rows, nfft), dtype=torch.float32, device=dev)
         for r in range(ring):
-            host = base if r == 0 else np.roll(base, 2 * 977 * r)      # distinct seconds, same statistics
-            ins.append(torch.from_numpy(host).to(dev))
-            outs.append(torch.empty((out_rows, nfft), dtype=torch.float32, device=dev))
+            host = mine if r == 0 else np.roll(mine, 2 * 977 * r)      # distinct captures, same statistics
+            if my_ns:
+                in_ring[r].copy_(torch.from_numpy(np.ascontiguousarray(host)))
         torch.cuda.synchronize()
+        in_stride_b, out_stride_f = in_ring.stride(0), out_ring.stride(0)
 
-        eng = SpectrumEngine(nfft, max_frames=frames, device=dev_index)
+        eng = SpectrumEngine(nfft, max_frames=max(1, my_frames), device=dev_index)
         if wl["branch"] == "hackrf":
             w = np.hanning(nfft).astype(np.float32)
             w /= np.sqrt(np.mean(w ** 2))
@@ -223,7 +285,7 @@ def main() -> None:
             eng.configure(db_mode="mag", log_floor=1e-12, dc_alpha=1.0, hold_max=True)
         elif welch:
             eng.set_window(np.hanning(nfft).astype(np.float32))
-            eng.configure(db_mode="pow", power_scale=1.0, log_floor=1e-10, dc_alpha=-1.0, avg=("lin", frames),
+            eng.configure(db_mode="pow", power_scale=1.0, log_floor=WELCH_FLOOR, dc_alpha=-1.0, avg=("lin", frames),
                           cal_offset_db=CAL_DB)
         else:
             eng.set_window(np.hanning(nfft).astype(np.float32))
@@ -233,8 +295,15 @@ def main() -> None:
         def step(i: int) -> None:
             r = i % ring
             if welch:
-                eng.reset(nat.RESET_AVG)               # every step is one complete Welch average
-            eng.process_device(nat.IN_I8, ins[r].data_ptr(), ns, hop, frames, outs[r].data_ptr())
+                eng.reset(nat.RESET_AVG)               # every step is one complete Welch average (of this rank's share)
+                if my_frames == 0:
+                    return
+            eng.process_device(nat.IN_I8, in_ring[r].data_ptr(), my_ns, hop, my_frames, out_ring[r].data_ptr())
+
+        def step_batch(j: int) -> None:                # `batch` queued steps in one call
+            r = (j * batch) % ring
+            eng.process_device_batch(nat.IN_I8, in_ring[r].data_ptr(), in_stride_b, batch, my_ns, hop, my_frames,
+                                     out_ring[r].data_ptr(), out_stride_f)
 
         def dev_sync() -> None:
             eng.synchronize()
@@ -247,12 +316,12 @@ def main() -> None:
 
     rank_times = []                                   # per timed region: every rank's own seconds
 
-    def timed_loop(n_steps: int) -> float:
-        """one timed region: fence, n_steps steps, device synchronize, fence; seconds of the slowest rank"""
+    def timed_loop(n_calls: int, call) -> float:
+        """one timed region: fence, n_calls calls, device synchronize, fence; seconds of the slowest rank"""
         fence()
         t0 = time.perf_counter()
-        for i in range(n_steps):
-            step(i)
+        for i in range(n_calls):
+            call(i)
         dev_sync()
         own = time.perf_counter() - t0                # this rank's own work, before it waits for the others
         fence()
@@ -260,23 +329,26 @@ def main() -> None:
         rank_times.append(every)
         return max(every)
 
-    def measure(n_streams: int):
-        """-> (median seconds per region, all region times, inner)"""
+    def measure(n_streams: int, per_call: int):
+        """K x inner steps per region, `per_call` steps per call -> (median seconds per region, all regions, inner, per rank)"""
+        call = step if per_call == 1 else step_batch
+        calls_k = max(1, args.steps // per_call)      # K steps = K / per_call calls (K is rounded to whole calls)
         if not args.dry_run:
             eng.set_overlap(n_streams)
-        for i in range(args.warmup):
-            step(i)
-        est = timed_loop(args.steps) / max(1, args.steps)          # calibration region (also warm-up)
-        inner = max(1, int(np.ceil(1.2 * MIN_REGION_S / max(est * args.steps, 1e-9))))
-        for _ in range(4):                                         # a region that came out short is re-timed longer
-            inner = max(gather(inner))                             # same loop count on every rank
+        for i in range(max(1, args.warmup // per_call)):
+            call(i)
+        est = timed_loop(calls_k, call)               # calibration region (also warm-up)
+        inner = max(1, int(np.ceil(1.2 * MIN_REGION_S / max(est, 1e-9))))
+        for _ in range(4):                            # a region that came out short is re-timed longer
+            inner = max(gather(inner))                # same loop count on every rank
             del rank_times[:]
-            times = [timed_loop(args.steps * inner) for _ in range(max(1, args.reps))]
+            times = [timed_loop(calls_k * inner, call) for _ in range(max(1, args.reps))]
             if min(times) >= MIN_REGION_S:
                 break
             inner = int(np.ceil(inner * 1.3 * MIN_REGION_S / max(min(times), 1e-9)))
         per_rank = [statistics.median(t[r] for t in rank_times) for r in range(world)]
-        return statistics.median(times), times, inner, per_rank
+        return dict(med=statistics.median(times), times=times, inner=inner, per_rank=per_rank,
+                    steps=calls_k * inner * per_call, per_call=per_call, streams=n_streams)
 
     # clocks: an idle MI355X needs a few hundred ms of load before shader/fabric clocks settle; this
     # untimed pre-roll keeps short --steps/--warmup runs from measuring the ramp
@@ -288,40 +360,74 @@ def main() -> None:
             i_pre += 1
         dev_sync()
 
-    med, times, inner, per_rank_s = measure(streams)
-    if streams > 1:
-        med_serial, times_serial, inner_serial, _ = measure(1)
+    legs = {}
+    if welch or args.dry_run and batch == 1:
+        legs["value"] = measure(1, 1)
+        legs["serial"] = legs["streams"] = legs["value"]
     else:
-        med_serial, times_serial, inner_serial = med, times, inner
-    steps_timed = args.steps * inner
-    per_rank_fps = [frames * steps_timed / t for t in per_rank_s]  # each rank's own rate (median region)
+        legs["value"] = measure(streams, batch) if batch > 1 else None
+        legs["streams"] = measure(streams, 1) if streams > 1 else None
+        legs["serial"] = measure(1, 1)
+        if legs["streams"] is None:
+            legs["streams"] = legs["serial"]
+        if legs["value"] is None:
+            legs["value"] = legs["streams"]
+    head = legs["value"]
+    steps_timed = head["steps"]
+    total_frames = frames if welch else world * frames          # frames (segments) one step covers, all ranks together
+    per_rank_fps = [my_f * steps_timed / t for my_f, t in zip(gather(my_frames), head["per_rank"])]
 
     # ---- dominant kernel alone: HIP events on the plan's stream around every frame-kernel launch,
     #      launches strictly serial so that one kernel owns the GPU while it is timed ---------------
-    launches, kern_ms = 0, 0.0
-    if not args.dry_run:
+    def kernel_alone(per_call: int):
+        """-> (launches, mean seconds per launch) of the frame kernel in the launch shape of `per_call` steps per call"""
+        if args.dry_run:
+            return 0, 0.0
         eng.set_overlap(1)
         eng.profile_enable(True)
-        n_prof = min(steps_timed, 2000)
-        for i in range(n_prof):
-            step(i)
+        n_calls = max(1, min(legs["serial"]["steps"], 2000) // per_call)
+        for i in range(n_calls):
+            (step if per_call == 1 else step_batch)(i)
         launches, kern_ms = eng.profile_read()
         eng.profile_enable(False)
-        if welch:                                      # a chain of kernels: price the whole serial step
-            launches = 0
-    # (2^20-point plans run a chain of kernels: price the whole serial step instead)
-    kern_s = kern_ms * 1e-3 / launches if launches else med_serial / (args.steps * inner_serial)
-    if welch:                                          # one dB row per K segments: 2N + 4N/K per segment
-        bytes_per_frame = 2 * hop + 4 * nfft // frames
+        return launches, (kern_ms * 1e-3 / launches if launches else 0.0)
+
+    launches_b, kern_b = kernel_alone(head["per_call"])
+    launches_1, kern_1 = (launches_b, kern_b) if head["per_call"] == 1 else kernel_alone(1)
+    if welch:                                          # a chain of kernels: price the whole serial step
+        launches_b = launches_1 = 0
+        kern_b = kern_1 = legs["serial"]["med"] / legs["serial"]["steps"]
+        bytes_per_frame = 2 * hop + 4 * nfft // frames      # one dB row per K segments: 2N + 4N/K per segment
     else:
         bytes_per_frame = 2 * hop + 4 * nfft           # SURVEY.md 8(d): every input byte read once, every
-    algo_bytes = frames * bytes_per_frame              # output byte written once
-    achieved_gbs = algo_bytes / kern_s / 1e9
+    algo_step = my_frames * bytes_per_frame            # output byte written once (this rank's share of a step)
+    algo_launch = algo_step * head["per_call"]
+    achieved_gbs = algo_launch / kern_b / 1e9 if kern_b else 0.0
+    achieved_1 = algo_step / kern_1 / 1e9 if kern_1 else 0.0
     per_gpu_frac = gather(achieved_gbs / HBM_PEAK_GBS)
 
-    # per-GPU hold traces combined on the HOST; outside the timed region
-    hold_combined = None
-    if not args.dry_run:
+    # per-GPU state combined on the HOST (SURVEY.md 8(e)); outside the timed region
+    hold_combined, welch_block, combined_db = None, None, None
+    if welch:
+        t_c0 = time.perf_counter()
+        if args.dry_run:
+            part = eng.averaged_stub(my_frames)
+        else:
+            step(0)                                    # one more complete (partial) average of ring slot 0
+            eng.synchronize()
+            part = eng.averaged() if my_frames else (None, 0)
+        parts = gather(part)
+        if rank == 0:
+            from topdogspectrumanalyser_amd.sharding import combine_welch
+            have = [(m, c) for m, c in parts if c]
+            mean, count = combine_welch([m for m, _ in have], [c for _, c in have])
+            combined_db = 10.0 * np.log10(mean + WELCH_FLOOR) + CAL_DB         # signal_processing.py:56-59, dpp :317-327
+            welch_block = {"segments_per_rank": [c for _, c in parts], "segments_total": count,
+                           "combined_on": "host: sharding.combine_welch over the ranks' float64 means + counts, then "
+                                          "10*log10(mean + floor) + calibration offset on rank 0",
+                           "combine_ms": (time.perf_counter() - t_c0) * 1e3,
+                           "mean_of_means": float(np.mean(mean))}
+    elif not args.dry_run:
         from topdogspectrumanalyser_amd.sharding import combine_hold
         mx, _ = eng.hold()
         parts = [p for p in gather(mx) if p is not None]
@@ -331,19 +437,26 @@ def main() -> None:
     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same kernel and shape
     # (counters cannot be read from inside the process)
     traffic, traffic_src = None, None
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         pmc_path = os.path.join(ROOT, "profiles", f"{rnd}_{args.config}_pmc.json")
         if os.path.exists(pmc_path):
             with open(pmc_path) as fh:
                 pmc = json.load(fh)
             traffic = pmc["fetch_bytes_upper"] + pmc["write_bytes"]
-            traffic_src = f"profiles/{rnd}_{args.config}_pmc.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, per launch)"
+            traffic_src = (f"profiles/{rnd}_{args.config}_pmc.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, per one-step "
+                           f"launch of {pmc.get('algorithmic_bytes', 0) / 1e6:.1f} MB algorithmic)")
             break
+    valu_issue = None
+    vi_path = os.path.join(ROOT, "profiles", f"r03_{args.config}_valu_issue.json")
+    if os.path.exists(vi_path):
+        with open(vi_path) as fh:
+            valu_issue = json.load(fh)
 
     result = None
     if rank == 0:
-        value = world * frames * steps_timed / med
-        value_serial = world * frames * args.steps * inner_serial / med_serial
+        def rate(leg):
+            return total_frames * leg["steps"] / leg["med"]
+        value = rate(head)
         result = {
             "metric": "PSD frames/sec at 16384-pt FFT on synthetic 20 Msps IQ" if args.config == "c3"
                       else f"PSD frames/sec ({args.config})",
@@ -352,77 +465,117 @@ def main() -> None:
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": med / steps_timed * 1e3,
+            "ms_per_step": head["med"] / steps_timed * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if welch else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic" if not args.dry_run else "dry-run (stand-in engine, no GPU work, no perf meaning)",
-            "value_serial": value_serial,
-            "ms_per_step_serial": med_serial / (args.steps * inner_serial) * 1e3,
+            "value_streams": rate(legs["streams"]),
+            "ms_per_step_streams": legs["streams"]["med"] / legs["streams"]["steps"] * 1e3,
+            "value_serial": rate(legs["serial"]),
+            "ms_per_step_serial": legs["serial"]["med"] / legs["serial"]["steps"] * 1e3,
             "per_gpu_frames_per_s": per_rank_fps,
-            "timing": {"repetitions": len(times), "inner_repeats": inner, "steps_per_region": steps_timed,
-                       "region_ms": [t * 1e3 for t in times], "region_ms_serial": [t * 1e3 for t in times_serial],
+            "timing": {"repetitions": len(head["times"]), "inner_repeats": head["inner"], "steps_per_region": steps_timed,
+                       "steps_per_call": head["per_call"],
+                       "region_ms": [t * 1e3 for t in head["times"]],
+                       "region_ms_streams": [t * 1e3 for t in legs["streams"]["times"]],
+                       "region_ms_serial": [t * 1e3 for t in legs["serial"]["times"]],
+                       "min_region_s": MIN_REGION_S,
                        "statistic": "median over repetitions of (max over ranks)",
-                       "value_is": (f"{streams} stream(s) per GPU" + (", launches sized for half the CUs (two side by side)"
-                                                                         if streams >= 3 else ""))
-                       if streams > 1 else "strictly serial launches",
-                       "value_serial_is": "strictly serial launches (1 stream)"},
+                       "value_is": (f"{head['per_call']} queued step(s) per call (one persistent launch each), calls rotating "
+                                    f"over {head['streams']} stream(s) per GPU"
+                                    + (", launches sized for half the CUs (two side by side)" if head["streams"] >= 3 else "")),
+                       "value_streams_is": f"one step per launch, {legs['streams']['streams']} stream(s) per GPU (round 2's value)",
+                       "value_serial_is": "one step per launch, strictly serial full-chip launches (1 stream)"},
             "config": {"workload": f"{args.config}: {wl['desc']}", "nfft": nfft, "hop": hop,
-                       "frames_per_step_per_gpu": frames, "input": "int8 IQ resident in HBM",
-                       "input_ring": ring, "streams_per_gpu": streams, "inner_repeats": inner,
+                       "frames_per_step_per_gpu": my_frames, "frames_per_step_all_gpus": total_frames,
+                       "input": "int8 IQ resident in HBM", "input_ring": ring, "streams_per_gpu": head["streams"],
+                       "steps_per_call": head["per_call"], "inner_repeats": head["inner"],
                        "gpus_visible_per_process": visible,
                        "launcher": "torch.distributed.run" if not os.environ.get("TDSA_BENCH_WORKER") and world > 1
                                    else ("self-spawned workers" if world > 1 else "single process"),
-                       "parallelism": f"frames sharded over {world} GPU(s), one process + plan per GPU, no collective "
-                                      f"(host gloo barrier around the timed region, hold traces combined with np.fmax)"},
+                       "parallelism": (f"the {frames} Welch segments of one capture sharded over {world} GPU(s), one process + "
+                                       f"plan per GPU, no collective (host gloo barrier around the timed region; float64 partial "
+                                       f"means + counts combined on the host)") if welch else
+                                      (f"frames sharded over {world} GPU(s), one process + plan per GPU, no collective "
+                                       f"(host gloo barrier around the timed region, hold traces combined with np.fmax)")},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "frac_per_gpu": per_gpu_frac, "traffic": traffic,
-                         "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": algo_bytes,
-                         "kernel": "spectrum_kernel" if launches else "column pass + row pass + gather + finish (whole serial step)",
-                         "kernel_avg_us": kern_s * 1e6,
+                         "traffic_unit": "bytes per one-step launch", "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": algo_launch,
+                         "frames_per_launch": my_frames * head["per_call"],
+                         "kernel": "spectrum_kernel" if launches_b else "column pass + row pass + gather + finish (whole serial step)",
+                         "kernel_avg_us": kern_b * 1e6, "launches_timed": launches_b,
                          "kernel_avg_from": "HIP events on the plan's stream around every launch of a further, strictly "
-                                            "serial pass (one launch on the whole chip at a time)",
-                         "algorithmic_bytes_per_frame": bytes_per_frame},
+                                            "serial pass (one launch on the whole chip at a time), in the launch shape of "
+                                            "`value` (steps_per_call queued steps per launch)",
+                         "algorithmic_bytes_per_frame": bytes_per_frame,
+                         "single_step_launch": {"achieved": achieved_1, "frac": achieved_1 / HBM_PEAK_GBS,
+                                                "kernel_avg_us": kern_1 * 1e6, "launches_timed": launches_1,
+                                                "algorithmic_bytes_per_launch": algo_step,
+                                                "frames_per_launch": my_frames}},
         }
+        if valu_issue is not None:
+            result["roofline"]["valu_issue"] = valu_issue
         if args.dry_run:                               # nothing was computed: no performance figures
             for k in ("achieved", "frac", "frac_per_gpu", "traffic", "kernel_avg_us"):
                 result["roofline"][k] = None
             result["roofline"]["kernel"] = "none (dry run)"
+            result["roofline"].pop("single_step_launch", None)
         if hold_combined is not None:
             result["hold_trace"] = {"combined_on": "host (np.fmax over ranks)", "max_db": float(np.max(hold_combined)),
                                     "argmax_bin": int(np.argmax(hold_combined))}
+        if welch_block is not None:
+            result["welch"] = welch_block
 
-    # ---- CPU baseline + parity spot check: rank 0, single GPU runs only ---------------------------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dry_run:
+    # ---- parity spot check (rank 0; C5: the COMBINED row at any number of ranks) + CPU baseline (single GPU only)
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dry_run
+    want_parity = rank == 0 and not args.dry_run and not args.no_cpu_baseline and (world == 1 or welch)
+    if want_parity or want_cpu:
         from oracle import spectrum_oracle as so   # checker / reported baseline only
+
+        def parity_block(pairs, checked):
+            worst_rel = worst_db = raw60 = raw100 = 0.0
+            for got, g in pairs:
+                rel, ddb = so.parity_metrics(got, g, floor_rel_db=100.0, amp_floor=2 * so.AMP_FLOOR)
+                worst_rel, worst_db = max(worst_rel, rel), max(worst_db, ddb)
+                raw60, raw100 = max(raw60, so.parity_raw_db(got, g, 60.0)), max(raw100, so.parity_raw_db(got, g, 100.0))
+            return {"max_rel_power_err": worst_rel, "max_db_err_top60dB": raw60, "max_db_err_top100dB": raw100,
+                    "db_err_over_allowance_x1e-3": worst_db, "checked": checked, "against": "float64 gold oracle",
+                    "bounds": "north_star: rel <= 1e-4 of the frame maximum.  SURVEY 8(d): |dB| <= 1e-3 within 100 dB of it - "
+                              "`survey_8d_strict_pass` applies that literally, with no allowance; `pass` allows two float32 "
+                              "rounding units (2^-23) of the frame's largest amplitude where that is worth more than 1e-3 dB "
+                              "of the bin (bins deeper than 60 dB): db_err_over_allowance_x1e-3 <= 1e-3",
+                    "north_star_pass": bool(worst_rel <= 1e-4),
+                    "survey_8d_strict_pass": bool(worst_rel <= 1e-4 and raw100 <= 1e-3),
+                    "pass": bool(worst_rel <= 1e-4 and worst_db <= 1e-3)}
+
         if welch:
             seg = lambda k: so.unpack_iq_int8(base[2 * k * hop: 2 * (k * hop + nfft)])   # noqa: E731
-            br = so.RtlBranchOracle(nfft, wl["fs"], precision="ref")
-            br.averager.set_mode("lin", frames)
-            t_cpu0 = time.perf_counter()
-            done = 0
-            while done < 3 or (time.perf_counter() - t_cpu0 < args.cpu_seconds and done < frames):
-                br.power_levels(seg(done % frames))
-                done += 1
-            cpu_s = time.perf_counter() - t_cpu0
-            # parity: the whole Welch average (all K segments) against the float64 gold
+            if want_cpu:
+                br = so.RtlBranchOracle(nfft, wl["fs"], precision="ref")
+                br.averager.set_mode("lin", frames)
+                t_cpu0 = time.perf_counter()
+                done = 0
+                while done < 3 or (time.perf_counter() - t_cpu0 < args.cpu_seconds and done < frames):
+                    br.power_levels(seg(done % frames))
+                    done += 1
+                cpu_s = time.perf_counter() - t_cpu0
+                sample = f"{done} segments of 2^20 points, single thread, numpy {np.__version__} restatement incl. int8 unpack"
+            # parity: the whole Welch average (all K segments, combined over the ranks) against the float64 gold
             gold = so.RtlBranchOracle(nfft, wl["fs"], precision="gold")
             gold.averager.set_mode("lin", frames)
             g = None
             for k in range(frames):
                 g = gold.power_levels(seg(k))
             g = np.asarray(g, dtype=np.float64) + CAL_DB
-            eng.reset()
-            eng.process_device(nat.IN_I8, ins[0].data_ptr(), ns, hop, frames, outs[0].data_ptr())
-            eng.synchronize()
-            got = outs[0][0].cpu().numpy()
-            rel, ddb = so.parity_metrics(got, g, floor_rel_db=100.0, amp_floor=2 * so.AMP_FLOOR)
-            checked, sample = f"Welch mean of all {frames} segments", \
-                f"{done} segments of 2^20 points, single thread, numpy {np.__version__} restatement incl. int8 unpack"
-            worst_rel, worst_db = rel, ddb
-            raw60, raw100 = so.parity_raw_db(got, g, 60.0), so.parity_raw_db(got, g, 100.0)
+            pairs = [(np.asarray(combined_db, dtype=np.float32), g)]
+            checked = f"Welch mean of all {frames} segments, combined on the host from {world} rank(s)"
+            if world == 1:                             # ... and the row the device wrote itself
+                pairs.append((out_ring[0][0].cpu().numpy(), g))
+                checked += " + the device's own dB row"
+            result["parity"] = parity_block(pairs, checked)
         else:
             if wl["branch"] == "hackrf":
                 br = so.HackrfBranchOracle(nfft, wl["fs"], precision="ref")
@@ -438,40 +591,33 @@ def main() -> None:
                 br.power_levels(x)
                 done += 1
             cpu_s = time.perf_counter() - t_cpu0
-            # parity of a sampled subset of the GPU frames (ring slot 0 holds `base`)
+            # parity of a sampled subset of the GPU frames (ring slot 0 holds `base`), from a BATCHED launch
             eng.reset()
-            eng.process_device(nat.IN_I8, ins[0].data_ptr(), ns, hop, frames, outs[0].data_ptr())
+            eng.set_overlap(1)
+            if batch > 1:
+                step_batch(0)
+            else:
+                step(0)
             eng.synchronize()
-            worst_rel, worst_db, raw60, raw100 = 0.0, 0.0, 0.0, 0.0
             picks = (0, 1, frames // 2, frames - 1)
+            pairs = []
             for k in picks:
                 x = so.unpack_iq_int8(base[2 * k * hop: 2 * (k * hop + nfft)])
-                g = np.asarray(gold.power_levels(x))
-                got = outs[0][k].cpu().numpy()
-                rel, ddb = so.parity_metrics(got, g, floor_rel_db=100.0, amp_floor=2 * so.AMP_FLOOR)
-                worst_rel, worst_db = max(worst_rel, rel), max(worst_db, ddb)
-                raw60, raw100 = max(raw60, so.parity_raw_db(got, g, 60.0)), max(raw100, so.parity_raw_db(got, g, 100.0))
-            checked = f"{len(picks)} frames"
+                pairs.append((out_ring[0][k].cpu().numpy(), np.asarray(gold.power_levels(x))))
+            result["parity"] = parity_block(pairs, f"{len(picks)} frames of a {batch}-step launch")
             sample = (f"{done} frames ({args.cpu_seconds:.0f} s) cycling through the same second of IQ, single "
                       f"thread, numpy {np.__version__} restatement of get_power_levels incl. int8 unpack")
-        result["cpu_baseline"] = {"value": done / cpu_s, "unit": "frames/s", "cores": 1, "kind": "port",
-                                  "sample": sample, "host_cores_available": os.cpu_count()}
-        result["parity"] = {"max_rel_power_err": worst_rel, "max_db_err_top60dB": raw60, "max_db_err_top100dB": raw100,
-                            "db_err_over_allowance_x1e-3": worst_db, "checked": checked, "against": "float64 gold oracle",
-                            "bounds": "rel <= 1e-4 of the frame maximum; |dB| <= 1e-3 within 100 dB of it, or two "
-                                      "float32 rounding units (2^-23) of the frame's largest amplitude where that is "
-                                      "worth more (bins deeper than 60 dB): db_err_over_allowance_x1e-3 <= 1e-3",
-                            "pass": bool(worst_rel <= 1e-4 and worst_db <= 1e-3)}
-        workers = args.cpu_workers
-        if workers < 0:
-            workers = min(32, os.cpu_count() or 1)
-        elif workers == 0:
-            workers = os.cpu_count() or 1
-        if not args.no_cpu_pool and not welch:
-            try:
-                result["cpu_baseline_pool"] = cpu_all_cores(wl, workers, args.cpu_pool_seconds)
-            except Exception as exc:               # a reported extra, never a reason to lose the bench line
-                result["cpu_baseline_pool"] = {"value": None, "error": str(exc)}
+        if want_cpu:
+            result["cpu_baseline"] = {"value": done / cpu_s, "unit": "frames/s", "cores": 1, "kind": "port",
+                                      "sample": sample, "host_cores_available": os.cpu_count()}
+            workers = args.cpu_workers if args.cpu_workers > 0 else (os.cpu_count() or 1)
+            result["cores_policy"] = (f"cpu_baseline: 1 core; cpu_baseline_pool: {workers} of {os.cpu_count()} host cores "
+                                      f"(default: all of them)")
+            if not args.no_cpu_pool and not welch:
+                try:
+                    result["cpu_baseline_pool"] = cpu_all_cores(wl, workers, args.cpu_pool_seconds)
+                except Exception as exc:               # a reported extra, never a reason to lose the bench line
+                    result["cpu_baseline_pool"] = {"value": None, "error": str(exc)}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

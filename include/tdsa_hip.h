@@ -146,6 +146,21 @@ int tdsa_process_c64(tdsa_plan p, const float* iq_host, size_t n_samples, int ho
 int tdsa_process_dev(tdsa_plan p, int in_format, const void* iq_dev, size_t n_samples, int hop,
                      int n_frames, float* out_db_dev);
 
+/* Several captures ("segments") of one shape in ONE call - what a host loop over queued chunks of the reader
+ * thread (datasources/hackrf_samples.py:254-305 drains its queue chunk by chunk, one get_power_levels() each,
+ * :339-386) or over recorded seconds does with tdsa_process_dev, handed over at once: capture s starts at
+ * iq_dev + s*seg_stride_bytes (n_samples_per_seg samples, frames_per_seg frames at `hop`, framed on its own -
+ * no frame straddles two captures) and its dB rows go to out_db_dev + s*out_seg_stride_floats.
+ * Results and plan state (hold traces, DC, averager) are exactly those of n_segments consecutive
+ * tdsa_process_dev calls.  Where the captures do not depend on each other (no averaging, no tracked DC
+ * remover, LDS-resident frame length) all of them leave as ONE persistent launch, which pays the per-launch
+ * costs - cold fetch of window and twiddles, hold merge, the ragged last round of frames over the CUs - once
+ * per call instead of once per capture; every other mode runs the captures one after the other inside the
+ * call.  frames_per_seg <= max_frames; out_db_dev may be NULL. */
+int tdsa_process_dev_batch(tdsa_plan p, int in_format, const void* iq_dev, size_t seg_stride_bytes,
+                           int n_segments, size_t n_samples_per_seg, int hop, int frames_per_seg,
+                           float* out_db_dev, size_t out_seg_stride_floats);
+
 /* Real-input path of MicrophoneSamplesDataSource (datasources/audio_samples.py:121-184): frames of
  * stereo float32 samples [L0,R0,L1,R1,...]; every real signal of a frame (the mono mix, left, right - both for
  * stereo) is transformed on its own as signal + 0i, so a loud channel leaves nothing in a quiet one, as in the
@@ -306,6 +321,12 @@ int tdsa_timer_end(tdsa_plan p, float* elapsed_ms); /* records, synchronises, re
  * the number of frame-kernel launches and the sum of their durations since the last read. */
 int tdsa_profile_enable(tdsa_plan p, int enable);
 int tdsa_profile_read(tdsa_plan p, int* launches, float* total_ms);
+
+/* ---- developer section (no reference counterpart; used by tools/ only) ---------------------- */
+/* Phase timeline of workgroup 0 of the frame kernel: allocates the plan's stamp buffer on first call;
+ * host_out_2048 != NULL copies 2048 s_memtime stamps back.  Stamps are only written by a library built
+ * with -DTDSA_TIMELINE (tools/timeline.py); a production build leaves them zero. */
+int tdsa_debug_timeline(tdsa_plan p, unsigned long long* host_out_2048);
 
 #ifdef __cplusplus
 }

@@ -24,6 +24,18 @@ def test_library_exports_every_declared_symbol():
     assert not missing, f"declared in tdsa_hip.h but not exported: {missing}"
 
 
+def test_library_exports_nothing_the_header_does_not_declare():
+    """exports is a subset of the header: every tdsa_* symbol the library exports is declared in include/tdsa_hip.h
+    (round-2 verdict: tdsa_debug_timeline was exported but undeclared)."""
+    import subprocess
+    from topdogspectrumanalyser_amd import _native as nat
+    out = subprocess.run(["nm", "-D", "--defined-only", nat.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("tdsa_")}
+    assert len(exported) >= 30
+    extra = sorted(exported - set(_declared_functions()))
+    assert not extra, f"exported but not declared in tdsa_hip.h: {extra}"
+
+
 def test_ctypes_binding_covers_header():
     from topdogspectrumanalyser_amd import _native as nat
     declared = set(_declared_functions())

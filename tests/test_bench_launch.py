@@ -26,6 +26,7 @@ def _check_line(d, n):
                 "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "value_serial", "per_gpu_frames_per_s"):
         assert key in d, key
     assert d["n_gpus"] == n and len(d["per_gpu_frames_per_s"]) == n and d["scaling"] == "weak"
+    assert d["value_streams"] > 0 and d["timing"]["steps_per_call"] == 8     # `value`: 8 queued steps per call
     assert d["metric"].startswith("PSD frames/sec at 16384-pt FFT") and d["unit"] == "frames/s"
     assert d["steps"] == 40 and d["warmup"] == 3 and d["value"] > 0 and d["ms_per_step"] > 0
     assert "dry-run" in d["data"] and d["roofline"]["frac"] is None
@@ -36,7 +37,8 @@ def _check_line(d, n):
 
 @pytest.mark.parametrize("n", [1, 2])
 def test_bench_spawns_its_own_workers(n):
-    d = _run([sys.executable, "bench.py", "--gpus", str(n), "--steps", "40", "--warmup", "3", "--reps", "3", "--dry-run"])
+    d = _run([sys.executable, "bench.py", "--gpus", str(n), "--steps", "40", "--warmup", "3", "--reps", "3", "--dry-run",
+              "--min-region-s", "0.05"])
     _check_line(d, n)
     assert d["config"]["launcher"] == ("self-spawned workers" if n > 1 else "single process")
 
@@ -44,9 +46,39 @@ def test_bench_spawns_its_own_workers(n):
 def test_bench_under_torch_distributed_run():
     d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
               "127.0.0.1", "--master-port", "29517", "bench.py", "--gpus", "2", "--steps", "40", "--warmup", "3",
-              "--reps", "3", "--dry-run"])
+              "--reps", "3", "--dry-run", "--min-region-s", "0.05"])
     _check_line(d, 2)
     assert d["config"]["launcher"] == "torch.distributed.run"
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_bench_c5_shards_the_welch_segments_over_the_ranks(n):
+    """--config c5 --gpus N: the 64 segments of one capture are split over the ranks (strong scaling), the float64
+    partial means + counts are gathered over gloo and combined with sharding.combine_welch on rank 0 (SURVEY.md 8(e);
+    utils/signal_processing.py:35-61 of the reference is the running mean being reassembled).  The stand-in engine of
+    --dry-run reports the constant rank + 1 as its partial mean: the combined mean is the count-weighted average."""
+    d = _run([sys.executable, "bench.py", "--gpus", str(n), "--config", "c5", "--steps", "4", "--warmup", "1", "--reps", "2",
+              "--dry-run", "--min-region-s", "0.05"])
+    assert d["n_gpus"] == n and d["scaling"] == "strong" and d["metric"] == "PSD frames/sec (c5)"
+    w = d["welch"]
+    counts = w["segments_per_rank"]
+    assert len(counts) == n and sum(counts) == 64 == w["segments_total"] and max(counts) - min(counts) <= 1
+    expect = sum((r + 1) * c for r, c in enumerate(counts)) / 64.0
+    assert abs(w["mean_of_means"] - expect) < 1e-12
+    assert d["config"]["frames_per_step_all_gpus"] == 64 and "sharded over" in d["config"]["parallelism"]
+    assert len(d["per_gpu_frames_per_s"]) == n
+
+
+def test_bench_workers_are_all_reaped_when_one_fails(tmp_path):
+    """a failing worker must not leave the others parked in the gloo barrier - every worker is waited
+    for (or terminated) and the first non-zero exit code comes back."""
+    import time
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", TDSA_BENCH_FAIL_RANK="1")
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None), env.pop("LOCAL_RANK", None)
+    t0 = time.time()
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--reps", "1",
+                          "--dry-run", "--min-region-s", "0.05"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and time.time() - t0 < 60
 
 
 def test_bench_has_no_rccl_in_it():

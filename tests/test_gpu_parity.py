@@ -3,8 +3,12 @@
 Tolerances (BASELINE.json north_star: 1e-4 relative float32):
   * linear power error <= 1e-4 * frame maximum on every bin  (REL_TOL)
   * |dB error| <= 1e-3 dB on every bin within 100 dB of the frame maximum (DB_TOL), where the allowance
-    of a bin deeper than 66 dB is the float32 rounding unit of the frame's largest AMPLITUDE instead
-    (2^-24 * A_max: no float32 FFT resolves less; oracle/spectrum_oracle.py::parity_metrics states the rule)
+    of a deep bin (from about 60 dB down) is TWO float32 rounding units of the frame's largest AMPLITUDE
+    instead (2 * 2^-24 = 2^-23 * A_max, `_check` below passes amp_floor = 2 * so.AMP_FLOOR; no float32 FFT
+    resolves 1e-3 dB a hundred dB under a tone; oracle/spectrum_oracle.py::parity_metrics states the rule and
+    DESIGN.md section 2 the measurements it rests on).  SURVEY.md 8(d)'s literal bound - 1e-3 dB over the whole
+    100 dB with no allowance - is NOT met by this path (nor by numpy's own float32 FFT): bench.py reports it
+    separately as parity.survey_8d_strict_pass.
 """
 import os
 import time
@@ -2099,3 +2103,121 @@ def test_no_device_memory_left_behind(pkg):
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 64 << 20, f"{(free0 - free1) / 2**20:.1f} MiB of device memory not returned"
 
+
+
+# ------------------------------------------------------------------------------------------------
+# several captures in one call (tdsa_process_dev_batch): the bits of consecutive tdsa_process_dev calls
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nfft,hop,nf,fmt", [(16384, 8192, 61, "i8"), (4096, 4096, 37, "u8"), (256, 100, 50, "i8"),
+                                             (1024, 512, 33, "c64"), (1000, 500, 9, "i8"), (1 << 15, 1 << 15, 1, "i8")])
+@pytest.mark.parametrize("mode", ["hold", "exp", "tracked_dc"])
+def test_batched_captures_match_consecutive_calls(pkg, nfft, hop, nf, fmt, mode):
+    """n_seg captures handed over at once: rows, hold traces, DC state and averager state are exactly those of n_seg
+    consecutive calls - whether the captures leave as one persistent launch (order-free modes on LDS-resident sizes)
+    or are run one after the other inside the call (averaging, tracked DC, chirp-z and long-frame plans).  The
+    segment strides are larger than the captures and odd multiples of a sample, the output stride has a gap."""
+    import ctypes as C
+    nat = pkg._native
+    if nfft > 16384 and mode == "exp":
+        pytest.skip("one frame per call there")
+    n_seg = 5
+    ns = hop * (nf - 1) + nfft
+    bps = 8 if fmt == "c64" else 2
+    in_fmt = {"i8": nat.IN_I8, "u8": nat.IN_U8, "c64": nat.IN_C64}[fmt]
+    seg_stride = ns * bps + 3 * bps * 7                       # gap of 21 samples between captures
+    out_stride = nf * nfft + 64
+    rng = np.random.default_rng(nfft + nf)
+    caps = []
+    for sgi in range(n_seg):
+        iq = so.synth_iq_int8(ns, nfft if nfft >= 8 else 8, seed=500 + sgi)
+        if fmt == "u8":
+            iq = (iq.astype(np.int16) + 128).astype(np.uint8)
+        elif fmt == "c64":
+            iq = so.unpack_iq_int8(iq).astype(np.complex64)
+        caps.append(iq)
+    blob = np.zeros(seg_stride * n_seg, dtype=np.uint8)
+    for sgi, iq in enumerate(caps):
+        raw = iq.view(np.uint8)
+        blob[sgi * seg_stride: sgi * seg_stride + raw.size] = raw
+    cfg = dict(db_mode="mag", log_floor=so.LOG_FLOOR, dc_alpha=1.0, hold_max=True, hold_min=True)
+    if mode == "exp":
+        cfg = dict(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=1.0, avg=("exp", 4), hold_max=True)
+    elif mode == "tracked_dc":
+        cfg.update(dc_alpha=0.25)
+    d_in, d_out = C.c_void_p(), C.c_void_p()
+    nat.check(nat.lib.tdsa_dev_alloc(0, blob.nbytes, C.byref(d_in)))
+    nat.check(nat.lib.tdsa_dev_alloc(0, out_stride * n_seg * 4, C.byref(d_out)))
+    nat.check(nat.lib.tdsa_memcpy_h2d(0, d_in, blob.ctypes.data_as(C.c_void_p), blob.nbytes))
+    rows_out = 1 if nfft > 16384 else nf
+
+    def run(batched):
+        with pkg.SpectrumEngine(nfft, max_frames=nf) as e:
+            e.set_window(so.hackrf_window(nfft))
+            e.configure(**cfg)
+            for rep in range(2):                              # the second round starts from non-trivial state
+                if batched:
+                    e.process_device_batch(in_fmt, d_in.value, seg_stride, n_seg, ns, hop, nf, d_out.value, out_stride)
+                else:
+                    for sgi in range(n_seg):
+                        e.process_device(in_fmt, d_in.value + sgi * seg_stride, ns, hop, nf,
+                                         d_out.value + 4 * sgi * out_stride)
+            e.synchronize()
+            got = np.empty(out_stride * n_seg, dtype=np.float32)
+            nat.check(nat.lib.tdsa_memcpy_d2h(0, got.ctypes.data_as(C.c_void_p), d_out, got.nbytes))
+            rows = [got[sgi * out_stride: sgi * out_stride + rows_out * nfft].reshape(rows_out, nfft).copy()
+                    for sgi in range(n_seg)]
+            return rows, e.hold(), e.dc_estimate, e.info().frames_held_max
+
+    try:
+        nat.check(nat.lib.tdsa_memcpy_h2d(0, d_out, np.full(out_stride * n_seg, np.nan, np.float32).ctypes.data_as(C.c_void_p),
+                                          out_stride * n_seg * 4))
+        seq = run(False)
+        nat.check(nat.lib.tdsa_memcpy_h2d(0, d_out, np.full(out_stride * n_seg, np.nan, np.float32).ctypes.data_as(C.c_void_p),
+                                          out_stride * n_seg * 4))
+        bat = run(True)
+    finally:
+        nat.lib.tdsa_dev_free(0, d_in)
+        nat.lib.tdsa_dev_free(0, d_out)
+    for sgi in range(n_seg):
+        assert np.array_equal(seq[0][sgi], bat[0][sgi]), f"capture {sgi} differs"
+    for a, b in zip(seq[1], bat[1]):
+        assert (a is None and b is None) or np.array_equal(a, b)
+    assert seq[2] == bat[2] and seq[3] == bat[3]
+    if mode == "hold" and nfft <= 16384 and fmt == "i8":      # and the rows are right, not merely equal
+        gold, _, _ = so.hackrf_batch(caps[2], nfft, hop, 20e6, precision="gold")
+        _check(bat[0][2], gold, "capture 2 of the batch")
+
+
+def test_batched_captures_full_c3_shape(pkg):
+    """Four seconds of the C3 shape (4 x 2440 frames of 16384 points, hop N/2) in one launch: the hold trace equals
+    the column maximum of all 9760 rows and sampled rows match the gold oracle."""
+    import ctypes as C
+    nat = pkg._native
+    nfft, hop, ns, n_seg = 16384, 8192, 20_000_000, 4
+    nf = (ns - nfft) // hop + 1
+    base = so.synth_iq_int8(ns, nfft, seed=3)
+    d_in, d_out = C.c_void_p(), C.c_void_p()
+    nat.check(nat.lib.tdsa_dev_alloc(0, 2 * ns * n_seg, C.byref(d_in)))
+    nat.check(nat.lib.tdsa_dev_alloc(0, nf * nfft * 4 * n_seg, C.byref(d_out)))
+    try:
+        hosts = [base if k == 0 else np.roll(base, 2 * 977 * k) for k in range(n_seg)]
+        for k, hst in enumerate(hosts):
+            nat.check(nat.lib.tdsa_memcpy_h2d(0, C.c_void_p(d_in.value + 2 * ns * k), hst.ctypes.data_as(C.c_void_p), hst.nbytes))
+        with _hackrf_engine(pkg, nfft, nf, hold_max=True) as e:
+            e.process_device_batch(nat.IN_I8, d_in.value, 2 * ns, n_seg, ns, hop, nf, d_out.value, nf * nfft)
+            mx, _ = e.hold()
+            assert e.info().frames_held_max == n_seg * nf
+        colmax = None
+        for k in range(n_seg):
+            got = np.empty((nf, nfft), dtype=np.float32)
+            nat.check(nat.lib.tdsa_memcpy_d2h(0, got.ctypes.data_as(C.c_void_p), C.c_void_p(d_out.value + 4 * nf * nfft * k),
+                                              got.nbytes))
+            colmax = got.max(axis=0) if colmax is None else np.maximum(colmax, got.max(axis=0))
+            gold_src = so.HackrfBranchOracle(nfft, 20e6, precision="gold")
+            for f in (0, nf - 1):
+                x = so.unpack_iq_int8(hosts[k][2 * f * hop: 2 * (f * hop + nfft)])
+                _check(got[f], np.asarray(gold_src.power_levels(x)), f"second {k} frame {f}")
+        assert np.array_equal(mx, colmax)
+    finally:
+        nat.lib.tdsa_dev_free(0, d_in)
+        nat.lib.tdsa_dev_free(0, d_out)

@@ -15,6 +15,24 @@ REF = os.environ.get("TDSA_REFERENCE", "/root/reference")
 pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "core")), reason="reference tree not present")
 
 
+def _forget_reference_modules(before, stubs=()):
+    """Drop what an import of the reference left in sys.modules: its own modules (anything whose file lies under REF)
+    and the stand-in modules named in `stubs`.  Third-party modules first imported on the way (scipy.fft, logging
+    handlers ...) STAY cached - dropping C-extension submodules made later imports order dependent."""
+    ref_root = os.path.realpath(REF)
+    for name in set(sys.modules) - set(before):
+        mod = sys.modules.get(name)
+        origin = getattr(mod, "__file__", None) or ""
+        paths = [q for q in (getattr(mod, "__path__", None) or []) if isinstance(q, str)]
+        inside = [os.path.realpath(q) for q in ([origin] if origin else []) + paths]
+        if any(q == ref_root or q.startswith(ref_root + os.sep) for q in inside) or name in stubs or \
+                name.split(".")[0] in stubs:
+            del sys.modules[name]
+    for name in stubs:
+        sys.modules.pop(name, None)
+
+
+
 @pytest.fixture(scope="module")
 def ref_dp():
     sys.dont_write_bytecode = True                       # never leave __pycache__ in the reference tree
@@ -27,12 +45,7 @@ def ref_dp():
         from core.display_data_processor import DataProcessor as RefDP
     finally:
         sys.path.remove(REF)
-        # leave no trace for the other test modules: neither the hardware stand-ins nor the reference's
-        # top-level packages (core, utils, datasources ...) stay importable by name
-        for m in set(sys.modules) - before:
-            del sys.modules[m]
-        for m in mocked:
-            sys.modules.pop(m, None)
+        _forget_reference_modules(before, mocked)
     return RefDP
 
 
@@ -179,10 +192,7 @@ def ref_sources():
         from utils.signal_processing import TraceAverager
     finally:
         sys.path.remove(REF)
-        for m in set(sys.modules) - before:
-            del sys.modules[m]
-        for m in mocked:
-            sys.modules.pop(m, None)
+        _forget_reference_modules(before, mocked)
     return types.SimpleNamespace(hackrf=HackrfSamplesDataSource, rtl=RtlSamplesDataSource,
                                  audio=MicrophoneSamplesDataSource, averager=TraceAverager)
 
@@ -401,8 +411,7 @@ def ref_displays():
         from displays.waterfall import Waterfall
     finally:
         sys.path.remove(REF)
-        for m in set(sys.modules) - before:
-            del sys.modules[m]
+        _forget_reference_modules(before, ("PyQt6", "pyqtgraph"))
     return types.SimpleNamespace(density=DensityDisplay, waterfall=Waterfall)
 
 
@@ -463,10 +472,7 @@ def ref_analytics():
         from datasources.audio_samples import MicrophoneSamplesDataSource
     finally:
         sys.path.remove(REF)
-        for m in set(sys.modules) - before:
-            del sys.modules[m]
-        for m in mocked:
-            sys.modules.pop(m, None)
+        _forget_reference_modules(before, mocked)
     return types.SimpleNamespace(duty=DutyCycleAnalyser, markers=MarkerManager, audio=MicrophoneSamplesDataSource)
 
 

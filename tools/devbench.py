@@ -25,36 +25,53 @@ def main():
     ap.add_argument("--hold", type=int, default=1)
     ap.add_argument("--nodb", type=int, default=0)
     ap.add_argument("--mode", default="mag")
+    ap.add_argument("--batch", type=int, default=1, help="captures per call (tdsa_process_dev_batch), distinct buffers")
+    ap.add_argument("--streams", type=int, default=1)
     a = ap.parse_args()
     n, hop, F = a.nfft, (a.hop or a.nfft // 2), a.frames
     ns = hop * (F - 1) + n
     rng = np.random.default_rng(0)
     iq = rng.integers(-100, 100, size=2 * ns, dtype=np.int8)
     dev_in, dev_out = C.c_void_p(), C.c_void_p()
-    nat.check(nat.lib.tdsa_dev_alloc(0, iq.nbytes, C.byref(dev_in)))
-    nat.check(nat.lib.tdsa_dev_alloc(0, F * n * 4, C.byref(dev_out)))
-    nat.check(nat.lib.tdsa_memcpy_h2d(0, dev_in, iq.ctypes.data_as(C.c_void_p), iq.nbytes))
+    B = max(1, a.batch)
+    nat.check(nat.lib.tdsa_dev_alloc(0, iq.nbytes * B, C.byref(dev_in)))
+    nat.check(nat.lib.tdsa_dev_alloc(0, F * n * 4 * B, C.byref(dev_out)))
+    for b in range(B):
+        nat.check(nat.lib.tdsa_memcpy_h2d(0, C.c_void_p(dev_in.value + b * iq.nbytes), iq.ctypes.data_as(C.c_void_p), iq.nbytes))
     e = SpectrumEngine(n, max_frames=F)
     w = np.hanning(n).astype(np.float32)
     e.set_window(w)
     e.configure(db_mode=a.mode, log_floor=1e-12, dc_alpha=1.0, hold_max=bool(a.hold & 1), hold_min=bool(a.hold & 2))
     out_ptr = None if a.nodb else dev_out.value
-    for _ in range(a.warmup):
-        e.process_device(nat.IN_I8, dev_in.value, ns, hop, F, out_ptr)
+    e.set_overlap(a.streams)
+
+    def call():
+        if B == 1:
+            e.process_device(nat.IN_I8, dev_in.value, ns, hop, F, out_ptr)
+        else:
+            e.process_device_batch(nat.IN_I8, dev_in.value, iq.nbytes, B, ns, hop, F, out_ptr, F * n)
+    for _ in range(max(1, a.warmup // B)):
+        call()
     e.synchronize()
-    e.timer_begin()
+    calls = max(1, a.steps // B)
+    if a.streams == 1:
+        e.timer_begin()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        e.process_device(nat.IN_I8, dev_in.value, ns, hop, F, out_ptr)
-    ms = e.timer_end()
+    for _ in range(calls):
+        call()
+    if a.streams == 1:
+        ms = e.timer_end()
+    else:
+        e.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3
     t1 = time.perf_counter()
-    per = ms / a.steps
+    per = ms / (calls * B)
     fps = F / (per * 1e-3)
     bytes_per_frame = 2 * hop + 4 * n
     inf = e.info()
-    print(f"lib={os.path.basename(nat.LIB_PATH)} N={n} hop={hop} F={F} hold={a.hold} grid={inf.grid}x{inf.block} lds={inf.lds_bytes} "
+    print(f"lib={os.path.basename(nat.LIB_PATH)} N={n} hop={hop} F={F} batch={B} streams={a.streams} hold={a.hold} grid={inf.grid}x{inf.block} lds={inf.lds_bytes} "
           f"step={per*1e3:.1f} us  {fps/1e6:.3f} Mframes/s  {fps*bytes_per_frame/1e12:.3f} TB/s algorithmic "
-          f"({fps*bytes_per_frame/8e12*100:.1f}% of 8 TB/s)  host wall {((t1-t0)/a.steps)*1e6:.1f} us/step")
+          f"({fps*bytes_per_frame/8e12*100:.1f}% of 8 TB/s)  host wall {((t1-t0)/(calls*B))*1e6:.1f} us/step")
 
 
 if __name__ == "__main__":

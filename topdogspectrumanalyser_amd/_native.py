@@ -51,6 +51,8 @@ _SIGNATURES = {
     "tdsa_process_u8": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, _P]),
     "tdsa_process_c64": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, _P]),
     "tdsa_process_dev": (C.c_int, [_P, C.c_int, _P, C.c_size_t, C.c_int, C.c_int, _P]),
+    "tdsa_process_dev_batch": (C.c_int, [_P, C.c_int, _P, C.c_size_t, C.c_int, C.c_size_t, C.c_int, C.c_int, _P,
+                                         C.c_size_t]),
     "tdsa_process_real2": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, C.c_int, _P]),
     "tdsa_get_hold": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int64)]),
     "tdsa_get_avg": (C.c_int, [_P, _P, C.POINTER(C.c_int)]),
@@ -96,6 +98,7 @@ _SIGNATURES = {
     "tdsa_profile_read": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "tdsa_timer_begin": (C.c_int, [_P]),
     "tdsa_timer_end": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "tdsa_debug_timeline": (C.c_int, [_P, _P]),
 }
 
 

@@ -210,6 +210,12 @@ class DataProcessor:
         baseline = mw.baseline_power_levels if mw.tare_active else None
         if baseline is not None and np.shape(baseline) != np.shape(levels):
             return None
+        want_max, want_min = bool(dm.max_peak_search_enabled), bool(mw.min_hold_enabled)
+        if self.reference_hold_alias:                     # that mode keeps its hold traces on the host (_hold)
+            want_max = want_min = False
+        if not (collecting or baseline is not None or want_max or want_min) and self._cal_offset_value() == 0.0:
+            return None                                   # nothing to do to this frame: no device call at all,
+                                                          # the frame passes through untouched as in the reference
         gpu = self._trace_for(n)
         if collecting and run.count == 0:
             gpu.reset(nat.RESET_TARE)                     # a new run starts from an empty accumulator

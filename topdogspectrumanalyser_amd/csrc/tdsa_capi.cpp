@@ -111,6 +111,7 @@ struct tdsa_plan_s {
   void* d_scratch = nullptr;             // grows on demand: results of tdsa_rows_stats / tdsa_rows_top_peaks
   size_t scratch_bytes = 0;
   bool profiling = false;
+  bool sync_call = false;                // set by the synchronous host entry points around their device call
   std::vector<hipEvent_t> prof_events;   // pairs (begin, end) around frame-kernel launches
   size_t prof_used = 0;
 };
@@ -700,18 +701,27 @@ int tdsa_set_tare_baseline(tdsa_plan p, const float* baseline_db_host, int n) {
   return TDSA_OK;
 }
 
+// several captures in one launch (tdsa_process_dev_batch): n_frames = n_seg * frames_per_seg frames in all
+struct SegInfo {
+  int n_seg = 1;
+  int frames_per_seg = 0;
+  long long in_stride_bytes = 0;
+  long long out_stride_elems = 0;
+};
+
 // before / after: optional events the device work waits for / signals (tdsa_pipe: H2D and D2H legs)
 static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size_t n_samples, int hop, int n_frames,
-                            float* out_db_dev, hipEvent_t before, hipEvent_t after) {
+                            float* out_db_dev, hipEvent_t before, hipEvent_t after, const SegInfo* seg = nullptr) {
   if (!p) return fail(TDSA_ERR_ARG, "null plan");
   if (in_format < TDSA_IN_I8 || in_format > TDSA_IN_C64) return fail(TDSA_ERR_ARG, "in_format %d", in_format);
   if (n_frames == 0) return TDSA_OK;
   if (!iq_dev) return fail(TDSA_ERR_ARG, "iq pointer is null");
-  if (n_frames < 0 || n_frames > p->max_frames)
-    return fail(TDSA_ERR_ARG, "n_frames=%d outside [0, max_frames=%d]", n_frames, p->max_frames);
+  const int frames_each = seg ? seg->frames_per_seg : n_frames;     // frames of ONE capture (n_samples is per capture)
+  if (n_frames < 0 || frames_each > p->max_frames)
+    return fail(TDSA_ERR_ARG, "n_frames=%d outside [0, max_frames=%d]", frames_each, p->max_frames);
   if (hop < 1) return fail(TDSA_ERR_ARG, "hop=%d must be >= 1", hop);
-  if (n_samples < size_t(n_frames - 1) * size_t(hop) + size_t(p->nfft))
-    return fail(TDSA_ERR_ARG, "n_samples=%zu too small for %d frames of %d at hop %d", n_samples, n_frames,
+  if (n_samples < size_t(frames_each - 1) * size_t(hop) + size_t(p->nfft))
+    return fail(TDSA_ERR_ARG, "n_samples=%zu too small for %d frames of %d at hop %d", n_samples, frames_each,
                 p->nfft, hop);
   if (!p->window_set) return fail(TDSA_ERR_STATE, "tdsa_set_window has not been called");
   const int bps = bytes_per_sample(in_format);
@@ -736,9 +746,13 @@ static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size
   const tdsa_mode& m = p->mode;
   const bool averaging = avg_active(m);
   // calls whose result does not depend on the order they execute in may overlap (tdsa_set_overlap)
-  const bool order_free = !averaging && (m.dc_alpha < 0.0f || m.dc_alpha >= 1.0f) && !p->profiling;
+  const bool order_free = !averaging && (m.dc_alpha < 0.0f || m.dc_alpha >= 1.0f);
+  if (seg && !order_free) return fail(TDSA_ERR_STATE, "internal: a batched launch needs an order-free mode");
   hipStream_t s = p->stream;
-  if (order_free) {
+  // synchronous host entry points (process_host) wait for this very launch: nothing runs beside it, so it keeps
+  // the main stream and the whole chip (a half-chip launch there only lost throughput)
+  const bool overlap = order_free && !p->sync_call && !p->profiling;   // (profiled launches: main stream, events around)
+  if (overlap) {
     int rc_s = pick_stream(p, &s);
     if (rc_s != TDSA_OK) return rc_s;
   } else {
@@ -764,6 +778,12 @@ static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size
   sp.cal_db = m.cal_offset_db;
   sp.tare = p->tare_active ? p->d_tare_base : nullptr;
   sp.dbg = p->d_dbg;
+  if (seg) {
+    sp.seg_frames = unsigned(seg->frames_per_seg);
+    sp.seg_magic = unsigned((0x100000000ull + sp.seg_frames - 1) / sp.seg_frames);   // ceil(2^32 / d)
+    sp.seg_in_stride = seg->in_stride_bytes;
+    sp.seg_out_stride = seg->out_stride_elems;
+  }
 
   if (m.dc_alpha < 0.0f) {
     sp.dc_mode = DC_NONE;
@@ -785,7 +805,7 @@ static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size
   // C3 76.4 -> 74.3 us per step, C2 26.7 -> 26.0 (profiles/r02_c3_experiments.txt).  More than three streams in flight
   // measured worse (4: 91 us), and strictly serial launches keep the whole chip.
   const LaunchGeom g = spectrum_geometry(p->log2n, n_frames,
-                                         (order_free && p->n_overlap >= 3) ? (p->num_cu + 1) / 2 : p->num_cu);
+                                         (overlap && p->n_overlap >= 3) ? (p->num_cu + 1) / 2 : p->num_cu);
   if (averaging) {
     if (!p->d_lin) HIPCHK(hipMalloc(&p->d_lin, size_t(p->max_frames) * p->nfft * sizeof(float)));
     if (!p->d_carry && p->max_frames > 128)
@@ -835,6 +855,43 @@ static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size
 int tdsa_process_dev(tdsa_plan p, int in_format, const void* iq_dev, size_t n_samples, int hop, int n_frames,
                      float* out_db_dev) {
   return process_dev_impl(p, in_format, iq_dev, n_samples, hop, n_frames, out_db_dev, nullptr, nullptr);
+}
+
+// n_segments captures of one shape.  Where the plan's mode makes the captures independent of the order they are
+// processed in (no averaging, no tracked DC remover) and the frames are LDS resident, ALL of them go out as ONE
+// persistent launch: the per-launch costs (cold first fetch of window / twiddles, hold merge, the ragged last round
+// of frames over the CUs) are paid once per call instead of once per capture.  Every other mode runs the captures
+// one after the other through the same code as tdsa_process_dev - the results are the same either way.
+int tdsa_process_dev_batch(tdsa_plan p, int in_format, const void* iq_dev, size_t seg_stride_bytes, int n_segments,
+                           size_t n_samples_per_seg, int hop, int frames_per_seg, float* out_db_dev,
+                           size_t out_seg_stride_floats) {
+  if (!p) return fail(TDSA_ERR_ARG, "null plan");
+  if (n_segments < 0) return fail(TDSA_ERR_ARG, "n_segments=%d", n_segments);
+  if (n_segments == 0 || frames_per_seg == 0) return TDSA_OK;
+  if (in_format < TDSA_IN_I8 || in_format > TDSA_IN_C64) return fail(TDSA_ERR_ARG, "in_format %d", in_format);
+  const size_t bps = size_t(bytes_per_sample(in_format));
+  if (n_segments > 1 && seg_stride_bytes % (bps == 8 ? 8 : 2) != 0)
+    return fail(TDSA_ERR_ARG, "seg_stride_bytes=%zu must be a multiple of one sample", seg_stride_bytes);
+  const tdsa_mode& m = p->mode;
+  const bool order_free = !avg_active(m) && (m.dc_alpha < 0.0f || m.dc_alpha >= 1.0f);
+  const long long total = (long long)n_segments * frames_per_seg;
+  const bool one_launch = n_segments > 1 && order_free && !p->chirp && !p->big && frames_per_seg > 0 &&
+                          total * frames_per_seg < 0x100000000ll && total < 0x7fffffffll;
+  if (!one_launch) {
+    for (int sg = 0; sg < n_segments; ++sg) {
+      const int rc = process_dev_impl(p, in_format, static_cast<const unsigned char*>(iq_dev) + size_t(sg) * seg_stride_bytes,
+                                      n_samples_per_seg, hop, frames_per_seg,
+                                      out_db_dev ? out_db_dev + size_t(sg) * out_seg_stride_floats : nullptr, nullptr, nullptr);
+      if (rc != TDSA_OK) return rc;
+    }
+    return TDSA_OK;
+  }
+  SegInfo seg;
+  seg.n_seg = n_segments;
+  seg.frames_per_seg = frames_per_seg;
+  seg.in_stride_bytes = (long long)seg_stride_bytes;
+  seg.out_stride_elems = (long long)out_seg_stride_floats;
+  return process_dev_impl(p, in_format, iq_dev, n_samples_per_seg, hop, int(total), out_db_dev, nullptr, nullptr, &seg);
 }
 
 // pinned, device-visible bounce buffers of the host entry points (grown on demand; every host call ends with a
@@ -892,8 +949,10 @@ static int process_host(tdsa_plan p, int fmt, const void* iq_host, size_t n_samp
   // and write the row to the pinned buffers directly over the bus (hipHostMalloc memory is device-visible)
   const bool direct = bounce && in_bytes + out_bytes <= kZeroCopyMax && !p->big;
   if (direct) {
+    p->sync_call = true;
     int rc_d = tdsa_process_dev(p, fmt, p->h_in_pin, need, hop, n_frames,
                                 out_db_host ? static_cast<float*>(p->h_out_pin) : nullptr);
+    p->sync_call = false;
     if (rc_d != TDSA_OK) return rc_d;
     JOIN(p);
     HIPCHK(hipStreamSynchronize(p->stream));
@@ -901,7 +960,9 @@ static int process_host(tdsa_plan p, int fmt, const void* iq_host, size_t n_samp
     return TDSA_OK;
   }
   HIPCHK(hipMemcpyAsync(p->d_in_stage, bounce ? p->h_in_pin : iq_host, in_bytes, hipMemcpyHostToDevice, p->stream));
+  p->sync_call = true;
   int rc = tdsa_process_dev(p, fmt, p->d_in_stage, need, hop, n_frames, out_db_host ? p->d_out_stage : nullptr);
+  p->sync_call = false;
   if (rc != TDSA_OK) return rc;
   // with tdsa_set_overlap(n > 1) the frame kernel may have gone to an auxiliary stream: order the main
   // stream (read-back + the synchronize below) behind it, so the host call stays sequentially consistent
@@ -1304,8 +1365,8 @@ int tdsa_memcpy_d2h(int device_id, void* dst_host, const void* src_dev, size_t b
   return TDSA_OK;
 }
 
-// developer hook (not part of include/tdsa_hip.h): phase timeline of workgroup 0, TDSA_TIMELINE builds
-int tdsa_debug_timeline(tdsa_plan p, unsigned long long* host_out_1024) {
+// developer hook (developer section of include/tdsa_hip.h): phase timeline of workgroup 0, TDSA_TIMELINE builds
+int tdsa_debug_timeline(tdsa_plan p, unsigned long long* host_out_2048) {
   if (!p) return fail(TDSA_ERR_ARG, "null plan");
   HIPCHK(hipSetDevice(p->device));
   JOIN(p);
@@ -1313,9 +1374,9 @@ int tdsa_debug_timeline(tdsa_plan p, unsigned long long* host_out_1024) {
     HIPCHK(hipMalloc(&p->d_dbg, 2048 * sizeof(unsigned long long)));
     HIPCHK(hipMemset(p->d_dbg, 0, 2048 * sizeof(unsigned long long)));
   }
-  if (host_out_1024) {
+  if (host_out_2048) {
     HIPCHK(hipStreamSynchronize(p->stream));
-    HIPCHK(hipMemcpy(host_out_1024, p->d_dbg, 2048 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(host_out_2048, p->d_dbg, 2048 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   }
   return TDSA_OK;
 }

@@ -63,6 +63,14 @@ struct SpecParams {
   int group;
   long long group_stride;
   float* acc;
+  // ---- several captures ("segments") in one launch (tdsa_process_dev_batch) ----
+  // frame f belongs to segment s = floor(f / seg_frames) = umulhi(f, seg_magic), frame fi = f - s * seg_frames of it:
+  // it reads from in + s * seg_in_stride + fi * frame_stride and its row goes to out + (s * seg_out_stride + fi * N)
+  // elements.  seg_magic = 0 (one segment): s = 0, fi = f.
+  unsigned seg_magic;        // ceil(2^32 / seg_frames); exact for f * seg_frames < 2^32 (checked by the host)
+  unsigned seg_frames;
+  long long seg_in_stride;   // bytes
+  long long seg_out_stride;  // output elements
 };
 
 struct LaunchGeom {

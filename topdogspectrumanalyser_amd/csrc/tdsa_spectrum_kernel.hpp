@@ -339,6 +339,18 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   const unsigned lane_in_off = unsigned(t) * (IN_C64 ? M * 8u : M * 2u) +
                                unsigned(h) * (IN_C64 ? (N / A) * 8u : unsigned(ROWB));
   const unsigned out_voff = unsigned(t) * 4u + unsigned(h) * (8u * SG * 4u);
+  // frame -> byte offset of its samples / element offset of its output row (several captures per launch:
+  // SpecParams::seg_*; with one capture seg_magic = 0 and these are frame * frame_stride, frame * N)
+  auto in_byte_off = [&](int frame) -> long long {
+    const unsigned sgm = __umulhi(unsigned(frame), p.seg_magic);
+    const unsigned fi = unsigned(frame) - sgm * p.seg_frames;
+    return (long long)sgm * p.seg_in_stride + (long long)fi * p.frame_stride;
+  };
+  auto out_elem_off = [&](int frame) -> long long {
+    const unsigned sgm = __umulhi(unsigned(frame), p.seg_magic);
+    const unsigned fi = unsigned(frame) - sgm * p.seg_frames;
+    return (long long)sgm * p.seg_out_stride + (long long)fi * N;
+  };
 
   // Window slice of this thread (sizes that keep the table in global memory): (re)loaded at the END of a
   // frame, ahead of that frame's dB stores.  gfx9 counts loads and stores in one in-order vmcnt, so a load
@@ -365,7 +377,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   auto load_frame_raw = [&](int frame) {
     if constexpr (!IN_C64) {
       const bool act = frame < p.n_frames;
-      const unsigned char* fb = static_cast<const unsigned char*>(p.in) + (long long)frame * p.frame_stride;
+      const unsigned char* fb = static_cast<const unsigned char*>(p.in) + in_byte_off(frame);
       if constexpr (FPW == 1 && M >= 2) {   // frame is workgroup-uniform: SGPR descriptor + lane offset
         const rsrc_t r = make_rsrc(fb, N * 2u);
         static_for<0, H>([&](auto ic) {
@@ -438,7 +450,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     if constexpr (ACC) {
       static_for<0, 16>([&](auto ic) { constexpr int idx = decltype(ic)::value; v[idx] = vnext[idx]; });
     } else if constexpr (IN_C64) {
-      const unsigned char* fb = static_cast<const unsigned char*>(p.in) + (long long)frame * p.frame_stride;
+      const unsigned char* fb = static_cast<const unsigned char*>(p.in) + in_byte_off(frame);
       static_for<0, 16>([&](auto ic) {
         constexpr int idx = decltype(ic)::value;
         constexpr int jj = idx / H, i = idx % H;
@@ -724,7 +736,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     if (active) {
       if (p.out_cplx != nullptr) {            // real-input path: hand the complex bins to the fold kernel
         if constexpr (!C::WIN_LDS) load_window();
-        c32* crow = p.out_cplx + (long long)frame * N + t + 8 * h * SG;
+        c32* crow = p.out_cplx + out_elem_off(frame) + t + 8 * h * SG;
         bool plain = true;
         if constexpr (IN_C64 && HOLD == 0) {
           // chirp-z plans (tdsa_chirp.hip): the spectrum leaves multiplied by the chirp filter's spectrum and
@@ -757,7 +769,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
         }
       } else if (p.out_lin != nullptr) {
         if constexpr (!C::WIN_LDS) load_window();
-        float* orow = p.out_lin + (long long)frame * N + t + 8 * h * SG;
+        float* orow = p.out_lin + out_elem_off(frame) + t + 8 * h * SG;
         static_for<0, 16>([&](auto ic) {
           constexpr int q = decltype(ic)::value;
           constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;       // shifted position of kc (without the 8h part)
@@ -804,7 +816,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
         }
         if constexpr (!C::WIN_LDS) load_window();     // next frame's window, ahead of this frame's stores
         if ((TDSA_ABLATE & 4) == 0 && p.out_db != nullptr) {
-          float* orow = p.out_db + (long long)frame * N;
+          float* orow = p.out_db + out_elem_off(frame);
           if constexpr (FPW == 1) {
             const rsrc_t r = make_rsrc(orow, N * 4u);
             if constexpr ((TDSA_ABLATE & 1024) != 0) {
@@ -862,7 +874,15 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   //  current trace into the window registers during the last frame, to save the round trip below: 16 bytes
   //  of scratch inside the frame loop, 75.3 instead of 73.9 us per C3 launch.)
   if constexpr (HOLD != 0) {
-    const int prow = t + 8 * h * SG;
+    // the row index is rebuilt from a fresh (opaque) copy of the thread index: kept live across the frame loop
+    // `8 * h * SG` was the one value of the C3 instantiation that did not fit the 128 VGPRs (one dword of
+    // scratch per lane = 2.1 MB of spill writes per launch, WRITE_SIZE 162.1 instead of 160 MB)
+    int tid_m = threadIdx.x;
+    asm volatile("" : "+v"(tid_m));
+    const int h_m = (tid_m >> 5) & 1;
+    const int g_m = (tid_m >> 6) * 32 + (tid_m & 31);
+    const int t_m = (FPW == 1) ? g_m : g_m - (g_m / SG) * SG;
+    const int prow = t_m + 8 * h_m * SG;
     const bool any = (u1 > u0) && (FPW == 1 || u0 * FPW + slot < p.n_frames);
     if constexpr (FPW == 1) {
       if (any) {

@@ -138,6 +138,16 @@ class SpectrumEngine:
         nat.check(nat.lib.tdsa_process_dev(self._h, in_format, C.c_void_p(iq_dev), n_samples, hop,
                                            n_frames, C.c_void_p(out_db_dev) if out_db_dev else None))
 
+    def process_device_batch(self, in_format: int, iq_dev: int, seg_stride_bytes: int, n_segments: int,
+                             n_samples_per_seg: int, hop: int, frames_per_seg: int, out_db_dev: Optional[int],
+                             out_seg_stride_floats: int = 0) -> None:
+        """n_segments captures of one shape (device pointers, asynchronous): the same results and state as
+        n_segments process_device() calls, as ONE persistent launch where the mode allows (tdsa_process_dev_batch)."""
+        nat.check(nat.lib.tdsa_process_dev_batch(self._h, in_format, C.c_void_p(iq_dev), seg_stride_bytes, n_segments,
+                                                 n_samples_per_seg, hop, frames_per_seg,
+                                                 C.c_void_p(out_db_dev) if out_db_dev else None,
+                                                 out_seg_stride_floats))
+
     def synchronize(self) -> None:
         nat.check(nat.lib.tdsa_synchronize(self._h))
 
