@@ -177,6 +177,9 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=8,
                     help="queued steps handed over per call in the `value` leg (tdsa_process_dev_batch); 1 = one launch per step")
     ap.add_argument("--min-region-s", type=float, default=0.5, help="every timed region lasts at least this long")
+    ap.add_argument("--legs", default="all", choices=["all", "value", "streams", "serial"],
+                    help="profiling aid: time only this submission mode (pre-roll and kernel-alone pass in its launch shape too), "
+                         "so that a rocprofv3 trace of the run holds launches of one shape; the other figures of the line repeat it")
     ap.add_argument("--preroll-seconds", type=float, default=0.4, help="untimed load before the warm-up steps")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the single-thread CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -242,7 +245,7 @@ def main() -> None:
         my_frames = seg1 - seg0
     else:
         seg0, my_frames = 0, frames
-    my_ns = (my_frames - 1) * hop + nfft if my_frames > 0 else 0
+    my_ns = ((my_frames - 1) * hop + nfft if my_frames > 0 else 0) if welch else ns   # samples of this rank's capture
 
     if args.dry_run:
         eng = _DryEngine(nfft, rank)
@@ -352,11 +355,13 @@ def main() -> None:
 
     # clocks: an idle MI355X needs a few hundred ms of load before shader/fabric clocks settle; this
     # untimed pre-roll keeps short --steps/--warmup runs from measuring the ramp
+    only = args.legs
+    pre_call = step_batch if (only == "value" and batch > 1) else step
     t_pre = time.perf_counter()
     i_pre = 0
     while time.perf_counter() - t_pre < args.preroll_seconds:
-        for _ in range(50):
-            step(i_pre)
+        for _ in range(50 if pre_call is step else max(1, 50 // batch)):
+            pre_call(i_pre)
             i_pre += 1
         dev_sync()
 
@@ -364,6 +369,9 @@ def main() -> None:
     if welch or args.dry_run and batch == 1:
         legs["value"] = measure(1, 1)
         legs["serial"] = legs["streams"] = legs["value"]
+    elif only != "all":                                # one submission mode only (rocprofv3 runs)
+        one = measure(streams, batch) if only == "value" else (measure(streams, 1) if only == "streams" else measure(1, 1))
+        legs["value"] = legs["streams"] = legs["serial"] = one
     else:
         legs["value"] = measure(streams, batch) if batch > 1 else None
         legs["streams"] = measure(streams, 1) if streams > 1 else None
@@ -393,7 +401,7 @@ def main() -> None:
         return launches, (kern_ms * 1e-3 / launches if launches else 0.0)
 
     launches_b, kern_b = kernel_alone(head["per_call"])
-    launches_1, kern_1 = (launches_b, kern_b) if head["per_call"] == 1 else kernel_alone(1)
+    launches_1, kern_1 = (launches_b, kern_b) if (head["per_call"] == 1 or only != "all") else kernel_alone(1)
     if welch:                                          # a chain of kernels: price the whole serial step
         launches_b = launches_1 = 0
         kern_b = kern_1 = legs["serial"]["med"] / legs["serial"]["steps"]
@@ -516,6 +524,10 @@ def main() -> None:
                                                 "algorithmic_bytes_per_launch": algo_step,
                                                 "frames_per_launch": my_frames}},
         }
+        if only != "all":
+            result["config"]["legs"] = f"--legs {only}: only that submission mode was timed; value_streams / value_serial repeat it"
+            if head["per_call"] > 1:
+                result["roofline"].pop("single_step_launch", None)
         if valu_issue is not None:
             result["roofline"]["valu_issue"] = valu_issue
         if args.dry_run:                               # nothing was computed: no performance figures

@@ -8,9 +8,9 @@
 //                         inputs of a column sit N2 samples apart: every load is a coalesced run along n2),
 //                         times W_N^(n2*k1), written as complex64 rows Z[seg][k1][n2]  (2N B in, 8N B out)
 //   (2) the frame kernel (tdsa_spectrum_kernel.hpp, ACC variant): every row Z[seg][k1][.] is one 16384-point
-//                         frame; |X|^2 of the K segments of one k1 is summed in registers and leaves as one
-//                         float atomic per bin: S[k1][k2]                             (8N B in, 4N/K B out)
-//   (3) gather_kernel   : S[k1][k2] -> natural bin order k = k1 + N1*k2, fftshift, float64 (LDS tile transpose)
+//                         frame; |X|^2 of the segments a workgroup takes of one k1 is summed in registers and
+//                         leaves as that workgroup's own row P[k1][j][k2]               (8N B in, 4N/K B out)
+//   (3) gather_kernel   : sum over j of P[k1][j][k2] -> natural bin order k = k1 + N1*k2, fftshift, float64
 //   (4) finish_kernel   : mean / averager state -> 10*log10(. * scale + floor) + cal (- tare) -> dB row, hold
 // Replaces np.fft.fft on a long frame + TraceAverager + _apply_cal_offset of the reference
 // (hackrf_samples.py:370, utils/signal_processing.py:35-61, core/display_data_processor.py:317-327).
@@ -94,8 +94,9 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
   });
 }
 
-// S[k1][k2] (float, this call's power sums; cleared here for the next call) -> natural bin order
-// k = k1 + N1*k2, fftshift-ed (ks = k ^ N/2), through an LDS tile so that reads and writes are coalesced.
+// P[k1 * split + j][k2] (float: the row pass's per-workgroup partial power sums of this call, summed over j in
+// double, in a fixed order: the result is reproducible bit for bit) -> natural bin order k = k1 + N1*k2,
+// fftshift-ed (ks = k ^ N/2), through an LDS tile so that reads and writes are coalesced.
 //   fin == null : dst[ks] = (add ? dst[ks] : 0) + S   (float64; the averager step follows separately)
 //   fin != null : the same, then the finish arithmetic of big_finish_kernel on dst[ks] in the same thread
 struct BigFinishParams;
@@ -132,23 +133,33 @@ __global__ void __launch_bounds__(256) big_finish_kernel(const BigFinishParams p
 }
 
 template <int LOG2N1>
-__global__ void __launch_bounds__(256) big_gather_kernel(float* s, double* dst, int add, BigFinishParams fin, int fuse) {
-  constexpr int N1 = 1 << LOG2N1, T = 64;                 // tile: all N1 rows x 64 columns k2
-  __shared__ float tile[N1][T + 1];
-  const int k2b = blockIdx.x * T;
-  for (int i = threadIdx.x; i < N1 * T; i += 256) {
+__global__ void __launch_bounds__(256) big_gather_kernel(const float* s, int split, double* dst, int add, BigFinishParams fin,
+                                                         int fuse) {
+  // tile: R rows k1 x 64 columns k2 per workgroup (1024 workgroups at 2^20 points: the partial rows are read with
+  // `split` independent loads per element in flight - as 256 workgroups of all N1 rows the pass took 23 us)
+  constexpr int N1 = 1 << LOG2N1, T = 64, R = N1 < 16 ? N1 : 16;
+  __shared__ double tile[R][T + 1];
+  const int k2b = blockIdx.x * T, k1b = blockIdx.y * R;
+  for (int i = threadIdx.x; i < R * T; i += 256) {
     const int k1 = i / T, c = i % T;
-    float* q = s + (long long)k1 * kRowN + k2b + c;
-    tile[k1][c] = *q;
-    *q = 0.f;
+    const float* q = s + (long long)(k1b + k1) * split * kRowN + k2b + c;
+    double acc = 0.0;                                     // the row pass's workgroup partials of this k1, in a fixed order
+    int j = 0;
+    for (; j + 4 <= split; j += 4) {
+      const float a0 = q[(long long)j * kRowN], a1 = q[(long long)(j + 1) * kRowN], a2 = q[(long long)(j + 2) * kRowN],
+                  a3 = q[(long long)(j + 3) * kRowN];
+      acc += double(a0); acc += double(a1); acc += double(a2); acc += double(a3);
+    }
+    for (; j < split; ++j) acc += double(q[(long long)j * kRowN]);
+    tile[k1][c] = acc;
   }
   __syncthreads();
   constexpr long long half = (long long)N1 * kRowN / 2;
-  for (int i = threadIdx.x; i < N1 * T; i += 256) {
-    const int c = i / N1, k1 = i % N1;
-    const long long k = (long long)(k2b + c) * N1 + k1;
+  for (int i = threadIdx.x; i < R * T; i += 256) {
+    const int c = i / R, k1 = i % R;
+    const long long k = (long long)(k2b + c) * N1 + k1b + k1;
     const long long ks = k ^ half;
-    const double x = double(tile[k1][c]);
+    const double x = tile[k1][c];
     const double sum = add ? dst[ks] + x : x;
     dst[ks] = sum;
     if (fuse) big_finish_bin(fin, ks, sum);
@@ -208,8 +219,10 @@ static hipError_t cols_launch(const BigColsParams& p, int n_seg, hipStream_t s) 
   return hipGetLastError();
 }
 template <int L>
-static hipError_t gather_launch(float* src, double* dst, int add, const BigFinishParams& fin, int fuse, hipStream_t s) {
-  hipLaunchKernelGGL(big_gather_kernel<L>, dim3(kRowN / 64), dim3(256), 0, s, src, dst, add, fin, fuse);
+static hipError_t gather_launch(const float* src, int split, double* dst, int add, const BigFinishParams& fin, int fuse,
+                                hipStream_t s) {
+  constexpr int N1 = 1 << L, R = N1 < 16 ? N1 : 16;
+  hipLaunchKernelGGL(big_gather_kernel<L>, dim3(kRowN / 64, N1 / R), dim3(256), 0, s, src, split, dst, add, fin, fuse);
   return hipGetLastError();
 }
 
@@ -229,31 +242,31 @@ hipError_t launch_big_cols(int log2n, const void* in, int in_c64, long long seg_
   }
 }
 
-static hipError_t gather_dispatch(int log2n, float* s_rows, double* dst, int add, const BigFinishParams& fin, int fuse,
-                                  hipStream_t s) {
+static hipError_t gather_dispatch(int log2n, const float* s_rows, int split, double* dst, int add, const BigFinishParams& fin,
+                                  int fuse, hipStream_t s) {
   switch (log2n - kRowLog2) {
-    case 1: return gather_launch<1>(s_rows, dst, add, fin, fuse, s);
-    case 2: return gather_launch<2>(s_rows, dst, add, fin, fuse, s);
-    case 3: return gather_launch<3>(s_rows, dst, add, fin, fuse, s);
-    case 4: return gather_launch<4>(s_rows, dst, add, fin, fuse, s);
-    case 5: return gather_launch<5>(s_rows, dst, add, fin, fuse, s);
-    case 6: return gather_launch<6>(s_rows, dst, add, fin, fuse, s);
+    case 1: return gather_launch<1>(s_rows, split, dst, add, fin, fuse, s);
+    case 2: return gather_launch<2>(s_rows, split, dst, add, fin, fuse, s);
+    case 3: return gather_launch<3>(s_rows, split, dst, add, fin, fuse, s);
+    case 4: return gather_launch<4>(s_rows, split, dst, add, fin, fuse, s);
+    case 5: return gather_launch<5>(s_rows, split, dst, add, fin, fuse, s);
+    case 6: return gather_launch<6>(s_rows, split, dst, add, fin, fuse, s);
     default: return hipErrorInvalidValue;
   }
 }
 
-hipError_t launch_big_gather(int log2n, float* s_rows, double* dst, int add, hipStream_t s) {
-  return gather_dispatch(log2n, s_rows, dst, add, BigFinishParams{}, 0, s);
+hipError_t launch_big_gather(int log2n, const float* s_rows, int split, double* dst, int add, hipStream_t s) {
+  return gather_dispatch(log2n, s_rows, split, dst, add, BigFinishParams{}, 0, s);
 }
 
 // gather + finish in one launch: dst (+)= S, then mean = dst / count -> dB row, hold (Welch and plain frames)
-hipError_t launch_big_gather_finish(int log2n, float* s_rows, double* dst, int add, double* mean_out, int count,
+hipError_t launch_big_gather_finish(int log2n, const float* s_rows, int split, double* dst, int add, double* mean_out, int count,
                                     int db_mode, float pscale, float log_floor, float cal_db, const float* tare,
                                     float* out_db, float* hold_max, float* hold_min, int max_first, int min_first,
                                     hipStream_t s) {
   const BigFinishParams fin{dst, mean_out, count, db_mode, pscale, log_floor, cal_db, tare, out_db, hold_max, hold_min,
                             max_first, min_first};
-  return gather_dispatch(log2n, s_rows, dst, add, fin, 1, s);
+  return gather_dispatch(log2n, s_rows, split, dst, add, fin, 1, s);
 }
 
 hipError_t launch_big_finish(const double* src, long long n, double* mean_out, int count, int db_mode, float pscale,

@@ -100,7 +100,7 @@ struct tdsa_plan_s {
   float2* d_tw_lo = nullptr;             // W_N^m, m < 1024
   float2* d_tw_row = nullptr;            // W_16384^m : the row pass's twiddle table
   float* d_ones = nullptr;               // [16384] unit window for the row pass
-  int big_group = 32;                    // segments per column-pass / row-pass round (Z stays cache resident)
+  int big_group = 64;                    // segments per column-pass / row-pass round (one round for the K = 64 Welch capture)
   // frame lengths that are not a power of two (tdsa_chirp.hip): chirp-z on the m_fft-point frame kernel
   bool chirp = false;
   int m_fft = 0, log2m = 0;              // M = 2^log2m >= 2 nfft - 1
@@ -222,11 +222,15 @@ int process_big(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n_f
                          double(in_off), double(in_scale), p->d_sums64, p->d_dc_state, p->d_dc_sub, p->stream));
     dc_sub = p->d_dc_sub;
   }
-  // (d_acc is all zero here: cleared at plan creation and by every gather)
-  // column pass and row pass alternate over groups of segments: the 8N-byte rows of a group are consumed
-  // right after they are produced, out of the Infinity Cache rather than HBM
+  // column pass and row pass alternate over rounds of segments.  The row pass leaves per-workgroup partial power
+  // sums in d_acc (P[k1 * split + j][k2]): the first round of a call overwrites its rows, later rounds add to them,
+  // the gather sums over j - nothing is carried from call to call, so a failed call leaves no residue
+  const int split_max = p->num_cu / n1 > 1 ? p->num_cu / n1 : 1;
+  int split_layout = 1;
   for (int s0 = 0; s0 < n_frames; s0 += group) {
     const int ns = n_frames - s0 < group ? n_frames - s0 : group;
+    const int act = ns < split_max ? ns : split_max;
+    if (s0 == 0) split_layout = act;
     HIPCHK(launch_big_cols(p->log2n, static_cast<const unsigned char*>(iq_dev) + (long long)s0 * stride, in_c64, stride, ns,
                            p->d_window[in_format], p->d_tw_hi, p->d_tw_lo, dc_sub ? dc_sub + s0 : nullptr, p->d_z,
                            xor_mask, in_off, p->stream));
@@ -244,7 +248,11 @@ int process_big(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n_f
     sp.db_mode = TDSA_DB_POW;
     sp.pscale = 1.0f;
     sp.acc = p->d_acc;
-    const LaunchGeom g = spectrum_geometry(14, sp.n_frames, p->num_cu);
+    sp.acc_split = split_layout;
+    sp.acc_active = act;
+    sp.acc_add = s0 > 0;
+    LaunchGeom g = spectrum_geometry(14, sp.n_frames, p->num_cu);
+    g.grid = n1 * act;                                           // workgroup b = k1 * act + j
     if (p->profiling) {
       if (p->prof_used + 2 > p->prof_events.size()) {
         hipEvent_t a, b;
@@ -267,19 +275,19 @@ int process_big(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n_f
   float* const hold_max = hmax ? p->d_hold_max : nullptr;
   float* const hold_min = hmin ? p->d_hold_min : nullptr;
   if (welch) {
-    HIPCHK(launch_big_gather_finish(p->log2n, p->d_acc, p->d_sum, p->avg_count > 0, p->d_avg, p->avg_count + n_frames,
+    HIPCHK(launch_big_gather_finish(p->log2n, p->d_acc, split_layout, p->d_sum, p->avg_count > 0, p->d_avg, p->avg_count + n_frames,
                                     m.db_mode, pscale, m.log_floor, m.cal_offset_db, tare, out_db_dev, hold_max, hold_min,
                                     p->held_max == 0, p->held_min == 0, p->stream));
     p->avg_count += n_frames;
   } else if (averaging) {    // TraceAverager exp / capped lin, one frame (signal_processing.py:35-61)
-    HIPCHK(launch_big_gather(p->log2n, p->d_acc, p->d_lin64, 0, p->stream));
+    HIPCHK(launch_big_gather(p->log2n, p->d_acc, split_layout, p->d_lin64, 0, p->stream));
     HIPCHK(launch_avg_host_frame(p->d_lin64, p->nfft, p->d_avg, p->avg_count, m.avg_mode, m.avg_n, p->stream));
     if (p->avg_count == 0) p->avg_count = 1;
     else if (m.avg_mode == TDSA_AVG_LIN && p->avg_count < m.avg_n) p->avg_count += 1;
     HIPCHK(launch_big_finish(p->d_avg, (long long)N, nullptr, 1, m.db_mode, pscale, m.log_floor, m.cal_offset_db, tare,
                              out_db_dev, hold_max, hold_min, p->held_max == 0, p->held_min == 0, p->stream));
   } else {
-    HIPCHK(launch_big_gather_finish(p->log2n, p->d_acc, p->d_lin64, 0, nullptr, 1, m.db_mode, pscale, m.log_floor,
+    HIPCHK(launch_big_gather_finish(p->log2n, p->d_acc, split_layout, p->d_lin64, 0, nullptr, 1, m.db_mode, pscale, m.log_floor,
                                     m.cal_offset_db, tare, out_db_dev, hold_max, hold_min, p->held_max == 0,
                                     p->held_min == 0, p->stream));
   }
@@ -535,8 +543,13 @@ static int plan_init(tdsa_plan p) {
     }
     HIPCHK(hipMalloc(&p->d_sum, size_t(nfft) * sizeof(double)));
     HIPCHK(hipMalloc(&p->d_lin64, size_t(nfft) * sizeof(double)));
-    HIPCHK(hipMalloc(&p->d_acc, size_t(nfft) * sizeof(float)));
-    HIPCHK(hipMemsetAsync(p->d_acc, 0, size_t(nfft) * sizeof(float), p->stream));
+    {   // per-workgroup partial power sums of the row pass: [N1 * split][16384], split = workgroups per k1 row
+      const int n1 = nfft >> 14;
+      int split = p->num_cu / n1 > 1 ? p->num_cu / n1 : 1;
+      const int gmax = p->max_frames < p->big_group ? p->max_frames : p->big_group;
+      if (split > gmax) split = gmax;
+      HIPCHK(hipMalloc(&p->d_acc, size_t(n1) * split * (size_t(1) << 14) * sizeof(float)));
+    }
     const int nhi = nfft / 1024, nrow = 1 << kMaxLog2N;
     HIPCHK(hipMalloc(&p->d_tw_hi, size_t(nhi) * sizeof(float2)));
     HIPCHK(hipMalloc(&p->d_tw_lo, 1024 * sizeof(float2)));

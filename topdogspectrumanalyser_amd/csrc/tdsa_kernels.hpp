@@ -57,12 +57,17 @@ struct SpecParams {
   int hold_flags;            // bit0 max, bit1 min
   unsigned long long* dbg;   // developer timeline buffer (TDSA_TIMELINE builds only), else null
   // ---- row pass of the N1 x 16384 big-FFT path (tdsa_big.hip): complex64 rows Z[seg][k1][n2] ----
-  // frame f reads from  in + (f % group) * frame_stride + (f / group) * group_stride  (group = 0: plain
-  // f * frame_stride) and ADDS its linear power |X|^2 into acc[(f / group) * N + bin] (bin in natural order,
-  // no dB, no fftshift): frames of one group (the K Welch segments of one k1) are summed in registers
+  // frame f reads from  in + (f % group) * frame_stride + (f / group) * group_stride  and its linear power |X|^2
+  // (bin in natural order, no dB, no fftshift) joins the sum of its group (the K Welch segments of one k1).
+  // Workgroup b = k1 * acc_active + j owns a contiguous share of group k1's frames: the sum stays in registers and
+  // leaves once, as the workgroup's own row of P - plain stores, summed over j by the gather kernel (round 2 added
+  // 4 M float atomics per launch here: 8 us, and results that changed from run to run)
   int group;
   long long group_stride;
-  float* acc;
+  float* acc;                // ACC: partial power sums P[k1 * acc_split + j][bin], one row per workgroup (no atomics)
+  int acc_split;             // rows of P per k1 (layout; the first round of a call fixes it)
+  int acc_active;            // workgroups per k1 in THIS launch (<= acc_split): grid = N1 * acc_active
+  int acc_add;               // 0: the row is overwritten (first round of a call), 1: added to what the row holds
   // ---- several captures ("segments") in one launch (tdsa_process_dev_batch) ----
   // frame f belongs to segment s = floor(f / seg_frames) = umulhi(f, seg_magic), frame fi = f - s * seg_frames of it:
   // it reads from in + s * seg_in_stride + fi * frame_stride and its row goes to out + (s * seg_out_stride + fi * N)
@@ -152,10 +157,10 @@ hipError_t launch_big_dc(const void* in, int in_c64, unsigned xor_mask, long lon
                          hipStream_t s);
 // row pass: the 16384-point frame kernel on complex64 rows, power summed per group into p.acc
 hipError_t launch_spectrum_acc(const SpecParams& p, const LaunchGeom& g, hipStream_t s);
-// S[k1][k2] float (cleared for the next call) -> dst[(k1 + N1*k2) ^ N/2] double (overwrite or accumulate)
-hipError_t launch_big_gather(int log2n, float* s_rows, double* dst, int add, hipStream_t s);
+// P[k1 * split + j][k2] float partial sums -> dst[(k1 + N1*k2) ^ N/2] double (overwrite or accumulate)
+hipError_t launch_big_gather(int log2n, const float* s_rows, int split, double* dst, int add, hipStream_t s);
 // the same + mean = dst / count -> dB (+cal, -tare) row and hold traces, one launch
-hipError_t launch_big_gather_finish(int log2n, float* s_rows, double* dst, int add, double* mean_out, int count,
+hipError_t launch_big_gather_finish(int log2n, const float* s_rows, int split, double* dst, int add, double* mean_out, int count,
                                     int db_mode, float pscale, float log_floor, float cal_db, const float* tare,
                                     float* out_db, float* hold_max, float* hold_min, int max_first, int min_first,
                                     hipStream_t s);

@@ -298,8 +298,17 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   // every launch, ahead of the first load).  The workgroups that take one unit more stay spread over the grid:
   // handing them out as one contiguous block instead measured +0.6 us per serial C3 launch.
   const unsigned upw = unsigned(n_units) / gridDim.x, urem = unsigned(n_units) - upw * gridDim.x;
-  const int u0 = int(blockIdx.x * upw + blockIdx.x * urem / gridDim.x);
-  const int u1 = int((blockIdx.x + 1) * upw + (blockIdx.x + 1) * urem / gridDim.x);
+  int u0 = int(blockIdx.x * upw + blockIdx.x * urem / gridDim.x);
+  int u1 = int((blockIdx.x + 1) * upw + (blockIdx.x + 1) * urem / gridDim.x);
+  if constexpr (ACC) {
+    // row pass of the long-frame path: workgroup b = k1 * acc_active + j takes the j-th share of group k1's frames,
+    // so that everything it sums belongs to ONE row of the result (its own row of P, no atomics)
+    const int k1 = int(blockIdx.x) / p.acc_active, j = int(blockIdx.x) - k1 * p.acc_active;
+    const int chunk = (p.group + p.acc_active - 1) / p.acc_active;
+    const int s0 = min(p.group, j * chunk), s1 = min(p.group, s0 + chunk);
+    u0 = k1 * p.group + s0;
+    u1 = k1 * p.group + s1;
+  }
 
   // ---- frame-invariant per-thread state ---------------------------------------------------------
   const rsrc_t win_rsrc = make_rsrc(p.window, N * 4u);
@@ -721,16 +730,6 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
           const c32 X = v[bitrev(q, 4)];
           pacc[q] = fmaf(X.x, X.x, fmaf(X.y, X.y, pacc[q]));
         });
-        const int fg = frame / p.group;
-        if (unit + 1 == u1 || (frame + 1) / p.group != fg) {
-          float* arow = p.acc + (long long)fg * N + t + 8 * h * SG;
-          static_for<0, 16>([&](auto ic) {
-            constexpr int q = decltype(ic)::value;
-            constexpr int kc = (q < 8 ? q : q + 8);
-            unsafeAtomicAdd(arow + kc * SG, pacc[q]);
-            pacc[q] = 0.f;
-          });
-        }
       }
     } else
     if (active) {
@@ -867,6 +866,24 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   if (p.dbg != nullptr && blockIdx.x == 0)
     for (int i = tid; i < 8 * 16 * 16; i += C::WGT) p.dbg[i] = tl[i];
 #endif
+  if constexpr (ACC) {
+    // the workgroup's share of its group's power sum leaves as its own row of P (a workgroup without frames
+    // contributes zeros in the first round of a call and nothing afterwards)
+    if (u1 > u0 || p.acc_add == 0) {
+      int tid_a = threadIdx.x;
+      asm volatile("" : "+v"(tid_a));
+      const int h_a = (tid_a >> 5) & 1, t_a = (tid_a >> 6) * 32 + (tid_a & 31);
+      const int k1 = int(blockIdx.x) / p.acc_active, j = int(blockIdx.x) - k1 * p.acc_active;
+      float* arow = p.acc + (long long)(k1 * p.acc_split + j) * N + t_a + 8 * h_a * SG;
+      static_for<0, 16>([&](auto ic) {
+        constexpr int q = decltype(ic)::value;
+        constexpr int kc = (q < 8 ? q : q + 8);
+        float v = pacc[q];
+        if (p.acc_add != 0) v += arow[kc * SG];
+        arow[kc * SG] = v;
+      });
+    }
+  }
   // fold this workgroup's register-resident hold traces straight into the plan's traces with
   // integer-punned float atomics (max/min are associative; the traces start at -inf / +inf).
   // (Issuing the bulk of them before the last frame to hide the tail was tried: the extra live state
