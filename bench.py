@@ -528,8 +528,18 @@ def main() -> None:
             result["config"]["legs"] = f"--legs {only}: only that submission mode was timed; value_streams / value_serial repeat it"
             if head["per_call"] > 1:
                 result["roofline"].pop("single_step_launch", None)
-        if valu_issue is not None:
-            result["roofline"]["valu_issue"] = valu_issue
+        if valu_issue is not None and not args.dry_run and kern_b:
+            # secondary roofline: the kernel's VALU issue time at the SIMDs' saturated per-class rates (committed
+            # counters + microbenchmarks, tools/valu_issue.py) against this run's own kernel time
+            live_us = kern_b / head["per_call"] * 1e6
+            vi = {k: valu_issue[k] for k in ("bound", "kernel", "insts_valu_per_wave_frame", "issue_ns_per_wave_frame",
+                                             "waves_per_simd", "issue_us_per_frame_slot", "measured_valu_only_us_per_frame_slot",
+                                             "floor_us_per_step", "unit", "hbm_frac_if_only_valu_issue_remained", "sources")}
+            vi.update({"achieved": live_us, "peak": valu_issue["floor_us_per_step"], "frac": valu_issue["floor_us_per_step"] / live_us,
+                       "reading": "frac = VALU issue time of one step (instruction counts x saturated issue cost per class, perfectly "
+                                  "balanced over 256 CUs) / this run's kernel time per step: the share of the launch the SIMDs need "
+                                  "just to issue the kernel's VALU instructions"})
+            result["roofline"]["valu_issue"] = vi
         if args.dry_run:                               # nothing was computed: no performance figures
             for k in ("achieved", "frac", "frac_per_gpu", "traffic", "kernel_avg_us"):
                 result["roofline"][k] = None
