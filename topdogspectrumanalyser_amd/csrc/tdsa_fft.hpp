@@ -153,14 +153,16 @@ __device__ __forceinline__ void bf_w(c32& e, c32& o) {
 
 // In-place radix-R DIT on the registers v[BASE + i*STRIDE], i < R (natural input order): afterwards
 // X[k] = v[BASE + STRIDE * bitrev(k, log2 R)] - the same output convention as dif<>.
-template <int R, int BASE, int STRIDE, int TOT>
+// SKIP_FIRST: the first layer (the R == 2 leaves: pairs b, b + TOT_R/2) has already been done by the caller
+// (bf_tw below, fused with the pass's pre-twiddle)
+template <int R, int BASE, int STRIDE, int TOT, bool SKIP_FIRST = false>
 __device__ __forceinline__ void dit_s(c32 (&v)[TOT]) {
   if constexpr (R == 2) {
-    bf_w<0, 2>(v[BASE], v[BASE + STRIDE]);
+    if constexpr (!SKIP_FIRST) bf_w<0, 2>(v[BASE], v[BASE + STRIDE]);
   } else if constexpr (R > 2) {
     constexpr int h = R / 2, L1 = ilog2(h);
-    dit_s<h, BASE, 2 * STRIDE, TOT>(v);              // E = DFT of the even samples
-    dit_s<h, BASE + STRIDE, 2 * STRIDE, TOT>(v);     // O = DFT of the odd samples
+    dit_s<h, BASE, 2 * STRIDE, TOT, SKIP_FIRST>(v);              // E = DFT of the even samples
+    dit_s<h, BASE + STRIDE, 2 * STRIDE, TOT, SKIP_FIRST>(v);     // O = DFT of the odd samples
     static_for<0, h>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
       constexpr int slot = BASE + 2 * STRIDE * bitrev(k, L1);       // E[k]; O[k] sits STRIDE above
@@ -170,6 +172,20 @@ __device__ __forceinline__ void dit_s(c32 (&v)[TOT]) {
 }
 template <int R, int BASE, int TOT>
 __device__ __forceinline__ void dit(c32 (&v)[TOT]) { dit_s<R, BASE, 1, TOT>(v); }
+// the same network without its first layer
+template <int R, int BASE, int TOT>
+__device__ __forceinline__ void dit_rest(c32 (&v)[TOT]) { dit_s<R, BASE, 1, TOT, true>(v); }
+
+// First layer of a pass fused with the pass's pre-twiddle:  (e, o) -> (e te + o to, e te - o to)  in ten
+// instructions (cmul for e te, four FMAs for the sum, the difference as 2 e te - sum) instead of twelve
+// (two complex multiplies, add, subtract)
+__device__ __forceinline__ void bf_tw(c32& e, c32& o, c32 te, c32 to) {
+  const c32 et = cmul(e, te);
+  const float x1 = fmaf(to.x, o.x, fmaf(-to.y, o.y, et.x));
+  const float y1 = fmaf(to.x, o.y, fmaf(to.y, o.x, et.y));
+  o = c32{fmaf(2.0f, et.x, -x1), fmaf(2.0f, et.y, -y1)};
+  e = c32{x1, y1};
+}
 
 // Same butterfly network, depth first, calling emit(integral_constant<register index>) as soon as a
 // register holds a final output: the LDS stores of the first outputs then issue while the rest of the

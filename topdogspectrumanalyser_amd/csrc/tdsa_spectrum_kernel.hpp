@@ -659,6 +659,27 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       int tw_o = h * A + ka_mid;
       asm volatile("" : "+v"(tw_o));                        // keep the table reads inside the loop
       // two batches of eight table reads, each issued back to back and waited for once
+#ifndef TDSA_UNFUSED_TW   // (-DTDSA_UNFUSED_TW: the separate pre-twiddle of rounds 1-2, kept for A/B timing)
+      // batch k serves the pairs (i, i + 8), i = 4k .. 4k + 3, of the radix-16's first layer: the pre-twiddle rides
+      // that layer's butterflies (bf_tw: 10 instead of 12 instructions per pair)
+      static_for<0, 2>([&](auto bc) {
+        constexpr int b0 = decltype(bc)::value * 4;
+        c32 tw8[8];
+        static_for<0, 8>([&](auto ic) {
+          constexpr int q = decltype(ic)::value;
+          constexpr int i = b0 + (q & 3) + 8 * (q >> 2);
+          tw8[q] = twm[tw_o + i * 2 * A];
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 4>([&](auto ic) {
+          constexpr int q = decltype(ic)::value;
+          bf_tw(v[b0 + q], v[b0 + q + 8], tw8[q], tw8[q + 4]);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      TDSA_STAMP(6);
+      dit_rest<16, 0, 16>(v);
+#else
       static_for<0, 2>([&](auto bc) {
         constexpr int b0 = decltype(bc)::value * 8;
         c32 tw8[8];
@@ -676,6 +697,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       });
       TDSA_STAMP(6);
       radix<16, 0, 16>(v);
+#endif
       static_for<0, 8>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
         constexpr int re = bitrev(u, 4), ro = bitrev(u + 8, 4);
@@ -703,6 +725,16 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     TDSA_STAMP(9);
     static_for<0, 3>([&](auto ic) { opaque(twf_lo[decltype(ic)::value]); });
     static_for<0, 4>([&](auto ic) { opaque(twf_hi[decltype(ic)::value]); });
+#ifndef TDSA_UNFUSED_TW   // (-DTDSA_UNFUSED_TW: the separate pre-twiddle of rounds 1-2, kept for A/B timing)
+    static_for<0, 8>([&](auto ic) {                          // pre-twiddle W_N^(t*(2i+h)), i = 4a + j, fused with the
+      constexpr int i = decltype(ic)::value;                 // radix-16's first layer: pairs (i, i + 8) = (a, a + 2)
+      constexpr int a = i >> 2, j = i & 3;
+      c32 te = twf_hi[a], to = twf_hi[a + 2];
+      if constexpr (j != 0) { te = cmul(te, twf_lo[j - 1]); to = cmul(to, twf_lo[j - 1]); }
+      bf_tw(v[i], v[i + 8], te, to);
+    });
+    dit_rest<16, 0, 16>(v);
+#else
     static_for<0, 16>([&](auto ic) {                         // pre-twiddle W_N^(t*(2i+h)), i = 4a + j
       constexpr int i = decltype(ic)::value;
       constexpr int a = i >> 2, j = i & 3;
@@ -711,6 +743,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       else v[i] = cmul(v[i], cmul(twf_hi[a], twf_lo[j - 1]));
     });
     if constexpr ((TDSA_ABLATE & 512) == 0) radix<16, 0, 16>(v);
+#endif
     static_for<0, 8>([&](auto uc) {
       constexpr int u = decltype(uc)::value;
       constexpr int re = bitrev(u, 4), ro = bitrev(u + 8, 4);
