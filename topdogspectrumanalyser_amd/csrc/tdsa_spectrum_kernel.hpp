@@ -592,18 +592,51 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     if constexpr (C::WIN_LDS) load_window();
 
     // ---- unpack + DC removal + window ------------------------------------------------------------
+    // FUSE_WIN: the window multiply rides the first butterfly layer of pass 1 (pairs i, i + H/2 of every radix-H
+    // group):  (e we + o wo, e we - o wo)  as  mul, fma, fma  per component instead of  mul, mul, add, sub  -
+    // 16 instructions less per thread and frame; here the samples are only unpacked and DC-freed
+#if defined(TDSA_UNFUSED_WIN) || defined(TDSA_DIF)
+    constexpr bool FUSE_WIN = false;
+#else
+    constexpr bool FUSE_WIN = !ACC && H >= 2;
+#endif
+    auto put = [&](auto ic, float xr, float xi) {          // sample idx, DC-free -> v[idx] (windowed unless fused)
+      constexpr int idx = decltype(ic)::value;
+      if constexpr (FUSE_WIN) v[idx] = c32{xr, xi};
+      else v[idx] = c32{xr * win[idx], xi * win[idx]};
+    };
     if constexpr (ACC) {
       // rows arrive windowed, DC-free and pre-twiddled from the column pass
     } else if constexpr (IN_C64) {
       static_for<0, 16>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        v[i] = c32{(v[i].x - sub_re) * win[i], (v[i].y - sub_im) * win[i]};
+        put(ic, v[i].x - sub_re, v[i].y - sub_im);
       });
     } else if constexpr (M == 1) {
       static_for<0, 16>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         const uint32_t u = raw[i];
-        v[i] = c32{(float(u & 0xffu) - sub_re) * win[i], (float((u >> 8) & 0xffu) - sub_im) * win[i]};
+        put(ic, float(u & 0xffu) - sub_re, float((u >> 8) & 0xffu) - sub_im);
+      });
+    } else if constexpr (FUSE_WIN) {
+      // pair by pair (rows i and i + H/2 of the same butterfly), so that raw bytes and window values die as they are used
+      auto pair = [&](auto ac, float exr, float exi, float oxr, float oxi) {
+        constexpr int a = decltype(ac)::value, b = a + H / 2;
+        const float er = (exr - sub_re) * win[a], ei = (exi - sub_im) * win[a];
+        const float orr = oxr - sub_re, oi = oxi - sub_im;
+        v[a] = c32{fmaf(orr, win[b], er), fmaf(oi, win[b], ei)};
+        v[b] = c32{fmaf(-orr, win[b], er), fmaf(-oi, win[b], ei)};
+      };
+      static_for<0, H / 2>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        static_for<0, DW>([&](auto dc) {
+          constexpr int d = decltype(dc)::value;
+          const uint32_t ue = raw[i * DW + d], uo = raw[(i + H / 2) * DW + d];
+          pair(std::integral_constant<int, (2 * d) * H + i>{}, float(ue & 0xffu), float((ue >> 8) & 0xffu),
+               float(uo & 0xffu), float((uo >> 8) & 0xffu));
+          pair(std::integral_constant<int, (2 * d + 1) * H + i>{}, float((ue >> 16) & 0xffu), float(ue >> 24),
+               float((uo >> 16) & 0xffu), float(uo >> 24));
+        });
       });
     } else {
       static_for<0, H>([&](auto ic) {
@@ -612,8 +645,21 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
           constexpr int d = decltype(dc)::value;
           const uint32_t u = raw[i * DW + d];
           constexpr int i0 = (2 * d) * H + i, i1 = (2 * d + 1) * H + i;
-          v[i0] = c32{(float(u & 0xffu) - sub_re) * win[i0], (float((u >> 8) & 0xffu) - sub_im) * win[i0]};
-          v[i1] = c32{(float((u >> 16) & 0xffu) - sub_re) * win[i1], (float(u >> 24) - sub_im) * win[i1]};
+          put(std::integral_constant<int, i0>{}, float(u & 0xffu) - sub_re, float((u >> 8) & 0xffu) - sub_im);
+          put(std::integral_constant<int, i1>{}, float((u >> 16) & 0xffu) - sub_re, float(u >> 24) - sub_im);
+        });
+      });
+    }
+    if constexpr (FUSE_WIN && (IN_C64 || M == 1)) {
+      // first layer of every radix-H group with the window folded in (the byte path above did it on the way)
+      static_for<0, M>([&](auto jc) {
+        constexpr int jj = decltype(jc)::value;
+        static_for<0, H / 2>([&](auto ic) {
+          constexpr int a = jj * H + decltype(ic)::value, b = a + H / 2;
+          const float er = v[a].x * win[a], ei = v[a].y * win[a];
+          const float orr = v[b].x, oi = v[b].y;
+          v[a] = c32{fmaf(orr, win[b], er), fmaf(oi, win[b], ei)};
+          v[b] = c32{fmaf(-orr, win[b], er), fmaf(-oi, win[b], ei)};
         });
       });
     }
@@ -621,11 +667,25 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       // Tracked DC remover: x - in_off above is exact (small integers / halves), the estimate follows as its own
       // term, v -= dc * w, instead of one float32 "128 + dc" whose 2^-17 LSB of resolution would add up coherently
       // in the DC bin (it was worth up to 3.8 rounding units of A_max there).  Wave-uniform branch, this mode only.
+      // Behind the fused first layer the term of a pair (a, b) is dc (w_a + w_b) on the sum and dc (w_a - w_b) on
+      // the difference.
       if (p.dc_mode == DC_TRACKED) {
-        static_for<0, 16>([&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          v[i] = c32{fmaf(-res_re, win[i], v[i].x), fmaf(-res_im, win[i], v[i].y)};
-        });
+        if constexpr (FUSE_WIN) {
+          static_for<0, M>([&](auto jc) {
+            constexpr int jj = decltype(jc)::value;
+            static_for<0, H / 2>([&](auto ic) {
+              constexpr int a = jj * H + decltype(ic)::value, b = a + H / 2;
+              const float ws = win[a] + win[b], wd = win[a] - win[b];
+              v[a] = c32{fmaf(-res_re, ws, v[a].x), fmaf(-res_im, ws, v[a].y)};
+              v[b] = c32{fmaf(-res_re, wd, v[b].x), fmaf(-res_im, wd, v[b].y)};
+            });
+          });
+        } else {
+          static_for<0, 16>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            v[i] = c32{fmaf(-res_re, win[i], v[i].x), fmaf(-res_im, win[i], v[i].y)};
+          });
+        }
       }
     }
     TDSA_STAMP(3);
@@ -633,7 +693,8 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     if (unit + 1 < u1) load_frame_raw((unit + 1) * FPW + slot);
 
     // ---- pass 1: per lane M radix-H DFTs on the even (odd) rows, then the cross-lane combine ------
-    static_for<0, M>([&](auto jc) { radix<H, decltype(jc)::value * H, 16>(v); });
+    if constexpr (FUSE_WIN) static_for<0, M>([&](auto jc) { dit_rest<H, decltype(jc)::value * H, 16>(v); });
+    else static_for<0, M>([&](auto jc) { radix<H, decltype(jc)::value * H, 16>(v); });
     static_for<0, 8>([&](auto uc) {
       constexpr int u = decltype(uc)::value;
       constexpr int jj0 = u / H, k0 = u % H, jj1 = (u + 8) / H, k1 = (u + 8) % H;
