@@ -265,9 +265,25 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   using C = Cfg<LOG2N>;
   constexpr int N = C::N, SG = C::SG, A = C::A, M = C::M, H = C::H, FPW = C::FPW, NPAD = C::NPAD;
   constexpr int LH = ilog2(H);
-  constexpr int DW = (M >= 2) ? M / 2 : 1;        // raw dwords per first-pass row
-  constexpr int NRAW = IN_C64 ? 1 : H * DW;       // rows a = 2i + h, i < H
+  // Pass 1 of a row = M adjacent radix-A butterflies.  INL: each half-thread takes M/2 of them WHOLE - all A input
+  // rows of its M/2 adjacent columns - and pass 1 stays inside the lane (no half-thread exchange: 16
+  // v_permlane32_swap less per thread and frame).  It costs twice the row reads of half the width, which is why it
+  // only pays where a row read stays >= 8 bytes: same-box A/B (profiles/r03_c3_experiments.txt) N = 4096 -2.6 %,
+  // 2048 -2.3 %, but 8192 (4-byte reads) +1.4 %, 256 +2.9 %, 128 +-0.  M = 2 (N = 16384, 512) would need 2-byte
+  // loads into twice the registers (gfx950's d16 loads do not preserve the other half with SRAM ECC on), M = 1 is
+  // one radix-32 butterfly per row: all of those keep the even / odd row split with the swap + combine stage.
+#ifdef TDSA_NO_INL    // developer A/B: the even / odd row split at every size, as in rounds 1-2
+  constexpr bool INL = false;
+#else
+  constexpr bool INL = (M >= 8) && (C::NPASS == 3) && !ACC;
+#endif
+  constexpr int R1 = INL ? A : H;                 // radix done inside one lane in pass 1
+  constexpr int LR1 = ilog2(R1);
+  constexpr int CPT = INL ? M / 2 : M;            // adjacent columns (samples) per row read of a half-thread
+  constexpr int DW = (CPT >= 2) ? CPT / 2 : 1;    // raw dwords per row read
+  constexpr int NRAW = IN_C64 ? 1 : R1 * DW;      // row reads r < R1: input row a = r (INL) or 2r + h
   constexpr int ROWB = (N / A) * 2;               // bytes per first-pass row (byte formats)
+  constexpr int RSTEP = INL ? 1 : 2;              // input rows between two row reads of a half-thread
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   c32* lds = reinterpret_cast<c32*>(smem);
@@ -317,7 +333,8 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     for (int i = tid; i < N; i += C::WGT) win_lds[i] = p.window[i];
     __syncthreads();
   }
-  const unsigned win_voff = unsigned(h) * (N / A) * 4u + unsigned(t) * (M * 4u);
+  const unsigned win_voff = INL ? (unsigned(t) * M + unsigned(h) * CPT) * 4u
+                                : unsigned(h) * (N / A) * 4u + unsigned(t) * (M * 4u);
   const bool odd_half = h != 0;   // upper half-wave: its radix-32 combine twiddle is W_32^(u+8) = -i * W_32^u
   float pacc[ACC ? 16 : 1];                 // ACC: linear power summed over the frames of one group
   static_for<0, (ACC ? 16 : 1)>([&](auto ic) { pacc[decltype(ic)::value] = 0.f; });
@@ -337,7 +354,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   const float cal_v = in_vgpr(p.cal_db);
 
   // LDS addressing in complex elements: element i of a pass lives at i + (i >> 5)
-  const int wr1_base = 33 * t + (A == 32 ? 8 : 16) * h;          // pass 1 writes row t
+  const int wr1_base = 33 * t + (A == 32 ? 8 : 16) * h;          // pass 1 writes row t (INL: CPT * A = 16 elements per half)
   constexpr int rd_stride = SG + SG / 32;
   const int rd_base = (SG % 32 == 0) ? t + (t >> 5) : 0;         // gather of y[t + b*SG]
   const int rdA = rd_base + h * rd_stride;                       // element b = 2i + h
@@ -345,8 +362,9 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   const int ka_mid = t % A;
   const int rd3A = (t / A) * rd_stride + ka_mid + h * A;         // last gather, element c = 2i + h
 
-  const unsigned lane_in_off = unsigned(t) * (IN_C64 ? M * 8u : M * 2u) +
-                               unsigned(h) * (IN_C64 ? (N / A) * 8u : unsigned(ROWB));
+  constexpr unsigned SB = IN_C64 ? 8u : 2u;                      // bytes per sample
+  const unsigned lane_in_off = INL ? (unsigned(t) * M + unsigned(h) * CPT) * SB
+                                   : unsigned(t) * (M * SB) + unsigned(h) * ((N / A) * SB);
   const unsigned out_voff = unsigned(t) * 4u + unsigned(h) * (8u * SG * 4u);
   // frame -> byte offset of its samples / element offset of its output row (several captures per launch:
   // SpecParams::seg_*; with one capture seg_magic = 0 and these are frame * frame_stride, frame * N)
@@ -366,20 +384,21 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   // issued behind the stores can only be waited for together with them - the waves that reach the next
   // barrier last would sit through their own stores' round trip to memory on the critical path.  The
   // reload is unconditional (the last one is simply unused) so that the old values are dead in between.
-  float win[16];                                            // win[jj*H + i] = w[(2i+h)*(N/A) + t*M + jj]
+  float win[16];                       // win[c*R1 + r] = w[a(r)*(N/A) + t*M + c (+ h*CPT if INL)], a(r) = r (INL) or 2r + h
   auto load_window = [&] {
-    static_for<0, H>([&](auto ic) {
+    static_for<0, R1>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      uint32_t wq[M];
+      uint32_t wq[CPT];
       if constexpr (C::WIN_LDS) {
-        static_for<0, M>([&](auto jc) {
+        static_for<0, CPT>([&](auto jc) {
           constexpr int jj = decltype(jc)::value;
-          wq[jj] = __float_as_uint(win_lds[(2 * i + h) * (N / A) + t * M + jj]);
+          if constexpr (INL) wq[jj] = __float_as_uint(win_lds[i * (N / A) + t * M + h * CPT + jj]);
+          else wq[jj] = __float_as_uint(win_lds[(2 * i + h) * (N / A) + t * M + jj]);
         });
       } else {
-        buf_load<M>(win_rsrc, win_voff, 2 * i * (N / A) * 4u, wq);
+        buf_load<CPT>(win_rsrc, win_voff, RSTEP * i * (N / A) * 4u, wq);
       }
-      static_for<0, M>([&](auto jc) { constexpr int jj = decltype(jc)::value; win[jj * H + i] = __uint_as_float(wq[jj]); });
+      static_for<0, CPT>([&](auto jc) { constexpr int jj = decltype(jc)::value; win[jj * R1 + i] = __uint_as_float(wq[jj]); });
     });
   };
   uint32_t raw[NRAW];
@@ -389,14 +408,14 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       const unsigned char* fb = static_cast<const unsigned char*>(p.in) + in_byte_off(frame);
       if constexpr (FPW == 1 && M >= 2) {   // frame is workgroup-uniform: SGPR descriptor + lane offset
         const rsrc_t r = make_rsrc(fb, N * 2u);
-        static_for<0, H>([&](auto ic) {
+        static_for<0, R1>([&](auto ic) {
           constexpr int i = decltype(ic)::value;
-          buf_load<DW>(r, lane_in_off, 2 * i * ROWB, &raw[i * DW]);
+          buf_load<DW>(r, lane_in_off, RSTEP * i * ROWB, &raw[i * DW]);
         });
       } else {
-        static_for<0, H>([&](auto ic) {
+        static_for<0, R1>([&](auto ic) {
           constexpr int i = decltype(ic)::value;
-          const unsigned char* row = fb + 2 * i * ROWB + lane_in_off;
+          const unsigned char* row = fb + RSTEP * i * ROWB + lane_in_off;
           if (act) {
             if constexpr (M == 1) raw[i] = *reinterpret_cast<const uint16_t*>(row);
             else load_raw<DW>(row, &raw[i * DW]);
@@ -462,12 +481,12 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       const unsigned char* fb = static_cast<const unsigned char*>(p.in) + in_byte_off(frame);
       static_for<0, 16>([&](auto ic) {
         constexpr int idx = decltype(ic)::value;
-        constexpr int jj = idx / H, i = idx % H;
-        const c32* row = reinterpret_cast<const c32*>(fb + 2 * i * (N / A) * 8 + lane_in_off);
+        constexpr int jj = idx / R1, i = idx % R1;
+        const c32* row = reinterpret_cast<const c32*>(fb + RSTEP * i * (N / A) * 8 + lane_in_off);
         if constexpr (HOLD == 0) {
           // zero-padded rows (chirp-z plans): the padding is not read.  Sample index of this element:
-          // (2 i + h) N/A + t M + jj
-          const int n_idx = (2 * i) * (N / A) + h * (N / A) + t * M + jj;
+          // a(i) N/A + t M + jj (+ h CPT), a(i) = i or 2 i + h
+          const int n_idx = INL ? i * (N / A) + t * M + h * CPT + jj : (2 * i) * (N / A) + h * (N / A) + t * M + jj;
           const bool there = active && (p.in_valid == 0 || n_idx < p.in_valid);
           v[idx] = there ? row[jj] : c32{0.f, 0.f};
         } else {
@@ -592,13 +611,14 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     if constexpr (C::WIN_LDS) load_window();
 
     // ---- unpack + DC removal + window ------------------------------------------------------------
-    // FUSE_WIN: the window multiply rides the first butterfly layer of pass 1 (pairs i, i + H/2 of every radix-H
+    // v[c*R1 + r] = sample of row read r (input row a(r)), column c of this half-thread (c < CPT).
+    // FUSE_WIN: the window multiply rides the first butterfly layer of pass 1 (pairs r, r + R1/2 of every radix-R1
     // group):  (e we + o wo, e we - o wo)  as  mul, fma, fma  per component instead of  mul, mul, add, sub  -
     // 16 instructions less per thread and frame; here the samples are only unpacked and DC-freed
 #if defined(TDSA_UNFUSED_WIN) || defined(TDSA_DIF)
     constexpr bool FUSE_WIN = false;
 #else
-    constexpr bool FUSE_WIN = !ACC && H >= 2;
+    constexpr bool FUSE_WIN = !ACC && R1 >= 2;
 #endif
     auto put = [&](auto ic, float xr, float xi) {          // sample idx, DC-free -> v[idx] (windowed unless fused)
       constexpr int idx = decltype(ic)::value;
@@ -619,43 +639,44 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
         put(ic, float(u & 0xffu) - sub_re, float((u >> 8) & 0xffu) - sub_im);
       });
     } else if constexpr (FUSE_WIN) {
-      // pair by pair (rows i and i + H/2 of the same butterfly), so that raw bytes and window values die as they are used
+      // pair by pair (row reads r and r + R1/2 of the same butterfly), so that raw bytes and window values die as they
+      // are used
       auto pair = [&](auto ac, float exr, float exi, float oxr, float oxi) {
-        constexpr int a = decltype(ac)::value, b = a + H / 2;
+        constexpr int a = decltype(ac)::value, b = a + R1 / 2;
         const float er = (exr - sub_re) * win[a], ei = (exi - sub_im) * win[a];
         const float orr = oxr - sub_re, oi = oxi - sub_im;
         v[a] = c32{fmaf(orr, win[b], er), fmaf(oi, win[b], ei)};
         v[b] = c32{fmaf(-orr, win[b], er), fmaf(-oi, win[b], ei)};
       };
-      static_for<0, H / 2>([&](auto ic) {
+      static_for<0, R1 / 2>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         static_for<0, DW>([&](auto dc) {
           constexpr int d = decltype(dc)::value;
-          const uint32_t ue = raw[i * DW + d], uo = raw[(i + H / 2) * DW + d];
-          pair(std::integral_constant<int, (2 * d) * H + i>{}, float(ue & 0xffu), float((ue >> 8) & 0xffu),
+          const uint32_t ue = raw[i * DW + d], uo = raw[(i + R1 / 2) * DW + d];
+          pair(std::integral_constant<int, (2 * d) * R1 + i>{}, float(ue & 0xffu), float((ue >> 8) & 0xffu),
                float(uo & 0xffu), float((uo >> 8) & 0xffu));
-          pair(std::integral_constant<int, (2 * d + 1) * H + i>{}, float((ue >> 16) & 0xffu), float(ue >> 24),
+          pair(std::integral_constant<int, (2 * d + 1) * R1 + i>{}, float((ue >> 16) & 0xffu), float(ue >> 24),
                float((uo >> 16) & 0xffu), float(uo >> 24));
         });
       });
     } else {
-      static_for<0, H>([&](auto ic) {
+      static_for<0, R1>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         static_for<0, DW>([&](auto dc) {
           constexpr int d = decltype(dc)::value;
           const uint32_t u = raw[i * DW + d];
-          constexpr int i0 = (2 * d) * H + i, i1 = (2 * d + 1) * H + i;
+          constexpr int i0 = (2 * d) * R1 + i, i1 = (2 * d + 1) * R1 + i;
           put(std::integral_constant<int, i0>{}, float(u & 0xffu) - sub_re, float((u >> 8) & 0xffu) - sub_im);
           put(std::integral_constant<int, i1>{}, float((u >> 16) & 0xffu) - sub_re, float(u >> 24) - sub_im);
         });
       });
     }
     if constexpr (FUSE_WIN && (IN_C64 || M == 1)) {
-      // first layer of every radix-H group with the window folded in (the byte path above did it on the way)
-      static_for<0, M>([&](auto jc) {
+      // first layer of every radix-R1 group with the window folded in (the byte path above did it on the way)
+      static_for<0, CPT>([&](auto jc) {
         constexpr int jj = decltype(jc)::value;
-        static_for<0, H / 2>([&](auto ic) {
-          constexpr int a = jj * H + decltype(ic)::value, b = a + H / 2;
+        static_for<0, R1 / 2>([&](auto ic) {
+          constexpr int a = jj * R1 + decltype(ic)::value, b = a + R1 / 2;
           const float er = v[a].x * win[a], ei = v[a].y * win[a];
           const float orr = v[b].x, oi = v[b].y;
           v[a] = c32{fmaf(orr, win[b], er), fmaf(oi, win[b], ei)};
@@ -671,10 +692,10 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       // the difference.
       if (p.dc_mode == DC_TRACKED) {
         if constexpr (FUSE_WIN) {
-          static_for<0, M>([&](auto jc) {
+          static_for<0, CPT>([&](auto jc) {
             constexpr int jj = decltype(jc)::value;
-            static_for<0, H / 2>([&](auto ic) {
-              constexpr int a = jj * H + decltype(ic)::value, b = a + H / 2;
+            static_for<0, R1 / 2>([&](auto ic) {
+              constexpr int a = jj * R1 + decltype(ic)::value, b = a + R1 / 2;
               const float ws = win[a] + win[b], wd = win[a] - win[b];
               v[a] = c32{fmaf(-res_re, ws, v[a].x), fmaf(-res_im, ws, v[a].y)};
               v[b] = c32{fmaf(-res_re, wd, v[b].x), fmaf(-res_im, wd, v[b].y)};
@@ -692,9 +713,18 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     // raw registers are free again: start the next frame's HBM read now, it lands during the FFT
     if (unit + 1 < u1) load_frame_raw((unit + 1) * FPW + slot);
 
-    // ---- pass 1: per lane M radix-H DFTs on the even (odd) rows, then the cross-lane combine ------
-    if constexpr (FUSE_WIN) static_for<0, M>([&](auto jc) { dit_rest<H, decltype(jc)::value * H, 16>(v); });
-    else static_for<0, M>([&](auto jc) { radix<H, decltype(jc)::value * H, 16>(v); });
+    // ---- pass 1: per lane CPT radix-R1 DFTs; INL: that is the whole pass, else (even / odd input rows per
+    //      half-thread) the cross-lane combine follows ------------------------------------------------
+    if constexpr (FUSE_WIN) static_for<0, CPT>([&](auto jc) { dit_rest<R1, decltype(jc)::value * R1, 16>(v); });
+    else static_for<0, CPT>([&](auto jc) { radix<R1, decltype(jc)::value * R1, 16>(v); });
+    if constexpr (INL) {
+      // butterfly g of this half-thread is butterfly h*CPT + g of the row: X[k] -> element (h*CPT + g)*A + k
+      static_for<0, 16>([&](auto ec) {
+        constexpr int e = decltype(ec)::value;
+        constexpr int g = e / A, k = e % A;
+        if constexpr ((TDSA_ABLATE & 2) == 0) lds_st(&buf[wr1_base + e], v[g * A + bitrev(k, LR1)]);
+      });
+    } else {
     static_for<0, 8>([&](auto uc) {
       constexpr int u = decltype(uc)::value;
       constexpr int jj0 = u / H, k0 = u % H, jj1 = (u + 8) / H, k1 = (u + 8) % H;
@@ -705,6 +735,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       constexpr int li = jj0 * A + k0;                       // + lane offset folded into wr1_base
       if constexpr ((TDSA_ABLATE & 2) == 0) { lds_st(&buf[wr1_base + li], v[re]); lds_st(&buf[wr1_base + li + H], v[ro]); }
     });
+    }
     TDSA_STAMP(4);
     if constexpr (ACC) { if (unit + 1 < u1) load_frame_c64((unit + 1) * FPW + slot); }
     TDSA_SYNC();
