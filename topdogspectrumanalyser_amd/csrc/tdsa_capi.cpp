@@ -57,6 +57,7 @@ struct tdsa_plan_s {
   tdsa_mode mode{};
   bool window_set = false;
   float* d_window[3] = {nullptr, nullptr, nullptr};   // window * input scale, per input format
+  float* d_window_perm[3] = {nullptr, nullptr, nullptr};   // the same in the frame kernel's thread order (N >= 2048)
   float2* d_tw = nullptr;
   float* d_hold_max = nullptr;
   float* d_hold_min = nullptr;
@@ -242,6 +243,7 @@ int process_big(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n_f
     sp.n_frames = n1 * ns;
     sp.first_frame_index = 1;
     sp.window = p->d_ones;
+    sp.window_perm = p->d_ones;                                 // all ones: any order
     sp.tw = p->d_tw_row;
     sp.in_scale = 1.0f;
     sp.dc_mode = DC_NONE;
@@ -312,6 +314,7 @@ int chirp_transform(tdsa_plan p, const void* in, int in_format, long long stride
   sp.n_frames = n_frames;
   sp.first_frame_index = 1;
   sp.window = p->d_ones;
+  sp.window_perm = p->d_ones;
   sp.tw = p->d_tw;
   sp.in_scale = 1.0f;
   sp.dc_mode = DC_NONE;
@@ -470,6 +473,8 @@ static int plan_init(tdsa_plan p) {
   HIPCHK(hipEventCreateWithFlags(&p->ev_state, hipEventDisableTiming));
   const size_t nb = size_t(nfft) * sizeof(float);
   for (int f = 0; f < 3; ++f) HIPCHK(hipMalloc(&p->d_window[f], nb));
+  if (!p->big && !p->chirp)
+    for (int f = 0; f < 3; ++f) HIPCHK(hipMalloc(&p->d_window_perm[f], nb));
   const int tw_n = p->chirp ? p->m_fft : nfft;       // the size the frame kernel transforms
   HIPCHK(hipMalloc(&p->d_tw, size_t(tw_n) * sizeof(float2)));
   HIPCHK(hipMalloc(&p->d_hold_max, nb));
@@ -595,7 +600,8 @@ int tdsa_destroy(tdsa_plan p) {
   for (hipStream_t a : p->aux)
     if (a) (void)hipStreamSynchronize(a);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
-  void* bufs[] = {p->d_window[0], p->d_window[1], p->d_window[2], p->d_tw, p->d_hold_max, p->d_hold_min,
+  void* bufs[] = {p->d_window[0], p->d_window[1], p->d_window[2], p->d_window_perm[0], p->d_window_perm[1],
+                  p->d_window_perm[2], p->d_tw, p->d_hold_max, p->d_hold_min,
                   p->d_avg, p->d_lin, p->d_carry, p->d_cplx, p->d_real, p->d_lin1, p->d_db1, p->d_dc_state, p->d_sums, p->d_dc_sub,
                   p->d_tare_base, p->d_tare_acc, p->d_in_stage, p->d_out_stage, p->d_trace_in,
                   p->d_trace_live, p->d_scratch, p->d_z, p->d_chirp_a, p->d_chirp_b, p->d_u0, p->d_u1, p->d_acc, p->d_sum, p->d_lin64, p->d_sums64, p->d_tw_hi, p->d_tw_lo, p->d_tw_row, p->d_ones,
@@ -647,6 +653,7 @@ int tdsa_set_window(tdsa_plan p, const float* w_host, int n) {
   for (int f = 0; f < 3; ++f) {
     for (int i = 0; i < n; ++i) tmp[i] = w_host[i] * scale[f];
     HIPCHK(hipMemcpy(p->d_window[f], tmp.data(), size_t(n) * sizeof(float), hipMemcpyHostToDevice));
+    if (p->d_window_perm[f]) HIPCHK(launch_window_perm(p->log2n, p->d_window[f], p->d_window_perm[f], p->stream));
   }
   p->window_set = true;
   return TDSA_OK;
@@ -781,6 +788,7 @@ static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size
   sp.n_frames = n_frames;
   sp.first_frame_index = p->frames_seen > 0 ? 1 : 0;
   sp.window = p->d_window[in_format];
+  sp.window_perm = p->d_window_perm[in_format];
   sp.tw = p->d_tw;
   sp.xor_mask = in_format == TDSA_IN_I8 ? 0x80808080u : 0u;
   sp.in_off = in_format == TDSA_IN_I8 ? 128.0f : (in_format == TDSA_IN_U8 ? 127.5f : 0.0f);
@@ -1078,6 +1086,7 @@ int tdsa_process_real2(tdsa_plan p, const float* lr_host, size_t n_samples, int 
     sp.n_frames = n_frames;
     sp.first_frame_index = 1;
     sp.window = p->d_window[TDSA_IN_C64];
+    sp.window_perm = p->d_window_perm[TDSA_IN_C64];
     sp.tw = p->d_tw;
     sp.out_cplx = p->d_cplx;
     sp.in_scale = 1.0f;

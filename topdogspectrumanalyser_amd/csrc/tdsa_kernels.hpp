@@ -33,7 +33,8 @@ struct SpecParams {
   long long frame_stride;    // bytes between consecutive frame starts (hop * bytes per sample)
   int n_frames;
   int first_frame_index;     // global index of frame 0 of this launch (nan_safe semantics of frame 0)
-  const float* window;       // [N] window * input scale
+  const float* window;       // [N] window * input scale (natural order: sizes that keep it in LDS, N <= 1024)
+  const float* window_perm;  // [N] the same values in the frame kernel's thread order (launch_window_perm), N >= 2048
   const float2* tw;          // [N] exp(-2 pi i m / N)
   float* out_db;             // [F][N] fftshift-ed dB, or null
   float* out_lin;            // [F][N] fftshift-ed linear power * pscale (averaging modes), or null
@@ -87,6 +88,9 @@ struct LaunchGeom {
 LaunchGeom spectrum_geometry(int log2n, int n_frames, int num_cu);
 hipError_t launch_spectrum(int log2n, int in_c64, const SpecParams& p, const LaunchGeom& g,
                            hipStream_t s);
+// window table in the order the frame kernel's threads consume it: thread (t, h) of a frame finds its 16 values as
+// 64 contiguous bytes (4 x 16-byte loads per frame instead of 8 x 8 at N = 16384); no-op for N <= 1024
+hipError_t launch_window_perm(int log2n, const float* w, float* w_perm, hipStream_t s);
 
 struct AvgParams {
   const float* lin;       // [F][N] linear power (already PSD-scaled)

@@ -15,6 +15,10 @@ template <>
 LaunchGeom geom_size<TDSA_LOG2N>(int n_frames, int num_cu) {
   return geom_for<TDSA_LOG2N>(n_frames, num_cu);
 }
+template <>
+hipError_t perm_size<TDSA_LOG2N>(const float* w, float* wp, hipStream_t s) {
+  return perm_for<TDSA_LOG2N>(w, wp, s);
+}
 #if TDSA_LOG2N == 14
 hipError_t launch_spectrum_acc(const SpecParams& p, const LaunchGeom& g, hipStream_t s) { return launch_acc<14>(p, g, s); }
 #endif

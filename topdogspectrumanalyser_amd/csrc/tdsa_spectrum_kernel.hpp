@@ -41,7 +41,16 @@ struct Cfg {
   static constexpr int NPASS = (N >= 2048) ? 3 : 2;
   static constexpr int A = (NPASS == 3) ? N / 1024 : N / 32;  // radix of the first pass
   static constexpr int M = 32 / A;                        // adjacent first-pass butterflies per row
-  static constexpr int H = A / 2;                         // first-pass radix done inside one lane
+  static constexpr int H = A / 2;                         // first-pass radix done inside one lane (even / odd row split)
+  // INL: pass 1 entirely inside a lane (see the kernel); R1 = in-lane radix of pass 1, CPT = adjacent columns
+  // (samples) per row read of a half-thread
+#ifdef TDSA_NO_INL    // developer A/B: the even / odd row split at every size, as in rounds 1-2
+  static constexpr bool INL = false;
+#else
+  static constexpr bool INL = (M >= 8) && (NPASS == 3);
+#endif
+  static constexpr int R1 = INL ? A : H;
+  static constexpr int CPT = INL ? M / 2 : M;
   static constexpr int WGT = TPF > 256 ? TPF : 256;       // threads per workgroup
   static constexpr int FPW = WGT / TPF;                   // frames in flight per workgroup
   static constexpr int NPAD = N + N / 32;                 // LDS slot: rows of 32 complex + 1 pad element
@@ -272,14 +281,10 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   // 2048 -2.3 %, but 8192 (4-byte reads) +1.4 %, 256 +2.9 %, 128 +-0.  M = 2 (N = 16384, 512) would need 2-byte
   // loads into twice the registers (gfx950's d16 loads do not preserve the other half with SRAM ECC on), M = 1 is
   // one radix-32 butterfly per row: all of those keep the even / odd row split with the swap + combine stage.
-#ifdef TDSA_NO_INL    // developer A/B: the even / odd row split at every size, as in rounds 1-2
-  constexpr bool INL = false;
-#else
-  constexpr bool INL = (M >= 8) && (C::NPASS == 3) && !ACC;
-#endif
-  constexpr int R1 = INL ? A : H;                 // radix done inside one lane in pass 1
+  constexpr bool INL = C::INL;                    // (the row pass ACC only exists at N = 16384, where INL is off)
+  constexpr int R1 = C::R1;                       // radix done inside one lane in pass 1
   constexpr int LR1 = ilog2(R1);
-  constexpr int CPT = INL ? M / 2 : M;            // adjacent columns (samples) per row read of a half-thread
+  constexpr int CPT = C::CPT;                     // adjacent columns (samples) per row read of a half-thread
   constexpr int DW = (CPT >= 2) ? CPT / 2 : 1;    // raw dwords per row read
   constexpr int NRAW = IN_C64 ? 1 : R1 * DW;      // row reads r < R1: input row a = r (INL) or 2r + h
   constexpr int ROWB = (N / A) * 2;               // bytes per first-pass row (byte formats)
@@ -327,14 +332,15 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   }
 
   // ---- frame-invariant per-thread state ---------------------------------------------------------
-  const rsrc_t win_rsrc = make_rsrc(p.window, N * 4u);
+  const rsrc_t win_rsrc = make_rsrc(C::WIN_LDS ? p.window : p.window_perm, N * 4u);
   float* win_lds = reinterpret_cast<float*>(smem + C::LDS_BYTES - C::WIN_BYTES);
   if constexpr (C::WIN_LDS) {
     for (int i = tid; i < N; i += C::WGT) win_lds[i] = p.window[i];
     __syncthreads();
   }
-  const unsigned win_voff = INL ? (unsigned(t) * M + unsigned(h) * CPT) * 4u
-                                : unsigned(h) * (N / A) * 4u + unsigned(t) * (M * 4u);
+  // the thread's 16 window values: quarter q of them are the 16 bytes at ((q * 2 SG + h SG + t) * 16 of the permuted
+  // table (window_perm_kernel below): every load instruction of a wave covers 2 x 512 contiguous bytes
+  const unsigned win_voff = (unsigned(h) * SG + unsigned(t)) * 16u;
   const bool odd_half = h != 0;   // upper half-wave: its radix-32 combine twiddle is W_32^(u+8) = -i * W_32^u
   float pacc[ACC ? 16 : 1];                 // ACC: linear power summed over the frames of one group
   static_for<0, (ACC ? 16 : 1)>([&](auto ic) { pacc[decltype(ic)::value] = 0.f; });
@@ -386,20 +392,22 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   // reload is unconditional (the last one is simply unused) so that the old values are dead in between.
   float win[16];                       // win[c*R1 + r] = w[a(r)*(N/A) + t*M + c (+ h*CPT if INL)], a(r) = r (INL) or 2r + h
   auto load_window = [&] {
-    static_for<0, R1>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      uint32_t wq[CPT];
-      if constexpr (C::WIN_LDS) {
+    if constexpr (C::WIN_LDS) {
+      static_for<0, R1>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
         static_for<0, CPT>([&](auto jc) {
           constexpr int jj = decltype(jc)::value;
-          if constexpr (INL) wq[jj] = __float_as_uint(win_lds[i * (N / A) + t * M + h * CPT + jj]);
-          else wq[jj] = __float_as_uint(win_lds[(2 * i + h) * (N / A) + t * M + jj]);
+          if constexpr (INL) win[jj * R1 + i] = win_lds[i * (N / A) + t * M + h * CPT + jj];
+          else win[jj * R1 + i] = win_lds[(2 * i + h) * (N / A) + t * M + jj];
         });
-      } else {
-        buf_load<CPT>(win_rsrc, win_voff, RSTEP * i * (N / A) * 4u, wq);
-      }
-      static_for<0, CPT>([&](auto jc) { constexpr int jj = decltype(jc)::value; win[jj * R1 + i] = __uint_as_float(wq[jj]); });
-    });
+      });
+    } else {
+      // four 16-byte loads (at N = 16384 the natural table order meant eight 8-byte ones: more, narrower vector
+      // memory instructions cost this kernel more than their bytes - profiles/r03_c3_experiments.txt)
+      uint32_t wq[16];
+      static_for<0, 4>([&](auto qc) { constexpr int q = decltype(qc)::value; buf_load<4>(win_rsrc, win_voff, q * (2u * SG * 16u), &wq[4 * q]); });
+      static_for<0, 16>([&](auto ic) { constexpr int i = decltype(ic)::value; win[i] = __uint_as_float(wq[i]); });
+    }
   };
   uint32_t raw[NRAW];
   auto load_frame_raw = [&](int frame) {
@@ -1088,6 +1096,29 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
 #endif
 }
 
+// window table -> the order the frame kernel's threads consume it: value idx = c*R1 + r of thread (t, h) of a frame,
+// w[a(r)*(N/A) + t*M + c (+ h*CPT)] with a(r) = r (INL) or 2r + h, sits at wp[((idx/4)*2SG + h*SG + t)*4 + idx%4]
+template <int LOG2N>
+__global__ void __launch_bounds__(256) window_perm_kernel(const float* w, float* wp) {
+  using C = Cfg<LOG2N>;
+  constexpr int N = C::N, SG = C::SG, A = C::A, M = C::M, R1 = C::R1, CPT = C::CPT;
+  const int th = blockIdx.x * 256 + threadIdx.x;
+  if (th >= 2 * SG) return;
+  const int h = th / SG, t = th - h * SG;
+#pragma unroll
+  for (int idx = 0; idx < 16; ++idx) {
+    const int c = idx / R1, r = idx % R1;
+    const int a = C::INL ? r : 2 * r + h;
+    wp[((idx >> 2) * 2 * SG + th) * 4 + (idx & 3)] = w[a * (N / A) + t * M + (C::INL ? h * CPT : 0) + c];
+  }
+}
+template <int LOG2N>
+inline hipError_t perm_for(const float* w, float* wp, hipStream_t s) {
+  if constexpr (Cfg<LOG2N>::WIN_LDS) return hipSuccess;       // those sizes read the natural table into LDS
+  hipLaunchKernelGGL(window_perm_kernel<LOG2N>, dim3((2 * Cfg<LOG2N>::SG + 255) / 256), dim3(256), 0, s, w, wp);
+  return hipGetLastError();
+}
+
 template <int LOG2N>
 inline LaunchGeom geom_for(int n_frames, int num_cu) {
   using C = Cfg<LOG2N>;
@@ -1150,5 +1181,6 @@ inline hipError_t launch_acc(const SpecParams& p, const LaunchGeom& g, hipStream
 // one translation unit per size (tdsa_spectrum_inst.hip, -DTDSA_LOG2N=k) provides these
 template <int LOG2N> hipError_t launch_size(int in_c64, const SpecParams& p, const LaunchGeom& g, hipStream_t s);
 template <int LOG2N> LaunchGeom geom_size(int n_frames, int num_cu);
+template <int LOG2N> hipError_t perm_size(const float* w, float* wp, hipStream_t s);
 
 }  // namespace tdsa
