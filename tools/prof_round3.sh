@@ -8,7 +8,7 @@
 set -x
 OUT=gpurun_out/prof_r03
 rm -rf $OUT && mkdir -p $OUT && export TMPDIR=/tmp
-python bench.py > $OUT/bench_c3.json 2> $OUT/bench.err
+( time python bench.py > $OUT/bench_c3.json 2> $OUT/bench.err ) 2> $OUT/bench_c3_time.txt
 for c in c2 c4 c5; do python bench.py --config $c > $OUT/bench_$c.json 2>> $OUT/bench.err; done
 python bench.py --config c5 --gpus 2 > $OUT/bench_c5_2ranks.json 2>> $OUT/bench.err
 FAST="--reps 3 --min-region-s 0.15 --no-cpu-baseline"

@@ -266,11 +266,13 @@ class DataProcessor:
             return fused["live"]
         mw, dm = self.mw, self.dm
         run = dm.tare_state
-        gpu = self._trace_for(len(power_levels))
         collecting = bool(run.collecting)
+        baseline = mw.baseline_power_levels if mw.tare_active else None
+        if not collecting and baseline is None:
+            return power_levels                           # nothing to do: the frame object passes through, no device call
+        gpu = self._trace_for(len(power_levels))
         if collecting and run.count == 0:
             gpu.reset(nat.RESET_TARE)                     # a new run starts from an empty accumulator
-        baseline = mw.baseline_power_levels if mw.tare_active else None
         if baseline is not None and baseline.shape != power_levels.shape:
             dm._clear_tare()                              # the span changed under an active baseline
             gpu.reset(nat.RESET_TARE)
