@@ -38,37 +38,48 @@ __device__ __forceinline__ c32 big_twiddle(const BigColsParams& p, unsigned e) {
   return cmul(p.tw_hi[e >> 10], p.tw_lo[e & 1023]);
 }
 
+// Buffer-descriptor access for the column pass: every load / store of a thread is "lane offset + compile-time row
+// offset" of a block-uniform base, so the row offsets travel as scalar offsets of one SGPR descriptor per array and no
+// 64-bit per-lane address arithmetic is left (round 2's pointer version spent 626 of its 3293 VALU instructions per
+// thread on v_add_co / v_addc pairs and 148 VGPRs: 3 waves per SIMD).
+using brsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ brsrc_t big_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, int(bytes), 0x00020000);
+}
+typedef unsigned bu32x2 __attribute__((ext_vector_type(2)));
+
 // One thread per column n2.  X[k1] of the column sits in v[bitrev(k1)] after the in-register DIF.
 template <int LOG2N1>
 __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
   constexpr int N1 = 1 << LOG2N1;
   const int n2 = blockIdx.x * 256 + threadIdx.x;
   const int seg = blockIdx.y;
-  const float* w = p.window + n2;
   // (x - in_off) is exact in float32 (small integers / halves); the DC estimate is passed as its small
   // residual so that no 24-bit rounding of "128 + something" enters (at 2^20 points that rounding alone
   // left 3e-7 * A_max in the DC bin)
   const float off = p.in_off;
   float sub_re = 0.f, sub_im = 0.f;
   if (p.dc_sub != nullptr) { const c32 s = p.dc_sub[seg]; sub_re = s.x; sub_im = s.y; }
+  const brsrc_t wr = big_rsrc(p.window, unsigned(N1) * kRowN * 4u);
+  const unsigned wv = unsigned(n2) * 4u;
   c32 v[N1];
   if (p.in_c64) {
-    const c32* src = reinterpret_cast<const c32*>(p.in + (long long)seg * p.seg_stride) + n2;
+    const brsrc_t ir = big_rsrc(p.in + (long long)seg * p.seg_stride, unsigned(N1) * kRowN * 8u);
     static_for<0, N1>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      const c32 x = src[(long long)i * kRowN];
-      const float ww = w[(long long)i * kRowN];
-      v[i] = c32{((x.x - off) - sub_re) * ww, ((x.y - off) - sub_im) * ww};
+      const bu32x2 q = __builtin_amdgcn_raw_buffer_load_b64(ir, unsigned(n2) * 8u, unsigned(i) * kRowN * 8u, 0);
+      const float ww = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wr, wv, unsigned(i) * kRowN * 4u, 0));
+      v[i] = c32{((__uint_as_float(q.x) - off) - sub_re) * ww, ((__uint_as_float(q.y) - off) - sub_im) * ww};
     });
   } else {
-    const unsigned char* src = p.in + (long long)seg * p.seg_stride + 2ll * n2;
+    const brsrc_t ir = big_rsrc(p.in + (long long)seg * p.seg_stride, unsigned(N1) * kRowN * 2u);
     const unsigned xm = p.xor_mask & 0xffffu;
     static_for<0, N1>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      // read once: non-temporal, so that the raw bytes do not displace Z from the Infinity Cache
-      const unsigned u = unsigned(__builtin_nontemporal_load(reinterpret_cast<const uint16_t*>(src + 2ll * i * kRowN))) ^ xm;
-      const float ww = w[(long long)i * kRowN];
-      v[i] = c32{((float(u & 0xffu) - off) - sub_re) * ww, ((float(u >> 8) - off) - sub_im) * ww};
+      // read once: non-temporal (aux bit 1), so that the raw bytes do not displace Z from the caches
+      const unsigned u = unsigned(__builtin_amdgcn_raw_buffer_load_b16(ir, unsigned(n2) * 2u, unsigned(i) * kRowN * 2u, 2)) ^ xm;
+      const float ww = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wr, wv, unsigned(i) * kRowN * 4u, 0));
+      v[i] = c32{((float(u & 0xffu) - off) - sub_re) * ww, ((float((u >> 8) & 0xffu) - off) - sub_im) * ww};
     });
   }
   dif<N1, 0, N1>(v);
@@ -77,7 +88,16 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
   constexpr int NA = N1 < 8 ? N1 : 8, NB = N1 / NA;
   c32 lo[NA];
   static_for<1, NA>([&](auto ac) { constexpr int a = decltype(ac)::value; lo[a] = big_twiddle(p, unsigned(n2) * a); });
-  float2* zo = p.z + ((long long)seg * N1) * kRowN + n2;
+  const brsrc_t zr = big_rsrc(p.z + (long long)seg * N1 * kRowN, unsigned(N1) * kRowN * 8u);
+#ifdef TDSA_COLS_STORE8
+  const unsigned zv = unsigned(n2) * 8u;
+#else
+  // 16-byte stores: the two lanes of a pair (columns n2, n2 + 1) exchange one value per pair of rows (k1, k1 + 1), the
+  // even lane then stores both columns of row k1, the odd lane both columns of row k1 + 1
+  const bool odd = (threadIdx.x & 1) != 0;
+  const unsigned zv = (unsigned(n2) & ~1u) * 8u + (odd ? unsigned(kRowN) * 8u : 0u);
+  c32 xprev = c32{0.f, 0.f};
+#endif
   static_for<0, NB>([&](auto bc) {
     constexpr int b = decltype(bc)::value;
     c32 hb = c32{1.f, 0.f};
@@ -89,7 +109,30 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
       if constexpr (b == 0 && a > 0) x = cmul(x, lo[a]);
       else if constexpr (b > 0 && a == 0) x = cmul(x, hb);
       else if constexpr (b > 0) x = cmul(x, cmul(hb, lo[a]));
-      zo[(long long)k1 * kRowN] = x;
+#ifdef TDSA_COLS_STORE8
+      const bu32x2 pk = {__float_as_uint(x.x), __float_as_uint(x.y)};
+      __builtin_amdgcn_raw_buffer_store_b64(pk, zr, zv, unsigned(k1) * kRowN * 8u, 0);
+#else
+      if constexpr (N1 >= 2 && (k1 & 1) == 0) {
+        xprev = x;                                  // row k1 (even): wait for row k1 + 1
+      } else if constexpr (N1 >= 2) {
+        // rows (k1 - 1, k1): the even lane keeps its row k1 - 1 value and sends its row k1 value, the odd lane the
+        // other way round
+        const float sx = odd ? xprev.x : x.x, sy = odd ? xprev.y : x.y;          // what the partner needs
+        const float rx = __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(sx), 0xB1, 0xf, 0xf, true));
+        const float ry = __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(sy), 0xB1, 0xf, 0xf, true));
+        const float ox = odd ? x.x : xprev.x, oy = odd ? x.y : xprev.y;          // own value of the row this lane stores
+        typedef unsigned bu32x4 __attribute__((ext_vector_type(4)));
+        const bu32x4 pk = {__float_as_uint(odd ? rx : ox), __float_as_uint(odd ? ry : oy),
+                           __float_as_uint(odd ? ox : rx), __float_as_uint(odd ? oy : ry)};
+        // The row offset goes into the VGPR offset, NOT into an SGPR soffset: a buffer store of more than 8 bytes
+        // whose data registers are overwritten by the next VALU instruction is a hazard on gfx950, and ROCm 7.2's
+        // hazard recognizer only pads it when soffset is not a register.  With `soffset = s4` the compiler re-used
+        // v[78:81] for the next pair right behind the store and rows came out corrupted run-to-run (1e-6 .. 6e-4 of
+        // the frame maximum, only when more than 256 workgroups were in flight; two 8-byte stores were always right).
+        __builtin_amdgcn_raw_buffer_store_b128(pk, zr, zv + unsigned(k1 - 1) * kRowN * 8u, 0, 0);
+      }
+#endif
     });
   });
 }
