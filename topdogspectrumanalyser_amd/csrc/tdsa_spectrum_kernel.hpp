@@ -957,7 +957,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
                 constexpr int g4 = decltype(gc)::value;
                 const u32x4 pk = {__float_as_uint(db[4 * g4]), __float_as_uint(db[4 * g4 + 1]),
                                   __float_as_uint(db[4 * g4 + 2]), __float_as_uint(db[4 * g4 + 3])};
-                __builtin_amdgcn_raw_buffer_store_b128(pk, r, unsigned(tid) * 16u, g4 * 16384u, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(pk, r, unsigned(tid) * 16u + g4 * 16384u, 0, kRowStorePolicy);   // (row offset in the VGPR: see tdsa_big.hip on the soffset hazard)
               });
             } else
             static_for<0, 16>([&](auto ic) {
