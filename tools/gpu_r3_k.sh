@@ -2,9 +2,7 @@
 OUT=gpurun_out/r3k
 rm -rf $OUT && mkdir -p $OUT && export TMPDIR=/tmp
 L=$PWD/topdogspectrumanalyser_amd
-for rep in 1 2 3; do
-for lib in hip abl1024; do
-  TDSA_HIP_LIB=$L/libtdsa_$lib.so python tools/devbench.py --steps 6000 --warmup 1500 >> $OUT/ab.txt 2>&1
-  TDSA_HIP_LIB=$L/libtdsa_$lib.so python tools/devbench.py --steps 6000 --warmup 1504 --batch 8 >> $OUT/ab.txt 2>&1
+for rep in 1 2 3; do for lib in hip early; do
+  TDSA_HIP_LIB=$L/libtdsa_$lib.so python bench.py --config c5 --no-cpu-baseline > $OUT/b.json 2>/dev/null; echo -n "$lib "; python -c "import json; print(json.load(open('$OUT/b.json'))['ms_per_step'])"
 done; done
-cut -c1-150 $OUT/ab.txt
+TDSA_HIP_LIB=$L/libtdsa_early.so timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "c5 or long or big or welch" 2>&1 | tail -2

@@ -52,6 +52,7 @@ struct tdsa_plan_s {
   hipEvent_t ev_aux[kMaxOverlap - 1] = {};
   hipEvent_t ev_state = nullptr;
   int n_overlap = 1, rr = 0;
+  int overlap_share = 50;                // percent of the CUs an overlapped launch is sized for (3+ streams)
   bool aux_busy = false, state_dirty = true;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   tdsa_mode mode{};
@@ -467,6 +468,10 @@ static int plan_init(tdsa_plan p) {
     const int v = atoi(c);
     if (v >= 1 && v <= p->num_cu) p->num_cu = v;
   }
+  if (const char* c = getenv("TDSA_OVERLAP_SHARE")) {   // developer knob: CU share (percent) of an overlapped launch
+    const int v = atoi(c);
+    if (v >= 10 && v <= 100) p->overlap_share = v;
+  }
   HIPCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreate(&p->ev0));
   HIPCHK(hipEventCreate(&p->ev1));
@@ -826,7 +831,7 @@ static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size
   // C3 76.4 -> 74.3 us per step, C2 26.7 -> 26.0 (profiles/r02_c3_experiments.txt).  More than three streams in flight
   // measured worse (4: 91 us), and strictly serial launches keep the whole chip.
   const LaunchGeom g = spectrum_geometry(p->log2n, n_frames,
-                                         (overlap && p->n_overlap >= 3) ? (p->num_cu + 1) / 2 : p->num_cu);
+                                         (overlap && p->n_overlap >= 3) ? (p->num_cu * p->overlap_share + 99) / 100 : p->num_cu);
   if (averaging) {
     if (!p->d_lin) HIPCHK(hipMalloc(&p->d_lin, size_t(p->max_frames) * p->nfft * sizeof(float)));
     if (!p->d_carry && p->max_frames > 128)
