@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of the working tree's library against libtdsa_prev.so (the previous commit), same box, alternating
-OUT=gpurun_out/r3g
+OUT=gpurun_out/ab
 rm -rf $OUT && mkdir -p $OUT && export TMPDIR=/tmp
 L=$PWD/topdogspectrumanalyser_amd
 ( timeout 900 python -m pytest tests -m gpu -x -q ) > $OUT/pytest.log 2>&1
