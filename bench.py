@@ -100,6 +100,22 @@ def cpu_all_cores(wl: dict, workers: int, seconds: float) -> dict:
             "host_cores_available": avail}
 
 
+def physical_cores() -> int:
+    """Distinct (package, core) pairs of /proc/cpuinfo - the host's physical cores; logical CPU count where that fails."""
+    try:
+        seen, pkg = set(), None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                pkg = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                seen.add((pkg, ln.split(":")[1].strip()))
+        if seen:
+            return len(seen)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
 class _DryEngine:
     """--dry-run only: stands in for the GPU plan so that the launch / barrier / aggregation plumbing of
     the multi-GPU leg can be exercised in a container without a GPU.  Does no arithmetic; the line it
@@ -184,7 +200,7 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the single-thread CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-workers", type=int, default=0,
-                    help="processes of the all-cores CPU leg: 0 = one per host core (BASELINE.md 3(ii)), N = N processes")
+                    help="processes of the all-cores CPU leg: 0 = one per physical host core (BASELINE.md 3(ii)), N = N processes")
     ap.add_argument("--no-cpu-pool", action="store_true")
     ap.add_argument("--cpu-pool-seconds", type=float, default=6.0)
     ap.add_argument("--dry-run", action="store_true",
@@ -632,9 +648,9 @@ def main() -> None:
         if want_cpu:
             result["cpu_baseline"] = {"value": done / cpu_s, "unit": "frames/s", "cores": 1, "kind": "port",
                                       "sample": sample, "host_cores_available": os.cpu_count()}
-            workers = args.cpu_workers if args.cpu_workers > 0 else (os.cpu_count() or 1)
-            result["cores_policy"] = (f"cpu_baseline: 1 core; cpu_baseline_pool: {workers} of {os.cpu_count()} host cores "
-                                      f"(default: all of them)")
+            workers = args.cpu_workers if args.cpu_workers > 0 else physical_cores()
+            result["cores_policy"] = (f"cpu_baseline: 1 core; cpu_baseline_pool: {workers} single-thread processes = one per "
+                                      f"physical core by default ({physical_cores()} cores, {os.cpu_count()} logical CPUs)")
             if not args.no_cpu_pool and not welch:
                 try:
                     result["cpu_baseline_pool"] = cpu_all_cores(wl, workers, args.cpu_pool_seconds)
