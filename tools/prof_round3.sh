@@ -5,6 +5,9 @@
 #   HBM counters (separate --pmc passes: FETCH_SIZE and WRITE_SIZE do not fit one pass) for C2..C5
 #   SQ issue / wait counters and the per-class VALU instruction counters of the C3 frame kernel
 #   per-class VALU issue cost (tools/ubench/valu_rate2) and the timing-only ablation builds of the frame kernel
+# Before sending it: tools/build_variants.sh abl2 "-DTDSA_ABLATE=2" abl4 "-DTDSA_ABLATE=4" abl6 "-DTDSA_ABLATE=6"
+# (the ablation libraries are git-ignored and travel with the snapshot); afterwards tools/prof_collect3.py and
+# tools/valu_issue.py turn gpurun_out/prof_r03 into profiles/r03_*.
 set -x
 OUT=gpurun_out/prof_r03
 rm -rf $OUT && mkdir -p $OUT && export TMPDIR=/tmp
@@ -39,9 +42,11 @@ pmc c3_cls2 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_IN
 ./tools/ubench/valu_rate2 > $OUT/ubench_valu_rate2.txt 2>&1
 # steady-state ablations of the frame kernel (timing only; cache-resident devbench shape, one box, back to back)
 for lib in hip abl2 abl4 abl6; do
+  [ -f $PWD/topdogspectrumanalyser_amd/libtdsa_$lib.so ] || continue
   TDSA_HIP_LIB=$PWD/topdogspectrumanalyser_amd/libtdsa_$lib.so python tools/devbench.py --steps 6000 --warmup 1500 >> $OUT/ablation.txt 2>&1
 done
 for lib in hip abl6; do
+  [ -f $PWD/topdogspectrumanalyser_amd/libtdsa_$lib.so ] || continue
   TDSA_HIP_LIB=$PWD/topdogspectrumanalyser_amd/libtdsa_$lib.so python tools/devbench.py --steps 6000 --warmup 1504 --batch 8 >> $OUT/ablation.txt 2>&1
 done
 cat $OUT/ablation.txt
