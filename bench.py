@@ -430,6 +430,26 @@ def main() -> None:
     achieved_1 = algo_step / kern_1 / 1e9 if kern_1 else 0.0
     per_gpu_frac = gather(achieved_gbs / HBM_PEAK_GBS)
 
+    # secondary denominator: the device-to-device copy bandwidth this box reaches, read + write bytes
+    copy_gbs = None
+    if not args.dry_run and rank == 0:
+        try:
+            nb = 1 << 30                                  # 1 GiB each way: well past the 256 MiB Infinity Cache
+            a = torch.empty(nb, dtype=torch.uint8, device=dev)
+            b = torch.empty(nb, dtype=torch.uint8, device=dev)
+            b.copy_(a)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                b.copy_(a)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbs = 10 * 2 * nb / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del a, b
+        except Exception:                                 # a reported extra only
+            copy_gbs = None
+
     # per-GPU state combined on the HOST; outside the timed region
     hold_combined, welch_block, combined_db = None, None, None
     if welch:
@@ -535,6 +555,10 @@ def main() -> None:
                                             "serial pass (one launch on the whole chip at a time), in the launch shape of "
                                             "`value` (steps_per_call queued steps per launch)",
                          "algorithmic_bytes_per_frame": bytes_per_frame,
+                         "measured_copy_gbs": copy_gbs,
+                         "frac_of_measured_copy": (achieved_gbs / copy_gbs) if copy_gbs else None,
+                         "measured_copy_is": "torch device-to-device copy of 1 GiB on this GPU, read + write bytes per second "
+                                             "(BASELINE.md 4: secondary denominator next to the 8 TB/s peak)",
                          "single_step_launch": {"achieved": achieved_1, "frac": achieved_1 / HBM_PEAK_GBS,
                                                 "kernel_avg_us": kern_1 * 1e6, "launches_timed": launches_1,
                                                 "algorithmic_bytes_per_launch": algo_step,
