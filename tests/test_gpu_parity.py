@@ -2221,3 +2221,29 @@ def test_batched_captures_full_c3_shape(pkg):
     finally:
         nat.lib.tdsa_dev_free(0, d_in)
         nat.lib.tdsa_dev_free(0, d_out)
+
+
+@pytest.mark.parametrize("group", [1, 3, 5])
+def test_long_frame_welch_over_several_rounds(pkg, monkeypatch, group):
+    """The column / row rounds of the long-frame path (TDSA_BIG_GROUP segments each, 64 by default: one round for the
+    C5 capture): with small rounds the row pass's per-workgroup partial rows are ADDED to from round to round (rounds of
+    unequal size, fewer workgroups per row in the last one) and the result must not depend on the round size."""
+    monkeypatch.setenv("TDSA_BIG_GROUP", str(group))
+    nfft, k, cal = 1 << 16, 8, -0.8087054556396822
+    iq = so.synth_iq_int8(nfft * k, nfft, seed=17)
+    gold, gold_mean = _welch_gold(iq, nfft, k, cal)
+    with pkg.SpectrumEngine(nfft, max_frames=k) as e:
+        e.set_window(so.rtl_window("hanning", nfft).astype(np.float32))
+        e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=-1.0, avg=("lin", k),
+                    cal_offset_db=cal)
+        out = e.process(iq, hop=nfft)
+        mean, cnt = e.averaged()
+    monkeypatch.delenv("TDSA_BIG_GROUP")
+    with pkg.SpectrumEngine(nfft, max_frames=k) as e:
+        e.set_window(so.rtl_window("hanning", nfft).astype(np.float32))
+        e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=-1.0, avg=("lin", k),
+                    cal_offset_db=cal)
+        one_round = e.process(iq, hop=nfft)
+    assert cnt == k and np.max(np.abs(mean - gold_mean) / gold_mean.max()) < 1e-5
+    _check(out[0], gold, f"Welch of {k} segments in rounds of {group}")
+    assert np.max(np.abs(out[0] - one_round[0])) < 1e-4          # float32 partial sums are grouped differently, no more
