@@ -2247,3 +2247,42 @@ def test_long_frame_welch_over_several_rounds(pkg, monkeypatch, group):
     assert cnt == k and np.max(np.abs(mean - gold_mean) / gold_mean.max()) < 1e-5
     _check(out[0], gold, f"Welch of {k} segments in rounds of {group}")
     assert np.max(np.abs(out[0] - one_round[0])) < 1e-4          # float32 partial sums are grouped differently, no more
+
+
+def test_batched_captures_without_rows_and_with_tare(pkg):
+    """tdsa_process_dev_batch with out_db_dev = NULL (only the hold traces are wanted) and with a tare baseline set:
+    the hold traces of the one-launch batch equal those of consecutive calls, with and without rows."""
+    import ctypes as C
+    nat = pkg._native
+    nfft, hop, nf, n_seg = 8192, 4096, 45, 4
+    ns = hop * (nf - 1) + nfft
+    caps = [so.synth_iq_int8(ns, nfft, seed=900 + s) for s in range(n_seg)]
+    blob = np.concatenate(caps)
+    base = (np.linspace(-3.0, 3.0, nfft)).astype(np.float32)
+    d_in, d_out = C.c_void_p(), C.c_void_p()
+    nat.check(nat.lib.tdsa_dev_alloc(0, blob.nbytes, C.byref(d_in)))
+    nat.check(nat.lib.tdsa_dev_alloc(0, n_seg * nf * nfft * 4, C.byref(d_out)))
+    nat.check(nat.lib.tdsa_memcpy_h2d(0, d_in, blob.ctypes.data_as(C.c_void_p), blob.nbytes))
+    try:
+        holds = []
+        for batched, rows in ((False, True), (True, True), (True, False)):
+            with _hackrf_engine(pkg, nfft, nf, hold_max=True, hold_min=True) as e:
+                nat.check(nat.lib.tdsa_set_tare_baseline(e._h, base.ctypes.data_as(C.c_void_p), nfft))
+                out = d_out.value if rows else None
+                if batched:
+                    e.process_device_batch(nat.IN_I8, d_in.value, 2 * ns, n_seg, ns, hop, nf, out, nf * nfft)
+                else:
+                    for s in range(n_seg):
+                        e.process_device(nat.IN_I8, d_in.value + 2 * ns * s, ns, hop, nf, d_out.value + 4 * nf * nfft * s)
+                holds.append(e.hold())
+                if rows:
+                    got = np.empty((n_seg * nf, nfft), dtype=np.float32)
+                    nat.check(nat.lib.tdsa_memcpy_d2h(0, got.ctypes.data_as(C.c_void_p), d_out, got.nbytes))
+                    assert np.array_equal(holds[-1][0], got.max(axis=0)) and np.array_equal(holds[-1][1], got.min(axis=0))
+        for h in holds[1:]:
+            assert np.array_equal(h[0], holds[0][0]) and np.array_equal(h[1], holds[0][1])
+        gold, _, _ = so.hackrf_batch(caps[1], nfft, hop, 20e6, precision="gold")
+        _check(got[nf: 2 * nf] + base[None, :], gold, "capture 1, tare added back")
+    finally:
+        nat.lib.tdsa_dev_free(0, d_in)
+        nat.lib.tdsa_dev_free(0, d_out)
