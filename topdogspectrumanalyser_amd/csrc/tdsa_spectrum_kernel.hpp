@@ -187,6 +187,17 @@ constexpr float kMagExactBelow = 1e-8f;                  // |X|^2 below this: th
     }                                                                      \
   } while (0)
 
+// Issue priority that falls as a wave advances through a barrier phase (s_setprio 3 .. 0 at the quarter marks).  The
+// SIMD arbiter serves the highest priority first and the oldest wave among equals: with one flat priority the oldest
+// wave of a SIMD races through every phase and then idles at the barrier while the youngest finishes the phase alone,
+// at the rate ONE wave can issue (about half of what the SIMD sustains).  With falling priorities a wave that is ahead
+// yields to the ones behind it, the four waves of a SIMD reach the barrier together and the SIMD stays saturated.
+#ifdef TDSA_DYN_PRIO
+#define TDSA_PRIO(n) __builtin_amdgcn_s_setprio(n)
+#else
+#define TDSA_PRIO(n) do { } while (0)
+#endif
+
 #ifdef TDSA_TIMELINE
 // developer build: wave 0..7 of workgroup 0 stamp s_memtime into LDS at phase boundaries (first 8 frames)
 #define TDSA_STAMP(i)                                                                              \
@@ -321,6 +332,13 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   const unsigned upw = unsigned(n_units) / gridDim.x, urem = unsigned(n_units) - upw * gridDim.x;
   int u0 = int(blockIdx.x * upw + blockIdx.x * urem / gridDim.x);
   int u1 = int((blockIdx.x + 1) * upw + (blockIdx.x + 1) * urem / gridDim.x);
+#ifdef TDSA_STAGGER   // developer experiment: workgroups with one unit less than the others start k/4 frame periods late
+  if (!ACC && urem != 0 && u1 - u0 == int(upw)) {
+    const unsigned k = (blockIdx.x * 2654435761u) >> 30;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)k * TDSA_STAGGER) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
   if constexpr (ACC) {
     // row pass of the long-frame path: workgroup b = k1 * acc_active + j takes the j-th share of group k1's frames,
     // so that everything it sums belongs to ONE row of the result (its own row of P, no atomics)
@@ -519,6 +537,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       }
       TDSA_STAMP(1);
       TDSA_SYNC();       // also the WAR fence between the previous frame's LDS reads and our writes
+      TDSA_PRIO(3);
       TDSA_STAMP(2);
       if (p.dc_mode == DC_FRAME_MEAN) {
         const int w0 = slot * C::WPF;
@@ -720,6 +739,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     TDSA_STAMP(3);
     // raw registers are free again: start the next frame's HBM read now, it lands during the FFT
     if (unit + 1 < u1) load_frame_raw((unit + 1) * FPW + slot);
+    TDSA_PRIO(2);
 
     // ---- pass 1: per lane CPT radix-R1 DFTs; INL: that is the whole pass, else (even / odd input rows per
     //      half-thread) the cross-lane combine follows ------------------------------------------------
@@ -733,8 +753,10 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
         if constexpr ((TDSA_ABLATE & 2) == 0) lds_st(&buf[wr1_base + e], v[g * A + bitrev(k, LR1)]);
       });
     } else {
+    TDSA_PRIO(1);
     static_for<0, 8>([&](auto uc) {
       constexpr int u = decltype(uc)::value;
+      if constexpr (u == 4) TDSA_PRIO(0);
       constexpr int jj0 = u / H, k0 = u % H, jj1 = (u + 8) / H, k1 = (u + 8) % H;
       constexpr int re = jj0 * H + bitrev(k0, LH), ro = jj1 * H + bitrev(k1, LH);
       if constexpr ((TDSA_ABLATE & 32) == 0) swap_halves(v[re], v[ro]);   // v[re] = E of unit u + 8h, v[ro] = O
@@ -747,6 +769,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     TDSA_STAMP(4);
     if constexpr (ACC) { if (unit + 1 < u1) load_frame_c64((unit + 1) * FPW + slot); }
     TDSA_SYNC();
+    TDSA_PRIO(3);
     TDSA_STAMP(5);
 
     // ---- middle radix-32 pass (3-pass sizes), IN PLACE: a row's two half-threads own the 32 slots
@@ -778,7 +801,9 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
         __builtin_amdgcn_sched_barrier(0);
       });
       TDSA_STAMP(6);
+      TDSA_PRIO(2);
       dit_rest<16, 0, 16>(v);
+      TDSA_PRIO(1);
 #else
       static_for<0, 2>([&](auto bc) {
         constexpr int b0 = decltype(bc)::value * 8;
@@ -800,6 +825,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
 #endif
       static_for<0, 8>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
+        if constexpr (u == 4) TDSA_PRIO(0);
         constexpr int re = bitrev(u, 4), ro = bitrev(u + 8, 4);
         if constexpr ((TDSA_ABLATE & 32) == 0) swap_halves(v[re], v[ro]);
         combine32<u>(v[re], v[ro], odd_half);                // outputs kb = u + 8h and kb + 16
@@ -810,6 +836,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       });
       TDSA_STAMP(7);
       TDSA_SYNC();
+      TDSA_PRIO(3);
       TDSA_STAMP(8);
       static_for<0, 16>([&](auto ic) {                       // element c = 2i + h of row (kb, ka)
         constexpr int i = decltype(ic)::value;
@@ -833,6 +860,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       if constexpr (j != 0) { te = cmul(te, twf_lo[j - 1]); to = cmul(to, twf_lo[j - 1]); }
       bf_tw(v[i], v[i + 8], te, to);
     });
+    TDSA_PRIO(2);
     dit_rest<16, 0, 16>(v);
 #else
     static_for<0, 16>([&](auto ic) {                         // pre-twiddle W_N^(t*(2i+h)), i = 4a + j
@@ -850,6 +878,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       if constexpr ((TDSA_ABLATE & 32) == 0) swap_halves(v[re], v[ro]);
       combine32<u, true>(v[re], v[ro], odd_half);            // bins kc = u + 8h (v[re]) and kc + 16 (v[ro])
     });
+    TDSA_PRIO(1);
     TDSA_STAMP(10);
 
     // ---- epilogue: |X|^2 -> dB -> hold ; bin k = t + kc*SG lands at k ^ N/2 (fftshift) -----------
@@ -947,6 +976,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
           });
         }
         if constexpr (!C::WIN_LDS) load_window();     // next frame's window, ahead of this frame's stores
+        TDSA_PRIO(0);
         if ((TDSA_ABLATE & 4) == 0 && p.out_db != nullptr) {
           float* orow = p.out_db + out_elem_off(frame);
           if constexpr (FPW == 1) {
