@@ -165,7 +165,7 @@ constexpr float kMagExactBelow = 1e-8f;                  // |X|^2 below this: th
 
 // developer ablation builds (-DTDSA_ABLATE=mask): 1 no barriers, 2 no LDS exchange, 4 no dB stores,
 // 16 no middle-pass table reads, 32 no half-wave swaps, 64 no log, 128 no last pre-twiddle, 256 no
-// middle pre-twiddle, 512 no last radix-16, 4096 / 8192 / 16384 only 1 / 2 / 3 waves per SIMD stay.  Results are
+// middle pre-twiddle, 512 no last radix-16, 2048 no global loads inside the frame loop (bytes and window of the first frame stay), 4096 / 8192 / 16384 only 1 / 2 / 3 waves per SIMD stay.  Results are
 // wrong by construction; timing only.
 #ifndef TDSA_ABLATE
 #define TDSA_ABLATE 0
@@ -738,7 +738,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     }
     TDSA_STAMP(3);
     // raw registers are free again: start the next frame's HBM read now, it lands during the FFT
-    if (unit + 1 < u1) load_frame_raw((unit + 1) * FPW + slot);
+    if ((TDSA_ABLATE & 2048) == 0 && unit + 1 < u1) load_frame_raw((unit + 1) * FPW + slot);
     TDSA_PRIO(2);
 
     // ---- pass 1: per lane CPT radix-R1 DFTs; INL: that is the whole pass, else (even / odd input rows per
@@ -975,7 +975,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
             db[q] -= __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(tr, out_voff, kcs * SG * 4u, 0));
           });
         }
-        if constexpr (!C::WIN_LDS) load_window();     // next frame's window, ahead of this frame's stores
+        if constexpr (!C::WIN_LDS && (TDSA_ABLATE & 2048) == 0) load_window();     // next frame's window, ahead of this frame's stores
         TDSA_PRIO(0);
         if ((TDSA_ABLATE & 4) == 0 && p.out_db != nullptr) {
           float* orow = p.out_db + out_elem_off(frame);
