@@ -62,6 +62,17 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
   if (p.dc_sub != nullptr) { const c32 s = p.dc_sub[seg]; sub_re = s.x; sub_im = s.y; }
   const brsrc_t wr = big_rsrc(p.window, unsigned(N1) * kRowN * 4u);
   const unsigned wv = unsigned(n2) * 4u;
+  // W_N^(n2*k1), k1 = a + 8b: seeds W^(n2*a) (a < 8) and W^(n2*8b) come from the two-level table (one rounded product
+  // each), the rest is one more product.  The seeds are fetched FIRST and parked in LDS: gfx9 counts loads and stores
+  // in one in-order vmcnt, so a table load issued between the row stores could only be waited for together with every
+  // store before it - round 2's kernel sat through a full round trip to memory eight times per thread (and seven more
+  // for the serialised seed loads): a wave lived 29 us for 3 us of arithmetic.
+  constexpr int NA = N1 < 8 ? N1 : 8, NB = N1 / NA;
+#ifndef TDSA_COLS_LATE_SEEDS
+  __shared__ c32 seeds[NA + NB][256];
+  static_for<1, NA>([&](auto ac) { constexpr int a = decltype(ac)::value; seeds[a][threadIdx.x] = big_twiddle(p, unsigned(n2) * a); });
+  static_for<1, NB>([&](auto bc) { constexpr int b = decltype(bc)::value; seeds[NA + b][threadIdx.x] = big_twiddle(p, unsigned(n2) * (8u * b)); });
+#endif
   c32 v[N1];
   if (p.in_c64) {
     const brsrc_t ir = big_rsrc(p.in + (long long)seg * p.seg_stride, unsigned(N1) * kRowN * 8u);
@@ -74,6 +85,25 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
   } else {
     const brsrc_t ir = big_rsrc(p.in + (long long)seg * p.seg_stride, unsigned(N1) * kRowN * 2u);
     const unsigned xm = p.xor_mask & 0xffffu;
+#ifndef TDSA_COLS_LOADS_BATCHED   // (-DTDSA_COLS_LOADS_BATCHED: round 2's order, for A/B timing)
+    // every load of the thread issued before the first conversion: the 2 N1 results land in the registers v[] will
+    // occupy anyway, and the memory latency is paid once instead of once per batch of ~20 the scheduler keeps in flight
+    unsigned ru[N1]; float rw[N1];
+    static_for<0, N1>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      ru[i] = unsigned(__builtin_amdgcn_raw_buffer_load_b16(ir, unsigned(n2) * 2u, unsigned(i) * kRowN * 2u, 2));
+    });
+    static_for<0, N1>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      rw[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wr, wv, unsigned(i) * kRowN * 4u, 0));
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, N1>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const unsigned u = ru[i] ^ xm;
+      v[i] = c32{((float(u & 0xffu) - off) - sub_re) * rw[i], ((float((u >> 8) & 0xffu) - off) - sub_im) * rw[i]};
+    });
+#else
     static_for<0, N1>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       // read once: non-temporal (aux bit 1), so that the raw bytes do not displace Z from the caches
@@ -81,13 +111,15 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
       const float ww = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wr, wv, unsigned(i) * kRowN * 4u, 0));
       v[i] = c32{((float(u & 0xffu) - off) - sub_re) * ww, ((float((u >> 8) & 0xffu) - off) - sub_im) * ww};
     });
+#endif
   }
   dif<N1, 0, N1>(v);
-  // W_N^(n2*k1), k1 = a + 8b: seeds W^(n2*a) (a < 8) and W^(n2*8b) come from the two-level table (one
-  // rounded product each), the rest is one more product
-  constexpr int NA = N1 < 8 ? N1 : 8, NB = N1 / NA;
   c32 lo[NA];
+#ifndef TDSA_COLS_LATE_SEEDS
+  static_for<1, NA>([&](auto ac) { constexpr int a = decltype(ac)::value; lo[a] = seeds[a][threadIdx.x]; });
+#else
   static_for<1, NA>([&](auto ac) { constexpr int a = decltype(ac)::value; lo[a] = big_twiddle(p, unsigned(n2) * a); });
+#endif
   const brsrc_t zr = big_rsrc(p.z + (long long)seg * N1 * kRowN, unsigned(N1) * kRowN * 8u);
 #ifdef TDSA_COLS_STORE8
   const unsigned zv = unsigned(n2) * 8u;
@@ -101,7 +133,11 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
   static_for<0, NB>([&](auto bc) {
     constexpr int b = decltype(bc)::value;
     c32 hb = c32{1.f, 0.f};
+#ifndef TDSA_COLS_LATE_SEEDS
+    if constexpr (b > 0) hb = seeds[NA + b][threadIdx.x];
+#else
     if constexpr (b > 0) hb = big_twiddle(p, unsigned(n2) * (8u * b));
+#endif
     static_for<0, NA>([&](auto ac) {
       constexpr int a = decltype(ac)::value;
       constexpr int k1 = a + 8 * b;
