@@ -767,7 +767,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     });
     }
     TDSA_STAMP(4);
-    if constexpr (ACC) { if (unit + 1 < u1) load_frame_c64((unit + 1) * FPW + slot); }
+    if constexpr (ACC) { if ((TDSA_ABLATE & 2048) == 0 && unit + 1 < u1) load_frame_c64((unit + 1) * FPW + slot); }
     TDSA_SYNC();
     TDSA_PRIO(3);
     TDSA_STAMP(5);
