@@ -80,3 +80,40 @@ def test_both_holds_at_16384_spill_is_bounded(reports):
     k = _kernel(reports, 14, False, 3)
     assert int(k["ScratchSize [bytes/lane]"]) <= 24, k
     assert int(k["Occupancy [waves/SIMD]"]) >= 4, k
+
+
+def test_long_frame_column_pass_keeps_three_waves_and_no_vmem_wait_between_its_stores(tmp_path):
+    """Column pass of the 2^20-point chain (C5): 64 complex points per thread must stay at <= 168 VGPRs (3 waves per
+    SIMD) without scratch, and its store loop must not contain a vector-memory load: gfx9 counts loads and stores in one
+    in-order vmcnt, so a table load between the row stores waits for every store before it (round 3: 154 -> 116 us)."""
+    if not shutil.which(HIPCC):
+        pytest.skip("hipcc not available")
+    asm = str(tmp_path / "big.s")
+    cmd = [HIPCC] + _flags_from_makefile() + ["-Rpass-analysis=kernel-resource-usage", "-S", "--cuda-device-only",
+                                              os.path.join(CSRC, "tdsa_big.hip"), "-o", asm]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC)
+    assert r.returncode == 0, r.stderr[-2000:]
+    name = "_ZN4tdsa15big_cols_kernelILi6EEEvNS_13BigColsParamsE"
+    rep, on = {}, False
+    for ln in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", ln)
+        if m:
+            on = m.group(1) == name
+            continue
+        m = re.search(r"remark:\s+([A-Za-z \[\]/]+?):\s+(\S+)\s+\[-Rpass", ln)
+        if m and on:
+            rep[m.group(1).strip()] = m.group(2)
+    assert int(rep["ScratchSize [bytes/lane]"]) == 0 and int(rep["VGPRs"]) <= 168 and int(rep["Occupancy [waves/SIMD]"]) >= 3, rep
+    body, on = [], False
+    for ln in open(asm):
+        if ln.startswith(name + ":"):
+            on = True
+        elif on and ln.startswith(".Lfunc_end"):
+            break
+        elif on:
+            body.append(ln.split(";")[0].strip())
+    stores = [i for i, ln in enumerate(body) if ln.startswith("buffer_store_dwordx4")]
+    assert len(stores) >= 32, len(stores)
+    tail = body[stores[0]:stores[-1] + 1]
+    assert not any(ln.startswith(("buffer_load", "global_load", "flat_load")) for ln in tail)
+    assert not any(ln.startswith("s_waitcnt") and "vmcnt" in ln for ln in tail)
