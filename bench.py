@@ -131,6 +131,12 @@ class _DryEngine:
     def synchronize(self):
         pass
 
+    def hold_stub(self):
+        """a recognisable per-rank hold trace: rank r 'held' r in every bin except bin r, where it held 100 + r"""
+        h = np.full(64, float(self.rank), dtype=np.float32)
+        h[self.rank % 64] = 100.0 + self.rank
+        return h
+
     def averaged_stub(self, count):
         """a recognisable partial Welch mean: rank r 'measured' the constant r + 1 in every bin (1024 bins)"""
         return np.full(1024, float(self.rank + 1)), count
@@ -198,6 +204,8 @@ def main() -> None:
                          "so that a rocprofv3 trace of the run holds launches of one shape; the other figures of the line repeat it")
     ap.add_argument("--preroll-seconds", type=float, default=0.4, help="untimed load before the warm-up steps")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the single-thread CPU baseline leg")
+    ap.add_argument("--cpu-seconds-multi", type=float, default=3.0,
+                    help="budget of the single-thread CPU baseline leg when more than one rank runs (rank 0 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-workers", type=int, default=0,
                     help="processes of the all-cores CPU leg: 0 = one per physical host core (BASELINE.md 3(ii)), N = N processes")
@@ -481,20 +489,30 @@ def main() -> None:
     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same kernel and shape
     # (counters cannot be read from inside the process)
     traffic, traffic_src = None, None
-    for rnd in ("r03", "r02", "r01"):
+    quoted = {}                                        # committed files the line quotes: sha + mtime, so a stale one shows
+
+    def _quote(path):
+        import hashlib
+        with open(path, "rb") as fh:
+            blob = fh.read()
+        quoted[os.path.relpath(path, ROOT)] = {"sha256_16": hashlib.sha256(blob).hexdigest()[:16],
+                                               "mtime_utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime(os.path.getmtime(path)))}
+        return json.loads(blob)
+
+    for rnd in ("r04", "r03", "r02", "r01"):
         pmc_path = os.path.join(ROOT, "profiles", f"{rnd}_{args.config}_pmc.json")
         if os.path.exists(pmc_path):
-            with open(pmc_path) as fh:
-                pmc = json.load(fh)
+            pmc = _quote(pmc_path)
             traffic = pmc["fetch_bytes_upper"] + pmc["write_bytes"]
             traffic_src = (f"profiles/{rnd}_{args.config}_pmc.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, per one-step "
                            f"launch of {pmc.get('algorithmic_bytes', 0) / 1e6:.1f} MB algorithmic)")
             break
     valu_issue = None
-    vi_path = os.path.join(ROOT, "profiles", f"r03_{args.config}_valu_issue.json")
-    if os.path.exists(vi_path):
-        with open(vi_path) as fh:
-            valu_issue = json.load(fh)
+    for rnd in ("r04", "r03"):
+        vi_path = os.path.join(ROOT, "profiles", f"{rnd}_{args.config}_valu_issue.json")
+        if os.path.exists(vi_path):
+            valu_issue = _quote(vi_path)
+            break
 
     result = None
     if rank == 0:
@@ -547,6 +565,7 @@ def main() -> None:
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "frac_per_gpu": per_gpu_frac, "traffic": traffic,
                          "traffic_unit": "bytes per one-step launch", "traffic_source": traffic_src,
+                         "quoted_files": quoted,
                          "algorithmic_bytes_per_launch": algo_launch,
                          "frames_per_launch": my_frames * head["per_call"],
                          "kernel": "spectrum_kernel" if launches_b else "column pass + row pass + gather + finish (whole serial step)",
@@ -591,9 +610,24 @@ def main() -> None:
         if welch_block is not None:
             result["welch"] = welch_block
 
-    # ---- parity spot check (rank 0; C5: the COMBINED row at any number of ranks) + CPU baseline (single GPU only)
-    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and not args.dry_run
-    want_parity = rank == 0 and not args.dry_run and not args.no_cpu_baseline and (world == 1 or welch)
+    # ---- parity (rows of rank 0's launch + the COMBINED hold trace of all ranks; C5: the combined Welch row) and the
+    #      CPU baseline (rank 0; a short leg when several ranks run) - at every world size
+    multi = world > 1
+    want_cpu = rank == 0 and not args.no_cpu_baseline and not args.dry_run
+    want_parity = not args.no_cpu_baseline and not args.dry_run          # every rank takes part in the hold-trace check
+    cpu_budget = min(args.cpu_seconds, args.cpu_seconds_multi) if multi else args.cpu_seconds
+    if args.dry_run and not welch:
+        # plumbing only: the per-rank stand-in traces travel the same gather + np.fmax combine
+        from topdogspectrumanalyser_amd.sharding import combine_hold
+        stubs = gather(eng.hold_stub())
+        if rank == 0:
+            comb = combine_hold(stubs, "max")
+            result["hold_trace"] = {"combined_on": "host (np.fmax over ranks)", "ranks_combined": len(stubs),
+                                    "max_db": float(np.max(comb)), "argmax_bin": int(np.argmax(comb)),
+                                    "checked_positions": 0, "max_db_err_vs_gold": None, "pass": None, "dry_run": True}
+            result["parity"] = {"dry_run": True, "pass": None, "hold_trace_pass": None, "checked": "nothing (dry run)"}
+            result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 1, "kind": "port", "dry_run": True,
+                                      "sample": f"none (dry run; a real run times {cpu_budget:.0f} s on rank 0)"}
     if want_parity or want_cpu:
         from oracle import spectrum_oracle as so   # checker / reported baseline only
 
@@ -613,69 +647,103 @@ def main() -> None:
                     "survey_8d_strict_pass": bool(worst_rel <= 1e-4 and raw100 <= 1e-3),
                     "pass": bool(worst_rel <= 1e-4 and worst_db <= 1e-3)}
 
+        done, cpu_s, sample = 0, 0.0, ""
         if welch:
             seg = lambda k: so.unpack_iq_int8(base[2 * k * hop: 2 * (k * hop + nfft)])   # noqa: E731
             if want_cpu:
                 br = so.RtlBranchOracle(nfft, wl["fs"], precision="ref")
                 br.averager.set_mode("lin", frames)
                 t_cpu0 = time.perf_counter()
-                done = 0
-                while done < 3 or (time.perf_counter() - t_cpu0 < args.cpu_seconds and done < frames):
+                while done < 3 or (time.perf_counter() - t_cpu0 < cpu_budget and done < frames):
                     br.power_levels(seg(done % frames))
                     done += 1
                 cpu_s = time.perf_counter() - t_cpu0
                 sample = f"{done} segments of 2^20 points, single thread, numpy {np.__version__} restatement incl. int8 unpack"
-            # parity: the whole Welch average (all K segments, combined over the ranks) against the float64 gold
-            gold = so.RtlBranchOracle(nfft, wl["fs"], precision="gold")
-            gold.averager.set_mode("lin", frames)
-            g = None
-            for k in range(frames):
-                g = gold.power_levels(seg(k))
-            g = np.asarray(g, dtype=np.float64) + CAL_DB
-            pairs = [(np.asarray(combined_db, dtype=np.float32), g)]
-            checked = f"Welch mean of all {frames} segments, combined on the host from {world} rank(s)"
-            if world == 1:                             # ... and the row the device wrote itself
-                pairs.append((out_ring[0][0].cpu().numpy(), g))
-                checked += " + the device's own dB row"
-            result["parity"] = parity_block(pairs, checked)
-        else:
-            if wl["branch"] == "hackrf":
-                br = so.HackrfBranchOracle(nfft, wl["fs"], precision="ref")
-                gold = so.HackrfBranchOracle(nfft, wl["fs"], precision="gold")
-            else:
-                br = so.RtlBranchOracle(nfft, wl["fs"], precision="ref")
+            if rank == 0 and want_parity:
+                # parity: the whole Welch average (all K segments, combined over the ranks) against the float64 gold
                 gold = so.RtlBranchOracle(nfft, wl["fs"], precision="gold")
-            t_cpu0 = time.perf_counter()
-            done = 0
-            while time.perf_counter() - t_cpu0 < args.cpu_seconds:      # the same second of IQ, over and over
-                k = done % frames
-                x = so.unpack_iq_int8(base[2 * k * hop: 2 * (k * hop + nfft)])
-                br.power_levels(x)
-                done += 1
-            cpu_s = time.perf_counter() - t_cpu0
-            # parity of a sampled subset of the GPU frames (ring slot 0 holds `base`), from a BATCHED launch
-            eng.reset()
-            eng.set_overlap(1)
-            if batch > 1:
-                step_batch(0)
-            else:
+                gold.averager.set_mode("lin", frames)
+                g = None
+                for k in range(frames):
+                    g = gold.power_levels(seg(k))
+                g = np.asarray(g, dtype=np.float64) + CAL_DB
+                pairs = [(np.asarray(combined_db, dtype=np.float32), g)]
+                checked = f"Welch mean of all {frames} segments, combined on the host from {world} rank(s)"
+                if world == 1:                             # ... and the row the device wrote itself
+                    pairs.append((out_ring[0][0].cpu().numpy(), g))
+                    checked += " + the device's own dB row"
+                result["parity"] = parity_block(pairs, checked)
+        else:
+            branch = "hackrf" if wl["branch"] == "hackrf" else "rtl"
+            if want_cpu:
+                br = (so.HackrfBranchOracle if branch == "hackrf" else so.RtlBranchOracle)(nfft, wl["fs"], precision="ref")
+                t_cpu0 = time.perf_counter()
+                while time.perf_counter() - t_cpu0 < cpu_budget:            # the same second of IQ, over and over
+                    k = done % frames
+                    br.power_levels(so.unpack_iq_int8(base[2 * k * hop: 2 * (k * hop + nfft)]))
+                    done += 1
+                cpu_s = time.perf_counter() - t_cpu0
+                sample = (f"{done} frames ({cpu_budget:.0f} s) cycling through the same second of IQ, single "
+                          f"thread, numpy {np.__version__} restatement of get_power_levels incl. int8 unpack")
+            if want_parity:
+                # (1) the hold trace, every rank: ONE step over this rank's own second (ring slot 0 = `base`) from a
+                #     fresh state; the trace must equal the column maximum of the rows the same launch wrote (bit for
+                #     bit) and - combined over the ranks with np.fmax - the float64 gold of
+                #     core/display_data_processor.py:371-382 at a sample of positions (tone bins, their neighbours, DC,
+                #     the edges, 16 others), which every rank evaluates for its own second from the DFT definition
+                from topdogspectrumanalyser_amd.sharding import combine_hold
+                eng.reset()
+                eng.set_overlap(1)
                 step(0)
-            eng.synchronize()
-            picks = (0, 1, frames // 2, frames - 1)
-            pairs = []
-            for k in picks:
-                x = so.unpack_iq_int8(base[2 * k * hop: 2 * (k * hop + nfft)])
-                pairs.append((out_ring[0][k].cpu().numpy(), np.asarray(gold.power_levels(x))))
-            result["parity"] = parity_block(pairs, f"{len(picks)} frames of a {batch}-step launch")
-            sample = (f"{done} frames ({args.cpu_seconds:.0f} s) cycling through the same second of IQ, single "
-                      f"thread, numpy {np.__version__} restatement of get_power_levels incl. int8 unpack")
+                eng.synchronize()
+                mine_hold, _ = eng.hold()
+                colmax = out_ring[0].amax(dim=0).cpu().numpy()
+                tone_k = [nfft // 8, int(round(-nfft / 5 + 0.3)), int(round(3 * nfft / 7 + 0.5)), 0]
+                pos = sorted({(k + d + nfft // 2) % nfft for k in tone_k for d in (-1, 0, 1)} | {0, nfft - 1}
+                             | {int(v) for v in np.random.default_rng(1234).integers(0, nfft, 16)})
+                gold_pos = so.max_hold_at_positions(base, nfft, hop, pos, branch=branch)
+                per_rank = gather((mine_hold[pos], gold_pos, bool(np.array_equal(mine_hold, colmax))))
+                if rank == 0:
+                    comb = combine_hold([h for h, _, _ in per_rank], "max")
+                    gold_comb = np.fmax.reduce(np.stack([g for _, g, _ in per_rank]), axis=0)
+                    err = float(np.max(np.abs(comb.astype(np.float64) - gold_comb)))
+                    eq = [e for _, _, e in per_rank]
+                    hold_pass = bool(err <= 1e-3 and all(eq))
+                    ht = result.setdefault("hold_trace", {"combined_on": "host (np.fmax over ranks)"})
+                    ht.update({"ranks_combined": len(per_rank), "checked_positions": len(pos), "max_db_err_vs_gold": err,
+                               "gold": "np.fmax over the ranks of each rank's float64 gold hold over its own second of IQ "
+                                       "(oracle.max_hold_at_positions: the branch's arithmetic from the DFT definition at the "
+                                       "sampled fftshift-ed positions), bound 1e-3 dB",
+                               "equals_column_max_of_own_rows": eq, "pass": hold_pass})
+                # (2) rows of rank 0: a sampled subset of the frames of a BATCHED launch (ring slot 0 holds `base`)
+                if rank == 0:
+                    gold = (so.HackrfBranchOracle if branch == "hackrf" else so.RtlBranchOracle)(nfft, wl["fs"], precision="gold")
+                    eng.reset()
+                    if batch > 1:
+                        step_batch(0)
+                    else:
+                        step(0)
+                    eng.synchronize()
+                    picks = (0, 1, frames // 2, frames - 1)
+                    pairs = []
+                    for k in picks:
+                        x = so.unpack_iq_int8(base[2 * k * hop: 2 * (k * hop + nfft)])
+                        pairs.append((out_ring[0][k].cpu().numpy(), np.asarray(gold.power_levels(x))))
+                    pb = parity_block(pairs, f"{len(picks)} frames of a {batch}-step launch of rank 0 + the hold trace "
+                                             f"combined over {world} rank(s) at {len(pos)} positions")
+                    pb["rows_pass"] = pb["pass"]
+                    pb["hold_trace_pass"] = hold_pass
+                    pb["hold_trace_max_db_err"] = err
+                    pb["pass"] = bool(pb["rows_pass"] and hold_pass)
+                    result["parity"] = pb
         if want_cpu:
-            result["cpu_baseline"] = {"value": done / cpu_s, "unit": "frames/s", "cores": 1, "kind": "port",
-                                      "sample": sample, "host_cores_available": os.cpu_count()}
+            result["cpu_baseline"] = {"value": done / cpu_s, "unit": "frames/s", "cores": 1,
+                                      "kind": "port", "sample": sample, "host_cores_available": os.cpu_count()}
             workers = args.cpu_workers if args.cpu_workers > 0 else physical_cores()
             result["cores_policy"] = (f"cpu_baseline: 1 core; cpu_baseline_pool: {workers} single-thread processes = one per "
-                                      f"physical core by default ({physical_cores()} cores, {os.cpu_count()} logical CPUs)")
-            if not args.no_cpu_pool and not welch:
+                                      f"physical core by default ({physical_cores()} cores, {os.cpu_count()} logical CPUs)"
+                                      + ("; not run with several ranks (the ranks' host threads share those cores)" if multi else ""))
+            if not args.no_cpu_pool and not welch and not multi:
                 try:
                     result["cpu_baseline_pool"] = cpu_all_cores(wl, workers, args.cpu_pool_seconds)
                 except Exception as exc:               # a reported extra, never a reason to lose the bench line

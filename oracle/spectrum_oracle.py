@@ -361,6 +361,39 @@ def rtl_batch(iq_i8: np.ndarray, nfft: int, hop: int, sample_rate: float, *,
     return out, h.max, h.min
 
 
+def max_hold_at_positions(iq_i8: np.ndarray, nfft: int, hop: int, positions, branch: str = "hackrf",
+                          n_frames: Optional[int] = None, chunk: int = 128) -> np.ndarray:
+    """float64 gold of the max-hold trace of a whole capture at a FEW fftshift-ed positions, evaluated from the DFT
+    definition X[k] = sum_n x[n] exp(-2 pi i k n / N) as one matrix product per chunk of frames - what bench.py checks
+    the (combined) hold trace against where a full FFT of every frame of every rank would take minutes.  Per frame the
+    arithmetic is the branch's own, in float64: HackRF (hackrf_samples.py:360-383: mean removal, power-normalised
+    Hann, 20 log10(|X| + 1e-12)) or RTL (rtl_samples.py:169-184: raw Hann, 10 log10(|X|^2 + 1e-10)); the hold is
+    np.fmax over the frames (core/display_data_processor.py:371-382)."""
+    x = unpack_iq_int8(iq_i8)
+    nf = num_frames(len(x), nfft, hop) if n_frames is None else n_frames
+    pos = np.asarray(positions, dtype=np.int64)
+    k = (pos + nfft // 2) % nfft                                   # fftshift: shifted[p] = X[(p + N/2) mod N]
+    n = np.arange(nfft, dtype=np.int64)
+    e = np.exp(-2j * np.pi * ((n[:, None] * k[None, :]) % nfft) / nfft)
+    if branch == "hackrf":
+        w = hackrf_window(nfft).astype(np.float64)
+    else:
+        w = rtl_window("hanning", nfft).astype(np.float64)
+    ew = e * w[:, None]
+    frames = np.lib.stride_tricks.as_strided(x, shape=(nf, nfft), strides=(hop * x.strides[0], x.strides[0]),
+                                             writeable=False)
+    hold = np.full(len(pos), -np.inf)
+    for f0 in range(0, nf, chunk):
+        blk = frames[f0: f0 + chunk].astype(np.complex128)
+        if branch == "hackrf":
+            blk = blk - blk.mean(axis=1, keepdims=True)
+            db = 20.0 * np.log10(np.abs(blk @ ew) + LOG_FLOOR)
+        else:
+            db = 10.0 * np.log10(np.abs(blk @ ew) ** 2 + POWER_LOG_FLOOR)
+        hold = np.fmax(hold, db.max(axis=0))
+    return hold
+
+
 # ----------------------------------------------------------------------------------------------
 # Synthetic IQ of SURVEY.md section 8(d): 3 tones + DC + complex Gaussian noise, int8 interleaved
 # ----------------------------------------------------------------------------------------------

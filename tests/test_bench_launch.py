@@ -33,6 +33,15 @@ def _check_line(d, n):
     assert d["timing"]["repetitions"] == 3 and d["timing"]["steps_per_region"] == 40 * d["timing"]["inner_repeats"]
     assert min(d["timing"]["region_ms"]) >= 50.0          # every timed region lasts >= 50 ms
     assert "no collective" in d["config"]["parallelism"]
+    # the N > 1 line carries its own evidence (round-3 verdict): a parity block, the hold trace combined over ALL ranks
+    # (core/display_data_processor.py:371-382 is what it must equal) and a CPU baseline leg - in --dry-run the per-rank
+    # stand-in traces (rank r holds 100 + r in bin r) travel the same gather + np.fmax combine
+    ht = d["hold_trace"]
+    assert ht["ranks_combined"] == n and ht["max_db"] == 100.0 + (n - 1) and ht["argmax_bin"] == n - 1
+    assert "pass" in d["parity"] and "hold_trace_pass" in d["parity"]
+    assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["kind"] == "port"
+    assert ("3 s" if n > 1 else "10 s") in d["cpu_baseline"]["sample"]
+    assert all("sha256_16" in v for v in d["roofline"]["quoted_files"].values())
 
 
 @pytest.mark.parametrize("n", [1, 2])

@@ -2188,6 +2188,73 @@ def test_batched_captures_match_consecutive_calls(pkg, nfft, hop, nf, fmt, mode)
         _check(bat[0][2], gold, "capture 2 of the batch")
 
 
+@pytest.mark.parametrize("nfft,fmt", [(4096, "i8"), (16384, "i8"), (512, "u8"), (2048, "c64")])
+@pytest.mark.parametrize("out_gap", [0, 96])
+def test_batched_single_frame_captures(pkg, nfft, fmt, out_gap):
+    """ONE frame per capture - one get_power_levels() per queued chunk, the use tdsa_hip.h cites for the batch call
+    (hackrf_samples.py:254-305).  ceil(2^32 / 1) does not fit the kernel's 32-bit segment divisor, so the library runs
+    such a batch as one capture whose frames sit a segment stride apart (contiguous rows) or capture by capture
+    (gapped rows): rows, hold traces and DC state must be those of consecutive calls either way, with gapped input."""
+    import ctypes as C
+    nat = pkg._native
+    n_seg, nf, hop = 7, 1, nfft
+    bps = 8 if fmt == "c64" else 2
+    in_fmt = {"i8": nat.IN_I8, "u8": nat.IN_U8, "c64": nat.IN_C64}[fmt]
+    seg_stride = nfft * bps + 5 * bps * 3                      # gap of 15 samples between captures
+    out_stride = nfft + out_gap
+    caps = []
+    for sgi in range(n_seg):
+        iq = so.synth_iq_int8(nfft, nfft, seed=700 + sgi)
+        if fmt == "u8":
+            iq = (iq.astype(np.int16) + 128).astype(np.uint8)
+        elif fmt == "c64":
+            iq = so.unpack_iq_int8(iq).astype(np.complex64)
+        caps.append(iq)
+    blob = np.zeros(seg_stride * n_seg, dtype=np.uint8)
+    for sgi, iq in enumerate(caps):
+        raw = iq.view(np.uint8)
+        blob[sgi * seg_stride: sgi * seg_stride + raw.size] = raw
+    d_in, d_out = C.c_void_p(), C.c_void_p()
+    nat.check(nat.lib.tdsa_dev_alloc(0, blob.nbytes, C.byref(d_in)))
+    nat.check(nat.lib.tdsa_dev_alloc(0, out_stride * n_seg * 4, C.byref(d_out)))
+    nat.check(nat.lib.tdsa_memcpy_h2d(0, d_in, blob.ctypes.data_as(C.c_void_p), blob.nbytes))
+
+    def run(batched):
+        nan = np.full(out_stride * n_seg, np.nan, np.float32)
+        nat.check(nat.lib.tdsa_memcpy_h2d(0, d_out, nan.ctypes.data_as(C.c_void_p), nan.nbytes))
+        with _hackrf_engine(pkg, nfft, 4, hold_max=True, hold_min=True) as e:
+            for rep in range(2):
+                if batched:
+                    e.process_device_batch(in_fmt, d_in.value, seg_stride, n_seg, nfft, hop, nf, d_out.value, out_stride)
+                else:
+                    for sgi in range(n_seg):
+                        e.process_device(in_fmt, d_in.value + sgi * seg_stride, nfft, hop, nf,
+                                         d_out.value + 4 * sgi * out_stride)
+            e.synchronize()
+            got = np.empty(out_stride * n_seg, dtype=np.float32)
+            nat.check(nat.lib.tdsa_memcpy_d2h(0, got.ctypes.data_as(C.c_void_p), d_out, got.nbytes))
+            return got, e.hold(), e.dc_estimate, e.info().frames_held_max
+
+    try:
+        seq = run(False)
+        bat = run(True)
+        with _hackrf_engine(pkg, nfft, 4) as e:               # rows that would overlap are refused, not raced
+            with pytest.raises(Exception):
+                e.process_device_batch(in_fmt, d_in.value, seg_stride, n_seg, nfft, hop, nf, d_out.value, nfft // 2)
+    finally:
+        nat.lib.tdsa_dev_free(0, d_in)
+        nat.lib.tdsa_dev_free(0, d_out)
+    assert np.array_equal(seq[0], bat[0], equal_nan=True)      # the gaps keep their NaN fill in both
+    for a, b in zip(seq[1], bat[1]):
+        assert np.array_equal(a, b)
+    assert seq[2] == bat[2] and seq[3] == bat[3] == 2 * n_seg
+    if fmt == "i8":
+        gold_src = so.HackrfBranchOracle(nfft, 20e6, precision="gold")
+        for sgi in (0, 3, n_seg - 1):
+            _check(bat[0][sgi * out_stride: sgi * out_stride + nfft],
+                   np.asarray(gold_src.power_levels(so.unpack_iq_int8(caps[sgi]))), f"capture {sgi}")
+
+
 def test_batched_captures_full_c3_shape(pkg):
     """Four seconds of the C3 shape (4 x 2440 frames of 16384 points, hop N/2) in one launch: the hold trace equals
     the column maximum of all 9760 rows and sampled rows match the gold oracle."""

@@ -120,7 +120,11 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
 #else
   static_for<1, NA>([&](auto ac) { constexpr int a = decltype(ac)::value; lo[a] = big_twiddle(p, unsigned(n2) * a); });
 #endif
+#ifdef TDSA_EXP_ZSLOTS   // timing experiment (wrong results): Z of segment s aliased onto slot s mod k, so that Z stays in the Infinity Cache
+  const brsrc_t zr = big_rsrc(p.z + (long long)(seg % TDSA_EXP_ZSLOTS) * N1 * kRowN, unsigned(N1) * kRowN * 8u);
+#else
   const brsrc_t zr = big_rsrc(p.z + (long long)seg * N1 * kRowN, unsigned(N1) * kRowN * 8u);
+#endif
 #ifdef TDSA_COLS_STORE8
   const unsigned zv = unsigned(n2) * 8u;
 #else

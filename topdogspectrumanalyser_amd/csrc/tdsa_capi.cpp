@@ -478,7 +478,7 @@ static int plan_init(tdsa_plan p) {
   HIPCHK(hipEventCreateWithFlags(&p->ev_state, hipEventDisableTiming));
   const size_t nb = size_t(nfft) * sizeof(float);
   for (int f = 0; f < 3; ++f) HIPCHK(hipMalloc(&p->d_window[f], nb));
-  if (!p->big && !p->chirp)
+  if (!p->big && !p->chirp && p->log2n >= 11)     // only the 3-pass sizes read the permuted table (Cfg::WIN_LDS below)
     for (int f = 0; f < 3; ++f) HIPCHK(hipMalloc(&p->d_window_perm[f], nb));
   const int tw_n = p->chirp ? p->m_fft : nfft;       // the size the frame kernel transforms
   HIPCHK(hipMalloc(&p->d_tw, size_t(tw_n) * sizeof(float2)));
@@ -732,6 +732,7 @@ struct SegInfo {
   int frames_per_seg = 0;
   long long in_stride_bytes = 0;
   long long out_stride_elems = 0;
+  bool single_frames = false;   // one frame per capture: launched as ONE capture whose frames are in_stride_bytes apart
 };
 
 // before / after: optional events the device work waits for / signals (tdsa_pipe: H2D and D2H legs)
@@ -804,7 +805,9 @@ static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size
   sp.cal_db = m.cal_offset_db;
   sp.tare = p->tare_active ? p->d_tare_base : nullptr;
   sp.dbg = p->d_dbg;
-  if (seg) {
+  if (seg && seg->single_frames) {
+    sp.frame_stride = seg->in_stride_bytes;      // seg_magic stays 0: frame f reads in + f * stride, row f follows row f - 1
+  } else if (seg) {
     sp.seg_frames = unsigned(seg->frames_per_seg);
     sp.seg_magic = unsigned((0x100000000ull + sp.seg_frames - 1) / sp.seg_frames);   // ceil(2^32 / d)
     sp.seg_in_stride = seg->in_stride_bytes;
@@ -898,11 +901,24 @@ int tdsa_process_dev_batch(tdsa_plan p, int in_format, const void* iq_dev, size_
   const size_t bps = size_t(bytes_per_sample(in_format));
   if (n_segments > 1 && seg_stride_bytes % (bps == 8 ? 8 : 2) != 0)
     return fail(TDSA_ERR_ARG, "seg_stride_bytes=%zu must be a multiple of one sample", seg_stride_bytes);
+  if (frames_per_seg < 0) return fail(TDSA_ERR_ARG, "frames_per_seg=%d", frames_per_seg);
+  // the captures' rows must not overlap: with a stride below one capture's rows the one-launch path would have
+  // several workgroups write the same rows concurrently (which capture survives would not be deterministic)
+  if (n_segments > 1 && out_db_dev != nullptr && !p->big &&
+      out_seg_stride_floats < size_t(frames_per_seg) * size_t(p->nfft))
+    return fail(TDSA_ERR_ARG, "out_seg_stride_floats=%zu is smaller than one capture's rows (%d x %d)",
+                out_seg_stride_floats, frames_per_seg, p->nfft);
   const tdsa_mode& m = p->mode;
   const bool order_free = !avg_active(m) && (m.dc_alpha < 0.0f || m.dc_alpha >= 1.0f);
   const long long total = (long long)n_segments * frames_per_seg;
+  // frames_per_seg == 1: ceil(2^32 / 1) does not fit SpecParams::seg_magic (it would read as 0 = "one capture").
+  // One frame per capture IS one capture whose frames sit seg_stride apart, as long as its rows are contiguous;
+  // with gapped rows the captures go out one by one.
+  const bool single_frames = frames_per_seg == 1;
+  const bool rows_contiguous = out_db_dev == nullptr || out_seg_stride_floats == size_t(p->nfft);
   const bool one_launch = n_segments > 1 && order_free && !p->chirp && !p->big && frames_per_seg > 0 &&
-                          total * frames_per_seg < 0x100000000ll && total < 0x7fffffffll;
+                          total * frames_per_seg < 0x100000000ll && total < 0x7fffffffll &&
+                          (!single_frames || rows_contiguous);
   if (!one_launch) {
     for (int sg = 0; sg < n_segments; ++sg) {
       const int rc = process_dev_impl(p, in_format, static_cast<const unsigned char*>(iq_dev) + size_t(sg) * seg_stride_bytes,
@@ -917,6 +933,7 @@ int tdsa_process_dev_batch(tdsa_plan p, int in_format, const void* iq_dev, size_
   seg.frames_per_seg = frames_per_seg;
   seg.in_stride_bytes = (long long)seg_stride_bytes;
   seg.out_stride_elems = (long long)out_seg_stride_floats;
+  seg.single_frames = single_frames;
   return process_dev_impl(p, in_format, iq_dev, n_samples_per_seg, hop, int(total), out_db_dev, nullptr, nullptr, &seg);
 }
 

@@ -459,8 +459,13 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   auto load_frame_c64 = [&](int frame) {
     if constexpr (ACC) {
       const int fg = frame / p.group;
+#ifdef TDSA_EXP_ZSLOTS   // timing experiment (wrong results): see tdsa_big.hip
+      const unsigned char* fb = static_cast<const unsigned char*>(p.in) + (long long)((frame - fg * p.group) % TDSA_EXP_ZSLOTS) * p.frame_stride +
+                                (long long)fg * p.group_stride;
+#else
       const unsigned char* fb = static_cast<const unsigned char*>(p.in) + (long long)(frame - fg * p.group) * p.frame_stride +
                                 (long long)fg * p.group_stride;
+#endif
       static_for<0, 16>([&](auto ic) {
         constexpr int idx = decltype(ic)::value;
         constexpr int jj = idx / H, i = idx % H;

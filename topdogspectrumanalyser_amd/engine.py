@@ -140,9 +140,13 @@ class SpectrumEngine:
 
     def process_device_batch(self, in_format: int, iq_dev: int, seg_stride_bytes: int, n_segments: int,
                              n_samples_per_seg: int, hop: int, frames_per_seg: int, out_db_dev: Optional[int],
-                             out_seg_stride_floats: int = 0) -> None:
+                             out_seg_stride_floats: Optional[int] = None) -> None:
         """n_segments captures of one shape (device pointers, asynchronous): the same results and state as
-        n_segments process_device() calls, as ONE persistent launch where the mode allows (tdsa_process_dev_batch)."""
+        n_segments process_device() calls, as ONE persistent launch where the mode allows (tdsa_process_dev_batch).
+        out_seg_stride_floats defaults to one capture's rows (frames_per_seg * nfft: captures back to back); a
+        smaller stride is refused by the library."""
+        if out_seg_stride_floats is None:
+            out_seg_stride_floats = int(frames_per_seg) * self.nfft
         nat.check(nat.lib.tdsa_process_dev_batch(self._h, in_format, C.c_void_p(iq_dev), seg_stride_bytes, n_segments,
                                                  n_samples_per_seg, hop, frames_per_seg,
                                                  C.c_void_p(out_db_dev) if out_db_dev else None,
