@@ -16,6 +16,7 @@
 // (hackrf_samples.py:370, utils/signal_processing.py:35-61, core/display_data_processor.py:317-327).
 #include "tdsa_fft.hpp"
 #include "tdsa_kernels.hpp"
+#include "tdsa_spectrum_kernel.hpp"   // Cfg<14>, the LDS / half-wave exchange helpers and the radix networks of the frame kernel
 
 namespace tdsa {
 
@@ -74,6 +75,10 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
   static_for<1, NB>([&](auto bc) { constexpr int b = decltype(bc)::value; seeds[NA + b][threadIdx.x] = big_twiddle(p, unsigned(n2) * (8u * b)); });
 #endif
   c32 v[N1];
+#if defined(TDSA_EXP_COLS) && TDSA_EXP_COLS == 2   // timing experiment: stores only (no loads, no arithmetic)
+  static_for<0, N1>([&](auto ic) { constexpr int i = decltype(ic)::value; v[i] = c32{float(n2 + i), float(seg)}; });
+  if (false)
+#endif
   if (p.in_c64) {
     const brsrc_t ir = big_rsrc(p.in + (long long)seg * p.seg_stride, unsigned(N1) * kRowN * 8u);
     static_for<0, N1>([&](auto ic) {
@@ -113,7 +118,9 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
     });
 #endif
   }
+#if !(defined(TDSA_EXP_COLS) && TDSA_EXP_COLS == 2)
   dif<N1, 0, N1>(v);
+#endif
   c32 lo[NA];
 #ifndef TDSA_COLS_LATE_SEEDS
   static_for<1, NA>([&](auto ac) { constexpr int a = decltype(ac)::value; lo[a] = seeds[a][threadIdx.x]; });
@@ -170,11 +177,194 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
         // hazard recognizer only pads it when soffset is not a register.  With `soffset = s4` the compiler re-used
         // v[78:81] for the next pair right behind the store and rows came out corrupted run-to-run (1e-6 .. 6e-4 of
         // the frame maximum, only when more than 256 workgroups were in flight; two 8-byte stores were always right).
+#if defined(TDSA_EXP_COLS) && TDSA_EXP_COLS == 1   // timing experiment: no stores (one store per thread that never happens keeps the work alive)
+        if (pk.x == 0x7fc12345u) __builtin_amdgcn_raw_buffer_store_b128(pk, zr, zv + unsigned(k1 - 1) * kRowN * 8u, 0, 0);
+#else
         __builtin_amdgcn_raw_buffer_store_b128(pk, zr, zv + unsigned(k1 - 1) * kRowN * 8u, 0, 0);
+#endif
       }
 #endif
     });
   });
+}
+
+// ---- row pass: 16384-point transforms of the rows Z[seg][k1][.], |X|^2 summed over the segments a workgroup takes ----
+// The frame kernel's three radix passes (A x 32 x 32 with A = 16: tdsa_spectrum_kernel.hpp) on complex64 rows, as a
+// kernel of its own since round 4.  Until then it was an instantiation of the frame kernel (ACC) that fetched the next
+// row - 128 KB per CU - in one burst behind pass 1 and waited for it at the top of the next row: the fetch had passes 2
+// and 3 (3.7 us) to land, needs 5 us at the read roof, and the memory pipe of the CU sat idle during pass 1 (7.7 us per
+// row against 4.7 us of arithmetic).  Issuing the whole fetch at the row top does not fit: its 32 landing registers and
+// pass 1's working set exceed the 128 VGPRs (round 3 tried: scratch).  Here the fetch is split: the first half (4 x 16
+// bytes per thread) is issued at the row top, the second half behind pass 1, so that the CU always has loads in flight;
+// the loop body is branch-free (the row after the last one is the last one again) and carries no other vector-memory
+// operation, so the only vmcnt wait the compiler places is the one at the row top.
+struct BigRowsParams {
+  const float2* z;           // [group][N1][16384] rows from the column pass
+  long long seg_stride;      // bytes between segments (N1 * 16384 * 8)
+  int group;                 // segments in this round
+  int act;                   // workgroups per k1 in this launch: grid = N1 * act, workgroup b = k1 * act + j
+  float* acc;                // P[(k1 * acc_split + j)][16384] partial power sums, one row per workgroup
+  int acc_split;             // rows of P per k1
+  int acc_add;               // 0: the row is overwritten (first round of a call), 1: added to
+  const float2* tw;          // exp(-2 pi i m / 16384)
+};
+
+__global__ void __launch_bounds__(1024, 4) big_rows_kernel(const BigRowsParams p) {
+  using C = Cfg<kRowLog2>;
+  constexpr int N = C::N, SG = C::SG, A = C::A, H = C::H;
+  static_assert(A == 16 && C::M == 2 && !C::INL && C::NPASS == 3 && C::FPW == 1, "row pass is written for N = 16 x 32 x 32");
+  constexpr int LH = ilog2(H);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  c32* buf = reinterpret_cast<c32*>(smem);
+  c32* twm = reinterpret_cast<c32*>(smem + C::DATA_BYTES);
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const int h = (tid >> 5) & 1;
+  const int t = wave * 32 + (tid & 31);
+  const bool odd_half = h != 0;
+  const int k1 = int(blockIdx.x) / p.act, j = int(blockIdx.x) - k1 * p.act;
+  const int chunk = (p.group + p.act - 1) / p.act;
+  const int s0 = min(p.group, j * chunk), s1 = min(p.group, s0 + chunk);
+
+  // element i of a pass lives at i + (i >> 5) (rows of 32 complex + 1 pad element)
+  const int wr1_base = 33 * t + 16 * h;
+  constexpr int rd_stride = SG + SG / 32;
+  const int rd_base = t + (t >> 5);
+  const int rdA = rd_base + h * rd_stride;
+  const int wrM = rd_base + 8 * h * rd_stride;
+  const int ka_mid = t % A;
+  const int rd3A = (t / A) * rd_stride + ka_mid + h * A;
+  const unsigned lane_in_off = unsigned(t) * 16u + unsigned(h) * 8192u;
+
+  c32 twf_lo[3], twf_hi[4];
+  static_for<0, 3>([&](auto ic) { constexpr int q = decltype(ic)::value; twf_lo[q] = p.tw[t * 2 * (q + 1)]; });
+  static_for<0, 4>([&](auto ic) { constexpr int a = decltype(ic)::value; twf_hi[a] = p.tw[t * (8 * a + h)]; });
+  if (tid < C::TWM) {
+    const int b = tid / A, ka = tid % A;
+    twm[tid] = p.tw[ka * b * (N / (32 * A))];
+  }
+  float pacc[16];
+  static_for<0, 16>([&](auto ic) { pacc[decltype(ic)::value] = 0.f; });
+
+  // row of segment s: 16384 complex64 values at z + s * seg_stride + k1 * 128 KiB; this thread's 16 values are the eight
+  // 16-byte pieces at lane_in_off + i * 16 KiB: (row 2i + h of the 16 x 1024 view, columns 2t, 2t + 1)
+  const unsigned char* zrow = reinterpret_cast<const unsigned char*>(p.z) + (long long)k1 * (N * 8);
+  auto row_rsrc = [&](int s) { return make_rsrc(zrow + (long long)s * p.seg_stride, N * 8u); };
+  u32x4 ld[8];
+  if (s0 < s1) {
+    const rsrc_t r = row_rsrc(s0);
+    static_for<0, 8>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      ld[i] = __builtin_amdgcn_raw_buffer_load_b128(r, lane_in_off, i * 16384, 2);   // last use of Z: non-temporal
+    });
+  }
+  __syncthreads();        // twm is in place
+  for (int s = s0; s < s1; ++s) {
+    c32 v[16];            // v[jj * 8 + i] = sample (row 2i + h, column 2t + jj)
+    static_for<0, 8>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      v[i] = c32{__uint_as_float(ld[i].x), __uint_as_float(ld[i].y)};
+      v[8 + i] = c32{__uint_as_float(ld[i].z), __uint_as_float(ld[i].w)};
+    });
+    const int sn = s + 1 < s1 ? s + 1 : s;          // (past the end: the same row again, so that the loop has no branch)
+    const rsrc_t rn = row_rsrc(sn);
+    static_for<0, 4>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      ld[i] = __builtin_amdgcn_raw_buffer_load_b128(rn, lane_in_off, i * 16384, 2);
+    });
+    // ---- pass 1: two radix-8 DFTs per half-thread, combine across the lane pair -> radix 16 ---------------
+    radix<8, 0, 16>(v);
+    radix<8, 8, 16>(v);
+    static_for<0, 8>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      constexpr int jj0 = u / H, k0 = u % H, jj1 = (u + 8) / H, k1r = (u + 8) % H;
+      constexpr int re = jj0 * H + bitrev(k0, LH), ro = jj1 * H + bitrev(k1r, LH);
+      swap_halves(v[re], v[ro]);
+      combine_const<k0, A>(v[re], v[ro]);
+      constexpr int li = jj0 * A + k0;
+      lds_st(&buf[wr1_base + li], v[re]);
+      lds_st(&buf[wr1_base + li + H], v[ro]);
+    });
+    static_for<4, 8>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      ld[i] = __builtin_amdgcn_raw_buffer_load_b128(rn, lane_in_off, i * 16384, 2);
+    });
+    __syncthreads();
+    // ---- middle radix-32 pass, in place --------------------------------------------------------------
+    static_for<0, 16>([&](auto ic) { constexpr int i = decltype(ic)::value; v[i] = lds_ld(&buf[rdA + i * 2 * rd_stride]); });
+    int tw_o = h * A + ka_mid;
+    asm volatile("" : "+v"(tw_o));
+    static_for<0, 2>([&](auto bc) {
+      constexpr int b0 = decltype(bc)::value * 4;
+      c32 tw8[8];
+      static_for<0, 8>([&](auto ic) {
+        constexpr int q = decltype(ic)::value;
+        constexpr int i = b0 + (q & 3) + 8 * (q >> 2);
+        tw8[q] = twm[tw_o + i * 2 * A];
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, 4>([&](auto ic) { constexpr int q = decltype(ic)::value; bf_tw(v[b0 + q], v[b0 + q + 8], tw8[q], tw8[q + 4]); });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    dit_rest<16, 0, 16>(v);
+    static_for<0, 8>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      constexpr int re = bitrev(u, 4), ro = bitrev(u + 8, 4);
+      swap_halves(v[re], v[ro]);
+      combine32<u>(v[re], v[ro], odd_half);
+      lds_st(&buf[wrM + u * rd_stride], v[re]);
+      lds_st(&buf[wrM + (u + 16) * rd_stride], v[ro]);
+    });
+    __syncthreads();
+    // ---- last radix-32 pass ----------------------------------------------------------------------------
+    static_for<0, 16>([&](auto ic) { constexpr int i = decltype(ic)::value; v[i] = lds_ld(&buf[rd3A + 2 * i * A + ((2 * i * A) >> 5)]); });
+    static_for<0, 3>([&](auto ic) { opaque(twf_lo[decltype(ic)::value]); });
+    static_for<0, 4>([&](auto ic) { opaque(twf_hi[decltype(ic)::value]); });
+    static_for<0, 8>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int a = i >> 2, q = i & 3;
+      c32 te = twf_hi[a], to = twf_hi[a + 2];
+      if constexpr (q != 0) { te = cmul(te, twf_lo[q - 1]); to = cmul(to, twf_lo[q - 1]); }
+      bf_tw(v[i], v[i + 8], te, to);
+    });
+    dit_rest<16, 0, 16>(v);
+    static_for<0, 8>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      constexpr int re = bitrev(u, 4), ro = bitrev(u + 8, 4);
+      swap_halves(v[re], v[ro]);
+      combine32<u, true>(v[re], v[ro], odd_half);
+    });
+    static_for<0, 16>([&](auto ic) {
+      constexpr int q = decltype(ic)::value;
+      const c32 X = v[bitrev(q, 4)];
+      pacc[q] = fmaf(X.x, X.x, fmaf(X.y, X.y, pacc[q]));
+    });
+    __syncthreads();      // the next row's pass-1 writes must not overtake this row's last gathers
+  }
+  // the workgroup's share of its row's power sum leaves as its own row of P (a workgroup without segments contributes
+  // zeros in the first round of a call and nothing afterwards)
+  if (s1 > s0 || p.acc_add == 0) {
+    float* arow = p.acc + (long long)(k1 * p.acc_split + j) * N + t + 8 * h * SG;
+    static_for<0, 16>([&](auto ic) {
+      constexpr int q = decltype(ic)::value;
+      constexpr int kc = (q < 8 ? q : q + 8);
+      float x = pacc[q];
+      if (p.acc_add != 0) x += arow[kc * SG];
+      arow[kc * SG] = x;
+    });
+  }
+}
+
+hipError_t launch_big_rows(const float2* z, long long seg_stride, int group, int n1, int act, float* acc, int acc_split,
+                           int acc_add, const float2* tw, hipStream_t s) {
+  using C = Cfg<kRowLog2>;
+  static std::atomic<unsigned long long> attr_done{0};
+  const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(big_rows_kernel), int(C::LDS_BYTES), attr_done);
+  if (e != hipSuccess) return e;
+  const BigRowsParams p{z, seg_stride, group, act, acc, acc_split, acc_add, tw};
+  hipLaunchKernelGGL(big_rows_kernel, dim3(n1 * act), dim3(C::WGT), C::LDS_BYTES, s, p);
+  return hipGetLastError();
 }
 
 // P[k1 * split + j][k2] (float: the row pass's per-workgroup partial power sums of this call, summed over j in

@@ -103,6 +103,7 @@ struct tdsa_plan_s {
   float2* d_tw_row = nullptr;            // W_16384^m : the row pass's twiddle table
   float* d_ones = nullptr;               // [16384] unit window for the row pass
   int big_group = 64;                    // segments per column-pass / row-pass round (one round for the K = 64 Welch capture)
+  bool big_rows_old = false;             // TDSA_BIG_ROWS_OLD=1: row pass through the frame kernel's ACC instantiation (rounds 2-3)
   // frame lengths that are not a power of two (tdsa_chirp.hip): chirp-z on the m_fft-point frame kernel
   bool chirp = false;
   int m_fft = 0, log2m = 0;              // M = 2^log2m >= 2 nfft - 1
@@ -266,7 +267,9 @@ int process_big(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n_f
       }
       HIPCHK(hipEventRecord(p->prof_events[p->prof_used], p->stream));
     }
-    HIPCHK(launch_spectrum_acc(sp, g, p->stream));
+    if (p->big_rows_old) HIPCHK(launch_spectrum_acc(sp, g, p->stream));    // developer A/B: the frame kernel's ACC instantiation
+    else HIPCHK(launch_big_rows(p->d_z, (long long)N * sizeof(float2), ns, n1, act, p->d_acc, split_layout, s0 > 0, p->d_tw_row,
+                                p->stream));
     if (p->profiling) {
       HIPCHK(hipEventRecord(p->prof_events[p->prof_used + 1], p->stream));
       p->prof_used += 2;
@@ -547,6 +550,7 @@ static int plan_init(tdsa_plan p) {
     HIPCHK(hipMemcpy(p->d_ones, ones.data(), size_t(M) * sizeof(float), hipMemcpyHostToDevice));
   }
   if (big) {
+    if (const char* o = getenv("TDSA_BIG_ROWS_OLD")) p->big_rows_old = atoi(o) != 0;
     if (const char* g = getenv("TDSA_BIG_GROUP")) {     // developer knob: segments per column/row round
       const int v = atoi(g);
       if (v >= 1 && v <= 64) p->big_group = v;
@@ -833,8 +837,18 @@ static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size
   // first fetch, hold merge: ~5 us) count half - and the ragged end of one launch is filled by the next:
   // C3 76.4 -> 74.3 us per step, C2 26.7 -> 26.0 (profiles/r02_c3_experiments.txt).  More than three streams in flight
   // measured worse (4: 91 us), and strictly serial launches keep the whole chip.
-  const LaunchGeom g = spectrum_geometry(p->log2n, n_frames,
-                                         (overlap && p->n_overlap >= 3) ? (p->num_cu * p->overlap_share + 99) / 100 : p->num_cu);
+  const LaunchGeom g0 = spectrum_geometry(p->log2n, n_frames,
+                                          (overlap && p->n_overlap >= 3) ? (p->num_cu * p->overlap_share + 99) / 100 : p->num_cu);
+  LaunchGeom g = g0;
+  {   // an instantiation built for fewer waves per SIMD hosts fewer workgroups per CU: size the persistent grid for that
+    const int hold_inst = averaging ? 0 : int(m.hold_flags & 3u);
+    const int waves = spectrum_waves_per_simd(p->log2n, in_c64 != 0, hold_inst);
+    if (waves < 4) {
+      const int cus = (overlap && p->n_overlap >= 3) ? (p->num_cu * p->overlap_share + 99) / 100 : p->num_cu;
+      const int cap = cus * (waves * 4 * 64 / g.block);
+      if (g.grid > cap && cap >= 1) g.grid = cap;
+    }
+  }
   if (averaging) {
     if (!p->d_lin) HIPCHK(hipMalloc(&p->d_lin, size_t(p->max_frames) * p->nfft * sizeof(float)));
     if (!p->d_carry && p->max_frames > 128)

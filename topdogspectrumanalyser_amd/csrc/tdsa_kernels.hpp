@@ -79,6 +79,14 @@ struct SpecParams {
   long long seg_out_stride;  // output elements
 };
 
+// Waves per SIMD an instantiation of the frame kernel is compiled for (its register budget: 512 / waves VGPRs).  Four
+// everywhere - except 1024-point byte frames with max AND min hold: one sample per row read means 16 prefetch registers,
+// two traces 32 more, and at 128 VGPRs eight values spilled (each reload behind the row stores' vmcnt: +11 % against
+// max hold alone); with three waves per SIMD (142 VGPRs, no scratch, three workgroups per CU) it is +6 %.
+constexpr int spectrum_waves_per_simd(int log2n, bool in_c64, int hold) {
+  return (log2n == 10 && !in_c64 && hold == 3) ? 3 : 4;
+}
+
 struct LaunchGeom {
   int grid, block, fpw;
   size_t lds_bytes;
@@ -161,6 +169,9 @@ hipError_t launch_big_dc(const void* in, int in_c64, unsigned xor_mask, long lon
                          hipStream_t s);
 // row pass: the 16384-point frame kernel on complex64 rows, power summed per group into p.acc
 hipError_t launch_spectrum_acc(const SpecParams& p, const LaunchGeom& g, hipStream_t s);
+// the same as a kernel of its own (round 4): split fetch of the next row, see tdsa_big.hip
+hipError_t launch_big_rows(const float2* z, long long seg_stride, int group, int n1, int act, float* acc, int acc_split,
+                           int acc_add, const float2* tw, hipStream_t s);
 // P[k1 * split + j][k2] float partial sums -> dst[(k1 + N1*k2) ^ N/2] double (overwrite or accumulate)
 hipError_t launch_big_gather(int log2n, const float* s_rows, int split, double* dst, int add, hipStream_t s);
 // the same + mean = dst / count -> dB (+cal, -tare) row and hold traces, one launch

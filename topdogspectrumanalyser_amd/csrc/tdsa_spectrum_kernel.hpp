@@ -261,16 +261,21 @@ __device__ __forceinline__ void combine32(c32& e, c32& o, bool odd_half) {
   bf_w<U, 32, EXACT>(e, o);
 #endif
 }
-template <int K, int R>   // compile-time twiddle W_R^K
+template <int K, int R, bool EXACT = false>   // compile-time twiddle W_R^K
 __device__ __forceinline__ void combine_const(c32& e, c32& o) {
 #ifdef TDSA_DIF
   const c32 t = mul_w<K, R>(o);
   o = csub(e, t);
   e = cadd(e, t);
 #else
-  bf_w<K, R>(e, o);
+  bf_w<K, R, EXACT>(e, o);
 #endif
 }
+// developer experiment (-DTDSA_EXACT_MASK=m): the difference output of the cross-lane combine of pass 1 (bit 0) / of the
+// middle pass (bit 1) formed with its own FMAs as in the last pass (parity soak: does the worst deep bin move?)
+#ifndef TDSA_EXACT_MASK
+#define TDSA_EXACT_MASK 0
+#endif
 
 // Thread layout: a wave owns 32 consecutive butterfly rows; lane l < 32 is the EVEN half-thread of row
 // (l & 31), lane l + 32 the ODD half-thread of the same row.  Every radix-R pass is done as two
@@ -281,7 +286,7 @@ __device__ __forceinline__ void combine_const(c32& e, c32& o) {
 // 4 waves per SIMD, which is what it takes to keep the VALU fed (one wave issues at most one VALU op
 // every 4 clocks; the SIMD retires one every 2).
 template <int LOG2N, bool IN_C64, int HOLD, bool ACC = false>   // HOLD: bit0 = max trace, bit1 = min trace
-__global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const SpecParams p) {
+__global__ void __launch_bounds__(Cfg<LOG2N>::WGT, (spectrum_waves_per_simd(LOG2N, IN_C64, HOLD))) spectrum_kernel(const SpecParams p) {
   using C = Cfg<LOG2N>;
   constexpr int N = C::N, SG = C::SG, A = C::A, M = C::M, H = C::H, FPW = C::FPW, NPAD = C::NPAD;
   constexpr int LH = ilog2(H);
@@ -320,7 +325,13 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   if constexpr ((TDSA_ABLATE & 16384) != 0) { if (wave >= 12) return; }
   const int h = (tid >> 5) & 1;                              // 0: even half-thread, 1: odd half-thread
   const int g = wave * 32 + (tid & 31);                      // row inside the workgroup
-  const int slot = (FPW == 1) ? 0 : g / SG;
+  // UNI: a frame is made of whole waves (N >= 1024), so its slot - and with it the frame index, the frame's base
+  // addresses and every "is this frame there" test - is wave-uniform: taken through readfirstlane it lives in SGPRs,
+  // the loads and row stores go through SGPR buffer descriptors and no per-lane 64-bit pointer is left (at N = 1024 /
+  // 2048, where several frames share a workgroup, those pointers and their v_add_co / v_addc pairs cost registers the
+  // max + min hold instantiation does not have)
+  constexpr bool UNI = C::TPF >= 64;
+  const int slot = (FPW == 1) ? 0 : (UNI ? __builtin_amdgcn_readfirstlane(g / SG) : g / SG);
   const int t = (FPW == 1) ? g : g - slot * SG;              // butterfly row inside the frame
   c32* buf = lds + slot * NPAD;
 
@@ -349,6 +360,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     u1 = k1 * p.group + s1;
   }
 
+  constexpr unsigned SB = IN_C64 ? 8u : 2u;                      // bytes per sample
   // ---- frame-invariant per-thread state ---------------------------------------------------------
   const rsrc_t win_rsrc = make_rsrc(C::WIN_LDS ? p.window : p.window_perm, N * 4u);
   float* win_lds = reinterpret_cast<float*>(smem + C::LDS_BYTES - C::WIN_BYTES);
@@ -368,14 +380,17 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     if constexpr ((HOLD & 1) != 0) hmax[i] = -INFINITY;
     if constexpr ((HOLD & 2) != 0) hmin[i] = INFINITY;
   });
-  const unsigned xm_v = [&] { unsigned x = (M == 1) ? (p.xor_mask & 0xffffu) : p.xor_mask; asm volatile("" : "+v"(x)); return x; }();
+  // (with max AND min hold in registers the loop has no VGPR to spare: the wave-uniform constants stay in SGPRs there
+  //  and their few uses issue at half rate)
+  constexpr bool PIN = HOLD != 3;
+  const unsigned xm_v = [&] { unsigned x = (M == 1) ? (p.xor_mask & 0xffffu) : p.xor_mask; if constexpr (PIN) asm volatile("" : "+v"(x)); return x; }();
   // epilogue constants in VGPRs.  DB_MAG is evaluated as 10*log10(|X|^2): identical to
   // 20*log10(|X| + 1e-12) in float32 whenever |X|^2 >= 1e-8 (the floor is below half an ulp of |X|);
   // frames with a smaller bin take the exact path below.
   const bool mag_mode = p.db_mode == 0;
-  const float ps_v = in_vgpr(mag_mode ? 1.0f : p.pscale);
-  const float fl_v = in_vgpr(mag_mode ? 0.0f : p.log_floor);
-  const float cal_v = in_vgpr(p.cal_db);
+  const float ps_v = PIN ? in_vgpr(mag_mode ? 1.0f : p.pscale) : (mag_mode ? 1.0f : p.pscale);
+  const float fl_v = PIN ? in_vgpr(mag_mode ? 0.0f : p.log_floor) : (mag_mode ? 0.0f : p.log_floor);
+  const float cal_v = PIN ? in_vgpr(p.cal_db) : p.cal_db;
 
   // LDS addressing in complex elements: element i of a pass lives at i + (i >> 5)
   const int wr1_base = 33 * t + (A == 32 ? 8 : 16) * h;          // pass 1 writes row t (INL: CPT * A = 16 elements per half)
@@ -386,7 +401,6 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   const int ka_mid = t % A;
   const int rd3A = (t / A) * rd_stride + ka_mid + h * A;         // last gather, element c = 2i + h
 
-  constexpr unsigned SB = IN_C64 ? 8u : 2u;                      // bytes per sample
   const unsigned lane_in_off = INL ? (unsigned(t) * M + unsigned(h) * CPT) * SB
                                    : unsigned(t) * (M * SB) + unsigned(h) * ((N / A) * SB);
   const unsigned out_voff = unsigned(t) * 4u + unsigned(h) * (8u * SG * 4u);
@@ -432,11 +446,13 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     if constexpr (!IN_C64) {
       const bool act = frame < p.n_frames;
       const unsigned char* fb = static_cast<const unsigned char*>(p.in) + in_byte_off(frame);
-      if constexpr (FPW == 1 && M >= 2) {   // frame is workgroup-uniform: SGPR descriptor + lane offset
-        const rsrc_t r = make_rsrc(fb, N * 2u);
+      if constexpr (UNI) {   // frame is wave-uniform: SGPR descriptor + lane offset (a frame that is not there: zero
+                             // records, its loads return zeros)
+        const rsrc_t r = make_rsrc(fb, (FPW == 1 || act) ? N * 2u : 0u);
         static_for<0, R1>([&](auto ic) {
           constexpr int i = decltype(ic)::value;
-          buf_load<DW>(r, lane_in_off, RSTEP * i * ROWB, &raw[i * DW]);
+          if constexpr (M == 1) raw[i] = unsigned(__builtin_amdgcn_raw_buffer_load_b16(r, lane_in_off, RSTEP * i * ROWB, 0));
+          else buf_load<DW>(r, lane_in_off, RSTEP * i * ROWB, &raw[i * DW]);
         });
       } else {
         static_for<0, R1>([&](auto ic) {
@@ -538,7 +554,16 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
           sq = __builtin_amdgcn_udot4(raw[i], 0x01000100u, sq, false);
         });
         const int wi = dpp_wave_sum(int(si)), wq = dpp_wave_sum(int(sq));
-        if ((tid & 63) == 63) *reinterpret_cast<int2*>(&redi[wave * 2]) = int2{wi, wq};
+        if constexpr (HOLD == 3) {
+          // both hold traces in registers: the slot address of this one-lane store is rebuilt from the (scalar) wave
+          // index per frame - kept in a VGPR across the loop it was the dword that got spilled at N = 16384, and its
+          // reload at the frame top waited (vmcnt(0)) for all of the previous frame's row stores
+          int ws = __builtin_amdgcn_readfirstlane(wave);
+          asm volatile("" : "+s"(ws));
+          if ((tid & 63) == 63) *reinterpret_cast<int2*>(&redi[ws * 2]) = int2{wi, wq};
+        } else {
+          if ((tid & 63) == 63) *reinterpret_cast<int2*>(&redi[wave * 2]) = int2{wi, wq};
+        }
       }
       TDSA_STAMP(1);
       TDSA_SYNC();       // also the WAR fence between the previous frame's LDS reads and our writes
@@ -617,7 +642,13 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       s_re = seg_sum<W>(s_re); s_im = seg_sum<W>(s_im);
       s_re += __shfl_xor(s_re, 32); s_im += __shfl_xor(s_im, 32);   // the other half-thread's rows
       if constexpr (SG > 32) {
-        if ((tid & 63) == 0) { red[wave * 2] = s_re; red[wave * 2 + 1] = s_im; }
+        if constexpr (HOLD == 3) {          // (scalar wave index rebuilt per frame: see the byte path above)
+          int ws = __builtin_amdgcn_readfirstlane(wave);
+          asm volatile("" : "+s"(ws));
+          if ((tid & 63) == 0) { red[ws * 2] = s_re; red[ws * 2 + 1] = s_im; }
+        } else {
+          if ((tid & 63) == 0) { red[wave * 2] = s_re; red[wave * 2 + 1] = s_im; }
+        }
       }
       TDSA_SYNC();
       if constexpr (SG > 32) {
@@ -765,8 +796,8 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       constexpr int jj0 = u / H, k0 = u % H, jj1 = (u + 8) / H, k1 = (u + 8) % H;
       constexpr int re = jj0 * H + bitrev(k0, LH), ro = jj1 * H + bitrev(k1, LH);
       if constexpr ((TDSA_ABLATE & 32) == 0) swap_halves(v[re], v[ro]);   // v[re] = E of unit u + 8h, v[ro] = O
-      if constexpr (A == 32) combine32<u>(v[re], v[ro], odd_half);
-      else combine_const<k0, A>(v[re], v[ro]);               // (u + 8h) % H == u % H for H <= 8
+      if constexpr (A == 32) combine32<u, (TDSA_EXACT_MASK & 1) != 0>(v[re], v[ro], odd_half);
+      else combine_const<k0, A, (TDSA_EXACT_MASK & 1) != 0>(v[re], v[ro]);               // (u + 8h) % H == u % H for H <= 8
       constexpr int li = jj0 * A + k0;                       // + lane offset folded into wr1_base
       if constexpr ((TDSA_ABLATE & 2) == 0) { lds_st(&buf[wr1_base + li], v[re]); lds_st(&buf[wr1_base + li + H], v[ro]); }
     });
@@ -833,7 +864,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
         if constexpr (u == 4) TDSA_PRIO(0);
         constexpr int re = bitrev(u, 4), ro = bitrev(u + 8, 4);
         if constexpr ((TDSA_ABLATE & 32) == 0) swap_halves(v[re], v[ro]);
-        combine32<u>(v[re], v[ro], odd_half);                // outputs kb = u + 8h and kb + 16
+        combine32<u, (TDSA_EXACT_MASK & 2) != 0>(v[re], v[ro], odd_half);                // outputs kb = u + 8h and kb + 16
         if constexpr ((TDSA_ABLATE & 2) == 0) {
           lds_st(&buf[wrM + u * rd_stride], v[re]);
           lds_st(&buf[wrM + (u + 16) * rd_stride], v[ro]);
@@ -984,7 +1015,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
         TDSA_PRIO(0);
         if ((TDSA_ABLATE & 4) == 0 && p.out_db != nullptr) {
           float* orow = p.out_db + out_elem_off(frame);
-          if constexpr (FPW == 1) {
+          if constexpr (UNI) {
             const rsrc_t r = make_rsrc(orow, N * 4u);
             if constexpr ((TDSA_ABLATE & 1024) != 0) {
               // timing experiment only (wrong layout): the same 64 KiB as four 16-byte stores per lane
