@@ -1322,6 +1322,55 @@ def test_long_batch_averaging_uses_chunked_scan(pkg, avg):
         _check(np.concatenate([a, b]), gold, f"chunked split {avg}")
 
 
+@pytest.mark.parametrize("avg", [("exp", 4), ("lin", 16), ("lin", 5000), ("exp", 2)])
+@pytest.mark.parametrize("nfft,nf", [(4096, 1500), (16384, 700), (8192, 513)])
+def test_batch_averaging_with_workgroup_chunks(pkg, monkeypatch, avg, nfft, nf):
+    """N >= 4096, > 128 frames: the chunks of the averager's chained scan are the frame ranges of the frame kernel's
+    workgroups, which form their chunk's aggregate themselves (float32 dot products; chain and re-scan in float64).  Rows,
+    hold traces and the averager state must follow the order-dependent recurrence of TraceAverager
+    (utils/signal_processing.py:35-61) - against the float64 gold, against the three-pass scan with float64 aggregates
+    (TDSA_AVG_OLD=1) to within what a float32 aggregate can move a row (1e-5 dB), and across a split batch."""
+    hop = nfft // 2
+    iq = so.synth_iq_int8(hop * (nf - 1) + nfft, nfft, seed=71)
+    gold, gmax, gmin = so.hackrf_batch(iq, nfft, hop, 20e6, precision="gold", avg=avg)
+    gold_src = so.HackrfBranchOracle(nfft, 20e6, precision="gold")
+    gold_src.averager.set_mode(*avg)
+    x = so.unpack_iq_int8(iq)
+    for k in range(nf):
+        gold_src.power_levels(so.frame(x, nfft, hop, k))
+    gold_state = np.asarray(gold_src.averager.buffer, dtype=np.float64)
+
+    def run(split):
+        with pkg.SpectrumEngine(nfft, max_frames=nf) as e:
+            e.set_window(so.hackrf_window(nfft))
+            e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=1.0, avg=avg,
+                        hold_max=True, hold_min=True)
+            if split:
+                k0 = 300
+                a = e.process(iq[:2 * (hop * (k0 - 1) + nfft)], hop=hop)
+                b = e.process(iq[2 * hop * k0:], hop=hop)
+                out = np.concatenate([a, b])
+            else:
+                out = e.process(iq, hop=hop)
+            mx, mn = e.hold()
+            buf, cnt = e.averaged()
+        return out, mx, mn, buf, cnt
+
+    out, mx, mn, buf, cnt = run(False)
+    assert out.shape == (nf, nfft)
+    _check(out, gold, f"workgroup chunks {avg}")
+    assert np.array_equal(mx, out.max(axis=0)) and np.array_equal(mn, out.min(axis=0))
+    assert cnt == (1 if avg[0] == "exp" else min(avg[1], nf))
+    assert np.max(np.abs(buf - gold_state)) <= 2e-5 * gold_state.max()        # float32 transform under a float64 average
+    out_s, _, _, buf_s, _ = run(True)
+    _check(out_s, gold, f"workgroup chunks, split batch {avg}")
+    monkeypatch.setenv("TDSA_AVG_OLD", "1")
+    out_o, mx_o, _, buf_o, _ = run(False)
+    monkeypatch.delenv("TDSA_AVG_OLD")
+    assert np.max(np.abs(out - out_o)) <= 1e-5, np.max(np.abs(out - out_o))
+    assert np.max(np.abs(buf - buf_o)) <= 3e-7 * buf_o.max()
+
+
 # ------------------------------------------------------------------------------------------------
 # real-input (audio) path: two real channels in one complex FFT
 # ------------------------------------------------------------------------------------------------

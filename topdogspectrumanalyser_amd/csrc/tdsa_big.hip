@@ -27,17 +27,13 @@ struct BigColsParams {
   int in_c64;
   long long seg_stride;      // bytes between segment starts
   const float* window;       // [N] window * input scale, natural order
-  const float2* tw_hi;       // W_(N/1024)^m, m < N/1024 : W_N^e = tw_hi[e >> 10] * tw_lo[e & 1023]
-  const float2* tw_lo;       // W_N^m, m < 1024
+  const float2* tw_seed;     // [NA - 1 + NB - 1][16384]: W_N^(n2 a), a = 1 .. NA-1, then W_N^(n2 8 b), b = 1 .. NB-1 (exact, rounded once)
   const float2* dc_sub;      // [K] per-segment DC estimate MINUS in_off, raw units (small: keeps float32 exact), or null
   float2* z;                 // [K][N1][N2]
   unsigned xor_mask;
   float in_off;
 };
 
-__device__ __forceinline__ c32 big_twiddle(const BigColsParams& p, unsigned e) {
-  return cmul(p.tw_hi[e >> 10], p.tw_lo[e & 1023]);
-}
 
 // Buffer-descriptor access for the column pass: every load / store of a thread is "lane offset + compile-time row
 // offset" of a block-uniform base, so the row offsets travel as scalar offsets of one SGPR descriptor per array and no
@@ -55,6 +51,15 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
   constexpr int N1 = 1 << LOG2N1;
   const int n2 = blockIdx.x * 256 + threadIdx.x;
   const int seg = blockIdx.y;
+#ifdef TDSA_EXP_COLS_STAGGER   // timing experiment: first-generation waves start k * TDSA_EXP_COLS_STAGGER clocks late, k = wave slot mod 3
+  if (blockIdx.y * gridDim.x + blockIdx.x < 768u) {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    const unsigned k = (hw & 0xfu) % 3u;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)k * TDSA_EXP_COLS_STAGGER) __builtin_amdgcn_s_sleep(32);
+  }
+#endif
   // (x - in_off) is exact in float32 (small integers / halves); the DC estimate is passed as its small
   // residual so that no 24-bit rounding of "128 + something" enters (at 2^20 points that rounding alone
   // left 3e-7 * A_max in the DC bin)
@@ -63,19 +68,19 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
   if (p.dc_sub != nullptr) { const c32 s = p.dc_sub[seg]; sub_re = s.x; sub_im = s.y; }
   const brsrc_t wr = big_rsrc(p.window, unsigned(N1) * kRowN * 4u);
   const unsigned wv = unsigned(n2) * 4u;
-  // W_N^(n2*k1), k1 = a + 8b: seeds W^(n2*a) (a < 8) and W^(n2*8b) come from the two-level table (one rounded product
-  // each), the rest is one more product.  The seeds are fetched FIRST and parked in LDS: gfx9 counts loads and stores
-  // in one in-order vmcnt, so a table load issued between the row stores could only be waited for together with every
-  // store before it - round 2's kernel sat through a full round trip to memory eight times per thread (and seven more
-  // for the serialised seed loads): a wave lived 29 us for 3 us of arithmetic.
+  // W_N^(n2*k1), k1 = a + 8b, is built from the seeds W^(n2*a) (a < 8) and W^(n2*8b) with at most one product.  The seeds
+  // depend on the column only: they come from a per-plan table [seed][n2] (evaluated in double, rounded once) as
+  // coalesced 8-byte loads.  Rounds 2-3 rebuilt each from a two-level table exp(-2 pi i m / N) = hi[m >> 10] lo[m & 1023]:
+  // 28 gathers per thread whose 64 lanes hit up to 64 different lines each - in the texture unit they cost more cycles
+  // than all of the column's sample, window and row accesses together - plus 14 complex products and one more rounding.
+  // They are fetched FIRST and parked in LDS: gfx9 counts loads and stores in one in-order vmcnt, so a table load issued
+  // between the row stores could only be waited for together with every store before it.
   constexpr int NA = N1 < 8 ? N1 : 8, NB = N1 / NA;
-#ifndef TDSA_COLS_LATE_SEEDS
   __shared__ c32 seeds[NA + NB][256];
-  static_for<1, NA>([&](auto ac) { constexpr int a = decltype(ac)::value; seeds[a][threadIdx.x] = big_twiddle(p, unsigned(n2) * a); });
-  static_for<1, NB>([&](auto bc) { constexpr int b = decltype(bc)::value; seeds[NA + b][threadIdx.x] = big_twiddle(p, unsigned(n2) * (8u * b)); });
-#endif
+  static_for<1, NA>([&](auto ac) { constexpr int a = decltype(ac)::value; seeds[a][threadIdx.x] = p.tw_seed[(a - 1) * kRowN + n2]; });
+  static_for<1, NB>([&](auto bc) { constexpr int b = decltype(bc)::value; seeds[NA + b][threadIdx.x] = p.tw_seed[(NA - 1 + b - 1) * kRowN + n2]; });
   c32 v[N1];
-#if defined(TDSA_EXP_COLS) && TDSA_EXP_COLS == 2   // timing experiment: stores only (no loads, no arithmetic)
+#if defined(TDSA_EXP_COLS) && (TDSA_EXP_COLS == 2 || TDSA_EXP_COLS == 3)   // timing experiments: 2 = stores only (no loads, no arithmetic), 3 = arithmetic + stores, no sample / window loads
   static_for<0, N1>([&](auto ic) { constexpr int i = decltype(ic)::value; v[i] = c32{float(n2 + i), float(seg)}; });
   if (false)
 #endif
@@ -96,11 +101,21 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
     unsigned ru[N1]; float rw[N1];
     static_for<0, N1>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
+#if defined(TDSA_EXP_COLS) && TDSA_EXP_COLS == 7      // timing experiment: no sample loads
+      ru[i] = unsigned(n2 + i);
+#else
       ru[i] = unsigned(__builtin_amdgcn_raw_buffer_load_b16(ir, unsigned(n2) * 2u, unsigned(i) * kRowN * 2u, 2));
+#endif
     });
     static_for<0, N1>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
+#if defined(TDSA_EXP_COLS) && TDSA_EXP_COLS == 5      // timing experiment: no window loads
+      rw[i] = 1.0f + float(i);
+#elif defined(TDSA_EXP_COLS) && TDSA_EXP_COLS == 6    // timing experiment: a quarter of the window loads
+      rw[i] = (i % 4 == 0) ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wr, wv, unsigned(i) * kRowN * 4u, 0)) : float(i);
+#else
       rw[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wr, wv, unsigned(i) * kRowN * 4u, 0));
+#endif
     });
     __builtin_amdgcn_sched_barrier(0);
     static_for<0, N1>([&](auto ic) {
@@ -118,15 +133,11 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
     });
 #endif
   }
-#if !(defined(TDSA_EXP_COLS) && TDSA_EXP_COLS == 2)
+#if !(defined(TDSA_EXP_COLS) && (TDSA_EXP_COLS == 2 || TDSA_EXP_COLS == 4))   // (4 = loads + stores, no DFT)
   dif<N1, 0, N1>(v);
 #endif
   c32 lo[NA];
-#ifndef TDSA_COLS_LATE_SEEDS
   static_for<1, NA>([&](auto ac) { constexpr int a = decltype(ac)::value; lo[a] = seeds[a][threadIdx.x]; });
-#else
-  static_for<1, NA>([&](auto ac) { constexpr int a = decltype(ac)::value; lo[a] = big_twiddle(p, unsigned(n2) * a); });
-#endif
 #ifdef TDSA_EXP_ZSLOTS   // timing experiment (wrong results): Z of segment s aliased onto slot s mod k, so that Z stays in the Infinity Cache
   const brsrc_t zr = big_rsrc(p.z + (long long)(seg % TDSA_EXP_ZSLOTS) * N1 * kRowN, unsigned(N1) * kRowN * 8u);
 #else
@@ -144,11 +155,7 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
   static_for<0, NB>([&](auto bc) {
     constexpr int b = decltype(bc)::value;
     c32 hb = c32{1.f, 0.f};
-#ifndef TDSA_COLS_LATE_SEEDS
     if constexpr (b > 0) hb = seeds[NA + b][threadIdx.x];
-#else
-    if constexpr (b > 0) hb = big_twiddle(p, unsigned(n2) * (8u * b));
-#endif
     static_for<0, NA>([&](auto ac) {
       constexpr int a = decltype(ac)::value;
       constexpr int k1 = a + 8 * b;
@@ -500,9 +507,9 @@ static hipError_t gather_launch(const float* src, int split, double* dst, int ad
 }
 
 hipError_t launch_big_cols(int log2n, const void* in, int in_c64, long long seg_stride, int n_seg, const float* window,
-                           const float2* tw_hi, const float2* tw_lo, const float2* dc_sub, float2* z,
+                           const float2* tw_seed, const float2* dc_sub, float2* z,
                            unsigned xor_mask, float in_off, hipStream_t s) {
-  const BigColsParams p{static_cast<const unsigned char*>(in), in_c64, seg_stride, window, tw_hi, tw_lo, dc_sub, z, xor_mask,
+  const BigColsParams p{static_cast<const unsigned char*>(in), in_c64, seg_stride, window, tw_seed, dc_sub, z, xor_mask,
                         in_off};
   switch (log2n - kRowLog2) {
     case 1: return cols_launch<1>(p, n_seg, s);

@@ -66,7 +66,13 @@ struct tdsa_plan_s {
   double* d_avg = nullptr;
   int avg_count = 0;
   float* d_lin = nullptr;                // [max_frames][N] linear power scratch (averaging modes)
-  double* d_carry = nullptr;             // [ceil(max_frames/64)][N] chunk carries of the averager scan
+  double* d_carry = nullptr;             // [chunks][N] chunk carries of the averager scan
+  size_t carry_chunks = 0;               // chunks d_carry has room for
+  float* d_agg = nullptr;                // [grid][N] chunk aggregates formed by the frame kernel's workgroups (sizes >= 4096)
+  float* d_agg_w = nullptr;              // [max_frames] weight of each frame in its workgroup's aggregate
+  double* d_chunk_a = nullptr;           // [kAvgMaxWgChunks + 64] per chunk: product of its frames' multipliers
+  float* d_chunk_v = nullptr;            // [kAvgMaxWgChunks + 64] per chunk: 1 = has frames
+  long long agg_w_key[5] = {-1, -1, -1, -1, -1};   // (count, mode, n, frames, grid) the weights in d_agg_w were made for
   float2* d_cplx = nullptr;              // [max_frames][N] complex spectra (real-input path)
   float2* d_real = nullptr;              // real-input path: the selected signal(s) as complex streams (two for stereo)
   size_t real_bytes = 0;
@@ -98,8 +104,7 @@ struct tdsa_plan_s {
   double* d_sum = nullptr;               // [N] fftshift-ed sums over the segments averaged so far
   double* d_lin64 = nullptr;             // [N] fftshift-ed power of one frame (exp / capped lin averaging)
   double* d_sums64 = nullptr;            // [max_frames][2] exact I / Q sums of the frames of a call
-  float2* d_tw_hi = nullptr;             // W_(N/1024)^m
-  float2* d_tw_lo = nullptr;             // W_N^m, m < 1024
+  float2* d_tw_seed = nullptr;           // [big_seed_rows][16384] per-column twiddle seeds of the column pass
   float2* d_tw_row = nullptr;            // W_16384^m : the row pass's twiddle table
   float* d_ones = nullptr;               // [16384] unit window for the row pass
   int big_group = 64;                    // segments per column-pass / row-pass round (one round for the K = 64 Welch capture)
@@ -235,7 +240,7 @@ int process_big(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n_f
     const int act = ns < split_max ? ns : split_max;
     if (s0 == 0) split_layout = act;
     HIPCHK(launch_big_cols(p->log2n, static_cast<const unsigned char*>(iq_dev) + (long long)s0 * stride, in_c64, stride, ns,
-                           p->d_window[in_format], p->d_tw_hi, p->d_tw_lo, dc_sub ? dc_sub + s0 : nullptr, p->d_z,
+                           p->d_window[in_format], p->d_tw_seed, dc_sub ? dc_sub + s0 : nullptr, p->d_z,
                            xor_mask, in_off, p->stream));
     SpecParams sp{};
     sp.in = p->d_z;
@@ -371,8 +376,10 @@ int process_chirp(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n
   const int first = p->frames_seen > 0 ? 1 : 0;
   if (averaging) {
     if (!p->d_lin) HIPCHK(hipMalloc(&p->d_lin, size_t(p->max_frames) * N * sizeof(float)));
-    if (!p->d_carry && p->max_frames > 128)
+    if (!p->d_carry && p->max_frames > 128) {
       HIPCHK(hipMalloc(&p->d_carry, size_t(avg_scan_chunks(p->max_frames)) * N * sizeof(double)));
+      p->carry_chunks = size_t(avg_scan_chunks(p->max_frames));
+    }
     HIPCHK(launch_chirp_post(p->d_u0, N, M, n_frames, first, m.db_mode, pscale, m.log_floor,
                              m.cal_offset_db, nullptr, nullptr, p->d_lin, nullptr, nullptr, s));
     AvgParams ap{};
@@ -564,27 +571,32 @@ static int plan_init(tdsa_plan p) {
       if (split > gmax) split = gmax;
       HIPCHK(hipMalloc(&p->d_acc, size_t(n1) * split * (size_t(1) << 14) * sizeof(float)));
     }
-    const int nhi = nfft / 1024, nrow = 1 << kMaxLog2N;
-    HIPCHK(hipMalloc(&p->d_tw_hi, size_t(nhi) * sizeof(float2)));
-    HIPCHK(hipMalloc(&p->d_tw_lo, 1024 * sizeof(float2)));
+    const int nrow = 1 << kMaxLog2N;
     HIPCHK(hipMalloc(&p->d_tw_row, size_t(nrow) * sizeof(float2)));
     HIPCHK(hipMalloc(&p->d_ones, size_t(nrow) * sizeof(float)));
-    std::vector<float2> t1(nhi), t2(1024), t3(nrow);
-    for (int m = 0; m < nhi; ++m) {
-      const double a1 = -2.0 * M_PI * double(m) / double(nhi);
-      t1[m] = float2{float(std::cos(a1)), float(std::sin(a1))};
-    }
-    for (int m = 0; m < 1024; ++m) {
-      const double a2 = -2.0 * M_PI * double(m) / double(nfft);
-      t2[m] = float2{float(std::cos(a2)), float(std::sin(a2))};
-    }
+    std::vector<float2> t3(nrow);
     for (int m = 0; m < nrow; ++m) {
       const double a3 = -2.0 * M_PI * double(m) / double(nrow);
       t3[m] = float2{float(std::cos(a3)), float(std::sin(a3))};
     }
+    {   // seeds of the column pass's twiddles W_N^(n2 k1), k1 = a + 8 b: per column n2 the factors W_N^(n2 a), a = 1 .. NA-1,
+        // and W_N^(n2 8 b), b = 1 .. NB-1 - exponent reduced mod N in integers, angle and sin / cos in double, rounded once
+      const int n1 = nfft >> kMaxLog2N, na = n1 < 8 ? n1 : 8, nb = n1 / na;
+      const int rows = big_seed_rows(p->log2n);
+      std::vector<float2> seed(size_t(rows > 0 ? rows : 1) * nrow);
+      for (int r = 0; r < rows; ++r) {
+        const long long mult = r < na - 1 ? (r + 1) : 8ll * (r - (na - 1) + 1);
+        for (int n2 = 0; n2 < nrow; ++n2) {
+          const long long e = (mult * n2) % nfft;
+          const double ang = -2.0 * M_PI * double(e) / double(nfft);
+          seed[size_t(r) * nrow + n2] = float2{float(std::cos(ang)), float(std::sin(ang))};
+        }
+      }
+      (void)nb;
+      HIPCHK(hipMalloc(&p->d_tw_seed, seed.size() * sizeof(float2)));
+      HIPCHK(hipMemcpy(p->d_tw_seed, seed.data(), seed.size() * sizeof(float2), hipMemcpyHostToDevice));
+    }
     std::vector<float> ones(nrow, 1.0f);
-    HIPCHK(hipMemcpy(p->d_tw_hi, t1.data(), size_t(nhi) * sizeof(float2), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(p->d_tw_lo, t2.data(), 1024 * sizeof(float2), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(p->d_tw_row, t3.data(), size_t(nrow) * sizeof(float2), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(p->d_ones, ones.data(), size_t(nrow) * sizeof(float), hipMemcpyHostToDevice));
   }
@@ -611,9 +623,9 @@ int tdsa_destroy(tdsa_plan p) {
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   void* bufs[] = {p->d_window[0], p->d_window[1], p->d_window[2], p->d_window_perm[0], p->d_window_perm[1],
                   p->d_window_perm[2], p->d_tw, p->d_hold_max, p->d_hold_min,
-                  p->d_avg, p->d_lin, p->d_carry, p->d_cplx, p->d_real, p->d_lin1, p->d_db1, p->d_dc_state, p->d_sums, p->d_dc_sub,
+                  p->d_avg, p->d_lin, p->d_carry, p->d_agg, p->d_agg_w, p->d_chunk_a, p->d_chunk_v, p->d_cplx, p->d_real, p->d_lin1, p->d_db1, p->d_dc_state, p->d_sums, p->d_dc_sub,
                   p->d_tare_base, p->d_tare_acc, p->d_in_stage, p->d_out_stage, p->d_trace_in,
-                  p->d_trace_live, p->d_scratch, p->d_z, p->d_chirp_a, p->d_chirp_b, p->d_u0, p->d_u1, p->d_acc, p->d_sum, p->d_lin64, p->d_sums64, p->d_tw_hi, p->d_tw_lo, p->d_tw_row, p->d_ones,
+                  p->d_trace_live, p->d_scratch, p->d_z, p->d_chirp_a, p->d_chirp_b, p->d_u0, p->d_u1, p->d_acc, p->d_sum, p->d_lin64, p->d_sums64, p->d_tw_seed, p->d_tw_row, p->d_ones,
                   p->d_dbg};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -851,12 +863,18 @@ static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size
   }
   if (averaging) {
     if (!p->d_lin) HIPCHK(hipMalloc(&p->d_lin, size_t(p->max_frames) * p->nfft * sizeof(float)));
-    if (!p->d_carry && p->max_frames > 128)
-      HIPCHK(hipMalloc(&p->d_carry, size_t(avg_scan_chunks(p->max_frames)) * p->nfft * sizeof(double)));
-    sp.out_lin = p->d_lin;
-    sp.hold_flags = 0;
-    int rc_p = launch_spectrum_profiled(p, in_c64, sp, g);
-    if (rc_p != TDSA_OK) return rc_p;
+    // Long batches run as a chained scan over chunks of frames (tdsa_trace.hip).  Sizes with one frame per workgroup slot
+    // (N >= 4096): the chunks ARE the frame ranges of the frame kernel's workgroups, which form their chunk's aggregate
+    // themselves while the rows pass through their registers - the scan's first pass over the rows disappears.
+    const bool wg_chunks = p->log2n >= 12 && n_frames > 128 && (n_frames + g.grid - 1) / g.grid <= 64 && g.grid <= 256 &&
+                           getenv("TDSA_AVG_OLD") == nullptr;
+    const size_t need_chunks = wg_chunks ? size_t(spectrum_geometry(p->log2n, p->max_frames, p->num_cu).grid)
+                                         : (p->max_frames > 128 ? size_t(avg_scan_chunks(p->max_frames)) : 0);
+    if (need_chunks > p->carry_chunks) {
+      if (p->d_carry) { HIPCHK(hipStreamSynchronize(p->stream)); HIPCHK(hipFree(p->d_carry)); p->d_carry = nullptr; p->carry_chunks = 0; }
+      HIPCHK(hipMalloc(&p->d_carry, need_chunks * p->nfft * sizeof(double)));
+      p->carry_chunks = need_chunks;
+    }
     AvgParams ap{};
     ap.lin = p->d_lin;
     ap.n_frames = n_frames;
@@ -871,6 +889,29 @@ static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size
     ap.out_db = out_db_dev;
     ap.state_max = (m.hold_flags & TDSA_HOLD_MAX) ? p->d_hold_max : nullptr;
     ap.state_min = (m.hold_flags & TDSA_HOLD_MIN) ? p->d_hold_min : nullptr;
+    if (wg_chunks) {
+      if (!p->d_agg) HIPCHK(hipMalloc(&p->d_agg, need_chunks * p->nfft * sizeof(float)));
+      if (!p->d_agg_w) HIPCHK(hipMalloc(&p->d_agg_w, size_t(p->max_frames) * sizeof(float)));
+      if (!p->d_chunk_a) HIPCHK(hipMalloc(&p->d_chunk_a, size_t(kAvgMaxWgChunks + 64) * sizeof(double)));
+      if (!p->d_chunk_v) HIPCHK(hipMalloc(&p->d_chunk_v, size_t(kAvgMaxWgChunks + 64) * sizeof(float)));
+      ap.chunk_a = p->d_chunk_a;
+      ap.chunk_v = p->d_chunk_v;
+      ap.wg_chunks = g.grid;
+      ap.agg = p->d_agg;
+      // the weights depend on where the averager stands and on the chunking only: in steady state (exp mode, or lin
+      // with its count at the cap) consecutive calls of one shape re-use them
+      const long long key[5] = {p->avg_count, m.avg_mode, m.avg_n, n_frames, g.grid};
+      if (std::memcmp(key, p->agg_w_key, sizeof(key)) != 0) {
+        HIPCHK(launch_avg_weights(ap, p->d_agg_w, p->d_chunk_a, p->d_chunk_v, p->stream));
+        std::memcpy(p->agg_w_key, key, sizeof(key));
+      }
+      sp.agg_w = p->d_agg_w;
+      sp.agg_out = p->d_agg;
+    }
+    sp.out_lin = p->d_lin;
+    sp.hold_flags = 0;
+    int rc_p = launch_spectrum_profiled(p, in_c64, sp, g);
+    if (rc_p != TDSA_OK) return rc_p;
     HIPCHK(launch_avg_scan(ap, p->stream, p->d_carry));
     if (m.avg_mode == TDSA_AVG_LIN) {
       long long c = (long long)p->avg_count + n_frames;

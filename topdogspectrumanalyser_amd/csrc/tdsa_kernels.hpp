@@ -73,6 +73,9 @@ struct SpecParams {
   // frame f belongs to segment s = floor(f / seg_frames) = umulhi(f, seg_magic), frame fi = f - s * seg_frames of it:
   // it reads from in + s * seg_in_stride + fi * frame_stride and its row goes to out + (s * seg_out_stride + fi * N)
   // elements.  seg_magic = 0 (one segment): s = 0, fi = f.
+  // ---- chunk aggregates of the TraceAverager scan (out_lin launches of the sizes with one frame per workgroup slot) ----
+  const float* agg_w;        // [F] per frame: weight of P_f in its workgroup's aggregate (avg_weights_kernel), or null
+  float* agg_out;            // [grid][N] sum over the workgroup's frames of agg_w[f] P_f, display order; null: not wanted
   unsigned seg_magic;        // ceil(2^32 / seg_frames); exact for f * seg_frames < 2^32 (checked by the host)
   unsigned seg_frames;
   long long seg_in_stride;   // bytes
@@ -100,6 +103,14 @@ hipError_t launch_spectrum(int log2n, int in_c64, const SpecParams& p, const Lau
 // 64 contiguous bytes (4 x 16-byte loads per frame instead of 8 x 8 at N = 16384); no-op for N <= 1024
 hipError_t launch_window_perm(int log2n, const float* w, float* w_perm, hipStream_t s);
 
+// frames [u0, u1) workgroup b of a persistent frame-kernel grid takes (one frame per workgroup slot): the formula of
+// tdsa_spectrum_kernel.hpp, shared with the averager's chained scan whose chunks are those ranges
+__host__ __device__ inline void spectrum_unit_range(unsigned b, unsigned n_units, unsigned grid, int& u0, int& u1) {
+  const unsigned upw = n_units / grid, urem = n_units - upw * grid;
+  u0 = int(b * upw + b * urem / grid);
+  u1 = int((b + 1) * upw + (b + 1) * urem / grid);
+}
+
 struct AvgParams {
   const float* lin;       // [F][N] linear power (already PSD-scaled)
   int n_frames, n;
@@ -112,10 +123,21 @@ struct AvgParams {
   float* state_max;       // hold state (updated in place) or null
   float* state_min;
   int first_frame_index;
+  // chunks = the frame ranges of the frame kernel's wg_chunks workgroups, whose aggregates (float32, agg[c][n]) the frame
+  // kernel has already formed (SpecParams::agg_out): the scan then needs no pass of its own for them.  0: chunks of 64.
+  int wg_chunks;
+  const float* agg;
+  const double* chunk_a;  // [kAvgMaxWgChunks + 64] per chunk: product of its frames' a_f (1 for an empty chunk and past the end)
+  const float* chunk_v;   // [kAvgMaxWgChunks + 64] 1: the chunk has frames (its aggregate row was written), else 0
 };
-// carry: [ceil(n_frames/64)][n] doubles of scratch for the chunked scan (null: sequential kernel)
+constexpr int kAvgMaxWgChunks = 1024;
+// carry: [chunks][n] doubles of scratch for the chunked scan (null: sequential kernel)
 hipError_t launch_avg_scan(const AvgParams& p, hipStream_t s, double* carry);
 int avg_scan_chunks(int n_frames);
+// weights of the frames in their workgroup's aggregate (see SpecParams::agg_w): w[f] = b_f * prod of a_g over the later
+// frames g of the same chunk, chunks = spectrum_unit_range(c, n_frames, wg_chunks)
+// ... and the per-chunk multipliers / validity flags the chain reads (chunk_a, chunk_v above)
+hipError_t launch_avg_weights(const AvgParams& p, float* w, double* chunk_a, float* chunk_v, hipStream_t s);
 
 // per-frame sums for the DC tracker (dc_alpha in (0,1)): sums[f] = sum of raw I, raw Q (float2)
 hipError_t launch_frame_sums(const void* in, int in_c64, unsigned xor_mask, long long frame_stride,
@@ -159,9 +181,15 @@ hipError_t launch_lin_to_db(const float* lin, size_t count, float log_floor, flo
 
 // ---- long frames, N = 2^15 .. 2^20 = N1 x 16384 (tdsa_big.hip) ----
 constexpr int kBigMinLog2N = 15, kBigMaxLog2N = 20;
-// column pass: raw IQ of n_seg segments -> Z[seg][k1][n2] (complex64), W_N^e = tw_hi[e >> 10] * tw_lo[e & 1023]
+// column pass: raw IQ of n_seg segments -> Z[seg][k1][n2] (complex64).  tw_seed[s][n2], n2 < 16384: the per-column seeds
+// of W_N^(n2 k1), k1 = a + 8 b: rows s = 0 .. NA-2 hold W_N^(n2 (s + 1)), rows NA-1 .. NA+NB-3 hold W_N^(n2 8 (s - NA + 2)),
+// with N1 = N / 16384, NA = min(N1, 8), NB = N1 / NA (big_seed_rows(log2n) rows in all)
+constexpr int big_seed_rows(int log2n) {
+  const int n1 = 1 << (log2n - 14), na = n1 < 8 ? n1 : 8, nb = n1 / na;
+  return (na - 1) + (nb - 1);
+}
 hipError_t launch_big_cols(int log2n, const void* in, int in_c64, long long seg_stride, int n_seg, const float* window,
-                           const float2* tw_hi, const float2* tw_lo, const float2* dc_sub, float2* z,
+                           const float2* tw_seed, const float2* dc_sub, float2* z,
                            unsigned xor_mask, float in_off, hipStream_t s);
 // exact per-frame sums + DC tracker in double; dc_res[f] = DC estimate in raw units MINUS in_off (small)
 hipError_t launch_big_dc(const void* in, int in_c64, unsigned xor_mask, long long frame_stride, int n, int n_frames,

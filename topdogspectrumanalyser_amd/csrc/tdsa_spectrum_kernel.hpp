@@ -285,7 +285,7 @@ __device__ __forceinline__ void combine_const(c32& e, c32& o) {
 // halves do full butterflies and no lane idles.  16 points per thread keeps the kernel under 128 VGPRs:
 // 4 waves per SIMD, which is what it takes to keep the VALU fed (one wave issues at most one VALU op
 // every 4 clocks; the SIMD retires one every 2).
-template <int LOG2N, bool IN_C64, int HOLD, bool ACC = false>   // HOLD: bit0 = max trace, bit1 = min trace
+template <int LOG2N, bool IN_C64, int HOLD, bool ACC = false>   // HOLD: bit0 = max trace, bit1 = min trace; 4 = AGG (see below)
 __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, (spectrum_waves_per_simd(LOG2N, IN_C64, HOLD))) spectrum_kernel(const SpecParams p) {
   using C = Cfg<LOG2N>;
   constexpr int N = C::N, SG = C::SG, A = C::A, M = C::M, H = C::H, FPW = C::FPW, NPAD = C::NPAD;
@@ -374,6 +374,18 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, (spectrum_waves_per_simd(LOG2
   const bool odd_half = h != 0;   // upper half-wave: its radix-32 combine twiddle is W_32^(u+8) = -i * W_32^u
   float pacc[ACC ? 16 : 1];                 // ACC: linear power summed over the frames of one group
   static_for<0, (ACC ? 16 : 1)>([&](auto ic) { pacc[decltype(ic)::value] = 0.f; });
+  // AGG (HOLD == 4: linear-power rows for the TraceAverager, one frame per workgroup slot): the workgroup also forms the
+  // chunk aggregate the chained scan of tdsa_trace.hip needs for ITS frames [u0, u1) - the averager's recurrence
+  // s <- a_f s + b_f P_f (utils/signal_processing.py:35-61) run from a zero state, which is the dot product
+  // L = sum_f w_f P_f with w_f = b_f prod_(g > f) a_g, the same weights for every bin (SpecParams::agg_w, made in float64
+  // and rounded once) - and leaves it as its row of agg_out.  Until round 4 that took a pass of its own over the rows.
+  // float32: sixteen registers are what this instantiation has to spare (float64 sums spilled 13 dwords); the aggregate
+  // only carries what the chunk's ~10 frames ADD to the state - its rounding (<= 2^-24 per term) enters the float64
+  // chain scaled by L / s <= 1 and decays with the chain's multipliers, while the chunks are re-scanned in float64.
+  constexpr bool AGG = HOLD == 4;
+  static_assert(!AGG || (FPW == 1 && !ACC), "chunk aggregates need one frame per workgroup slot");
+  float agg[AGG ? 16 : 1];
+  static_for<0, (AGG ? 16 : 1)>([&](auto ic) { agg[decltype(ic)::value] = 0.f; });
   float hmax[(HOLD & 1) ? 16 : 1], hmin[(HOLD & 2) ? 16 : 1];
   static_for<0, 16>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
@@ -382,7 +394,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, (spectrum_waves_per_simd(LOG2
   });
   // (with max AND min hold in registers the loop has no VGPR to spare: the wave-uniform constants stay in SGPRs there
   //  and their few uses issue at half rate)
-  constexpr bool PIN = HOLD != 3;
+  constexpr bool PIN = HOLD < 3;
   const unsigned xm_v = [&] { unsigned x = (M == 1) ? (p.xor_mask & 0xffffu) : p.xor_mask; if constexpr (PIN) asm volatile("" : "+v"(x)); return x; }();
   // epilogue constants in VGPRs.  DB_MAG is evaluated as 10*log10(|X|^2): identical to
   // 20*log10(|X| + 1e-12) in float32 whenever |X|^2 >= 1e-8 (the floor is below half an ulp of |X|);
@@ -554,8 +566,8 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, (spectrum_waves_per_simd(LOG2
           sq = __builtin_amdgcn_udot4(raw[i], 0x01000100u, sq, false);
         });
         const int wi = dpp_wave_sum(int(si)), wq = dpp_wave_sum(int(sq));
-        if constexpr (HOLD == 3) {
-          // both hold traces in registers: the slot address of this one-lane store is rebuilt from the (scalar) wave
+        if constexpr (HOLD >= 3) {
+          // both hold traces (or the averager's chunk aggregate) in registers: the slot address of this one-lane store is rebuilt from the (scalar) wave
           // index per frame - kept in a VGPR across the loop it was the dword that got spilled at N = 16384, and its
           // reload at the frame top waited (vmcnt(0)) for all of the previous frame's row stores
           int ws = __builtin_amdgcn_readfirstlane(wave);
@@ -642,7 +654,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, (spectrum_waves_per_simd(LOG2
       s_re = seg_sum<W>(s_re); s_im = seg_sum<W>(s_im);
       s_re += __shfl_xor(s_re, 32); s_im += __shfl_xor(s_im, 32);   // the other half-thread's rows
       if constexpr (SG > 32) {
-        if constexpr (HOLD == 3) {          // (scalar wave index rebuilt per frame: see the byte path above)
+        if constexpr (HOLD >= 3) {          // (scalar wave index rebuilt per frame: see the byte path above)
           int ws = __builtin_amdgcn_readfirstlane(wave);
           asm volatile("" : "+s"(ws));
           if ((tid & 63) == 0) { red[ws * 2] = s_re; red[ws * 2 + 1] = s_im; }
@@ -965,8 +977,20 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, (spectrum_waves_per_simd(LOG2
           });
         }
       } else if (p.out_lin != nullptr) {
-        if constexpr (!C::WIN_LDS) load_window();
+        if constexpr (!C::WIN_LDS && !AGG) load_window();
         float* orow = p.out_lin + out_elem_off(frame) + t + 8 * h * SG;
+        if constexpr (AGG) {
+          const float w_f = in_vgpr(p.agg_w[frame]);          // frame is workgroup-uniform: a scalar load
+          static_for<0, 16>([&](auto ic) {
+            constexpr int q = decltype(ic)::value;
+            constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
+            const c32 X = v[bitrev(q, 4)];
+            const float pw = (X.x * X.x + X.y * X.y) * ps_v;
+            orow[kcs * SG] = pw;
+            agg[q] = fmaf(w_f, pw, agg[q]);
+          });
+          if constexpr (!C::WIN_LDS) load_window();
+        } else
         static_for<0, 16>([&](auto ic) {
           constexpr int q = decltype(ic)::value;
           constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;       // shifted position of kc (without the 8h part)
@@ -1040,7 +1064,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, (spectrum_waves_per_simd(LOG2
             });
           }
         }
-        if constexpr (HOLD != 0) {
+        if constexpr ((HOLD & 3) != 0) {
           const bool nanfix = IN_C64 && (p.first_frame_index + frame == 0);
           static_for<0, 16>([&](auto ic) {
             constexpr int q = decltype(ic)::value;
@@ -1089,7 +1113,20 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, (spectrum_waves_per_simd(LOG2
   //  pushed the kernel into 39 scratch spills and cost more than the ~6 us tail it removed.  Fetching the
   //  current trace into the window registers during the last frame, to save the round trip below: 16 bytes
   //  of scratch inside the frame loop, 75.3 instead of 73.9 us per C3 launch.)
-  if constexpr (HOLD != 0) {
+  if constexpr (AGG) {
+    if (u1 > u0) {                          // (a workgroup without frames leaves no row: the chain skips empty chunks)
+      int tid_a = threadIdx.x;
+      asm volatile("" : "+v"(tid_a));
+      const int h_a = (tid_a >> 5) & 1, t_a = (tid_a >> 6) * 32 + (tid_a & 31);
+      float* arow = p.agg_out + (long long)blockIdx.x * N + t_a + 8 * h_a * SG;
+      static_for<0, 16>([&](auto ic) {
+        constexpr int q = decltype(ic)::value;
+        constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
+        arow[kcs * SG] = agg[q];
+      });
+    }
+  }
+  if constexpr ((HOLD & 3) != 0) {
     // the row index is rebuilt from a fresh (opaque) copy of the thread index: kept live across the frame loop
     // `8 * h * SG` was the one value of the C3 instantiation that did not fit the 128 VGPRs (one dword of
     // scratch per lane = 2.1 MB of spill writes per launch, WRITE_SIZE 162.1 instead of 160 MB)
@@ -1217,6 +1254,10 @@ inline hipError_t launch_one(const SpecParams& p, const LaunchGeom& g, hipStream
 template <int LOG2N>
 hipError_t launch_n(int in_c64, const SpecParams& p, const LaunchGeom& g, hipStream_t s) {
   const int hold = p.out_lin == nullptr ? (p.hold_flags & 3) : 0;
+  if constexpr (Cfg<LOG2N>::FPW == 1) {
+    if (p.out_lin != nullptr && p.agg_out != nullptr)
+      return in_c64 ? launch_one<LOG2N, true, 4>(p, g, s) : launch_one<LOG2N, false, 4>(p, g, s);
+  }
   if (in_c64) {
     switch (hold) {
       case 0: return launch_one<LOG2N, true, 0>(p, g, s);

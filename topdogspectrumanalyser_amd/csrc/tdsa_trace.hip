@@ -89,6 +89,16 @@ __device__ __forceinline__ double avg_step(const AvgParams& p, int f, double s, 
 }
 
 constexpr int kAvgChunk = 64;
+// chunk c of the scan: fixed runs of 64 frames, or (wg_chunks > 0) the frame range of workgroup c of the frame kernel's
+// persistent grid - at most 64 frames long (checked by the host), possibly empty
+__device__ __forceinline__ void avg_chunk_bounds(const AvgParams& p, int c, int& f0, int& f1) {
+  if (p.wg_chunks > 0) {
+    spectrum_unit_range(unsigned(c), unsigned(p.n_frames), unsigned(p.wg_chunks), f0, f1);
+  } else {
+    f0 = c * kAvgChunk;
+    f1 = f0 + kAvgChunk < p.n_frames ? f0 + kAvgChunk : p.n_frames;
+  }
+}
 typedef float avg_f4 __attribute__((ext_vector_type(4)));
 
 // per-frame coefficients of one chunk, computed once per workgroup (one frame per thread; they hold float64
@@ -159,7 +169,8 @@ __global__ void __launch_bounds__(64) avg_chunk_chain_kernel(const AvgParams p, 
       const int c = cb + tid;
       double A = 1.0;
       if (c < n_chunks) {
-        const int f0 = c * kAvgChunk, f1 = f0 + kAvgChunk < p.n_frames ? f0 + kAvgChunk : p.n_frames;
+        int f0, f1;
+        avg_chunk_bounds(p, c, f0, f1);
         for (int f = f0; f < f1; ++f) { double a, bs; bool bf; avg_coeff(p, f, a, bs, bf); A *= a; }
       }
       As[tid] = A;
@@ -184,11 +195,88 @@ __global__ void __launch_bounds__(64) avg_chunk_chain_kernel(const AvgParams p, 
   }
   if (live) p.state[k] = s;
 }
+// Chain for workgroup chunks (aggregates from the frame kernel, float32): hundreds of chunks per bin.  One thread per bin
+// walking them in order is bound by latency twice over - few waves, and gfx9 counts loads and stores in one in-order
+// vmcnt, so every batch of aggregate loads waits for the carry stores issued before it (93 us for 256 chunks of a
+// C3-sized step).  Here wave q of a workgroup takes the q-th run of 64 chunks of its 64 bins: all 64 aggregates of a
+// thread are fetched at once (64 registers), scanned from a zero state, the runs' (state, multiplier) pairs are folded
+// through LDS, and every thread walks its run again from its true carry-in, now only storing.
+template <int MAXQ>     // runs of 64 chunks per bin = waves per workgroup (4: up to 256 chunks)
+__global__ void __launch_bounds__(64 * MAXQ) avg_wg_chain_kernel(const AvgParams p, double* carry) {
+  __shared__ double Lq[16][64];
+  __shared__ double Aq[16];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int q = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave index = run of 64 chunks: scalar
+  const int nc = p.wg_chunks;
+  const int k = min(int(blockIdx.x) * 64 + lane, p.n - 1);      // (a bin past the end redoes the last one)
+  const double s_in = p.count_in > 0 ? p.state[k] : 0.0;
+  // chunk multipliers / validity flags: the same for every bin, made once per call by avg_weights_kernel; this wave's 64
+  // of each are parked in LDS and read back eight at a time (fenced: left to itself the compiler hoists all 64 broadcasts
+  // of a run into VGPRs, which the 1024-thread instantiation does not have)
+  __shared__ double As[16 * 64];
+  __shared__ float Vs[16 * 64];
+  const int c0 = q * 64;
+  As[c0 + lane] = p.chunk_a[c0 + lane];
+  Vs[c0 + lane] = p.chunk_v[c0 + lane];
+  // every aggregate load unconditional and issued before anything depends on one (a row that was never written is read and
+  // dropped); SGPR buffer descriptors: the chunk offset is scalar, the bin offset the only per-lane address
+  float loc[64];
+  const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.agg), 0, int(unsigned(nc) * unsigned(p.n) * 4u), 0x00020000);
+#pragma unroll
+  for (int u = 0; u < 64; ++u)
+    loc[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ar, unsigned(k) * 4u, unsigned(min(c0 + u, nc - 1)) * unsigned(p.n) * 4u, 0));
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // As / Vs of this run are wave-private
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  double s = 0.0, ap = 1.0;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    double a8[8]; float v8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a8[u] = As[c0 + 8 * g + u]; v8[u] = Vs[c0 + 8 * g + u]; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      loc[8 * g + u] = v8[u] != 0.f ? loc[8 * g + u] : 0.f;
+      s = fma(a8[u], s, double(loc[8 * g + u]));
+      ap *= a8[u];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  Lq[q][lane] = s;
+  if (lane == 0) Aq[q] = ap;
+  __syncthreads();
+  s = s_in;
+  for (int qq = 0; qq < q; ++qq) s = fma(Aq[qq], s, Lq[qq][lane]);
+  const int nu = min(64, nc - c0);                               // scalar: chunks of this run
+  const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc(carry, 0, int(unsigned(nc) * unsigned(p.n) * 8u), 0x00020000);
+  typedef unsigned cu32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    double a8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a8[u] = As[c0 + 8 * g + u];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (8 * g + u < nu) {
+        const cu32x2 pk = {unsigned(__double_as_longlong(s)), unsigned(__double_as_longlong(s) >> 32)};
+        __builtin_amdgcn_raw_buffer_store_b64(pk, cr, unsigned(k) * 8u, unsigned(c0 + 8 * g + u) * unsigned(p.n) * 8u, 0);   // carry-in of chunk c0 + 8 g + u
+        s = fma(a8[u], s, double(loc[8 * g + u]));
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (nu > 0 && c0 + 64 >= nc) p.state[k] = s;                   // the run that holds the last chunk leaves the new state
+}
+
 template <int V>
 __global__ void __launch_bounds__(64) avg_chunk_final_kernel(const AvgParams p, const double* carry) {
   const int k = (blockIdx.x * 64 + threadIdx.x) * V, c = blockIdx.y;
   if (k >= p.n) return;
-  const int f0 = c * kAvgChunk, f1 = f0 + kAvgChunk < p.n_frames ? f0 + kAvgChunk : p.n_frames;
+  int f0, f1;
+  avg_chunk_bounds(p, c, f0, f1);
+  if (f1 <= f0) return;
   double s[V];
   float tare[V], hmax[V], hmin[V];
 #pragma unroll
@@ -232,7 +320,45 @@ __global__ void __launch_bounds__(64) avg_chunk_final_kernel(const AvgParams p, 
 
 int avg_scan_chunks(int n_frames) { return (n_frames + kAvgChunk - 1) / kAvgChunk; }
 
+// one thread per chunk walks its frames backwards: w[f] = b_f * (product of a_g over the later frames of the chunk)
+__global__ void __launch_bounds__(64) avg_weights_kernel(const AvgParams p, float* w, double* chunk_a, float* chunk_v) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= kAvgMaxWgChunks + 64) return;
+  double tail = 1.0;
+  float valid = 0.f;
+  if (c < p.wg_chunks) {
+    int f0, f1;
+    avg_chunk_bounds(p, c, f0, f1);
+    for (int f = f1 - 1; f >= f0; --f) {
+      double a, bs; bool bf;
+      avg_coeff(p, f, a, bs, bf);
+      w[f] = float((bf ? double(float(bs)) : bs) * tail);
+      tail *= a;
+    }
+    valid = f1 > f0 ? 1.f : 0.f;
+  }
+  chunk_a[c] = tail;        // product of the chunk's a_f; 1 for an empty chunk and past the end
+  chunk_v[c] = valid;
+}
+
+hipError_t launch_avg_weights(const AvgParams& p, float* w, double* chunk_a, float* chunk_v, hipStream_t s) {
+  hipLaunchKernelGGL(avg_weights_kernel, dim3((kAvgMaxWgChunks + 64 + 63) / 64), dim3(64), 0, s, p, w, chunk_a, chunk_v);
+  return hipGetLastError();
+}
+
 hipError_t launch_avg_scan(const AvgParams& p, hipStream_t s, double* carry) {
+  if (carry != nullptr && p.wg_chunks > 0) {
+    // the frame kernel's workgroups have formed their chunks' aggregates (p.agg): chain them, re-scan the chunks
+    const bool vec = (p.n % 4 == 0) && (reinterpret_cast<uintptr_t>(p.lin) % 16 == 0) &&
+                     (p.out_db == nullptr || reinterpret_cast<uintptr_t>(p.out_db) % 16 == 0);
+    if (p.wg_chunks > kAvgMaxWgChunks || size_t(p.wg_chunks) * p.n * 8 > 0xffffffffull) return hipErrorInvalidValue;
+    const int runs = (p.wg_chunks + 63) / 64;
+    if (runs > 4) return hipErrorInvalidValue;        // (the host only takes this path for up to 256 chunks)
+    hipLaunchKernelGGL(avg_wg_chain_kernel<4>, dim3((p.n + 63) / 64), dim3(64 * runs), 0, s, p, carry);
+    if (vec) hipLaunchKernelGGL(avg_chunk_final_kernel<4>, dim3((p.n / 4 + 63) / 64, p.wg_chunks), dim3(64), 0, s, p, carry);
+    else hipLaunchKernelGGL(avg_chunk_final_kernel<1>, dim3((p.n + 63) / 64, p.wg_chunks), dim3(64), 0, s, p, carry);
+    return hipGetLastError();
+  }
   if (carry != nullptr && p.n_frames > 2 * kAvgChunk) {
     const int n_chunks = (p.n_frames + kAvgChunk - 1) / kAvgChunk;
     // four bins per thread when every row starts on a 16-byte boundary (not the N/2+1-bin rows of the audio path)
