@@ -51,15 +51,6 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
   constexpr int N1 = 1 << LOG2N1;
   const int n2 = blockIdx.x * 256 + threadIdx.x;
   const int seg = blockIdx.y;
-#ifdef TDSA_EXP_COLS_STAGGER   // timing experiment: first-generation waves start k * TDSA_EXP_COLS_STAGGER clocks late, k = wave slot mod 3
-  if (blockIdx.y * gridDim.x + blockIdx.x < 768u) {
-    unsigned hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    const unsigned k = (hw & 0xfu) % 3u;
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)k * TDSA_EXP_COLS_STAGGER) __builtin_amdgcn_s_sleep(32);
-  }
-#endif
   // (x - in_off) is exact in float32 (small integers / halves); the DC estimate is passed as its small
   // residual so that no 24-bit rounding of "128 + something" enters (at 2^20 points that rounding alone
   // left 3e-7 * A_max in the DC bin)
