@@ -87,6 +87,38 @@ def test_hackrf_plain_int8_sizes_that_are_not_a_power_of_two(pkg, nfft):
     assert np.array_equal(mx, out.max(axis=0)) and np.array_equal(mn, out.min(axis=0))
 
 
+@pytest.mark.parametrize("nfft", [8193, 10000, 12000, 16383, 16385, 20000, 30011, 65537, 100000, 262145, 500000, 524287])
+@pytest.mark.parametrize("branch", ["hackrf", "rtl_exp"])
+def test_long_frames_that_are_not_a_power_of_two(pkg, nfft, branch):
+    """np.fft.fft / scipy.fft.fft take any N and the sources' size setters any positive size (hackrf_samples.py:370,
+    :392-405; rtl_samples.py:170, :208-214): sizes above 8192 that are not a power of two run as a chirp-z convolution
+    whose two M-point transforms (M = 2^ceil(log2(2N-1)) = 2^15 .. 2^20) go through the long-frame kernels - the second
+    one transposed, rows first (tdsa_big.hip).  HackRF branch with both hold traces, and the RTL branch with exponential
+    averaging (one frame per call on the float64 state)."""
+    if nfft > 70000 and branch == "rtl_exp":
+        pytest.skip("covered by the HackRF branch at this size")
+    nf = 3
+    hop = nfft // 2 if branch == "hackrf" else nfft
+    iq = so.synth_iq_int8(hop * (nf - 1) + nfft, 4096, seed=nfft % 1000)
+    if branch == "hackrf":
+        gold, gmax, gmin = so.hackrf_batch(iq, nfft, hop, 20e6, precision="gold")
+        with _hackrf_engine(pkg, nfft, nf, hold_max=True, hold_min=True) as e:
+            assert e.info().nfft == nfft
+            out = e.process(iq, hop=hop)
+            mx, mn = e.hold()
+        assert out.shape == gold.shape and out.dtype == np.float32
+        _check(out, gold, f"N={nfft}")
+        _check(mx, gmax, "max hold")
+        assert np.array_equal(mx, out.max(axis=0)) and np.array_equal(mn, out.min(axis=0))
+    else:
+        gold, _, _ = so.rtl_batch(iq, nfft, hop, 2e6, precision="gold", avg=("exp", 3))
+        with pkg.SpectrumEngine(nfft, max_frames=nf) as e:
+            e.set_window(so.rtl_window("hanning", nfft).astype(np.float32))
+            e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=-1.0, avg=("exp", 3))
+            out = e.process(iq, hop=hop)
+        _check(out, gold, f"RTL exp N={nfft}")
+
+
 @pytest.mark.parametrize("nfft", [64, 1024, 4096, 16384])
 def test_hackrf_plain_c64(pkg, nfft):
     nf = 3
@@ -968,7 +1000,7 @@ def test_empty_and_error_paths(pkg):
         with pytest.raises(TypeError):
             e.process(np.zeros(2048, dtype=np.float64))
     with pytest.raises(nat.TdsaError):
-        pkg.SpectrumEngine(12000)                                                # not a power of two AND above 8192
+        pkg.SpectrumEngine(600000)                                               # not a power of two AND above 2^19
     with pytest.raises(nat.TdsaError):
         pkg.SpectrumEngine(1 << 21)                                              # beyond the largest plan (2^20)
     with pytest.raises(nat.TdsaError):
@@ -1838,7 +1870,8 @@ def test_stream_spectra_helper(pkg):
 # ------------------------------------------------------------------------------------------------
 def _any_size(rng):
     """A frame length the native kernels do not cover: anything in [3, 8192] that is not a power of two >= 64
-    (small, prime, highly composite and just-below-the-limit sizes all get their share)."""
+    (small, prime, highly composite and just-below-the-limit sizes all get their share; the sizes above 8192 have
+    their own sweep below)."""
     while True:
         kind = int(rng.integers(0, 4))
         n = int([rng.integers(3, 64), rng.integers(64, 1025), rng.integers(1025, 8193),
@@ -1904,6 +1937,23 @@ def test_random_configuration_sweep_any_size(pkg, case_id):
     """The same sweep over frame lengths that are NOT a power of two (np.fft.fft / scipy.fft.fft take any N,
     hackrf_samples.py:370, rtl_samples.py:170): chirp-z path of tdsa_chirp.hip, same bounds."""
     _run_sweep_case(pkg, case_id, _random_case(np.random.default_rng(777 + case_id), any_size=True))
+
+
+@pytest.mark.parametrize("case_id", range(int(os.environ.get("TDSA_ANYSIZE_LONG_CASES", "16"))))
+def test_random_configuration_sweep_any_long_size(pkg, case_id):
+    """... and over the sizes above 8192 that are not a power of two (8193 .. 65536: M = 2^15 .. 2^17, the two M-point
+    transforms of the chirp-z convolution on the long-frame kernels), every branch / window / averaging / PSD / DC mode
+    of the sweep, same bounds."""
+    rng = np.random.default_rng(31337 + case_id)
+    c = _random_case(rng, any_size=True)
+    while True:
+        n = int(rng.choice([rng.integers(8193, 16384), rng.integers(16385, 32768), rng.integers(32769, 65536),
+                            rng.choice([8193, 10000, 16383, 16385, 20000, 44100, 48000, 65535])]))
+        if n & (n - 1):
+            break
+    c["nfft"], c["nf"] = n, int(rng.integers(1, 7))
+    c["hop"] = int(rng.choice([n, n // 2, n // 4 + 1, int(rng.integers(1, 2 * n))]))
+    _run_sweep_case(pkg, case_id, c)
 
 
 # ------------------------------------------------------------------------------------------------

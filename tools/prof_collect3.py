@@ -15,7 +15,7 @@ from collections import defaultdict
 
 SRC = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r03"
 DST = "profiles"
-TAG = "r03"
+TAG = sys.argv[2] if len(sys.argv) > 2 else "r03"
 ALGO = {"c3": 2440 * 81920, "c3b": 8 * 2440 * 81920, "c2": 4096 * 24576, "c4": 8192 * 49152, "c5": 64 * 2162688}
 
 
@@ -31,7 +31,8 @@ def counters(name):
     if f:
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"]
-            short = "frame" if "spectrum_kernel" in k else ("cols" if "big_cols" in k else ("gather" if "big_gather" in k else None))
+            short = "frame" if "spectrum_kernel" in k else ("cols" if "big_cols" in k else ("gather" if "big_gather" in k else
+                                                             ("rows" if "big_rows" in k else None)))
             if short:
                 acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
     # steady state: the MEDIAN dispatch (the first launch after a hold reset also writes the 16384-bin hold trace with
@@ -76,7 +77,7 @@ def trace_summary(name):
 
 def main():
     os.makedirs(DST, exist_ok=True)
-    for c in ("c2", "c3", "c4", "c5", "c5_2ranks"):
+    for c in ("c2", "c3", "c4", "c5", "c5_2ranks", "c3_2ranks", "c4_2ranks"):
         src = os.path.join(SRC, f"bench_{c}.json")
         if os.path.exists(src):
             shutil.copy(src, os.path.join(DST, f"{TAG}_{c}_bench.json"))
@@ -93,7 +94,7 @@ def main():
                "c3_serial": conc["c3_serial"], "c3_batch8_serial": conc["c3_batch"], "c3_value_batch8_3streams": conc["c3_value"],
                "c3_streams3_one_step_per_launch": conc["c3_streams"]},
               open(os.path.join(DST, f"{TAG}_c3_concurrency.json"), "w"), indent=1)
-    lines = ["# rocprofv3 --pmc passes, round 3 (tools/prof_round3.sh; FETCH_SIZE and WRITE_SIZE in separate passes)",
+    lines = [f"# rocprofv3 --pmc passes, {TAG} (tools/prof_round3.sh / prof_round4.sh; FETCH_SIZE and WRITE_SIZE in separate passes)",
              "# FETCH_SIZE is reported in KB and counts 64 B per 128-B request on gfx950 for wide coalesced reads",
              "# (MI355X_MICROARCH.md): the upper bound doubles it; WRITE_SIZE (KB) is 1:1 (calibrated in round 1)."]
     for c in ("c2", "c3", "c3b", "c4", "c5"):
@@ -104,7 +105,7 @@ def main():
         per_step = {}
         if c == "c5":
             ng = max(1, nrd.get("gather", 1))
-            launches = {"cols": nrd.get("cols", 0) / ng, "frame": nrd.get("frame", 0) / ng, "gather": 1}
+            launches = {"cols": nrd.get("cols", 0) / ng, "frame": nrd.get("frame", 0) / ng, "rows": nrd.get("rows", 0) / ng, "gather": 1}
             fetch = sum(rd.get(k, {}).get("FETCH_SIZE", 0.0) * n for k, n in launches.items()) * 1024
             write = sum(wr.get(k, {}).get("WRITE_SIZE", 0.0) * n for k, n in launches.items()) * 1024
             per_step = {k: {"fetch_kb_per_launch": rd.get(k, {}).get("FETCH_SIZE"),

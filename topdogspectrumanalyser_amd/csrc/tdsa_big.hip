@@ -32,6 +32,7 @@ struct BigColsParams {
   float2* z;                 // [K][N1][N2]
   unsigned xor_mask;
   float in_off;
+  unsigned in_valid;         // complex64 rows: samples from this index on are zeros and are not read (0: the whole row is there)
 };
 
 
@@ -76,7 +77,9 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
   if (false)
 #endif
   if (p.in_c64) {
-    const brsrc_t ir = big_rsrc(p.in + (long long)seg * p.seg_stride, unsigned(N1) * kRowN * 8u);
+    // (chirp-z rows: the padding behind the first in_valid samples is implied - the descriptor ends there and a load
+    //  past its end returns zeros)
+    const brsrc_t ir = big_rsrc(p.in + (long long)seg * p.seg_stride, (p.in_valid ? p.in_valid : unsigned(N1) * kRowN) * 8u);
     static_for<0, N1>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       const bu32x2 q = __builtin_amdgcn_raw_buffer_load_b64(ir, unsigned(n2) * 8u, unsigned(i) * kRowN * 8u, 0);
@@ -365,6 +368,76 @@ hipError_t launch_big_rows(const float2* z, long long seg_stride, int group, int
   return hipGetLastError();
 }
 
+// ---- the transposed four-step transform (complex in, complex out in natural order): second transform of the chirp-z
+//      convolution of long frames that are not a power of two ----------------------------------------------------------
+// Its input arrives in the layout the first transform's row pass leaves: T[k1][k2] = V[k1 + N1 k2].  With the output index
+// m = m2 + 16384 m1:   Y[m] = sum_k1 W_N1^(k1 m1) W_M^(k1 m2) ( sum_k2 T[k1][k2] W_16384^(k2 m2) )
+// - the rows T[k1][.] go through the frame kernel first (complex bins out), and this kernel finishes per column m2: times
+// W_M^(k1 m2) (the column pass's seed table), an N1-point DFT over k1 in registers, rows Y[m1][m2] = natural order.  Every
+// access is a coalesced run along m2; only the bins below out_valid are stored.
+struct BigColsOutParams {
+  const float2* r;           // [seg][N1][16384] row transforms R[k1][m2]
+  long long seg_stride;      // bytes between segments, input and output (N1 * 16384 * 8)
+  const float2* tw_seed;     // the column pass's table for this M
+  float2* y;                 // [seg][N1 * 16384] natural order
+  unsigned out_valid;        // bins wanted (0: all)
+};
+
+template <int LOG2N1>
+__global__ void __launch_bounds__(256) big_cols_out_kernel(const BigColsOutParams p) {
+  constexpr int N1 = 1 << LOG2N1;
+  constexpr int NA = N1 < 8 ? N1 : 8, NB = N1 / NA;
+  const int m2 = blockIdx.x * 256 + threadIdx.x;
+  const int seg = blockIdx.y;
+  const brsrc_t rr = big_rsrc(reinterpret_cast<const unsigned char*>(p.r) + (long long)seg * p.seg_stride, unsigned(N1) * kRowN * 8u);
+  c32 v[N1];
+  static_for<0, N1>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    const bu32x2 q = __builtin_amdgcn_raw_buffer_load_b64(rr, unsigned(m2) * 8u, unsigned(i) * kRowN * 8u, 0);
+    v[i] = c32{__uint_as_float(q.x), __uint_as_float(q.y)};
+  });
+  c32 lo[NA], hi[NB];
+  static_for<1, NA>([&](auto ac) { constexpr int a = decltype(ac)::value; lo[a] = p.tw_seed[(a - 1) * kRowN + m2]; });
+  static_for<1, NB>([&](auto bc) { constexpr int b = decltype(bc)::value; hi[b] = p.tw_seed[(NA - 1 + b - 1) * kRowN + m2]; });
+  static_for<1, N1>([&](auto kc) {                      // input k1 = a + 8 b times W_M^(k1 m2)
+    constexpr int k1 = decltype(kc)::value;
+    constexpr int a = k1 % 8, b = k1 / 8;
+    if constexpr (b == 0) v[k1] = cmul(v[k1], lo[a]);
+    else if constexpr (a == 0) v[k1] = cmul(v[k1], hi[b]);
+    else v[k1] = cmul(v[k1], cmul(hi[b], lo[a]));
+  });
+  dif<N1, 0, N1>(v);                                     // Y[m1] in v[bitrev(m1)]
+  const unsigned nvalid = p.out_valid ? p.out_valid : unsigned(N1) * kRowN;
+  // the descriptor ends behind the last wanted bin: stores past it are dropped by the hardware
+  const brsrc_t yr = big_rsrc(reinterpret_cast<unsigned char*>(p.y) + (long long)seg * p.seg_stride, nvalid * 8u);
+  static_for<0, N1>([&](auto mc) {
+    constexpr int m1 = decltype(mc)::value;
+    const c32 x = v[bitrev(m1, LOG2N1)];
+    const bu32x2 pk = {__float_as_uint(x.x), __float_as_uint(x.y)};
+    __builtin_amdgcn_raw_buffer_store_b64(pk, yr, unsigned(m2) * 8u, unsigned(m1) * kRowN * 8u, 0);
+  });
+}
+
+template <int L>
+static hipError_t cols_out_launch(const BigColsOutParams& p, int n_seg, hipStream_t s) {
+  hipLaunchKernelGGL(big_cols_out_kernel<L>, dim3(kRowN / 256, n_seg), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_big_cols_out(int log2m, const float2* r, long long seg_stride, int n_seg, const float2* tw_seed, float2* y,
+                               unsigned out_valid, hipStream_t s) {
+  const BigColsOutParams p{r, seg_stride, tw_seed, y, out_valid};
+  switch (log2m - kRowLog2) {
+    case 1: return cols_out_launch<1>(p, n_seg, s);
+    case 2: return cols_out_launch<2>(p, n_seg, s);
+    case 3: return cols_out_launch<3>(p, n_seg, s);
+    case 4: return cols_out_launch<4>(p, n_seg, s);
+    case 5: return cols_out_launch<5>(p, n_seg, s);
+    case 6: return cols_out_launch<6>(p, n_seg, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 // P[k1 * split + j][k2] (float: the row pass's per-workgroup partial power sums of this call, summed over j in
 // double, in a fixed order: the result is reproducible bit for bit) -> natural bin order k = k1 + N1*k2,
 // fftshift-ed (ks = k ^ N/2), through an LDS tile so that reads and writes are coalesced.
@@ -499,9 +572,9 @@ static hipError_t gather_launch(const float* src, int split, double* dst, int ad
 
 hipError_t launch_big_cols(int log2n, const void* in, int in_c64, long long seg_stride, int n_seg, const float* window,
                            const float2* tw_seed, const float2* dc_sub, float2* z,
-                           unsigned xor_mask, float in_off, hipStream_t s) {
+                           unsigned xor_mask, float in_off, hipStream_t s, unsigned in_valid) {
   const BigColsParams p{static_cast<const unsigned char*>(in), in_c64, seg_stride, window, tw_seed, dc_sub, z, xor_mask,
-                        in_off};
+                        in_off, in_valid};
   switch (log2n - kRowLog2) {
     case 1: return cols_launch<1>(p, n_seg, s);
     case 2: return cols_launch<2>(p, n_seg, s);

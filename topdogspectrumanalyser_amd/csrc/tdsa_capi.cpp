@@ -112,6 +112,7 @@ struct tdsa_plan_s {
   // frame lengths that are not a power of two (tdsa_chirp.hip): chirp-z on the m_fft-point frame kernel
   bool chirp = false;
   int m_fft = 0, log2m = 0;              // M = 2^log2m >= 2 nfft - 1
+  bool chirp_big = false;                // M > 16384: the two M-point transforms run on the long-frame kernels (N1 x 16384)
   float2* d_chirp_a = nullptr;           // [nfft] a[n] = exp(-i pi n^2 / nfft)
   float2* d_chirp_b = nullptr;           // [M]    FFT_M of conj(a) wrapped around M
   float2* d_u0 = nullptr;                // [max_frames][M] work rows (allocated on first use)
@@ -318,6 +319,42 @@ int chirp_transform(tdsa_plan p, const void* in, int in_format, long long stride
   if (!p->d_u1) HIPCHK(hipMalloc(&p->d_u1, size_t(p->max_frames) * M * sizeof(float2)));
   HIPCHK(launch_chirp_pre(in, in_format == TDSA_IN_C64, stride, N, M, n_frames, p->d_window[in_format], p->d_chirp_a, dc_sub,
                           xor_mask, in_off, p->d_u0, s));
+  if (p->chirp_big) {
+    // M = N1 x 16384: first transform as for a native long frame (column pass -> rows through the frame kernel, which
+    // stores conj(X B) in its own [k1][k2] order); second transform transposed (rows first, then the per-column N1-point
+    // DFT that leaves natural order): tdsa_big.hip
+    const int n1 = M >> kMaxLog2N;
+    const long long rowb = (long long)(1 << kMaxLog2N) * sizeof(float2), segb = (long long)M * sizeof(float2);
+    if (!p->d_z) HIPCHK(hipMalloc(&p->d_z, size_t(p->max_frames) * M * sizeof(float2)));
+    HIPCHK(launch_big_cols(p->log2m, p->d_u0, 1, segb, n_frames, p->d_ones, p->d_tw_seed, nullptr, p->d_z, 0u, 0.0f, s,
+                           unsigned(N)));
+
+    SpecParams sp{};
+    sp.frame_stride = rowb;
+    sp.n_frames = n_frames * n1;
+    sp.first_frame_index = 1;
+    sp.window = p->d_ones;
+    sp.window_perm = p->d_ones;
+    sp.tw = p->d_tw;
+    sp.in_scale = 1.0f;
+    sp.dc_mode = DC_NONE;
+    sp.db_mode = TDSA_DB_POW;
+    sp.pscale = 1.0f;
+    const LaunchGeom g = spectrum_geometry(kMaxLog2N, sp.n_frames, p->num_cu);
+    sp.in = p->d_z;
+    sp.out_cplx = p->d_u1;
+    sp.out_mul = p->d_chirp_b;          // [k1][k2] order, row k1 = frame mod N1
+    sp.out_mul_rows = n1;
+    { const int rc = launch_spectrum_profiled(p, 1, sp, g); if (rc != TDSA_OK) return rc; }
+    sp.in = p->d_u1;
+    sp.out_cplx = p->d_z;
+    sp.out_mul = nullptr;
+    sp.out_mul_rows = 0;
+    { const int rc = launch_spectrum_profiled(p, 1, sp, g); if (rc != TDSA_OK) return rc; }
+
+    HIPCHK(launch_big_cols_out(p->log2m, p->d_z, segb, n_frames, p->d_tw_seed, p->d_u0, unsigned(N), s));
+    return TDSA_OK;
+  }
   SpecParams sp{};
   sp.frame_stride = (long long)M * sizeof(float2);
   sp.n_frames = n_frames;
@@ -457,7 +494,8 @@ int tdsa_create(int device_id, int nfft, int max_frames, tdsa_plan* out) {
     while (m < 2 * nfft - 1) m <<= 1;
     p->m_fft = m;
     p->log2m = ilog2i(m);
-    p->log2n = p->log2m;      // what the frame kernel of this plan transforms
+    p->chirp_big = p->log2m > kMaxLog2N;
+    p->log2n = p->chirp_big ? kMaxLog2N : p->log2m;      // what the frame kernel of this plan transforms
   }
   const int rc_init = plan_init(p);          // a failure half way leaves nothing behind
   if (rc_init != TDSA_OK) {
@@ -490,7 +528,7 @@ static int plan_init(tdsa_plan p) {
   for (int f = 0; f < 3; ++f) HIPCHK(hipMalloc(&p->d_window[f], nb));
   if (!p->big && !p->chirp && p->log2n >= 11)     // only the 3-pass sizes read the permuted table (Cfg::WIN_LDS below)
     for (int f = 0; f < 3; ++f) HIPCHK(hipMalloc(&p->d_window_perm[f], nb));
-  const int tw_n = p->chirp ? p->m_fft : nfft;       // the size the frame kernel transforms
+  const int tw_n = p->chirp ? (p->chirp_big ? (1 << kMaxLog2N) : p->m_fft) : nfft;       // the size the frame kernel transforms
   HIPCHK(hipMalloc(&p->d_tw, size_t(tw_n) * sizeof(float2)));
   HIPCHK(hipMalloc(&p->d_hold_max, nb));
   HIPCHK(hipMalloc(&p->d_hold_min, nb));
@@ -531,11 +569,17 @@ static int plan_init(tdsa_plan p) {
       j ^= bit;
       if (i < j) { std::swap(br[i], br[j]); std::swap(bi[i], bi[j]); }
     }
+    std::vector<double> twc(M / 2), tws(M / 2);      // exp(-2 pi i k / M), k < M / 2: one table for every stage
+    for (int k = 0; k < M / 2; ++k) {
+      const double ang = -2.0 * M_PI * double(k) / double(M);
+      twc[k] = std::cos(ang);
+      tws[k] = std::sin(ang);
+    }
     for (int len = 2; len <= M; len <<= 1) {
+      const int step = M / len;
       for (int i = 0; i < M; i += len) {
         for (int k = 0; k < len / 2; ++k) {
-          const double ang = -2.0 * M_PI * double(k) / double(len);
-          const double wr = std::cos(ang), wi = std::sin(ang);
+          const double wr = twc[k * step], wi = tws[k * step];
           const double xr = br[i + k + len / 2] * wr - bi[i + k + len / 2] * wi;
           const double xi = br[i + k + len / 2] * wi + bi[i + k + len / 2] * wr;
           br[i + k + len / 2] = br[i + k] - xr;
@@ -547,7 +591,14 @@ static int plan_init(tdsa_plan p) {
     }
     std::vector<float2> a32(nfft), b32(M);
     for (int n = 0; n < nfft; ++n) a32[n] = float2{float(ar[n]), float(ai[n])};
-    for (int k = 0; k < M; ++k) b32[k] = float2{float(br[k]), float(bi[k])};
+    if (p->chirp_big) {
+      // the first transform's row pass leaves bin k = k1 + N1 k2 at [k1][k2]: B in that order, one row of 16384 per k1
+      const int n1 = M >> kMaxLog2N, n2 = 1 << kMaxLog2N;
+      for (int k1 = 0; k1 < n1; ++k1)
+        for (int k2 = 0; k2 < n2; ++k2) b32[size_t(k1) * n2 + k2] = float2{float(br[k1 + n1 * k2]), float(bi[k1 + n1 * k2])};
+    } else {
+      for (int k = 0; k < M; ++k) b32[k] = float2{float(br[k]), float(bi[k])};
+    }
     HIPCHK(hipMalloc(&p->d_chirp_a, size_t(nfft) * sizeof(float2)));
     HIPCHK(hipMalloc(&p->d_chirp_b, size_t(M) * sizeof(float2)));
     HIPCHK(hipMalloc(&p->d_ones, size_t(M) * sizeof(float)));
@@ -555,6 +606,21 @@ static int plan_init(tdsa_plan p) {
     HIPCHK(hipMemcpy(p->d_chirp_a, a32.data(), size_t(nfft) * sizeof(float2), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(p->d_chirp_b, b32.data(), size_t(M) * sizeof(float2), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(p->d_ones, ones.data(), size_t(M) * sizeof(float), hipMemcpyHostToDevice));
+    if (p->chirp_big) {   // the M-point transforms' column-pass seeds (as for a native long frame of M points)
+      const int nrow = 1 << kMaxLog2N, n1 = M >> kMaxLog2N, na = n1 < 8 ? n1 : 8;
+      const int rows = big_seed_rows(p->log2m);
+      std::vector<float2> seed(size_t(rows > 0 ? rows : 1) * nrow);
+      for (int r = 0; r < rows; ++r) {
+        const long long mult = r < na - 1 ? (r + 1) : 8ll * (r - (na - 1) + 1);
+        for (int c = 0; c < nrow; ++c) {
+          const long long e = (mult * c) % M;
+          const double ang = -2.0 * M_PI * double(e) / double(M);
+          seed[size_t(r) * nrow + c] = float2{float(std::cos(ang)), float(std::sin(ang))};
+        }
+      }
+      HIPCHK(hipMalloc(&p->d_tw_seed, seed.size() * sizeof(float2)));
+      HIPCHK(hipMemcpy(p->d_tw_seed, seed.data(), seed.size() * sizeof(float2), hipMemcpyHostToDevice));
+    }
   }
   if (big) {
     if (const char* o = getenv("TDSA_BIG_ROWS_OLD")) p->big_rows_old = atoi(o) != 0;

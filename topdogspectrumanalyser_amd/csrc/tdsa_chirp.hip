@@ -1,4 +1,4 @@
-// tdsa_chirp.hip - frames whose length is NOT a power of two (and the powers of two below 64): 2 <= N <= 8192.
+// tdsa_chirp.hip - frames whose length is NOT a power of two (and the powers of two below 64): 2 <= N <= 2^19.
 //
 // np.fft.fft / scipy.fft.fft take any N (hackrf_samples.py:370, rtl_samples.py:170) and
 // HackrfSamplesDataSource.set_num_samples / RtlSamplesDataSource.set_fft_size accept any positive size
@@ -17,6 +17,9 @@
 //   (3) frame kernel : FFT_M of that = M * conj(convolution)      (inverse transform through conjugation)
 //   (4) chirp_post   : |X[k]|^2 = |./M|^2 for k < N (|a[k]| = 1) -> fftshift by N/2 (np.fft.fftshift for any N)
 //                      -> dB (+cal, -tare) rows and hold traces, or linear power rows for the averager scan
+// N > 8192 (M = 2^15 .. 2^20, round 4): steps (2) and (3) run on the long-frame kernels of tdsa_big.hip - (2) as column
+// pass + rows through the frame kernel, which leaves conj(X B) in its own [k1][k2] order (B is stored in that order),
+// (3) transposed: rows first, then big_cols_out_kernel's per-column N1-point DFT, which leaves natural order.
 //
 // Cost: two M-point complex-to-complex transforms and two element-wise passes over [F][M] complex64 rows - about
 // ten times the time of a native size of similar length; the point of this path is that every size the reference

@@ -40,6 +40,7 @@ struct SpecParams {
   float* out_lin;            // [F][N] fftshift-ed linear power * pscale (averaging modes), or null
   float2* out_cplx;          // [F][N] complex spectrum X[k] in natural bin order (real-input path), or null
   const float2* out_mul;     // [N] with out_cplx, complex64 input, no hold: conj(X[k] * out_mul[k]) is stored instead (chirp-z), or null
+  int out_mul_rows;          // > 1: out_mul holds this many rows of N, frame f takes row f mod out_mul_rows (long chirp-z frames)
   int in_valid;              // complex64 input, no hold: samples from this index on are zeros and are not read (0: all N are read)
   int out_valid;             // with out_cplx, complex64 input, no hold: only bins below this index are stored (0: all N)
   const float2* dc_sub;      // [F] per-frame DC estimate in raw-sample units, WITHOUT in_off (DC_TRACKED), or null
@@ -190,7 +191,11 @@ constexpr int big_seed_rows(int log2n) {
 }
 hipError_t launch_big_cols(int log2n, const void* in, int in_c64, long long seg_stride, int n_seg, const float* window,
                            const float2* tw_seed, const float2* dc_sub, float2* z,
-                           unsigned xor_mask, float in_off, hipStream_t s);
+                           unsigned xor_mask, float in_off, hipStream_t s, unsigned in_valid = 0);
+// transposed four-step, second half: R[seg][k1][m2] (row transforms of T[k1][k2] = V[k1 + N1 k2]) -> Y[seg][m] in natural
+// order, M = N1 * 16384 points; bins from out_valid on are not stored (tdsa_big.hip)
+hipError_t launch_big_cols_out(int log2m, const float2* r, long long seg_stride, int n_seg, const float2* tw_seed, float2* y,
+                               unsigned out_valid, hipStream_t s);
 // exact per-frame sums + DC tracker in double; dc_res[f] = DC estimate in raw units MINUS in_off (small)
 hipError_t launch_big_dc(const void* in, int in_c64, unsigned xor_mask, long long frame_stride, int n, int n_frames,
                          double alpha, double in_off, double in_scale, double* sums, float2* dc_state, float2* dc_res,
@@ -213,7 +218,7 @@ hipError_t launch_big_finish(const double* src, long long n, double* mean_out, i
 
 
 // ---- frame lengths that are not a power of two, 2 <= N <= 8192 (tdsa_chirp.hip): chirp-z on the frame kernel ----
-constexpr int kChirpMaxN = 8192;
+constexpr int kChirpMaxN = 1 << 19;      // M = 2^ceil(log2(2N-1)) <= 2^20; M > 16384 runs on the long-frame kernels
 // res[f] = frame mean minus the format's zero level, raw units (twice_zero: 256 int8 after the xor, 255 uint8, 0 c64)
 // dc_state (or null): receives the last frame's mean in units of x - the per-frame mean mode needs no tracker pass
 hipError_t launch_chirp_sums(const void* in, int in_c64, unsigned xor_mask, long long frame_stride, int n, int n_frames,

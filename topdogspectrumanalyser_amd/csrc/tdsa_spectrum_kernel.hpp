@@ -953,6 +953,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, (spectrum_waves_per_simd(LOG2
           if (p.out_mul != nullptr) {
             plain = false;
             const c32* brow = p.out_mul + t + 8 * h * SG;
+            if constexpr (FPW == 1) { if (p.out_mul_rows > 1) brow += (long long)(frame % p.out_mul_rows) * N; }
             static_for<0, 16>([&](auto ic) {
               constexpr int q = decltype(ic)::value;
               constexpr int kc = (q < 8 ? q : q + 8);

@@ -108,7 +108,10 @@ class SpectrumEngine:
             raise TypeError(f"unsupported IQ dtype {iq.dtype}; need int8, uint8 or complex64")
         if n_frames is None:
             n_frames = 0 if n_samples < self.nfft else (n_samples - self.nfft) // hop + 1
-        rows = n_frames if self.nfft <= 16384 else min(n_frames, 1)   # long-frame plans return ONE row (Welch)
+        # native long-frame plans (2^15 .. 2^20 points) return ONE row (Welch average / one frame per call); every other
+        # plan - the chirp-z plans of long frames that are not a power of two included - one row per frame
+        long_native = self.nfft > 16384 and (self.nfft & (self.nfft - 1)) == 0
+        rows = min(n_frames, 1) if long_native else n_frames
         out = np.empty((rows, self.nfft), dtype=np.float32) if want_db else None
         nat.check(fn(self._h, _ptr(iq), n_samples, hop, n_frames, _ptr(out)))
         return out

@@ -21,7 +21,7 @@ class DisplayMode(IntEnum):
 
 
 class FFTSize(IntEnum):
-    """FFT sizes the reference enumerates (512..8192); the GPU path takes every size up to 8192 and every power
+    """FFT sizes the reference enumerates (512..8192); the GPU path takes every size up to 2^19 and every power
     of two up to 2^20 (gpu_fft_size_supported)."""
     SIZE_512 = 512
     SIZE_1024 = 1024
@@ -44,11 +44,11 @@ class FFTSize(IntEnum):
 
 GPU_MIN_FFT = 64
 GPU_MAX_FFT = 1 << 20      # 64 .. 16384 in one LDS-resident pass, 2^15 .. 2^20 as N1 x 16384 (two passes)
-GPU_MAX_ANY_FFT = 8192     # any size from 2 up to here (chirp-z on the power-of-two kernel), power of two or not
+GPU_MAX_ANY_FFT = 1 << 19  # any size from 2 up to here, power of two or not: chirp-z on the power-of-two kernels, M = 2^ceil(log2(2N-1)) <= 2^20
 
 
 def gpu_fft_size_supported(nfft: int) -> bool:
-    """Sizes the device library has a plan for: every N in [2, 8192], every power of two up to 2^20."""
+    """Sizes the device library has a plan for: every N in [2, 2^19], every power of two up to 2^20."""
     nfft = int(nfft)
     if 2 <= nfft <= GPU_MAX_ANY_FFT:
         return True
