@@ -41,7 +41,7 @@ def run_case(c):
     with SpectrumEngine(nfft, max_frames=nf) as e:
         e.set_window(window)
         e.configure(dc_alpha=dc, avg=c["avg"], cal_offset_db=c["cal"], **mode)
-        if nfft > 16384:
+        if nfft > 16384 and nfft & (nfft - 1) == 0:       # native long-frame plans: one frame per call
             out = np.concatenate([e.process(iq[2 * hop * k: 2 * (hop * k + nfft)], hop=nfft, n_frames=1) for k in range(nf)])
         else:
             out = e.process(iq, hop=hop, n_frames=nf)
@@ -53,8 +53,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=1500)
     ap.add_argument("--long", type=int, default=60)
+    ap.add_argument("--longany", type=int, default=60, help="long frames that are not a power of two (8193 .. 300000 points)")
     a = ap.parse_args()
-    classes = {"N <= 16384": [], "N <= 16384, tracked DC": [], "long frames": []}
+    classes = {"N <= 16384": [], "N <= 16384, tracked DC": [], "long frames": [], "long frames, not a power of two": []}
     worst_rel = 0.0
     for i in range(a.cases):
         c = T._random_case(np.random.default_rng(4242 + i))
@@ -70,6 +71,19 @@ def main():
         rel, units, dc = run_case(c)
         worst_rel = max(worst_rel, rel)
         classes["long frames"].append(units)
+    rng = np.random.default_rng(78)
+    for i in range(a.longany):
+        while True:
+            n = int(rng.choice([rng.integers(8193, 20000), rng.integers(20000, 70000), rng.integers(70000, 300000)]))
+            if n & (n - 1):
+                break
+        c = dict(nfft=n, nf=int(rng.integers(1, 4)), hop=int(rng.choice([n, n // 2])), branch=str(rng.choice(["hackrf", "rtl"])),
+                 avg=[("off", 1), ("exp", 3)][int(rng.integers(0, 2))], psd=bool(rng.integers(0, 2)),
+                 dc_alpha=float(rng.choice([1.0, 1.0, 0.25])), cal=0.0,
+                 window=str(rng.choice(["hanning", "hamming", "rectangle"])), seed=int(rng.integers(1, 1 << 30)))
+        rel, units, dc = run_case(c)
+        worst_rel = max(worst_rel, rel)
+        classes["long frames, not a power of two"].append(units)
     # real-input (audio) path: tdsa_process_real2 against the float64 restatement of audio_samples.py:121-131
     classes["real input (audio)"] = []
     rng = np.random.default_rng(99)
