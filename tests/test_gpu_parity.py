@@ -1155,6 +1155,28 @@ def test_c5_full_size_properties(pkg):
     assert abs(one[n // 2 + n // 8] - peak) < 0.05
 
 
+def test_c5_welch_is_reproducible_bit_for_bit(pkg):
+    """Six runs of the same 16 segments of 2^20 points (1024 column-pass workgroups in flight: more than the 256 it took
+    to expose the gfx950 store-data hazard of the column pass's 16-byte row stores, tdsa_big.hip - its padding depends on
+    the compiler keeping the row offset in the VGPR): the Welch row and the float64 mean must come out identical bit for
+    bit every time (per-workgroup partial rows summed in a fixed order; a hazard shows as run-to-run differences of
+    1e-6 .. 6e-4 of the frame maximum) and right."""
+    n, k = 1 << 20, 16
+    iq = so.synth_iq_int8(n * k, n, seed=19)
+    rows, means = [], []
+    with pkg.SpectrumEngine(n, max_frames=k) as e:
+        e.set_window(so.rtl_window("hanning", n).astype(np.float32))
+        e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=-1.0, avg=("lin", k))
+        for _ in range(6):
+            e.reset()
+            rows.append(e.process(iq, hop=n)[0].copy())
+            means.append(e.averaged()[0].copy())
+    for r, m in zip(rows[1:], means[1:]):
+        assert np.array_equal(r, rows[0]) and np.array_equal(m, means[0])
+    gold, _ = _welch_gold(iq, n, k, 0.0)
+    _check(rows[0], gold, "Welch of 16 segments of 2^20 points")
+
+
 def test_c5_single_frame_with_dc_removal(pkg):
     nfft = 1 << 20
     iq = so.synth_iq_int8(nfft, nfft, seed=6)

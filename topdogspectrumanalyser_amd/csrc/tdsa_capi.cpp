@@ -932,9 +932,12 @@ static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size
     // Long batches run as a chained scan over chunks of frames (tdsa_trace.hip).  Sizes with one frame per workgroup slot
     // (N >= 4096): the chunks ARE the frame ranges of the frame kernel's workgroups, which form their chunk's aggregate
     // themselves while the rows pass through their registers - the scan's first pass over the rows disappears.
-    const bool wg_chunks = p->log2n >= 12 && n_frames > 128 && (n_frames + g.grid - 1) / g.grid <= 64 && g.grid <= 256 &&
-                           getenv("TDSA_AVG_OLD") == nullptr;
-    const size_t need_chunks = wg_chunks ? size_t(spectrum_geometry(p->log2n, p->max_frames, p->num_cu).grid)
+    // Up to 256 chunks: grids of more workgroups (N = 8192: 512, N = 4096: 1024) fold 2 / 4 consecutive ranges into one.
+    const int wg_fold = (g.grid + 255) / 256;
+    const bool wg_chunks = p->log2n >= 12 && n_frames > 128 && g.grid <= kAvgMaxWgChunks &&
+                           ((n_frames + g.grid - 1) / g.grid) * wg_fold <= 64 && getenv("TDSA_AVG_OLD") == nullptr;
+    const size_t agg_rows = size_t(spectrum_geometry(p->log2n, p->max_frames, p->num_cu).grid);
+    const size_t need_chunks = wg_chunks ? (agg_rows < 256 ? agg_rows : size_t(256))
                                          : (p->max_frames > 128 ? size_t(avg_scan_chunks(p->max_frames)) : 0);
     if (need_chunks > p->carry_chunks) {
       if (p->d_carry) { HIPCHK(hipStreamSynchronize(p->stream)); HIPCHK(hipFree(p->d_carry)); p->d_carry = nullptr; p->carry_chunks = 0; }
@@ -956,13 +959,14 @@ static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size
     ap.state_max = (m.hold_flags & TDSA_HOLD_MAX) ? p->d_hold_max : nullptr;
     ap.state_min = (m.hold_flags & TDSA_HOLD_MIN) ? p->d_hold_min : nullptr;
     if (wg_chunks) {
-      if (!p->d_agg) HIPCHK(hipMalloc(&p->d_agg, need_chunks * p->nfft * sizeof(float)));
+      if (!p->d_agg) HIPCHK(hipMalloc(&p->d_agg, agg_rows * p->nfft * sizeof(float)));
       if (!p->d_agg_w) HIPCHK(hipMalloc(&p->d_agg_w, size_t(p->max_frames) * sizeof(float)));
       if (!p->d_chunk_a) HIPCHK(hipMalloc(&p->d_chunk_a, size_t(kAvgMaxWgChunks + 64) * sizeof(double)));
       if (!p->d_chunk_v) HIPCHK(hipMalloc(&p->d_chunk_v, size_t(kAvgMaxWgChunks + 64) * sizeof(float)));
       ap.chunk_a = p->d_chunk_a;
       ap.chunk_v = p->d_chunk_v;
       ap.wg_chunks = g.grid;
+      ap.wg_fold = wg_fold;
       ap.agg = p->d_agg;
       // the weights depend on where the averager stands and on the chunking only: in steady state (exp mode, or lin
       // with its count at the cap) consecutive calls of one shape re-use them

@@ -127,9 +127,10 @@ struct AvgParams {
   // chunks = the frame ranges of the frame kernel's wg_chunks workgroups, whose aggregates (float32, agg[c][n]) the frame
   // kernel has already formed (SpecParams::agg_out): the scan then needs no pass of its own for them.  0: chunks of 64.
   int wg_chunks;
+  int wg_fold;            // consecutive workgroup ranges per chunk of the scan (1 .. 4): ceil(wg_chunks / wg_fold) <= 256 chunks
   const float* agg;
-  const double* chunk_a;  // [kAvgMaxWgChunks + 64] per chunk: product of its frames' a_f (1 for an empty chunk and past the end)
-  const float* chunk_v;   // [kAvgMaxWgChunks + 64] 1: the chunk has frames (its aggregate row was written), else 0
+  const double* chunk_a;  // [kAvgMaxWgChunks + 64] per workgroup range: product of its frames' a_f (1 for an empty one and past the end)
+  const float* chunk_v;   // [kAvgMaxWgChunks + 64] 1: the range has frames (its aggregate row was written), else 0
 };
 constexpr int kAvgMaxWgChunks = 1024;
 // carry: [chunks][n] doubles of scratch for the chunked scan (null: sequential kernel)

@@ -93,7 +93,13 @@ constexpr int kAvgChunk = 64;
 // persistent grid - at most 64 frames long (checked by the host), possibly empty
 __device__ __forceinline__ void avg_chunk_bounds(const AvgParams& p, int c, int& f0, int& f1) {
   if (p.wg_chunks > 0) {
-    spectrum_unit_range(unsigned(c), unsigned(p.n_frames), unsigned(p.wg_chunks), f0, f1);
+    // wg_fold consecutive workgroup ranges make one chunk (sizes whose grid has more than 256 workgroups)
+    const int r = p.wg_fold > 1 ? p.wg_fold : 1;
+    const int first = c * r, last = min(first + r, p.wg_chunks) - 1;
+    int t;
+    spectrum_unit_range(unsigned(first), unsigned(p.n_frames), unsigned(p.wg_chunks), f0, t);
+    spectrum_unit_range(unsigned(last), unsigned(p.n_frames), unsigned(p.wg_chunks), t, f1);
+    if (last < first) f1 = f0;
   } else {
     f0 = c * kAvgChunk;
     f1 = f0 + kAvgChunk < p.n_frames ? f0 + kAvgChunk : p.n_frames;
@@ -207,37 +213,65 @@ __global__ void __launch_bounds__(64 * MAXQ) avg_wg_chain_kernel(const AvgParams
   __shared__ double Aq[16];
   const int tid = threadIdx.x, lane = tid & 63;
   const int q = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave index = run of 64 chunks: scalar
-  const int nc = p.wg_chunks;
+  const int r = p.wg_fold > 1 ? p.wg_fold : 1;                   // workgroup ranges folded into one chunk (<= 4)
+  const int nsub = p.wg_chunks;
+  const int nc = (nsub + r - 1) / r;
   const int k = min(int(blockIdx.x) * 64 + lane, p.n - 1);      // (a bin past the end redoes the last one)
   const double s_in = p.count_in > 0 ? p.state[k] : 0.0;
-  // chunk multipliers / validity flags: the same for every bin, made once per call by avg_weights_kernel; this wave's 64
-  // of each are parked in LDS and read back eight at a time (fenced: left to itself the compiler hoists all 64 broadcasts
-  // of a run into VGPRs, which the 1024-thread instantiation does not have)
-  __shared__ double As[16 * 64];
-  __shared__ float Vs[16 * 64];
+  // multipliers / validity flags of the workgroup ranges: the same for every bin, made once per call by
+  // avg_weights_kernel; this wave's share is parked in LDS and read back eight at a time (fenced: left to itself the
+  // compiler hoists all the broadcasts of a run into VGPRs)
+  __shared__ double As[4 * 64];          // per chunk: product over its ranges
+  __shared__ float Asub[4 * 64 * 4];     // per range (float: it only scales a float32 aggregate while ranges are folded)
+  __shared__ float Vsub[4 * 64 * 4];
   const int c0 = q * 64;
-  As[c0 + lane] = p.chunk_a[c0 + lane];
-  Vs[c0 + lane] = p.chunk_v[c0 + lane];
-  // every aggregate load unconditional and issued before anything depends on one (a row that was never written is read and
-  // dropped); SGPR buffer descriptors: the chunk offset is scalar, the bin offset the only per-lane address
-  float loc[64];
-  const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.agg), 0, int(unsigned(nc) * unsigned(p.n) * 4u), 0x00020000);
-#pragma unroll
-  for (int u = 0; u < 64; ++u)
-    loc[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ar, unsigned(k) * 4u, unsigned(min(c0 + u, nc - 1)) * unsigned(p.n) * 4u, 0));
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // As / Vs of this run are wave-private
+  {
+    double a = 1.0;
+    for (int j = 0; j < r; ++j) {
+      const int idx = (c0 + lane) * r + j;
+      const bool in = idx < kAvgMaxWgChunks + 64;
+      const double aj = in ? p.chunk_a[idx] : 1.0;
+      Asub[(c0 + lane) * 4 + j] = float(aj);
+      Vsub[(c0 + lane) * 4 + j] = in ? p.chunk_v[idx] : 0.f;
+      a *= aj;
+    }
+    As[c0 + lane] = a;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // this run's entries are wave-private
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // aggregates: every load unconditional and issued before anything depends on one (a row that was never written is read
+  // and dropped); SGPR buffer descriptors: the range offset is scalar, the bin offset the only per-lane address.  The r
+  // ranges of a chunk are folded as they arrive: L <- a_j L + L_j.
+  float loc[64];
+#pragma unroll
+  for (int u = 0; u < 64; ++u) loc[u] = 0.f;
+  const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.agg), 0, int(unsigned(nsub) * unsigned(p.n) * 4u), 0x00020000);
+  for (int j = 0; j < r; ++j) {
+    float tmp[64];
+#pragma unroll
+    for (int u = 0; u < 64; ++u)
+      tmp[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ar, unsigned(k) * 4u, unsigned(min((c0 + u) * r + j, nsub - 1)) * unsigned(p.n) * 4u, 0));
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      float a8[8], v8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a8[u] = Asub[(c0 + 8 * g + u) * 4 + j]; v8[u] = Vsub[(c0 + 8 * g + u) * 4 + j]; }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) loc[8 * g + u] = fmaf(a8[u], loc[8 * g + u], v8[u] != 0.f ? tmp[8 * g + u] : 0.f);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
   double s = 0.0, ap = 1.0;
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
-    double a8[8]; float v8[8];
+    double a8[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { a8[u] = As[c0 + 8 * g + u]; v8[u] = Vs[c0 + 8 * g + u]; }
+    for (int u = 0; u < 8; ++u) a8[u] = As[c0 + 8 * g + u];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      loc[8 * g + u] = v8[u] != 0.f ? loc[8 * g + u] : 0.f;
       s = fma(a8[u], s, double(loc[8 * g + u]));
       ap *= a8[u];
     }
@@ -328,7 +362,7 @@ __global__ void __launch_bounds__(64) avg_weights_kernel(const AvgParams p, floa
   float valid = 0.f;
   if (c < p.wg_chunks) {
     int f0, f1;
-    avg_chunk_bounds(p, c, f0, f1);
+    spectrum_unit_range(unsigned(c), unsigned(p.n_frames), unsigned(p.wg_chunks), f0, f1);     // ONE workgroup's range
     for (int f = f1 - 1; f >= f0; --f) {
       double a, bs; bool bf;
       avg_coeff(p, f, a, bs, bf);
@@ -352,11 +386,13 @@ hipError_t launch_avg_scan(const AvgParams& p, hipStream_t s, double* carry) {
     const bool vec = (p.n % 4 == 0) && (reinterpret_cast<uintptr_t>(p.lin) % 16 == 0) &&
                      (p.out_db == nullptr || reinterpret_cast<uintptr_t>(p.out_db) % 16 == 0);
     if (p.wg_chunks > kAvgMaxWgChunks || size_t(p.wg_chunks) * p.n * 8 > 0xffffffffull) return hipErrorInvalidValue;
-    const int runs = (p.wg_chunks + 63) / 64;
-    if (runs > 4) return hipErrorInvalidValue;        // (the host only takes this path for up to 256 chunks)
+    const int fold = p.wg_fold > 1 ? p.wg_fold : 1;
+    const int chunks = (p.wg_chunks + fold - 1) / fold;
+    const int runs = (chunks + 63) / 64;
+    if (runs > 4 || fold > 4) return hipErrorInvalidValue;        // (the host only takes this path for up to 256 chunks)
     hipLaunchKernelGGL(avg_wg_chain_kernel<4>, dim3((p.n + 63) / 64), dim3(64 * runs), 0, s, p, carry);
-    if (vec) hipLaunchKernelGGL(avg_chunk_final_kernel<4>, dim3((p.n / 4 + 63) / 64, p.wg_chunks), dim3(64), 0, s, p, carry);
-    else hipLaunchKernelGGL(avg_chunk_final_kernel<1>, dim3((p.n + 63) / 64, p.wg_chunks), dim3(64), 0, s, p, carry);
+    if (vec) hipLaunchKernelGGL(avg_chunk_final_kernel<4>, dim3((p.n / 4 + 63) / 64, chunks), dim3(64), 0, s, p, carry);
+    else hipLaunchKernelGGL(avg_chunk_final_kernel<1>, dim3((p.n + 63) / 64, chunks), dim3(64), 0, s, p, carry);
     return hipGetLastError();
   }
   if (carry != nullptr && p.n_frames > 2 * kAvgChunk) {
