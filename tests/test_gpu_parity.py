@@ -1515,6 +1515,33 @@ def test_audio_quiet_channel_is_not_polluted(pkg):
             _check(both[0], gold_l, f"stereo left, level ratio {ratio}")
 
 
+@pytest.mark.parametrize("n", [10000, 44100, 48000])
+def test_audio_long_frames_that_are_not_a_power_of_two(pkg, n):
+    """MicrophoneSamplesDataSource.set_fft_size takes any size (audio_samples.py:208-214) and scipy.fft.rfft any n (:125):
+    one second of audio as ONE frame (44100 / 48000 points) rides the chirp-z path of the long-frame kernels like any
+    other size above 8192 - mono mix, left and stereo, one-sided power with the inner bins doubled."""
+    fs = 48000
+    rng = np.random.default_rng(n)
+    t = np.arange(2 * n)
+    st = np.stack([0.4 * np.sin(2 * np.pi * 997.3 * t / fs) + 0.01 * rng.standard_normal(2 * n) + 0.02,
+                   0.1 * np.sin(2 * np.pi * 5003.1 * t / fs) + 0.02 * rng.standard_normal(2 * n)], axis=1).astype(np.float32)
+    win = so.rtl_window("hanning", n)
+    with pkg.SpectrumEngine(n, max_frames=2) as e:
+        e.set_window(win.astype(np.float32))
+        e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=1.0)
+        mono = e.process_real2(st, "mono")
+        both = e.process_real2(st, "stereo")
+    assert mono.shape == (2, n // 2 + 1) and both.shape == (2, 2, n // 2 + 1)
+    for k in range(2):
+        blk = st[k * n:(k + 1) * n].astype(np.float64)
+        gold_m = so.audio_db(so.audio_compute_power((blk[:, 0] + blk[:, 1]) * 0.5, win, n, fs, False, precision="gold"), False)
+        gold_l = so.audio_db(so.audio_compute_power(blk[:, 0], win, n, fs, False, precision="gold"), False)
+        gold_r = so.audio_db(so.audio_compute_power(blk[:, 1], win, n, fs, False, precision="gold"), False)
+        _check(mono[k], gold_m, f"mono frame {k}")
+        _check(both[k, 0], gold_l, f"left frame {k}")
+        _check(both[k, 1], gold_r, f"right frame {k}")
+
+
 class _EndlessStream:
     """a stereo float32 stream that hands out consecutive blocks of whatever length is asked for"""
 
