@@ -194,12 +194,12 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
 // kernel of its own since round 4.  Until then it was an instantiation of the frame kernel (ACC) that fetched the next
 // row - 128 KB per CU - in one burst behind pass 1 and waited for it at the top of the next row: the fetch had passes 2
 // and 3 (3.7 us) to land, needs 5 us at the read roof, and the memory pipe of the CU sat idle during pass 1 (7.7 us per
-// row against 4.7 us of arithmetic).  Issuing the whole fetch at the row top does not fit: its 32 landing registers and
-// pass 1's working set exceeded the 128 VGPRs of the shared kernel (round 3: scratch), and in this kernel, where it
-// fits (127 VGPRs), the whole row at the top measured slower than the split (125.0 against 121.7 us).  The fetch is split: the first half (4 x 16
-// bytes per thread) is issued at the row top, the second half behind pass 1, so that the CU always has loads in flight;
+// row against 4.7 us of arithmetic).  The whole fetch at the row top is no answer: in the shared kernel its 32 landing
+// registers and pass 1's working set exceeded the 128 VGPRs (round 3: scratch); in this kernel it fits (127 VGPRs) and
+// measures slower than the split (125.0 against 121.7 us per 64 segments).  So the fetch is split: the first half (4 x 16
+// bytes per thread) is issued at the row top, the second half behind pass 1, and the CU always has loads in flight;
 // the loop body is branch-free (the row after the last one is the last one again) and carries no other vector-memory
-// operation, so the only vmcnt wait the compiler places is the one at the row top.
+// operation, so the only vmcnt waits the compiler places are the ones for the landing row.
 struct BigRowsParams {
   const float2* z;           // [group][N1][16384] rows from the column pass
   long long seg_stride;      // bytes between segments (N1 * 16384 * 8)
