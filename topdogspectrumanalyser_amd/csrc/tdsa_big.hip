@@ -271,15 +271,40 @@ __global__ void __launch_bounds__(1024, 4) big_rows_kernel(const BigRowsParams p
     });
     const int sn = s + 1 < s1 ? s + 1 : s;          // (past the end: the same row again, so that the loop has no branch)
     const rsrc_t rn = row_rsrc(sn);
-    static_for<0, 4>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      ld[i] = __builtin_amdgcn_raw_buffer_load_b128(rn, lane_in_off, i * 16384, 2);
-    });
+    // The next row's eight 16-byte loads are spread over the row's work, one here, one there (fetch_at<position>):
+    // positions 0 row top | 1 between pass 1's two radix-8 networks | 2 behind them | 3 middle of pass 1's combine |
+    // 4 behind pass 1's LDS writes | 5 behind the middle pass's gather | 6 between its two twiddle batches | 7 behind its
+    // radix network | 8 middle of its combine | 9 behind its LDS writes | 10 behind the last pass's gather | 11 behind its
+    // pre-twiddle | 12 behind its radix network | 13 middle of its combine.   TDSA_ROWS_FA / _FB: loads per position, a
+    // leading 1 (keeps the literal decimal) and 7 decimal digits each (positions 0-6 / 7-13).
+#ifndef TDSA_ROWS_FA
+#define TDSA_ROWS_FA 11010110
+#define TDSA_ROWS_FB 11011010
+#endif
+    auto fetch_at = [&](auto pc) {
+      constexpr int P = decltype(pc)::value;
+      constexpr auto cnt = [](int q) constexpr { int d = q < 7 ? TDSA_ROWS_FA : TDSA_ROWS_FB, e = q < 7 ? 6 - q : 13 - q; while (e-- > 0) d /= 10; return d % 10; };
+      constexpr int lo = [&] { int x = 0; for (int q = 0; q < P; ++q) x += cnt(q); return x; }();
+      constexpr int n = cnt(P);
+      static_assert(P < 13 || lo + n == 8, "eight loads per row");
+      static_for<lo, lo + n>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+#ifndef TDSA_ROWS_AUX
+#define TDSA_ROWS_AUX 2       // last use of Z: non-temporal
+#endif
+        ld[i] = __builtin_amdgcn_raw_buffer_load_b128(rn, lane_in_off, i * 16384, TDSA_ROWS_AUX);
+      });
+    };
+#define TDSA_FETCH(P) fetch_at(std::integral_constant<int, P>{})
+    TDSA_FETCH(0);
     // ---- pass 1: two radix-8 DFTs per half-thread, combine across the lane pair -> radix 16 ---------------
     radix<8, 0, 16>(v);
+    TDSA_FETCH(1);
     radix<8, 8, 16>(v);
+    TDSA_FETCH(2);
     static_for<0, 8>([&](auto uc) {
       constexpr int u = decltype(uc)::value;
+      if constexpr (u == 4) TDSA_FETCH(3);
       constexpr int jj0 = u / H, k0 = u % H, jj1 = (u + 8) / H, k1r = (u + 8) % H;
       constexpr int re = jj0 * H + bitrev(k0, LH), ro = jj1 * H + bitrev(k1r, LH);
       swap_halves(v[re], v[ro]);
@@ -288,17 +313,16 @@ __global__ void __launch_bounds__(1024, 4) big_rows_kernel(const BigRowsParams p
       lds_st(&buf[wr1_base + li], v[re]);
       lds_st(&buf[wr1_base + li + H], v[ro]);
     });
-    static_for<4, 8>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      ld[i] = __builtin_amdgcn_raw_buffer_load_b128(rn, lane_in_off, i * 16384, 2);
-    });
+    TDSA_FETCH(4);
     __syncthreads();
     // ---- middle radix-32 pass, in place --------------------------------------------------------------
     static_for<0, 16>([&](auto ic) { constexpr int i = decltype(ic)::value; v[i] = lds_ld(&buf[rdA + i * 2 * rd_stride]); });
+    TDSA_FETCH(5);
     int tw_o = h * A + ka_mid;
     asm volatile("" : "+v"(tw_o));
     static_for<0, 2>([&](auto bc) {
       constexpr int b0 = decltype(bc)::value * 4;
+      if constexpr (b0 == 4) TDSA_FETCH(6);
       c32 tw8[8];
       static_for<0, 8>([&](auto ic) {
         constexpr int q = decltype(ic)::value;
@@ -310,17 +334,21 @@ __global__ void __launch_bounds__(1024, 4) big_rows_kernel(const BigRowsParams p
       __builtin_amdgcn_sched_barrier(0);
     });
     dit_rest<16, 0, 16>(v);
+    TDSA_FETCH(7);
     static_for<0, 8>([&](auto uc) {
       constexpr int u = decltype(uc)::value;
+      if constexpr (u == 4) TDSA_FETCH(8);
       constexpr int re = bitrev(u, 4), ro = bitrev(u + 8, 4);
       swap_halves(v[re], v[ro]);
       combine32<u>(v[re], v[ro], odd_half);
       lds_st(&buf[wrM + u * rd_stride], v[re]);
       lds_st(&buf[wrM + (u + 16) * rd_stride], v[ro]);
     });
+    TDSA_FETCH(9);
     __syncthreads();
     // ---- last radix-32 pass ----------------------------------------------------------------------------
     static_for<0, 16>([&](auto ic) { constexpr int i = decltype(ic)::value; v[i] = lds_ld(&buf[rd3A + 2 * i * A + ((2 * i * A) >> 5)]); });
+    TDSA_FETCH(10);
     static_for<0, 3>([&](auto ic) { opaque(twf_lo[decltype(ic)::value]); });
     static_for<0, 4>([&](auto ic) { opaque(twf_hi[decltype(ic)::value]); });
     static_for<0, 8>([&](auto ic) {
@@ -330,9 +358,12 @@ __global__ void __launch_bounds__(1024, 4) big_rows_kernel(const BigRowsParams p
       if constexpr (q != 0) { te = cmul(te, twf_lo[q - 1]); to = cmul(to, twf_lo[q - 1]); }
       bf_tw(v[i], v[i + 8], te, to);
     });
+    TDSA_FETCH(11);
     dit_rest<16, 0, 16>(v);
+    TDSA_FETCH(12);
     static_for<0, 8>([&](auto uc) {
       constexpr int u = decltype(uc)::value;
+      if constexpr (u == 4) TDSA_FETCH(13);
       constexpr int re = bitrev(u, 4), ro = bitrev(u + 8, 4);
       swap_halves(v[re], v[ro]);
       combine32<u, true>(v[re], v[ro], odd_half);
