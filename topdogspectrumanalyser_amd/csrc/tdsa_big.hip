@@ -192,14 +192,15 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
 // ---- row pass: 16384-point transforms of the rows Z[seg][k1][.], |X|^2 summed over the segments a workgroup takes ----
 // The frame kernel's three radix passes (A x 32 x 32 with A = 16: tdsa_spectrum_kernel.hpp) on complex64 rows, as a
 // kernel of its own since round 4.  Until then it was an instantiation of the frame kernel (ACC) that fetched the next
-// row - 128 KB per CU - in one burst behind pass 1 and waited for it at the top of the next row: the fetch had passes 2
-// and 3 (3.7 us) to land, needs 5 us at the read roof, and the memory pipe of the CU sat idle during pass 1 (7.7 us per
-// row against 4.7 us of arithmetic).  The whole fetch at the row top is no answer: in the shared kernel its 32 landing
-// registers and pass 1's working set exceeded the 128 VGPRs (round 3: scratch); in this kernel it fits (127 VGPRs) and
-// measures slower than the split (125.0 against 121.7 us per 64 segments).  So the fetch is split: the first half (4 x 16
-// bytes per thread) is issued at the row top, the second half behind pass 1, and the CU always has loads in flight;
-// the loop body is branch-free (the row after the last one is the last one again) and carries no other vector-memory
-// operation, so the only vmcnt waits the compiler places are the ones for the landing row.
+// row - 128 KB per CU - in one burst behind pass 1 and waited for it at the top of the next row (7.7 us per row against
+// 4.7 us of arithmetic).  What the row needs is not an EARLY fetch but a SPREAD one: the CU's share of the fabric
+// (~26 GB/s) has to flow for ~90 % of the row's period, and a burst of loads from 1024 threads at once is served worse
+// than the same bytes in a trickle.  Measured per 64 segments, same box (profiles/r04_c5_experiments.txt): all eight
+// 16-byte loads of a thread at the row top 125 us | 4 at the top + 4 behind pass 1: 122 | 2 / 2 / 2 / 2 over pass 1 and
+// the middle pass's gather: 117 | one load at each of eight points through all three passes: 105.5 (shipped; 14 points
+// are wired, the knobs TDSA_ROWS_FA / _FB choose among them: six other spreads 105 - 109).
+// The loop body is branch-free (the row after the last one is the last one again) and carries no other vector-memory
+// operation, so the only vmcnt waits the compiler places are the ones for the landing row.  123 VGPRs, no scratch.
 struct BigRowsParams {
   const float2* z;           // [group][N1][16384] rows from the column pass
   long long seg_stride;      // bytes between segments (N1 * 16384 * 8)
@@ -253,13 +254,15 @@ __global__ void __launch_bounds__(1024, 4) big_rows_kernel(const BigRowsParams p
   // 16-byte pieces at lane_in_off + i * 16 KiB: (row 2i + h of the 16 x 1024 view, columns 2t, 2t + 1)
   const unsigned char* zrow = reinterpret_cast<const unsigned char*>(p.z) + (long long)k1 * (N * 8);
   auto row_rsrc = [&](int s) { return make_rsrc(zrow + (long long)s * p.seg_stride, N * 8u); };
+  constexpr int NL = 8;     // 16-byte loads per thread and row (sixteen 8-byte ones: 126 us against 107)
   u32x4 ld[8];
+  auto row_load = [&](const rsrc_t& r, auto ic) {
+    constexpr int i = decltype(ic)::value;
+    ld[i] = __builtin_amdgcn_raw_buffer_load_b128(r, lane_in_off, i * 16384, 2);   // last use of Z: non-temporal (plain: 144 us)
+  };
   if (s0 < s1) {
     const rsrc_t r = row_rsrc(s0);
-    static_for<0, 8>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      ld[i] = __builtin_amdgcn_raw_buffer_load_b128(r, lane_in_off, i * 16384, 2);   // last use of Z: non-temporal
-    });
+    static_for<0, NL>([&](auto ic) { row_load(r, ic); });
   }
   __syncthreads();        // twm is in place
   for (int s = s0; s < s1; ++s) {
@@ -286,14 +289,8 @@ __global__ void __launch_bounds__(1024, 4) big_rows_kernel(const BigRowsParams p
       constexpr auto cnt = [](int q) constexpr { int d = q < 7 ? TDSA_ROWS_FA : TDSA_ROWS_FB, e = q < 7 ? 6 - q : 13 - q; while (e-- > 0) d /= 10; return d % 10; };
       constexpr int lo = [&] { int x = 0; for (int q = 0; q < P; ++q) x += cnt(q); return x; }();
       constexpr int n = cnt(P);
-      static_assert(P < 13 || lo + n == 8, "eight loads per row");
-      static_for<lo, lo + n>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-#ifndef TDSA_ROWS_AUX
-#define TDSA_ROWS_AUX 2       // last use of Z: non-temporal
-#endif
-        ld[i] = __builtin_amdgcn_raw_buffer_load_b128(rn, lane_in_off, i * 16384, TDSA_ROWS_AUX);
-      });
+      static_assert(P < 13 || lo + n == NL, "all of the row's loads must be placed");
+      static_for<lo, lo + n>([&](auto ic) { row_load(rn, ic); });
     };
 #define TDSA_FETCH(P) fetch_at(std::integral_constant<int, P>{})
     TDSA_FETCH(0);
