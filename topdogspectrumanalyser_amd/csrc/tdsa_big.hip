@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(1024, 4) big_rows_kernel(const BigRowsParams p
   constexpr int NL = 8;     // 16-byte loads per thread and row (sixteen 8-byte ones: 126 us against 107)
   u32x4 ld[8];
   auto row_load = [&](const rsrc_t& r, auto ic) {
-    constexpr int i = decltype(ic)::value;
+    constexpr int i = decltype(ic)::value;     // (issued in the order pass 1's first butterflies consume them: no change)
     ld[i] = __builtin_amdgcn_raw_buffer_load_b128(r, lane_in_off, i * 16384, 2);   // last use of Z: non-temporal (plain: 144 us)
   };
   if (s0 < s1) {
