@@ -1,3 +1,5 @@
-L=$PWD/topdogspectrumanalyser_amd
-TDSA_HIP_LIB=$L/libtdsa_perm.so timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "c5_million or c5_reference" 2>&1 | tail -1
-bash tools/c5_ab.sh 3 hip perm 2>&1 | tail -3
+#!/bin/bash
+mkdir -p gpurun_out/r4u
+python tools/c5_two_plans.py --plans 3 > gpurun_out/r4u/two_plans.txt 2>&1
+cat gpurun_out/r4u/two_plans.txt
+python -m pytest tests -m gpu -x -q -k "averaging" 2>&1 | tail -3
