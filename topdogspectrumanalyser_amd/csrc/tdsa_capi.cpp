@@ -917,18 +917,8 @@ static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size
   // first fetch, hold merge: ~5 us) count half - and the ragged end of one launch is filled by the next:
   // C3 76.4 -> 74.3 us per step, C2 26.7 -> 26.0 (profiles/r02_c3_experiments.txt).  More than three streams in flight
   // measured worse (4: 91 us), and strictly serial launches keep the whole chip.
-  const LaunchGeom g0 = spectrum_geometry(p->log2n, n_frames,
-                                          (overlap && p->n_overlap >= 3) ? (p->num_cu * p->overlap_share + 99) / 100 : p->num_cu);
-  LaunchGeom g = g0;
-  {   // an instantiation built for fewer waves per SIMD hosts fewer workgroups per CU: size the persistent grid for that
-    const int hold_inst = averaging ? 0 : int(m.hold_flags & 3u);
-    const int waves = spectrum_waves_per_simd(p->log2n, in_c64 != 0, hold_inst);
-    if (waves < 4) {
-      const int cus = (overlap && p->n_overlap >= 3) ? (p->num_cu * p->overlap_share + 99) / 100 : p->num_cu;
-      const int cap = cus * (waves * 4 * 64 / g.block);
-      if (g.grid > cap && cap >= 1) g.grid = cap;
-    }
-  }
+  const LaunchGeom g = spectrum_geometry(p->log2n, n_frames,
+                                         (overlap && p->n_overlap >= 3) ? (p->num_cu * p->overlap_share + 99) / 100 : p->num_cu);
   if (averaging) {
     if (!p->d_lin) HIPCHK(hipMalloc(&p->d_lin, size_t(p->max_frames) * p->nfft * sizeof(float)));
     // Long batches run as a chained scan over chunks of frames (tdsa_trace.hip).  Sizes with one frame per workgroup slot

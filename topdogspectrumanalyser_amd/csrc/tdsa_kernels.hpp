@@ -83,14 +83,6 @@ struct SpecParams {
   long long seg_out_stride;  // output elements
 };
 
-// Waves per SIMD an instantiation of the frame kernel is compiled for (its register budget: 512 / waves VGPRs).  Four
-// everywhere - except 1024-point byte frames with max AND min hold: one sample per row read means 16 prefetch registers,
-// two traces 32 more, and at 128 VGPRs eight values spilled (each reload behind the row stores' vmcnt: +11 % against
-// max hold alone); with three waves per SIMD (142 VGPRs, no scratch, three workgroups per CU) it is +6 %.
-constexpr int spectrum_waves_per_simd(int log2n, bool in_c64, int hold) {
-  return (log2n == 10 && !in_c64 && hold == 3) ? 3 : 4;
-}
-
 struct LaunchGeom {
   int grid, block, fpw;
   size_t lds_bytes;

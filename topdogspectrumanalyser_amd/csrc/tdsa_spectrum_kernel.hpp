@@ -63,7 +63,10 @@ struct Cfg {
   // loads and stores in one in-order vmcnt): those sizes keep the window table in LDS instead.
   static constexpr bool WIN_LDS = TPF <= 64;
   static constexpr size_t WIN_BYTES = WIN_LDS ? size_t(N) * sizeof(float) : 0;
-  static constexpr size_t LDS_BYTES = DATA_BYTES + size_t(TWM) * sizeof(c32) + NWAVE * 2 * sizeof(double) + WIN_BYTES;
+  // N = 1024: room for the last pass's seven per-thread twiddles (max + min hold instantiation of the byte formats: its
+  // loop has no 14 VGPRs to keep them in) - 3 x SG + 4 x TPF entries; with it four workgroups still fit a CU exactly
+  static constexpr size_t TWF_BYTES = (LOG2N == 10) ? size_t(3 * SG + 4 * TPF) * sizeof(c32) : 0;
+  static constexpr size_t LDS_BYTES = DATA_BYTES + size_t(TWM) * sizeof(c32) + NWAVE * 2 * sizeof(double) + TWF_BYTES + WIN_BYTES;
   static constexpr size_t LDS_ALLOC = LDS_BYTES
 #ifdef TDSA_TIMELINE
       + 16 * 8 * 16 * 8
@@ -286,7 +289,7 @@ __device__ __forceinline__ void combine_const(c32& e, c32& o) {
 // 4 waves per SIMD, which is what it takes to keep the VALU fed (one wave issues at most one VALU op
 // every 4 clocks; the SIMD retires one every 2).
 template <int LOG2N, bool IN_C64, int HOLD, bool ACC = false>   // HOLD: bit0 = max trace, bit1 = min trace; 4 = AGG (see below)
-__global__ void __launch_bounds__(Cfg<LOG2N>::WGT, (spectrum_waves_per_simd(LOG2N, IN_C64, HOLD))) spectrum_kernel(const SpecParams p) {
+__global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const SpecParams p) {
   using C = Cfg<LOG2N>;
   constexpr int N = C::N, SG = C::SG, A = C::A, M = C::M, H = C::H, FPW = C::FPW, NPAD = C::NPAD;
   constexpr int LH = ilog2(H);
@@ -364,6 +367,16 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, (spectrum_waves_per_simd(LOG2
   // ---- frame-invariant per-thread state ---------------------------------------------------------
   const rsrc_t win_rsrc = make_rsrc(C::WIN_LDS ? p.window : p.window_perm, N * 4u);
   float* win_lds = reinterpret_cast<float*>(smem + C::LDS_BYTES - C::WIN_BYTES);
+  // TWF_LDS: the last pass's per-thread twiddles W_N^(t (8a + h)), W_N^(2 t j) are re-read from LDS every frame instead
+  // of living in 14 VGPRs (see Cfg::TWF_BYTES)
+  constexpr bool TWF_LDS = C::TWF_BYTES != 0 && HOLD >= 3 && !IN_C64 && !ACC;
+  c32* twf_tab = reinterpret_cast<c32*>(smem + C::LDS_BYTES - C::WIN_BYTES - C::TWF_BYTES);    // [3][SG] lo, then [4][TPF] hi
+  if constexpr (TWF_LDS) {
+    if (slot == 0) {
+      if (h == 0) static_for<0, 3>([&](auto ic) { constexpr int j = decltype(ic)::value; twf_tab[j * SG + t] = p.tw[t * 2 * (j + 1)]; });
+      static_for<0, 4>([&](auto ic) { constexpr int a = decltype(ic)::value; twf_tab[3 * SG + a * C::TPF + h * SG + t] = p.tw[t * (8 * a + h)]; });
+    }
+  }
   if constexpr (C::WIN_LDS) {
     for (int i = tid; i < N; i += C::WGT) win_lds[i] = p.window[i];
     __syncthreads();
@@ -509,8 +522,10 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, (spectrum_waves_per_simd(LOG2
   // middle-pass table goes through registers into LDS, which waits for everything issued before it), the
   // window slice last (64 KiB per workgroup, not needed before the first barrier has been passed)
   c32 twf_lo[3], twf_hi[4];   // last pass: W_N^(t*(2i+h)), i = 4a + j  ->  hi[a] = W^(t(8a+h)), lo[j-1] = W^(2tj)
-  static_for<0, 3>([&](auto ic) { constexpr int j = decltype(ic)::value; twf_lo[j] = p.tw[t * 2 * (j + 1)]; });
-  static_for<0, 4>([&](auto ic) { constexpr int a = decltype(ic)::value; twf_hi[a] = p.tw[t * (8 * a + h)]; });
+  if constexpr (!TWF_LDS) {
+    static_for<0, 3>([&](auto ic) { constexpr int j = decltype(ic)::value; twf_lo[j] = p.tw[t * 2 * (j + 1)]; });
+    static_for<0, 4>([&](auto ic) { constexpr int a = decltype(ic)::value; twf_hi[a] = p.tw[t * (8 * a + h)]; });
+  }
   if constexpr (C::NPASS == 3) {   // middle pass table twm[b*A + ka] = W_(32A)^(ka*b)
     if (tid < C::TWM) {
       const int b = tid / A, ka = tid % A;
@@ -898,8 +913,13 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, (spectrum_waves_per_simd(LOG2
       });
     }
     TDSA_STAMP(9);
-    static_for<0, 3>([&](auto ic) { opaque(twf_lo[decltype(ic)::value]); });
-    static_for<0, 4>([&](auto ic) { opaque(twf_hi[decltype(ic)::value]); });
+    if constexpr (TWF_LDS) {
+      static_for<0, 3>([&](auto ic) { constexpr int j = decltype(ic)::value; twf_lo[j] = lds_ld(&twf_tab[j * SG + t]); });
+      static_for<0, 4>([&](auto ic) { constexpr int a = decltype(ic)::value; twf_hi[a] = lds_ld(&twf_tab[3 * SG + a * C::TPF + h * SG + t]); });
+    } else {
+      static_for<0, 3>([&](auto ic) { opaque(twf_lo[decltype(ic)::value]); });
+      static_for<0, 4>([&](auto ic) { opaque(twf_hi[decltype(ic)::value]); });
+    }
 #ifndef TDSA_UNFUSED_TW   // (-DTDSA_UNFUSED_TW: the separate pre-twiddle of rounds 1-2, kept for A/B timing)
     static_for<0, 8>([&](auto ic) {                          // pre-twiddle W_N^(t*(2i+h)), i = 4a + j, fused with the
       constexpr int i = decltype(ic)::value;                 // radix-16's first layer: pairs (i, i + 8) = (a, a + 2)
