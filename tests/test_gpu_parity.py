@@ -1377,10 +1377,12 @@ def test_long_batch_averaging_uses_chunked_scan(pkg, avg):
 
 
 @pytest.mark.parametrize("avg", [("exp", 4), ("lin", 16), ("lin", 5000), ("exp", 2)])
-@pytest.mark.parametrize("nfft,nf", [(4096, 1500), (16384, 700), (8192, 513)])
+@pytest.mark.parametrize("nfft,nf", [(4096, 1500), (16384, 700), (8192, 513), (1024, 2500), (512, 17000), (2048, 1100), (1000, 1300)])
 def test_batch_averaging_with_workgroup_chunks(pkg, monkeypatch, avg, nfft, nf):
     """N >= 4096, > 128 frames: the chunks of the averager's chained scan are the frame ranges of the frame kernel's
-    workgroups, which form their chunk's aggregate themselves (float32 dot products; chain and re-scan in float64).  Rows,
+    workgroups, which form their chunk's aggregate themselves (float32 dot products; chain and re-scan in float64).
+    Below 4096 points and for chirp-z sizes, > 1024 frames: up to 256 equal ranges of the batch, aggregates by a pass of
+    the scan's own, the same chain.  Rows,
     hold traces and the averager state must follow the order-dependent recurrence of TraceAverager
     (utils/signal_processing.py:35-61) - against the float64 gold, against the three-pass scan with float64 aggregates
     (TDSA_AVG_OLD=1) to within what a float32 aggregate can move a row (1e-5 dB), and across a split batch."""

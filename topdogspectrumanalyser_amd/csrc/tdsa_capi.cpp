@@ -203,6 +203,34 @@ int launch_spectrum_profiled(tdsa_plan p, int in_c64, const SpecParams& sp, cons
   return TDSA_OK;
 }
 
+// Long averaged batches of the sizes whose frame kernel cannot form the scan's chunk aggregates itself (several frames per
+// workgroup slot below 4096 points; chirp-z plans): the chunks become up to 256 equal ranges of the batch, a pass of the
+// scan's own forms their float32 aggregates (avg_agg_local_kernel) and the two-level chain of the workgroup-chunk path
+// takes it from there.  With fixed chunks of 64 frames one thread per bin walked hundreds of chunks in order: 75 of the
+// 169 us of a 19 531-frame batch at N = 1024.  Short batches keep the 64-frame chunks.
+static int avg_use_ranges(tdsa_plan p, AvgParams& ap, int n_frames, hipStream_t s) {
+  if (p->avg_scan_old || n_frames <= 1024 || p->d_carry == nullptr) return TDSA_OK;
+  const int ranges = (n_frames + 63) / 64 < 256 ? (n_frames + 63) / 64 : 256;
+  if (size_t(ranges) > p->carry_chunks) return TDSA_OK;
+  const size_t row = size_t(ap.n);
+  if (!p->d_agg) HIPCHK(hipMalloc(&p->d_agg, 256 * row * sizeof(float)));
+  if (!p->d_agg_w) HIPCHK(hipMalloc(&p->d_agg_w, size_t(p->max_frames) * sizeof(float)));
+  if (!p->d_chunk_a) HIPCHK(hipMalloc(&p->d_chunk_a, size_t(kAvgMaxWgChunks + 64) * sizeof(double)));
+  if (!p->d_chunk_v) HIPCHK(hipMalloc(&p->d_chunk_v, size_t(kAvgMaxWgChunks + 64) * sizeof(float)));
+  ap.chunk_a = p->d_chunk_a;
+  ap.chunk_v = p->d_chunk_v;
+  ap.wg_chunks = ranges;
+  ap.wg_fold = 1;
+  ap.agg = p->d_agg;
+  ap.agg_w_local = p->d_agg_w;
+  const long long key[5] = {p->avg_count, ap.mode, ap.avg_n, n_frames, ranges};
+  if (std::memcmp(key, p->agg_w_key, sizeof(key)) != 0) {
+    HIPCHK(launch_avg_weights(ap, p->d_agg_w, p->d_chunk_a, p->d_chunk_v, s));
+    std::memcpy(p->agg_w_key, key, sizeof(key));
+  }
+  return TDSA_OK;
+}
+
 // Long-frame plans.  Modes (decided by the plan's averaging settings):
 //   * "lin" with avg_n >= frames seen so far + n_frames: Welch - the K segments of the call (and of earlier
 //     calls since the last reset) are averaged, out_db_dev receives ONE row, the dB of the running mean;
@@ -434,6 +462,7 @@ int process_chirp(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n
     ap.out_db = out_db_dev;
     ap.state_max = (m.hold_flags & TDSA_HOLD_MAX) ? p->d_hold_max : nullptr;
     ap.state_min = (m.hold_flags & TDSA_HOLD_MIN) ? p->d_hold_min : nullptr;
+    { const int rc = avg_use_ranges(p, ap, n_frames, s); if (rc != TDSA_OK) return rc; }
     HIPCHK(launch_avg_scan(ap, s, p->d_carry));
     if (m.avg_mode == TDSA_AVG_LIN) {
       const long long c = (long long)p->avg_count + n_frames;
@@ -969,6 +998,9 @@ static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size
       }
       sp.agg_w = p->d_agg_w;
       sp.agg_out = p->d_agg;
+    } else if (p->log2n < 12) {
+      const int rc = avg_use_ranges(p, ap, n_frames, p->stream);
+      if (rc != TDSA_OK) return rc;
     }
     sp.out_lin = p->d_lin;
     sp.hold_flags = 0;

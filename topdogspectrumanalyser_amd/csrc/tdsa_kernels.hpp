@@ -123,6 +123,10 @@ struct AvgParams {
   const float* agg;
   const double* chunk_a;  // [kAvgMaxWgChunks + 64] per workgroup range: product of its frames' a_f (1 for an empty one and past the end)
   const float* chunk_v;   // [kAvgMaxWgChunks + 64] 1: the range has frames (its aggregate row was written), else 0
+  // Sizes below 4096 (several frames per workgroup slot of the frame kernel: its workgroups' frames are not a range): the
+  // chunks are wg_chunks equal ranges of the batch and a pass of the scan's own forms their aggregates with these weights
+  // (agg_w_local[f], as launch_avg_weights makes them) into agg.  Null: the frame kernel has formed them.
+  const float* agg_w_local;
 };
 constexpr int kAvgMaxWgChunks = 1024;
 // carry: [chunks][n] doubles of scratch for the chunked scan (null: sequential kernel)

@@ -304,6 +304,40 @@ __global__ void __launch_bounds__(64 * MAXQ) avg_wg_chain_kernel(const AvgParams
   if (nu > 0 && c0 + 64 >= nc) p.state[k] = s;                   // the run that holds the last chunk leaves the new state
 }
 
+// Aggregates of equal ranges of the batch for the sizes whose frame kernel cannot form them (AvgParams::agg_w_local): the
+// same float32 dot product, in frame order, as the frame kernel's (tdsa_spectrum_kernel.hpp, AGG) - V bins per thread,
+// eight rows fetched ahead of the dependent chain.
+template <int V>
+__global__ void __launch_bounds__(64) avg_agg_local_kernel(const AvgParams p, float* agg) {
+  const int c = blockIdx.y;
+  int f0, f1;
+  spectrum_unit_range(unsigned(c), unsigned(p.n_frames), unsigned(p.wg_chunks), f0, f1);
+  const int k = (blockIdx.x * 64 + threadIdx.x) * V;
+  if (k >= p.n || f1 <= f0) return;
+  float s[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) s[v] = 0.f;
+  constexpr int U = 8;
+  for (int fb = f0; fb < f1; fb += U) {
+    float x[U][V], w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int f = fb + u < f1 ? fb + u : f1 - 1;          // (past the end: the last row again, weight 0 - no branch)
+      avg_load_row<V>(p.lin + (size_t)f * p.n + k, x[u]);
+      w[u] = fb + u < f1 ? p.agg_w_local[f] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (fb + u < f1) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) s[v] = fmaf(w[u], x[u][v], s[v]);
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < V; ++v) agg[(size_t)c * p.n + k + v] = s[v];
+}
+
 template <int V>
 __global__ void __launch_bounds__(64) avg_chunk_final_kernel(const AvgParams p, const double* carry) {
   const int k = (blockIdx.x * 64 + threadIdx.x) * V, c = blockIdx.y;
@@ -390,6 +424,12 @@ hipError_t launch_avg_scan(const AvgParams& p, hipStream_t s, double* carry) {
     const int chunks = (p.wg_chunks + fold - 1) / fold;
     const int runs = (chunks + 63) / 64;
     if (runs > 4 || fold > 4) return hipErrorInvalidValue;        // (the host only takes this path for up to 256 chunks)
+    if (p.agg_w_local != nullptr) {
+      if (fold != 1) return hipErrorInvalidValue;
+      float* agg = const_cast<float*>(p.agg);
+      if (vec) hipLaunchKernelGGL(avg_agg_local_kernel<4>, dim3((p.n / 4 + 63) / 64, chunks), dim3(64), 0, s, p, agg);
+      else hipLaunchKernelGGL(avg_agg_local_kernel<1>, dim3((p.n + 63) / 64, chunks), dim3(64), 0, s, p, agg);
+    }
     hipLaunchKernelGGL(avg_wg_chain_kernel<4>, dim3((p.n + 63) / 64), dim3(64 * runs), 0, s, p, carry);
     if (vec) hipLaunchKernelGGL(avg_chunk_final_kernel<4>, dim3((p.n / 4 + 63) / 64, chunks), dim3(64), 0, s, p, carry);
     else hipLaunchKernelGGL(avg_chunk_final_kernel<1>, dim3((p.n + 63) / 64, chunks), dim3(64), 0, s, p, carry);
