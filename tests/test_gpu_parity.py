@@ -1377,7 +1377,7 @@ def test_long_batch_averaging_uses_chunked_scan(pkg, avg):
 
 
 @pytest.mark.parametrize("avg", [("exp", 4), ("lin", 16), ("lin", 5000), ("exp", 2)])
-@pytest.mark.parametrize("nfft,nf", [(4096, 1500), (16384, 700), (8192, 513), (1024, 2500), (512, 17000), (2048, 1100), (1000, 1300)])
+@pytest.mark.parametrize("nfft,nf", [(4096, 1500), (16384, 700), (8192, 513), (1024, 2500), (512, 17000), (2048, 1100), (1000, 1300), (256, 45000)])
 def test_batch_averaging_with_workgroup_chunks(pkg, monkeypatch, avg, nfft, nf):
     """N >= 4096, > 128 frames: the chunks of the averager's chained scan are the frame ranges of the frame kernel's
     workgroups, which form their chunk's aggregate themselves (float32 dot products; chain and re-scan in float64).

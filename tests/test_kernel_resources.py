@@ -63,10 +63,10 @@ def _kernel(reports, log2n, in_c64, hold, acc=False):
 
 @pytest.mark.parametrize("log2n", SIZES)
 @pytest.mark.parametrize("in_c64", [False, True])
-@pytest.mark.parametrize("hold", [0, 1, 2, 3])
+@pytest.mark.parametrize("hold", [0, 1, 2, 3, 4])
 def test_every_instantiation_is_free_of_scratch(reports, log2n, in_c64, hold):
     """All nine sizes x both input formats x hold off / max / min / max + min (an ordinary GUI state of the reference,
-    core/display_data_processor.py:371-395): no scratch, no spilled VGPR, and the register count of the occupancy the
+    core/display_data_processor.py:371-395) / 4 = the averager's chunk aggregates (utils/signal_processing.py:35-61): no scratch, no spilled VGPR, and the register count of the occupancy the
     instantiation is launched for (round-3 verdict: five max + min instantiations carried 8 - 84 bytes of scratch per
     lane, and a spilled value is reloaded behind the row stores' vmcnt)."""
     k = _kernel(reports, log2n, in_c64, hold)

@@ -1,0 +1,10 @@
+#!/bin/bash
+mkdir -p gpurun_out/r4am
+O=gpurun_out/r4am/avg.txt
+for n in 256 512 1024 2048 4096; do
+  f=$((20000000/n))
+  python tools/avgbench.py --nfft $n --hop $n --frames $f --avg exp 4 --steps 400 --warmup 50 >> $O 2>&1
+  python tools/avgbench.py --nfft $n --hop $n --frames $f --avg lin 16 --steps 400 --warmup 50 >> $O 2>&1
+done
+cat $O
+python -m pytest tests -m gpu -q -k "averag" 2>&1 | tail -3

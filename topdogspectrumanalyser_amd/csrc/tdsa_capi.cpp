@@ -213,7 +213,10 @@ static int avg_use_ranges(tdsa_plan p, AvgParams& ap, int n_frames, hipStream_t 
   const int ranges = (n_frames + 63) / 64 < 256 ? (n_frames + 63) / 64 : 256;
   if (size_t(ranges) > p->carry_chunks) return TDSA_OK;
   const size_t row = size_t(ap.n);
-  if (!p->d_agg) HIPCHK(hipMalloc(&p->d_agg, 256 * row * sizeof(float)));
+  if (!p->d_agg) {      // (a native plan may also take the workgroup-chunk path on another call: one row per workgroup of its grid)
+    const size_t grid_rows = (p->chirp || p->big) ? 0 : size_t(spectrum_geometry(p->log2n, p->max_frames, p->num_cu).grid);
+    HIPCHK(hipMalloc(&p->d_agg, (grid_rows > 256 ? grid_rows : size_t(256)) * row * sizeof(float)));
+  }
   if (!p->d_agg_w) HIPCHK(hipMalloc(&p->d_agg_w, size_t(p->max_frames) * sizeof(float)));
   if (!p->d_chunk_a) HIPCHK(hipMalloc(&p->d_chunk_a, size_t(kAvgMaxWgChunks + 64) * sizeof(double)));
   if (!p->d_chunk_v) HIPCHK(hipMalloc(&p->d_chunk_v, size_t(kAvgMaxWgChunks + 64) * sizeof(float)));
@@ -950,13 +953,15 @@ static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size
                                          (overlap && p->n_overlap >= 3) ? (p->num_cu * p->overlap_share + 99) / 100 : p->num_cu);
   if (averaging) {
     if (!p->d_lin) HIPCHK(hipMalloc(&p->d_lin, size_t(p->max_frames) * p->nfft * sizeof(float)));
-    // Long batches run as a chained scan over chunks of frames (tdsa_trace.hip).  Sizes with one frame per workgroup slot
-    // (N >= 4096): the chunks ARE the frame ranges of the frame kernel's workgroups, which form their chunk's aggregate
-    // themselves while the rows pass through their registers - the scan's first pass over the rows disappears.
-    // Up to 256 chunks: grids of more workgroups (N = 8192: 512, N = 4096: 1024) fold 2 / 4 consecutive ranges into one.
+    // Long batches run as a chained scan over chunks of frames (tdsa_trace.hip).  The chunks ARE the frame ranges of the
+    // frame kernel's workgroups, which form their chunk's aggregate themselves while the rows pass through their
+    // registers - the scan's first pass over the rows disappears (below 4096 points a workgroup's slots take consecutive
+    // runs of its range and add their partial sums through LDS).
+    // Up to 256 chunks: grids of more workgroups (N = 8192: 512, N <= 4096: 1024) fold 2 / 4 consecutive ranges into one.
     const int wg_fold = (g.grid + 255) / 256;
-    const bool wg_chunks = p->log2n >= 12 && n_frames > 128 && g.grid <= kAvgMaxWgChunks &&
-                           ((n_frames + g.grid - 1) / g.grid) * wg_fold <= 64 && !p->avg_scan_old;
+    const int units = (n_frames + g.fpw - 1) / g.fpw;
+    const bool wg_chunks = n_frames > 128 && g.grid <= kAvgMaxWgChunks &&
+                           ((units + g.grid - 1) / g.grid) * g.fpw * wg_fold <= 160 && !p->avg_scan_old;
     const size_t agg_rows = size_t(spectrum_geometry(p->log2n, p->max_frames, p->num_cu).grid);
     const size_t need_chunks = wg_chunks ? (agg_rows < 256 ? agg_rows : size_t(256))
                                          : (p->max_frames > 128 ? size_t(avg_scan_chunks(p->max_frames)) : 0);
@@ -980,7 +985,7 @@ static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size
     ap.state_max = (m.hold_flags & TDSA_HOLD_MAX) ? p->d_hold_max : nullptr;
     ap.state_min = (m.hold_flags & TDSA_HOLD_MIN) ? p->d_hold_min : nullptr;
     if (wg_chunks) {
-      if (!p->d_agg) HIPCHK(hipMalloc(&p->d_agg, agg_rows * p->nfft * sizeof(float)));
+      if (!p->d_agg) HIPCHK(hipMalloc(&p->d_agg, (agg_rows > 256 ? agg_rows : size_t(256)) * p->nfft * sizeof(float)));
       if (!p->d_agg_w) HIPCHK(hipMalloc(&p->d_agg_w, size_t(p->max_frames) * sizeof(float)));
       if (!p->d_chunk_a) HIPCHK(hipMalloc(&p->d_chunk_a, size_t(kAvgMaxWgChunks + 64) * sizeof(double)));
       if (!p->d_chunk_v) HIPCHK(hipMalloc(&p->d_chunk_v, size_t(kAvgMaxWgChunks + 64) * sizeof(float)));
@@ -988,6 +993,7 @@ static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size
       ap.chunk_v = p->d_chunk_v;
       ap.wg_chunks = g.grid;
       ap.wg_fold = wg_fold;
+      ap.wg_fpw = g.fpw;
       ap.agg = p->d_agg;
       // the weights depend on where the averager stands and on the chunking only: in steady state (exp mode, or lin
       // with its count at the cap) consecutive calls of one shape re-use them
@@ -998,7 +1004,7 @@ static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size
       }
       sp.agg_w = p->d_agg_w;
       sp.agg_out = p->d_agg;
-    } else if (p->log2n < 12) {
+    } else {
       const int rc = avg_use_ranges(p, ap, n_frames, p->stream);
       if (rc != TDSA_OK) return rc;
     }

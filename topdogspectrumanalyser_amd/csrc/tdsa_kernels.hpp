@@ -120,6 +120,7 @@ struct AvgParams {
   // kernel has already formed (SpecParams::agg_out): the scan then needs no pass of its own for them.  0: chunks of 64.
   int wg_chunks;
   int wg_fold;            // consecutive workgroup ranges per chunk of the scan (1 .. 4): ceil(wg_chunks / wg_fold) <= 256 chunks
+  int wg_fpw;             // frames per workgroup unit of that grid (Cfg::FPW; 0 or 1: one): range b = frames [u0 fpw, u1 fpw)
   const float* agg;
   const double* chunk_a;  // [kAvgMaxWgChunks + 64] per workgroup range: product of its frames' a_f (1 for an empty one and past the end)
   const float* chunk_v;   // [kAvgMaxWgChunks + 64] 1: the range has frames (its aggregate row was written), else 0
@@ -129,6 +130,14 @@ struct AvgParams {
   const float* agg_w_local;
 };
 constexpr int kAvgMaxWgChunks = 1024;
+// frames [f0, f1) of workgroup range b (wg_chunks > 0)
+__host__ __device__ inline void avg_wg_range(const AvgParams& p, int b, int& f0, int& f1) {
+  const int fpw = p.wg_fpw > 1 ? p.wg_fpw : 1;
+  int u0, u1;
+  spectrum_unit_range(unsigned(b), unsigned((p.n_frames + fpw - 1) / fpw), unsigned(p.wg_chunks), u0, u1);
+  f0 = u0 * fpw < p.n_frames ? u0 * fpw : p.n_frames;
+  f1 = u1 * fpw < p.n_frames ? u1 * fpw : p.n_frames;
+}
 // carry: [chunks][n] doubles of scratch for the chunked scan (null: sequential kernel)
 hipError_t launch_avg_scan(const AvgParams& p, hipStream_t s, double* carry);
 int avg_scan_chunks(int n_frames);

@@ -363,13 +363,19 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     u1 = k1 * p.group + s1;
   }
 
+  // frame of this slot in workgroup-unit `unit`: every FPW-th frame of the workgroup's range - or, where the averager's
+  // chunk aggregate is formed (HOLD == 4), the slot's own run of consecutive frames
+  auto frame_of = [&](int unit) -> int {
+    if constexpr (HOLD == 4 && FPW > 1) return u0 * FPW + slot * (u1 - u0) + (unit - u0);
+    else return unit * FPW + slot;
+  };
   constexpr unsigned SB = IN_C64 ? 8u : 2u;                      // bytes per sample
   // ---- frame-invariant per-thread state ---------------------------------------------------------
   const rsrc_t win_rsrc = make_rsrc(C::WIN_LDS ? p.window : p.window_perm, N * 4u);
   float* win_lds = reinterpret_cast<float*>(smem + C::LDS_BYTES - C::WIN_BYTES);
   // TWF_LDS: the last pass's per-thread twiddles W_N^(t (8a + h)), W_N^(2 t j) are re-read from LDS every frame instead
   // of living in 14 VGPRs (see Cfg::TWF_BYTES)
-  constexpr bool TWF_LDS = C::TWF_BYTES != 0 && HOLD >= 3 && !IN_C64 && !ACC;
+  constexpr bool TWF_LDS = C::TWF_BYTES != 0 && HOLD == 3 && !IN_C64 && !ACC;
   c32* twf_tab = reinterpret_cast<c32*>(smem + C::LDS_BYTES - C::WIN_BYTES - C::TWF_BYTES);    // [3][SG] lo, then [4][TPF] hi
   if constexpr (TWF_LDS) {
     if (slot == 0) {
@@ -396,7 +402,10 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   // only carries what the chunk's ~10 frames ADD to the state - its rounding (<= 2^-24 per term) enters the float64
   // chain scaled by L / s <= 1 and decays with the chain's multipliers, while the chunks are re-scanned in float64.
   constexpr bool AGG = HOLD == 4;
-  static_assert(!AGG || (FPW == 1 && !ACC), "chunk aggregates need one frame per workgroup slot");
+  // Several frames per workgroup (N <= 2048): slot s takes the s-th run of consecutive frames of the workgroup's range
+  // (frame_of below) instead of every FPW-th one, the weights are those of the workgroup's whole range, and the slots'
+  // partial sums are added through LDS at the end - one aggregate row per workgroup as at the larger sizes.
+  static_assert(!AGG || !ACC, "chunk aggregates: frame instantiations only");
   float agg[AGG ? 16 : 1];
   static_for<0, (AGG ? 16 : 1)>([&](auto ic) { agg[decltype(ic)::value] = 0.f; });
   float hmax[(HOLD & 1) ? 16 : 1], hmin[(HOLD & 2) ? 16 : 1];
@@ -493,7 +502,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       }
     }
   };
-  if (u0 < u1) load_frame_raw(u0 * FPW + slot);
+  if (u0 < u1) load_frame_raw(frame_of(u0));
   // ACC (row pass of the long-frame path): no window, no raw bytes, no hold traces - the registers they
   // would take hold the NEXT frame's complex64 samples instead, fetched while this frame is transformed
   c32 vnext[ACC ? 16 : 1];
@@ -541,7 +550,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   }
 #endif
   for (int unit = u0; unit < u1; ++unit) {
-    const int frame = unit * FPW + slot;
+    const int frame = frame_of(unit);
     const bool active = frame < p.n_frames;
     TDSA_STAMP(0);
 
@@ -801,7 +810,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     }
     TDSA_STAMP(3);
     // raw registers are free again: start the next frame's HBM read now, it lands during the FFT
-    if ((TDSA_ABLATE & 2048) == 0 && unit + 1 < u1) load_frame_raw((unit + 1) * FPW + slot);
+    if ((TDSA_ABLATE & 2048) == 0 && unit + 1 < u1) load_frame_raw(frame_of(unit + 1));
     TDSA_PRIO(2);
 
     // ---- pass 1: per lane CPT radix-R1 DFTs; INL: that is the whole pass, else (even / odd input rows per
@@ -1001,7 +1010,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
         if constexpr (!C::WIN_LDS && !AGG) load_window();
         float* orow = p.out_lin + out_elem_off(frame) + t + 8 * h * SG;
         if constexpr (AGG) {
-          const float w_f = in_vgpr(p.agg_w[frame]);          // frame is workgroup-uniform: a scalar load
+          const float w_f = in_vgpr(p.agg_w[frame]);          // FPW == 1: frame is workgroup-uniform, a scalar load
           static_for<0, 16>([&](auto ic) {
             constexpr int q = decltype(ic)::value;
             constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
@@ -1134,7 +1143,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   //  pushed the kernel into 39 scratch spills and cost more than the ~6 us tail it removed.  Fetching the
   //  current trace into the window registers during the last frame, to save the round trip below: 16 bytes
   //  of scratch inside the frame loop, 75.3 instead of 73.9 us per C3 launch.)
-  if constexpr (AGG) {
+  if constexpr (AGG && FPW == 1) {
     if (u1 > u0) {                          // (a workgroup without frames leaves no row: the chain skips empty chunks)
       int tid_a = threadIdx.x;
       asm volatile("" : "+v"(tid_a));
@@ -1145,6 +1154,24 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
         constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
         arow[kcs * SG] = agg[q];
       });
+    }
+  } else if constexpr (AGG) {
+    // the slots' partial sums (weights of the workgroup's whole range: they simply add) meet in LDS, in slot order
+    float* lagg = reinterpret_cast<float*>(smem);                 // [FPW][N], display order
+    __syncthreads();                                              // every slot is done with the frame buffers
+    static_for<0, 16>([&](auto ic) {
+      constexpr int q = decltype(ic)::value;
+      constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
+      lagg[slot * N + t + 8 * h * SG + kcs * SG] = agg[q];
+    });
+    __syncthreads();
+    if (u1 > u0) {
+      for (int i = tid; i < N; i += C::WGT) {
+        float sum = lagg[i];
+#pragma unroll
+        for (int sl = 1; sl < FPW; ++sl) sum += lagg[sl * N + i];
+        p.agg_out[(long long)blockIdx.x * N + i] = sum;
+      }
     }
   }
   if constexpr ((HOLD & 3) != 0) {
@@ -1275,10 +1302,8 @@ inline hipError_t launch_one(const SpecParams& p, const LaunchGeom& g, hipStream
 template <int LOG2N>
 hipError_t launch_n(int in_c64, const SpecParams& p, const LaunchGeom& g, hipStream_t s) {
   const int hold = p.out_lin == nullptr ? (p.hold_flags & 3) : 0;
-  if constexpr (Cfg<LOG2N>::FPW == 1) {
-    if (p.out_lin != nullptr && p.agg_out != nullptr)
-      return in_c64 ? launch_one<LOG2N, true, 4>(p, g, s) : launch_one<LOG2N, false, 4>(p, g, s);
-  }
+  if (p.out_lin != nullptr && p.agg_out != nullptr)
+    return in_c64 ? launch_one<LOG2N, true, 4>(p, g, s) : launch_one<LOG2N, false, 4>(p, g, s);
   if (in_c64) {
     switch (hold) {
       case 0: return launch_one<LOG2N, true, 0>(p, g, s);

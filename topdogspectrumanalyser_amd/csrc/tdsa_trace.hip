@@ -97,8 +97,8 @@ __device__ __forceinline__ void avg_chunk_bounds(const AvgParams& p, int c, int&
     const int r = p.wg_fold > 1 ? p.wg_fold : 1;
     const int first = c * r, last = min(first + r, p.wg_chunks) - 1;
     int t;
-    spectrum_unit_range(unsigned(first), unsigned(p.n_frames), unsigned(p.wg_chunks), f0, t);
-    spectrum_unit_range(unsigned(last), unsigned(p.n_frames), unsigned(p.wg_chunks), t, f1);
+    avg_wg_range(p, first, f0, t);
+    avg_wg_range(p, last, t, f1);
     if (last < first) f1 = f0;
   } else {
     f0 = c * kAvgChunk;
@@ -311,7 +311,7 @@ template <int V>
 __global__ void __launch_bounds__(64) avg_agg_local_kernel(const AvgParams p, float* agg) {
   const int c = blockIdx.y;
   int f0, f1;
-  spectrum_unit_range(unsigned(c), unsigned(p.n_frames), unsigned(p.wg_chunks), f0, f1);
+  avg_wg_range(p, c, f0, f1);
   const int k = (blockIdx.x * 64 + threadIdx.x) * V;
   if (k >= p.n || f1 <= f0) return;
   float s[V];
@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(64) avg_chunk_final_kernel(const AvgParams p, 
     tare[v] = p.tare != nullptr ? p.tare[k + v] : 0.f;
     hmax[v] = -INFINITY; hmin[v] = INFINITY;
   }
-  constexpr int U = 4;
+  constexpr int U = V == 1 ? 8 : 4;      // rows fetched ahead of the dependent chain
   for (int fb = f0; fb < f1; fb += U) {
     float x[U][V];
 #pragma unroll
@@ -396,7 +396,7 @@ __global__ void __launch_bounds__(64) avg_weights_kernel(const AvgParams p, floa
   float valid = 0.f;
   if (c < p.wg_chunks) {
     int f0, f1;
-    spectrum_unit_range(unsigned(c), unsigned(p.n_frames), unsigned(p.wg_chunks), f0, f1);     // ONE workgroup's range
+    avg_wg_range(p, c, f0, f1);     // ONE workgroup's range
     for (int f = f1 - 1; f >= f0; --f) {
       double a, bs; bool bf;
       avg_coeff(p, f, a, bs, bf);
@@ -431,7 +431,10 @@ hipError_t launch_avg_scan(const AvgParams& p, hipStream_t s, double* carry) {
       else hipLaunchKernelGGL(avg_agg_local_kernel<1>, dim3((p.n + 63) / 64, chunks), dim3(64), 0, s, p, agg);
     }
     hipLaunchKernelGGL(avg_wg_chain_kernel<4>, dim3((p.n + 63) / 64), dim3(64 * runs), 0, s, p, carry);
-    if (vec) hipLaunchKernelGGL(avg_chunk_final_kernel<4>, dim3((p.n / 4 + 63) / 64, chunks), dim3(64), 0, s, p, carry);
+    // short rows: four bins per thread leave the re-scan with too few waves (N = 512: 512 of them walking ~150 frames each,
+    // 73 us for what N = 1024 does in 41) - one bin per thread there
+    const bool wide = vec && size_t((p.n / 4 + 63) / 64) * size_t(chunks) >= 2048;     // (N = 2048 / 4096 either way: 78 / 81 against 80 / 81 us)
+    if (wide) hipLaunchKernelGGL(avg_chunk_final_kernel<4>, dim3((p.n / 4 + 63) / 64, chunks), dim3(64), 0, s, p, carry);
     else hipLaunchKernelGGL(avg_chunk_final_kernel<1>, dim3((p.n + 63) / 64, chunks), dim3(64), 0, s, p, carry);
     return hipGetLastError();
   }
