@@ -143,7 +143,9 @@ int tdsa_process_c64(tdsa_plan p, const float* iq_host, size_t n_samples, int ho
 
 /* Device-resident variant: iq_dev / out_db_dev are device pointers on the plan's device; the work
  * is enqueued on the plan's stream and the call returns immediately (tdsa_synchronize to wait).
- * This is what bench.py times (inputs resident in HBM).  out_db_dev may be NULL. */
+ * This is what bench.py times (inputs resident in HBM).  out_db_dev may be NULL: the plan's state (hold traces,
+ * averager) is still updated; with averaging on and both holds off the call then costs the transforms and a short
+ * chain only (the averaged spectrum of a capture - Welch at a native size - without its rows: tdsa_get_avg). */
 int tdsa_process_dev(tdsa_plan p, int in_format, const void* iq_dev, size_t n_samples, int hop,
                      int n_frames, float* out_db_dev);
 

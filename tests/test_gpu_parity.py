@@ -1427,6 +1427,51 @@ def test_batch_averaging_with_workgroup_chunks(pkg, monkeypatch, avg, nfft, nf):
     assert np.max(np.abs(buf - buf_o)) <= 3e-7 * buf_o.max()
 
 
+@pytest.mark.parametrize("avg", [("lin", 100000), ("exp", 4), ("lin", 16)])
+@pytest.mark.parametrize("nfft,nf", [(1024, 900), (4096, 600), (16384, 400), (2048, 100)])
+def test_averaging_for_the_state_alone(pkg, avg, nfft, nf):
+    """A batch whose dB rows and hold traces are not wanted (out = NULL, hold off) - the averaged spectrum of a capture, e.g.
+    Welch at a native size (utils/signal_processing.py:35-61 with lin n >= frames): the frame kernel forms the chunk
+    aggregates without writing the linear rows and the scan ends with its chain.  The state must be the one the full path
+    leaves, bit for bit, and continue correctly into a following call that does want rows."""
+    import ctypes as C
+    nat = pkg._native
+    hop = nfft // 2
+    ns = hop * (nf - 1) + nfft
+    iq = so.synth_iq_int8(ns, nfft, seed=83)
+    iq2 = so.synth_iq_int8(ns, nfft, seed=84)
+
+    def configured():
+        e = pkg.SpectrumEngine(nfft, max_frames=nf)
+        e.set_window(so.hackrf_window(nfft))
+        e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=1.0, avg=avg)
+        return e
+    with configured() as e:
+        e.process(iq, hop=hop)
+        want, want_cnt = e.averaged()
+        rows2 = e.process(iq2, hop=hop)
+        want2, _ = e.averaged()
+    d_in = C.c_void_p()
+    nat.check(nat.lib.tdsa_dev_alloc(0, iq.nbytes, C.byref(d_in)))
+    nat.check(nat.lib.tdsa_memcpy_h2d(0, d_in, iq.ctypes.data_as(C.c_void_p), iq.nbytes))
+    try:
+        with configured() as e:
+            e.process_device(nat.IN_I8, d_in.value, ns, hop, nf, None)
+            got, got_cnt = e.averaged()
+            assert got_cnt == want_cnt and np.array_equal(got, want)
+            assert np.array_equal(e.process(iq2, hop=hop), rows2)
+            assert np.array_equal(e.averaged()[0], want2)
+    finally:
+        nat.check(nat.lib.tdsa_dev_free(0, d_in))
+    gold_src = so.HackrfBranchOracle(nfft, 20e6, precision="gold")
+    gold_src.averager.set_mode(*avg)
+    x = so.unpack_iq_int8(iq)
+    for k in range(nf):
+        gold_src.power_levels(so.frame(x, nfft, hop, k))
+    gold_state = np.asarray(gold_src.averager.buffer, dtype=np.float64)
+    assert np.max(np.abs(got - gold_state)) <= 2e-5 * gold_state.max()
+
+
 # ------------------------------------------------------------------------------------------------
 # real-input (audio) path: two real channels in one complex FFT
 # ------------------------------------------------------------------------------------------------

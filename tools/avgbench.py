@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--hop", type=int, default=8192)
     ap.add_argument("--frames", type=int, default=2440)
     ap.add_argument("--hold", type=int, default=0)
+    ap.add_argument("--state-only", action="store_true", help="no dB rows wanted (out = NULL): only the averager's state")
     ap.add_argument("--ring", type=int, default=4, help="distinct input / output buffers cycled through")
     a = ap.parse_args()
     n, hop, F = a.nfft, a.hop, a.frames
@@ -43,7 +44,7 @@ def main():
 
     def step(i):
         r = i % a.ring
-        e.process_device(nat.IN_I8, di.value + r * iq.nbytes, ns, hop, F, do.value + r * F * n * 4)
+        e.process_device(nat.IN_I8, di.value + r * iq.nbytes, ns, hop, F, None if a.state_only else do.value + r * F * n * 4)
     for i in range(a.warmup):
         step(i)
     e.synchronize()
@@ -53,7 +54,7 @@ def main():
     ms = e.timer_end()
     us = ms / a.steps * 1e3
     algo = F * (2 * hop + 4 * n)
-    print(f"avg={avg} N={n} hop={hop} F={F} hold={a.hold} old={os.environ.get('TDSA_AVG_OLD', '0')}  step {us:.1f} us  "
+    print(f"avg={avg} N={n} hop={hop} F={F} hold={a.hold} state_only={int(a.state_only)} old={os.environ.get('TDSA_AVG_OLD', '0')}  step {us:.1f} us  "
           f"{algo / us / 1e6:.3f} TB/s algorithmic ({algo / us / 1e6 / 8 * 100:.1f} % of 8 TB/s)")
 
 

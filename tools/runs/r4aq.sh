@@ -1,0 +1,2 @@
+#!/bin/bash
+python -m pytest tests -m gpu -x -q 2>&1 | tail -3

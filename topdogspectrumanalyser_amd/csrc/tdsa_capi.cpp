@@ -1004,6 +1004,9 @@ static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size
       }
       sp.agg_w = p->d_agg_w;
       sp.agg_out = p->d_agg;
+      // only the averager's state is wanted (no dB rows, no hold: the averaged spectrum of a capture - Welch at a native
+      // size): the linear rows are neither written nor re-scanned
+      if (out_db_dev == nullptr && ap.state_max == nullptr && ap.state_min == nullptr) { sp.agg_only = 1; ap.state_only = 1; }
     } else {
       const int rc = avg_use_ranges(p, ap, n_frames, p->stream);
       if (rc != TDSA_OK) return rc;

@@ -77,6 +77,7 @@ struct SpecParams {
   // ---- chunk aggregates of the TraceAverager scan (out_lin launches of the sizes with one frame per workgroup slot) ----
   const float* agg_w;        // [F] per frame: weight of P_f in its workgroup's aggregate (avg_weights_kernel), or null
   float* agg_out;            // [grid][N] sum over the workgroup's frames of agg_w[f] P_f, display order; null: not wanted
+  int agg_only;              // 1: the linear rows themselves are not wanted (no dB rows, no hold: only the averager's state)
   unsigned seg_magic;        // ceil(2^32 / seg_frames); exact for f * seg_frames < 2^32 (checked by the host)
   unsigned seg_frames;
   long long seg_in_stride;   // bytes
@@ -128,6 +129,7 @@ struct AvgParams {
   // chunks are wg_chunks equal ranges of the batch and a pass of the scan's own forms their aggregates with these weights
   // (agg_w_local[f], as launch_avg_weights makes them) into agg.  Null: the frame kernel has formed them.
   const float* agg_w_local;
+  int state_only;         // 1: no dB rows and no hold traces wanted and the frame kernel wrote no linear rows: chain only
 };
 constexpr int kAvgMaxWgChunks = 1024;
 // frames [f0, f1) of workgroup range b (wg_chunks > 0)

@@ -1016,7 +1016,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
             constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
             const c32 X = v[bitrev(q, 4)];
             const float pw = (X.x * X.x + X.y * X.y) * ps_v;
-            orow[kcs * SG] = pw;
+            if (!p.agg_only) orow[kcs * SG] = pw;
             agg[q] = fmaf(w_f, pw, agg[q]);
           });
           if constexpr (!C::WIN_LDS) load_window();

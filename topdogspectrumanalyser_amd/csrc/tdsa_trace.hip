@@ -431,6 +431,7 @@ hipError_t launch_avg_scan(const AvgParams& p, hipStream_t s, double* carry) {
       else hipLaunchKernelGGL(avg_agg_local_kernel<1>, dim3((p.n + 63) / 64, chunks), dim3(64), 0, s, p, agg);
     }
     hipLaunchKernelGGL(avg_wg_chain_kernel<4>, dim3((p.n + 63) / 64), dim3(64 * runs), 0, s, p, carry);
+    if (p.state_only) return hipGetLastError();                   // the chain has left the new state: nothing else is wanted
     // short rows: four bins per thread leave the re-scan with too few waves (N = 512: 512 of them walking ~150 frames each,
     // 73 us for what N = 1024 does in 41) - one bin per thread there
     const bool wide = vec && size_t((p.n / 4 + 63) / 64) * size_t(chunks) >= 2048;     // (N = 2048 / 4096 either way: 78 / 81 against 80 / 81 us)
