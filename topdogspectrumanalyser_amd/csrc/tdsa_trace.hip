@@ -534,10 +534,11 @@ hipError_t launch_frame_sums(const void* in, int in_c64, unsigned xor_mask, long
 
 // dc_f = (1 - alpha) dc_(f-1) + alpha mean_f  (hackrf_samples.py:361-364) over the frames of a batch.  The recurrence is
 // linear with a constant multiplier, so one workgroup scans it in three steps: every thread scans its own run of
-// consecutive frames from a zero state, thread 0 chains the 256 run results, every thread re-scans its run from its
-// true carry-in and writes the per-frame subtract values.  (The first version walked all frames on one thread with a
-// dependent global load per frame: 470 us for the 2440 frames of a C3 batch, six times the frame kernel.)  The scan
-// runs in float64 on the float32 frame means; the state handed from call to call stays float32 like the reference's.
+// consecutive frames from a zero state, the 256 runs' (multiplier, result) pairs are scanned in LDS (eight doubling steps),
+// every thread re-scans its run from its true carry-in and writes the per-frame subtract values.  (The first version
+// walked all frames on one thread with a dependent global load per frame: 470 us for the 2440 frames of a C3 batch; the
+// second chained the 256 runs on thread 0 and fetched one frame sum per step: 15 us.)  The scan runs in float64 on the
+// float32 frame means; the state handed from call to call stays float32 like the reference's.
 __global__ void __launch_bounds__(256) dc_track_kernel(const float2* sums, int n, int n_frames, float alpha, float in_off,
                                                         float in_scale, float2* dc_state, float2* dc_sub) {
   __shared__ double run_re[256], run_im[256], run_a[256];
@@ -547,39 +548,62 @@ __global__ void __launch_bounds__(256) dc_track_kernel(const float2* sums, int n
   const int f1 = f0 + per < n_frames ? f0 + per : n_frames;
   const double a = double(1.0f - alpha), b = double(alpha);
   const float inv_n = 1.0f / float(n);
-  auto mean_of = [&](int f, double& mr, double& mi) {
-    const float2 q = sums[f];
+  auto mean_of = [&](const float2 q, double& mr, double& mi) {
     mr = double((q.x * inv_n - in_off) * in_scale);
     mi = double((q.y * inv_n - in_off) * in_scale);
   };
+  constexpr int U = 8;                       // frame sums fetched ahead of the dependent chain
   double sr = 0.0, si = 0.0, A = 1.0;
-  for (int f = f0; f < f1; ++f) {
-    double mr, mi;
-    mean_of(f, mr, mi);
-    sr = a * sr + b * mr;
-    si = a * si + b * mi;
-    A *= a;
+  for (int fb = f0; fb < f1; fb += U) {
+    float2 q[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) q[u] = sums[fb + u < f1 ? fb + u : f1 - 1];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (fb + u < f1) {
+        double mr, mi;
+        mean_of(q[u], mr, mi);
+        sr = a * sr + b * mr;
+        si = a * si + b * mi;
+        A *= a;
+      }
+    }
   }
+  // inclusive scan of the runs: (A, L) o (A', L') = (A' A, L' + A' L), earlier run on the left
   run_re[tid] = sr; run_im[tid] = si; run_a[tid] = A;
   __syncthreads();
-  if (tid == 0) {
-    double cr = double(dc_state->x), ci = double(dc_state->y);      // units of x
-    for (int t = 0; t < 256; ++t) {
-      const double lr = run_re[t], li = run_im[t], At = run_a[t];
-      run_re[t] = cr; run_im[t] = ci;                                // carry-in of run t
-      cr = lr + At * cr;
-      ci = li + At * ci;
+  for (int d = 1; d < 256; d <<= 1) {
+    double pr = 0.0, pi = 0.0, pa = 1.0;
+    if (tid >= d) { pr = run_re[tid - d]; pi = run_im[tid - d]; pa = run_a[tid - d]; }
+    __syncthreads();
+    if (tid >= d) {
+      run_re[tid] = sr = sr + A * pr;
+      run_im[tid] = si = si + A * pi;
+      run_a[tid] = A = A * pa;
     }
-    *dc_state = float2{float(cr), float(ci)};
+    __syncthreads();
   }
-  __syncthreads();
-  sr = run_re[tid]; si = run_im[tid];
-  for (int f = f0; f < f1; ++f) {
-    double mr, mi;
-    mean_of(f, mr, mi);
-    sr = a * sr + b * mr;
-    si = a * si + b * mi;
-    dc_sub[f] = float2{float(sr) / in_scale, float(si) / in_scale};      // residual on top of in_off, raw units
+  const double c0r = double(dc_state->x), c0i = double(dc_state->y);      // units of x
+  // carry-in of run tid: runs 0 .. tid - 1 applied to the state the call started from
+  double cr = c0r, ci = c0i;
+  if (tid > 0) { cr = run_re[tid - 1] + run_a[tid - 1] * c0r; ci = run_im[tid - 1] + run_a[tid - 1] * c0i; }
+  __syncthreads();                                                          // every thread has read the state
+  if (tid == 255) *dc_state = float2{float(sr + A * c0r), float(si + A * c0i)};
+  sr = cr; si = ci;
+  for (int fb = f0; fb < f1; fb += U) {
+    float2 q[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) q[u] = sums[fb + u < f1 ? fb + u : f1 - 1];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (fb + u < f1) {
+        double mr, mi;
+        mean_of(q[u], mr, mi);
+        sr = a * sr + b * mr;
+        si = a * si + b * mi;
+        dc_sub[fb + u] = float2{float(sr) / in_scale, float(si) / in_scale};      // residual on top of in_off, raw units
+      }
+    }
   }
 }
 
