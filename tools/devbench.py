@@ -27,11 +27,16 @@ def main():
     ap.add_argument("--mode", default="mag")
     ap.add_argument("--batch", type=int, default=1, help="captures per call (tdsa_process_dev_batch), distinct buffers")
     ap.add_argument("--streams", type=int, default=1)
+    ap.add_argument("--fmt", default="i8", choices=["i8", "c64"])
     a = ap.parse_args()
     n, hop, F = a.nfft, (a.hop or a.nfft // 2), a.frames
     ns = hop * (F - 1) + n
     rng = np.random.default_rng(0)
     iq = rng.integers(-100, 100, size=2 * ns, dtype=np.int8)
+    if a.fmt == "c64":
+        iq = (iq.astype(np.float32) / 128.0)
+    fmt = nat.IN_I8 if a.fmt == "i8" else nat.IN_C64
+    sb = 2 if a.fmt == "i8" else 8
     dev_in, dev_out = C.c_void_p(), C.c_void_p()
     B = max(1, a.batch)
     nat.check(nat.lib.tdsa_dev_alloc(0, iq.nbytes * B, C.byref(dev_in)))
@@ -47,9 +52,9 @@ def main():
 
     def call():
         if B == 1:
-            e.process_device(nat.IN_I8, dev_in.value, ns, hop, F, out_ptr)
+            e.process_device(fmt, dev_in.value, ns, hop, F, out_ptr)
         else:
-            e.process_device_batch(nat.IN_I8, dev_in.value, iq.nbytes, B, ns, hop, F, out_ptr, F * n)
+            e.process_device_batch(fmt, dev_in.value, iq.nbytes, B, ns, hop, F, out_ptr, F * n)
     for _ in range(max(1, a.warmup // B)):
         call()
     e.synchronize()
@@ -67,9 +72,9 @@ def main():
     t1 = time.perf_counter()
     per = ms / (calls * B)
     fps = F / (per * 1e-3)
-    bytes_per_frame = 2 * hop + 4 * n
+    bytes_per_frame = sb * hop + 4 * n
     inf = e.info()
-    print(f"lib={os.path.basename(nat.LIB_PATH)} N={n} hop={hop} F={F} batch={B} streams={a.streams} hold={a.hold} grid={inf.grid}x{inf.block} lds={inf.lds_bytes} "
+    print(f"lib={os.path.basename(nat.LIB_PATH)} fmt={a.fmt} N={n} hop={hop} F={F} batch={B} streams={a.streams} hold={a.hold} grid={inf.grid}x{inf.block} lds={inf.lds_bytes} "
           f"step={per*1e3:.1f} us  {fps/1e6:.3f} Mframes/s  {fps*bytes_per_frame/1e12:.3f} TB/s algorithmic "
           f"({fps*bytes_per_frame/8e12*100:.1f}% of 8 TB/s)  host wall {((t1-t0)/(calls*B))*1e6:.1f} us/step")
 
