@@ -503,6 +503,7 @@ __global__ void __launch_bounds__(256) frame_sums_kernel(const void* in, unsigne
     struct __attribute__((packed, aligned(2))) U2 { unsigned x, y; };
     const U2* x = reinterpret_cast<const U2*>(fb);
     unsigned ui = 0, uq = 0;
+#pragma unroll 8
     for (int i = threadIdx.x; i < n / 4; i += 256) {
       const U2 q = x[i];
       const unsigned a = q.x ^ xor_mask, b = q.y ^ xor_mask;
