@@ -1539,6 +1539,31 @@ def test_audio_stereo_and_averaging(pkg, golden_dir):
     src.stop()
 
 
+@pytest.mark.parametrize("avg", [("exp", 4), ("lin", 5000)])
+@pytest.mark.parametrize("n,nf", [(1024, 1500), (2048, 300)])
+def test_audio_long_averaged_batch(pkg, avg, n, nf):
+    """Real-input path (audio_samples.py:121-131) over a long batch with the TraceAverager on (utils/signal_processing.py:35-61):
+    above 128 frames the averager runs as the chunked scan of the complex path (above 1024: equal ranges + two-level chain)
+    instead of one thread per bin walking every frame."""
+    rng = np.random.default_rng(5)
+    t = np.arange(n * nf)
+    sig = (0.4 * np.sin(2 * np.pi * 0.0317 * t) + 0.01 * rng.standard_normal(n * nf) + 0.02).astype(np.float32)
+    st = np.stack([sig, 0.5 * sig], axis=1).astype(np.float32)
+    win = so.rtl_window("hanning", n)
+    fs = 44100
+    with pkg.SpectrumEngine(n, max_frames=nf) as e:
+        e.set_window(win.astype(np.float32))
+        e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=1.0, avg=avg)
+        out = e.process_real2(st, "left")
+    av = so.TraceAveragerOracle()
+    av.set_mode(*avg)
+    for k in range(nf):
+        blk = st[k * n:(k + 1) * n, 0].astype(np.float64)
+        gold = so.audio_db(np.array(av.process(so.audio_compute_power(blk, win, n, fs, False, precision="gold"))), False)
+        if k % 37 == 0 or k == nf - 1:
+            _check(out[k], gold, f"audio averaged batch row {k} {avg}")
+
+
 def test_audio_quiet_channel_is_not_polluted(pkg):
     """Each channel is transformed on its own (as the reference does): a channel 80 dB below the other, or silent,
     keeps the same parity as a loud one.  (A packed z = L + iR transform leaves ~1e-7 of the louder channel's

@@ -212,7 +212,7 @@ static int avg_use_ranges(tdsa_plan p, AvgParams& ap, int n_frames, hipStream_t 
   if (p->avg_scan_old || n_frames <= 1024 || p->d_carry == nullptr) return TDSA_OK;
   const int ranges = (n_frames + 63) / 64 < 256 ? (n_frames + 63) / 64 : 256;
   if (size_t(ranges) > p->carry_chunks) return TDSA_OK;
-  const size_t row = size_t(ap.n);
+  const size_t row = size_t(p->nfft);                  // (rows of the real-input path are shorter: nfft / 2 + 1)
   if (!p->d_agg) {      // (a native plan may also take the workgroup-chunk path on another call: one row per workgroup of its grid)
     const size_t grid_rows = (p->chirp || p->big) ? 0 : size_t(spectrum_geometry(p->log2n, p->max_frames, p->num_cu).grid);
     HIPCHK(hipMalloc(&p->d_agg, (grid_rows > 256 ? grid_rows : size_t(256)) * row * sizeof(float)));
@@ -1290,7 +1290,18 @@ int tdsa_process_real2(tdsa_plan p, const float* lr_host, size_t n_samples, int 
     ap.log_floor = m.log_floor;
     ap.cal_db = m.cal_offset_db;
     ap.out_db = db_dst;
-    HIPCHK(launch_avg_scan(ap, p->stream, nullptr));
+    // long batches: the chunked scan of the complex path (one thread per bin walking 2000 frames took 284 us)
+    if (n_frames > 128) {
+      const size_t need_chunks = size_t(avg_scan_chunks(p->max_frames));
+      if (need_chunks > p->carry_chunks) {
+        if (p->d_carry) { HIPCHK(hipStreamSynchronize(p->stream)); HIPCHK(hipFree(p->d_carry)); p->d_carry = nullptr; p->carry_chunks = 0; }
+        HIPCHK(hipMalloc(&p->d_carry, need_chunks * p->nfft * sizeof(double)));
+        p->carry_chunks = need_chunks;
+      }
+      const int rc = avg_use_ranges(p, ap, n_frames, p->stream);
+      if (rc != TDSA_OK) return rc;
+    }
+    HIPCHK(launch_avg_scan(ap, p->stream, n_frames > 128 ? p->d_carry : nullptr));
     if (m.avg_mode == TDSA_AVG_LIN) {
       long long c = (long long)p->avg_count + n_frames;
       p->avg_count = int(c < m.avg_n ? c : m.avg_n);
