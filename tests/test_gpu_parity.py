@@ -1427,6 +1427,29 @@ def test_batch_averaging_with_workgroup_chunks(pkg, monkeypatch, avg, nfft, nf):
     assert np.max(np.abs(buf - buf_o)) <= 3e-7 * buf_o.max()
 
 
+@pytest.mark.parametrize("avg", [("exp", 4), ("lin", 16)])
+@pytest.mark.parametrize("nfft,nf", [(1024, 100), (4096, 60), (512, 49)])
+def test_short_averaged_batches_take_the_chunked_scan_too(pkg, monkeypatch, avg, nfft, nf):
+    """Up to 4096 points the workgroup-chunk scan takes over from the one-thread-per-bin kernel at 49 frames already
+    (TDSA_AVG_WG_MIN): same rows as the sequential kernel to within a float32 aggregate, and the float64 gold."""
+    iq = so.synth_iq_int8(nfft * nf, nfft, seed=91)
+    gold, _, _ = so.hackrf_batch(iq, nfft, nfft, 20e6, precision="gold", avg=avg)
+
+    def run():
+        with pkg.SpectrumEngine(nfft, max_frames=nf) as e:
+            e.set_window(so.hackrf_window(nfft))
+            e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=1.0, avg=avg)
+            out = e.process(iq, hop=nfft)
+            return out, e.averaged()[0]
+    out, buf = run()
+    _check(out, gold, f"short averaged batch {avg}")
+    monkeypatch.setenv("TDSA_AVG_WG_MIN", "100000")
+    out_s, buf_s = run()
+    monkeypatch.delenv("TDSA_AVG_WG_MIN")
+    assert np.max(np.abs(out - out_s)) <= 1e-5
+    assert np.max(np.abs(buf - buf_s)) <= 3e-7 * buf_s.max()
+
+
 @pytest.mark.parametrize("avg", [("lin", 100000), ("exp", 4), ("lin", 16)])
 @pytest.mark.parametrize("nfft,nf", [(1024, 900), (4096, 600), (16384, 400), (2048, 100)])
 def test_averaging_for_the_state_alone(pkg, avg, nfft, nf):

@@ -107,6 +107,7 @@ struct tdsa_plan_s {
   float2* d_tw_seed = nullptr;           // [big_seed_rows][16384] per-column twiddle seeds of the column pass
   float2* d_tw_row = nullptr;            // W_16384^m : the row pass's twiddle table
   float* d_ones = nullptr;               // [16384] unit window for the row pass
+  int avg_wg_min = 128;                  // batches of more frames than this take the workgroup-chunk scan (developer knob TDSA_AVG_WG_MIN)
   bool avg_scan_old = false;             // developer A/B (TDSA_AVG_OLD): chunk aggregates by the scan's own pass over the rows
   int big_group = 64;                    // segments per column-pass / row-pass round (one round for the K = 64 Welch capture)
   bool big_rows_old = false;             // TDSA_BIG_ROWS_OLD=1: row pass through the frame kernel's ACC instantiation (rounds 2-3)
@@ -550,6 +551,10 @@ static int plan_init(tdsa_plan p) {
     if (v >= 1 && v <= p->num_cu) p->num_cu = v;
   }
   p->avg_scan_old = getenv("TDSA_AVG_OLD") != nullptr;
+  // one thread per bin walking the frames beats the three launches of the chunked scan up to ~48 frames at N <= 4096
+  // (N = 1024, 128 frames: 24.5 against 13.9 us) and up to ~128 at the larger sizes (N = 16384: 33.7 against 35.0 us)
+  p->avg_wg_min = nfft <= 4096 ? 48 : 128;
+  if (const char* c = getenv("TDSA_AVG_WG_MIN")) { const int v = atoi(c); if (v >= 1) p->avg_wg_min = v; }
   if (const char* c = getenv("TDSA_OVERLAP_SHARE")) {   // developer knob: CU share (percent) of an overlapped launch
     const int v = atoi(c);
     if (v >= 10 && v <= 100) p->overlap_share = v;
@@ -960,7 +965,7 @@ static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size
     // Up to 256 chunks: grids of more workgroups (N = 8192: 512, N <= 4096: 1024) fold 2 / 4 consecutive ranges into one.
     const int wg_fold = (g.grid + 255) / 256;
     const int units = (n_frames + g.fpw - 1) / g.fpw;
-    const bool wg_chunks = n_frames > 128 && g.grid <= kAvgMaxWgChunks &&
+    const bool wg_chunks = n_frames > p->avg_wg_min && g.grid <= kAvgMaxWgChunks &&
                            ((units + g.grid - 1) / g.grid) * g.fpw * wg_fold <= 160 && !p->avg_scan_old;
     const size_t agg_rows = size_t(spectrum_geometry(p->log2n, p->max_frames, p->num_cu).grid);
     const size_t need_chunks = wg_chunks ? (agg_rows < 256 ? agg_rows : size_t(256))
