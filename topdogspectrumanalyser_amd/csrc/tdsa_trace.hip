@@ -89,8 +89,8 @@ __device__ __forceinline__ double avg_step(const AvgParams& p, int f, double s, 
 }
 
 constexpr int kAvgChunk = 64;
-// chunk c of the scan: fixed runs of 64 frames, or (wg_chunks > 0) the frame range of workgroup c of the frame kernel's
-// persistent grid - at most 64 frames long (checked by the host), possibly empty
+// chunk c of the scan: fixed runs of 64 frames, or (wg_chunks > 0) wg_fold consecutive workgroup ranges of the frame
+// kernel's persistent grid (or equal ranges of the batch: agg_w_local) - possibly empty
 __device__ __forceinline__ void avg_chunk_bounds(const AvgParams& p, int c, int& f0, int& f1) {
   if (p.wg_chunks > 0) {
     // wg_fold consecutive workgroup ranges make one chunk (sizes whose grid has more than 256 workgroups)
