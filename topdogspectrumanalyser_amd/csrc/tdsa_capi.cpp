@@ -573,7 +573,7 @@ static int plan_init(tdsa_plan p) {
   HIPCHK(hipMalloc(&p->d_hold_min, nb));
   HIPCHK(hipMalloc(&p->d_avg, size_t(nfft) * sizeof(double)));
   HIPCHK(hipMalloc(&p->d_dc_state, sizeof(float2)));
-  HIPCHK(hipMalloc(&p->d_sums, size_t(max_frames) * sizeof(float2)));
+  HIPCHK(hipMalloc(&p->d_sums, (size_t(max_frames) + 8) * sizeof(float2)));   // (+ 7: block sums of overlapping frames)
   HIPCHK(hipMalloc(&p->d_dc_sub, size_t(max_frames) * sizeof(float2)));
   HIPCHK(hipMalloc(&p->d_tare_base, nb));
   HIPCHK(hipMalloc(&p->d_tare_acc, nb));
@@ -942,10 +942,14 @@ static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size
     sp.dc_state = p->d_dc_state;
   } else {
     sp.dc_mode = DC_TRACKED;
-    HIPCHK(launch_frame_sums(iq_dev, in_c64, sp.xor_mask, sp.frame_stride, p->nfft, n_frames, p->d_sums,
-                             p->stream));
+    // overlapping byte frames (the hop divides the frame): the sums of the hop-long blocks are formed once and a frame's
+    // sum is `parts` of them - integer-valued floats, exact in any order - instead of every sample being summed parts times
+    const int parts = (!in_c64 && hop >= 64 && hop % 4 == 0 && p->nfft % hop == 0 && p->nfft / hop >= 2 && p->nfft / hop <= 8)
+                          ? p->nfft / hop : 1;
+    HIPCHK(launch_frame_sums(iq_dev, in_c64, sp.xor_mask, sp.frame_stride, parts > 1 ? hop : p->nfft,
+                             parts > 1 ? n_frames + parts - 1 : n_frames, p->d_sums, p->stream));
     HIPCHK(launch_dc_track(p->d_sums, p->nfft, n_frames, m.dc_alpha, sp.in_off, sp.in_scale, p->d_dc_state,
-                           p->d_dc_sub, p->stream));
+                           p->d_dc_sub, p->stream, parts));
     sp.dc_sub = p->d_dc_sub;
   }
 

@@ -153,7 +153,7 @@ hipError_t launch_frame_sums(const void* in, int in_c64, unsigned xor_mask, long
                              int n, int n_frames, float2* sums, hipStream_t s);
 // sequential tracker: dc <- (1-a) dc + a mean ; writes dc_sub[f] (raw units) and the final state
 hipError_t launch_dc_track(const float2* sums, int n, int n_frames, float alpha, float in_off,
-                           float in_scale, float2* dc_state, float2* dc_sub, hipStream_t s);
+                           float in_scale, float2* dc_state, float2* dc_sub, hipStream_t s, int parts = 1);
 
 struct TraceParams {
   const float* db_in;   // [n]

@@ -540,7 +540,9 @@ hipError_t launch_frame_sums(const void* in, int in_c64, unsigned xor_mask, long
 // walked all frames on one thread with a dependent global load per frame: 470 us for the 2440 frames of a C3 batch; the
 // second chained the 256 runs on thread 0 and fetched one frame sum per step: 15 us.)  The scan runs in float64 on the
 // float32 frame means; the state handed from call to call stays float32 like the reference's.
-__global__ void __launch_bounds__(256) dc_track_kernel(const float2* sums, int n, int n_frames, float alpha, float in_off,
+// parts > 1: sums[] holds the sums of hop-long blocks and frame f is blocks f .. f + parts - 1 (byte formats with a hop
+// that divides the frame: integer-valued floats, their sum is the frame's exact sum whatever the order)
+__global__ void __launch_bounds__(256) dc_track_kernel(const float2* sums, int parts, int n, int n_frames, float alpha, float in_off,
                                                         float in_scale, float2* dc_state, float2* dc_sub) {
   __shared__ double run_re[256], run_im[256], run_a[256];
   const int tid = threadIdx.x;
@@ -554,11 +556,16 @@ __global__ void __launch_bounds__(256) dc_track_kernel(const float2* sums, int n
     mi = double((q.y * inv_n - in_off) * in_scale);
   };
   constexpr int U = 8;                       // frame sums fetched ahead of the dependent chain
+  auto frame_sum = [&](int f) -> float2 {
+    float2 q = sums[f];
+    for (int j = 1; j < parts; ++j) { const float2 b2 = sums[f + j]; q.x += b2.x; q.y += b2.y; }
+    return q;
+  };
   double sr = 0.0, si = 0.0, A = 1.0;
   for (int fb = f0; fb < f1; fb += U) {
     float2 q[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) q[u] = sums[fb + u < f1 ? fb + u : f1 - 1];
+    for (int u = 0; u < U; ++u) q[u] = frame_sum(fb + u < f1 ? fb + u : f1 - 1);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (fb + u < f1) {
@@ -594,7 +601,7 @@ __global__ void __launch_bounds__(256) dc_track_kernel(const float2* sums, int n
   for (int fb = f0; fb < f1; fb += U) {
     float2 q[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) q[u] = sums[fb + u < f1 ? fb + u : f1 - 1];
+    for (int u = 0; u < U; ++u) q[u] = frame_sum(fb + u < f1 ? fb + u : f1 - 1);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (fb + u < f1) {
@@ -609,8 +616,8 @@ __global__ void __launch_bounds__(256) dc_track_kernel(const float2* sums, int n
 }
 
 hipError_t launch_dc_track(const float2* sums, int n, int n_frames, float alpha, float in_off, float in_scale,
-                           float2* dc_state, float2* dc_sub, hipStream_t s) {
-  hipLaunchKernelGGL(dc_track_kernel, dim3(1), dim3(256), 0, s, sums, n, n_frames, alpha, in_off, in_scale,
+                           float2* dc_state, float2* dc_sub, hipStream_t s, int parts) {
+  hipLaunchKernelGGL(dc_track_kernel, dim3(1), dim3(256), 0, s, sums, parts < 1 ? 1 : parts, n, n_frames, alpha, in_off, in_scale,
                      dc_state, dc_sub);
   return hipGetLastError();
 }
