@@ -187,6 +187,32 @@ int tdsa_get_hold(tdsa_plan p, float* max_host, float* min_host, int64_t* frames
  * combine per-GPU Welch partials. */
 int tdsa_get_avg(tdsa_plan p, double* avg_linear_host, int* count);
 
+/* ---- Welch partials across GPUs ----------------------------------------------------------------
+ * One capture whose K segments are averaged on W GPUs (one plan each, avg lin with avg_n >= K): every plan hands out
+ * its running mean of linear power - TraceAverager._buffer after `count` frames, utils/signal_processing.py:56-59 -
+ * and ONE plan reassembles the overall mean on its device: mean = sum_r count_r mean_r / sum_r count_r in float64, in
+ * rank order (reproducible), which becomes that plan's averager state (count = the total) exactly as if it had seen
+ * every segment itself, and the dB row 10*log10(mean*scale + floor) + cal offset - tare (+ hold traces) that
+ * get_power_levels + _apply_cal_offset would return (core/display_data_processor.py:317-327).  No collective: the
+ * partials travel through host memory the caller owns (bench.py: a POSIX shared-memory slab every rank maps). */
+/* Pin a range of caller memory (e.g. a shared-memory mapping) so that copies from / to it are plain DMA. */
+int tdsa_host_register(void* host, size_t bytes);
+int tdsa_host_unregister(void* host);
+/* mean_host receives nfft values, float32 (as_f32 != 0: 4 MiB instead of 8 at 2^20 points; the combined dB row moves by
+ * < 1e-6 dB) or float64 (exact); *count = frames behind it (0: nothing averaged, buffer untouched).  Synchronous. */
+int tdsa_welch_export(tdsa_plan p, void* mean_host, int as_f32, int* count);
+/* parts_host: n_parts (<= 64) partial means as tdsa_welch_export wrote them, part_stride_bytes apart; counts[r] = 0
+ * skips part r.  The plan must be in avg lin mode with avg_n >= the total.  The dB row goes to out_db_dev (device
+ * pointer, asynchronous) and / or out_db_host (then the call synchronises); either may be NULL. */
+int tdsa_welch_combine(tdsa_plan p, const void* parts_host, size_t part_stride_bytes, const int32_t* counts, int n_parts,
+                       int as_f32, float* out_db_dev, float* out_db_host);
+
+/* Saturated VALU rate of the SIMDs right now - independent v_add_f32 chains, four waves per SIMD on every CU, about a
+ * millisecond, timed with events on the plan's stream: *ns_per_valu = ns per wave-instruction per SIMD,
+ * *shader_mhz = 2 clocks / that (a gfx950 SIMD retires one fp32 wave-instruction per 2 clocks).  bench.py reports it
+ * next to the frame kernel's time: the kernel is VALU-issue bound, so kernel time x clock is what compares across boxes. */
+int tdsa_shader_clock(tdsa_plan p, float* shader_mhz, float* ns_per_valu);
+
 /* HackrfSamplesDataSource._dc_estimate (complex, units of x). */
 int tdsa_get_dc(tdsa_plan p, float* re, float* im);
 /* ... and its assignment: the estimate belongs to the source, not to an FFT size - the reference keeps it across

@@ -206,6 +206,31 @@ class RtlBranchOracle:
         return 10 * np.log10(power + POWER_LOG_FLOOR)
 
 
+def welch_gold(segment, n_segments: int, nfft: int, sample_rate: float, threads: int = 1) -> np.ndarray:
+    """Float64 gold of a Welch capture in the RTL branch (BASELINE config 5): segment(k) -> complex samples of segment k;
+    returns get_power_levels() of the LAST segment with `lin` averaging over all of them (rtl_samples.py:167-184 +
+    TraceAverager.process, utils/signal_processing.py:56-59) - exactly RtlBranchOracle(precision="gold") called segment
+    by segment.  The segments' power spectra are independent of each other: `threads` host threads form them (numpy and
+    scipy release the GIL in their loops), the running mean takes them in capture order, so the result does not depend
+    on `threads` (tests/test_oracle_golden.py)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from scipy import fft as sfft
+    window = rtl_window("hanning", nfft)
+
+    def power(k: int) -> np.ndarray:
+        x = np.asarray(segment(k)).astype(np.complex128) * window        # :169
+        return np.abs(sfft.fftshift(sfft.fft(x, n=nfft))) ** 2          # :170-173, :181
+    avg = TraceAveragerOracle()
+    avg.set_mode("lin", n_segments)
+    out = None
+    with ThreadPoolExecutor(max(1, threads)) as ex:
+        block = max(1, threads) * 2                                      # bounded memory: two blocks of spectra alive
+        for k0 in range(0, n_segments, block):
+            for p in ex.map(power, range(k0, min(n_segments, k0 + block))):
+                out = avg.process(p)                                     # :184 (float64 state)
+    return 10 * np.log10(out + POWER_LOG_FLOOR)
+
+
 # ----------------------------------------------------------------------------------------------
 # Audio branch: audio_samples.py:121-132 (_compute_power) and :158-180 (dB + floors)
 # ----------------------------------------------------------------------------------------------

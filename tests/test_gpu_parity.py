@@ -1066,6 +1066,9 @@ def test_c64_nan_first_frame_hold_semantics(pkg):
 # ------------------------------------------------------------------------------------------------
 # C5: 2^20-point FFT, Welch averaging over K segments, calibration offset (four-step kernels)
 # ------------------------------------------------------------------------------------------------
+CAL = -0.8087054556396822       # calibration.json:3 of the reference (rtl_samples), BASELINE config 5's offset
+
+
 def _welch_gold(iq, nfft, k, cal, window="hanning", dc=False):
     x = so.unpack_iq_int8(iq).astype(np.complex128)
     w = so.rtl_window(window, nfft)
@@ -1209,6 +1212,68 @@ def test_c5_sharded_welch_combines_on_host(pkg):
     mean, total = sharding.combine_welch(means, counts)
     assert total == k
     _check(10 * np.log10(mean + so.POWER_LOG_FLOOR), gold, "sharded Welch")
+
+
+@pytest.mark.parametrize("nfft,k,dtype", [(1 << 20, 5, np.float32), (1 << 20, 5, np.float64), (1 << 16, 7, np.float32),
+                                          (4096, 300, np.float32), (4096, 300, np.float64)])
+def test_welch_partials_combined_on_one_device(pkg, nfft, k, dtype):
+    """tdsa_welch_export / tdsa_welch_combine (what bench.py --config c5 --gpus N does inside every timed
+    step): three plans average unequal shares of a capture's segments (one of them none at all), hand out their running
+    means as float32 / float64, and a fourth plan reassembles the overall mean ON ITS DEVICE.  The dB row must match the
+    float64 gold of the whole capture, float64 partials must give the row and the state of one plan that saw every
+    segment (the row to float32 rounding of the log, the state to 1e-15), float32 partials move the row by < 1e-6 dB;
+    afterwards the combining plan carries the state: one more segment continues the running mean
+    (utils/signal_processing.py:56-59)."""
+    from topdogspectrumanalyser_amd import sharding
+    iq = so.synth_iq_int8(nfft * (k + 1), nfft, seed=11)
+    gold, _ = _welch_gold(iq[: 2 * nfft * k], nfft, k, CAL)
+    gold_next, _ = _welch_gold(iq, nfft, k + 1, CAL)
+
+    def plan(frames):
+        e = pkg.SpectrumEngine(nfft, max_frames=max(1, frames))
+        e.set_window(so.rtl_window("hanning", nfft).astype(np.float32))
+        e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=-1.0, avg=("lin", k + 1),
+                    cal_offset_db=CAL)
+        return e
+    shares = [(0, k // 2), (k // 2, k // 2), (k // 2, k)]      # the middle "GPU" gets nothing
+    parts = np.zeros((len(shares), nfft + 16), dtype=dtype)[:, :nfft]   # strided rows, as in a shared slab
+    counts = []
+    for r, (f0, f1) in enumerate(shares):
+        with plan(f1 - f0) as e:
+            if f1 > f0:
+                e.process(iq[2 * f0 * nfft: 2 * f1 * nfft], hop=nfft, want_db=False)
+            counts.append(e.welch_export(parts[r]))
+    assert counts == [f1 - f0 for f0, f1 in shares]
+    with plan(k) as one:                                         # the reference: one plan, every segment
+        row_one = one.process(iq[: 2 * nfft * k], hop=nfft)
+        row_one = row_one[-1] if row_one.ndim == 2 else row_one
+        mean_one, _ = one.averaged()
+    with plan(1) as comb:
+        row = comb.welch_combine(parts, counts, want_host=True)
+        _check(row, gold, f"Welch partials combined on the device ({np.dtype(dtype).name})")
+        mean, cnt = comb.averaged()
+        assert cnt == k
+        host_mean, _ = sharding.combine_welch([p.astype(np.float64) for p in parts], counts)
+        assert np.max(np.abs(mean - host_mean)) <= 1e-15 * np.max(host_mean) * k
+        if dtype == np.float64:
+            assert np.max(np.abs(mean - mean_one)) <= 4e-15 * np.max(mean_one)
+            assert np.max(np.abs(row - row_one)) <= 2e-6
+        else:
+            assert np.max(np.abs(row - row_one)) <= 1e-6 + 2e-6
+        # the combining plan carries the state on: segment k + 1 joins the running mean
+        nxt = comb.process(iq[2 * nfft * k:], hop=nfft)
+        _check(nxt[-1], gold_next, "running mean continued after the combine")
+        assert comb.averaged()[1] == k + 1
+    with plan(1) as bad:                                         # a capped mean cannot take partials
+        bad.configure(avg=("lin", k - 1))
+        with pytest.raises(pkg._native.TdsaError):
+            bad.welch_combine(parts, counts, want_host=True)
+
+
+def test_shader_clock_is_plausible(pkg):
+    with pkg.SpectrumEngine(1024, max_frames=1) as e:
+        mhz, ns = e.shader_clock()
+    assert 800.0 < mhz < 3000.0 and abs(2e3 / ns - mhz) < 1.0
 
 
 @pytest.mark.parametrize("log2n", [15, 16, 17, 18, 19, 20])

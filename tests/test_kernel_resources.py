@@ -101,30 +101,35 @@ def test_long_frame_column_pass_keeps_three_waves_and_no_vmem_wait_between_its_s
                                               os.path.join(CSRC, "tdsa_big.hip"), "-o", asm]
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC)
     assert r.returncode == 0, r.stderr[-2000:]
-    name = "_ZN4tdsa15big_cols_kernelILi6EEEvNS_13BigColsParamsE"
-    rep, on = {}, False
-    for ln in r.stderr.splitlines():
-        m = re.search(r"Function Name: (\S+)", ln)
-        if m:
-            on = m.group(1) == name
-            continue
-        m = re.search(r"remark:\s+([A-Za-z \[\]/]+?):\s+(\S+)\s+\[-Rpass", ln)
-        if m and on:
-            rep[m.group(1).strip()] = m.group(2)
-    assert int(rep["ScratchSize [bytes/lane]"]) == 0 and int(rep["VGPRs"]) <= 168 and int(rep["Occupancy [waves/SIMD]"]) >= 3, rep
-    body, on = [], False
-    for ln in open(asm):
-        if ln.startswith(name + ":"):
-            on = True
-        elif on and ln.startswith(".Lfunc_end"):
-            break
-        elif on:
-            body.append(ln.split(";")[0].strip())
-    stores = [i for i, ln in enumerate(body) if ln.startswith("buffer_store_dwordx4")]
-    assert len(stores) >= 32, len(stores)
-    tail = body[stores[0]:stores[-1] + 1]
-    assert not any(ln.startswith(("buffer_load", "global_load", "flat_load")) for ln in tail)
-    assert not any(ln.startswith("s_waitcnt") and "vmcnt" in ln for ln in tail)
+    # three instantiations per size: the window from a table, evaluated in the kernel (cosine-sum windows), one value
+    for wmode in (0, 1, 2):
+        name = f"_ZN4tdsa15big_cols_kernelILi6ELi{wmode}EEEvNS_13BigColsParamsE"
+        rep, on = {}, False
+        for ln in r.stderr.splitlines():
+            m = re.search(r"Function Name: (\S+)", ln)
+            if m:
+                on = m.group(1) == name
+                continue
+            m = re.search(r"remark:\s+([A-Za-z \[\]/]+?):\s+(\S+)\s+\[-Rpass", ln)
+            if m and on:
+                rep[m.group(1).strip()] = m.group(2)
+        assert int(rep["ScratchSize [bytes/lane]"]) == 0 and int(rep["VGPRs"]) <= 168 and int(rep["Occupancy [waves/SIMD]"]) >= 3, rep
+        assert int(rep["SGPRs Spill"]) == 0, rep        # (the cosine window's row constants: 32 SGPRs at a time, not 192)
+        body, on = [], False
+        for ln in open(asm):
+            if ln.startswith(name + ":"):
+                on = True
+            elif on and ln.startswith(".Lfunc_end"):
+                break
+            elif on:
+                body.append(ln.split(";")[0].strip())
+        stores = [i for i, ln in enumerate(body) if ln.startswith("buffer_store_dwordx4")]
+        assert len(stores) >= 32, len(stores)
+        tail = body[stores[0]:stores[-1] + 1]
+        assert not any(ln.startswith(("buffer_load", "global_load", "flat_load")) for ln in tail)
+        assert not any(ln.startswith("s_waitcnt") and "vmcnt" in ln for ln in tail)
+        loads = sum(ln.startswith("buffer_load_dword ") for ln in body)       # the table's 4-byte window loads
+        assert (loads >= 64) == (wmode == 0), (wmode, loads)
 
     # row pass (big_rows_kernel): 128 VGPRs / 4 waves per SIMD without scratch, and the fetch of the next row spread over
     # the row's work - eight 16-byte loads, one at a time, each behind a stretch of arithmetic (bursts cost 13 %)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Developer experiment: the long-frame chain (2^20-point Welch) over K segments per capture, K = 16 ... 128 - what of a C5 step
-is per-segment work and what is per-launch fill / drain.  Prints us per capture and a least-squares line.
-python tools/c5_scaling.py [--steps 200]"""
+"""Developer experiment: the long-frame chain (2^20-point Welch) over K segments per capture, K = 8 ... 128 - what of a C5 step
+is per-segment work and what is per-launch fill / drain (the K / W segments a rank of a W-GPU strong-scaling run gets).
+Prints us per capture, a least-squares line and the strong-scaling speed-ups that follow for one capture of --capture segments.
+python tools/c5_scaling.py [--steps 200] [--ks 8,16,32,64]"""
 import argparse
 import ctypes as C
 import os
@@ -18,8 +19,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--ks", default="8,16,32,64,128")
+    ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--capture", type=int, default=64, help="segments of the capture whose strong-scaling curve is predicted")
     a = ap.parse_args()
-    n, kmax = 1 << 20, 128
+    ks = [int(k) for k in a.ks.split(",")]
+    n, kmax = 1 << 20, max(ks)
     iq = np.random.default_rng(0).integers(-100, 100, size=2 * n * kmax, dtype=np.int8)
     ring = 2
     di, do = C.c_void_p(), C.c_void_p()
@@ -28,8 +33,8 @@ def main():
     for r in range(ring):
         nat.check(nat.lib.tdsa_memcpy_h2d(0, C.c_void_p(di.value + r * iq.nbytes), iq.ctypes.data_as(C.c_void_p), iq.nbytes))
     pts = []
-    for rep in range(2):
-        for K in (16, 32, 64, 128):
+    for rep in range(a.reps):
+        for K in ks:
             e = SpectrumEngine(n, max_frames=K)
             e.set_window(np.hanning(n).astype(np.float32))
             e.configure(db_mode="pow", power_scale=1.0, log_floor=1e-12, dc_alpha=-1.0, avg=("lin", K), cal_offset_db=-0.8087)
@@ -49,11 +54,19 @@ def main():
             us = (time.perf_counter() - t0) / steps * 1e6
             pts.append((K, us))
             print(f"K={K:4d}: {us:8.1f} us per capture, {us / K:.3f} us per segment", flush=True)
-            e.close() if hasattr(e, "close") else None
-    ks = np.array([p[0] for p in pts], float)
+            e.close()
+    ks_a = np.array([p[0] for p in pts], float)
     ts = np.array([p[1] for p in pts], float)
-    b, c = np.polyfit(ks, ts, 1)
+    b, c = np.polyfit(ks_a, ts, 1)
     print(f"fit: {c:.1f} us per capture + {b:.3f} us per segment  (K = 64 -> {c + 64 * b:.1f})")
+    best = {K: min(t for k, t in pts if k == K) for K in ks}
+    if a.capture in best:
+        t1 = best[a.capture]
+        for w in (2, 4, 8):
+            kw = a.capture // w
+            if kw in best:
+                print(f"strong scaling of one {a.capture}-segment capture, compute only: {w} GPUs x {kw} segments = {best[kw]:.1f} us "
+                      f"-> {t1 / best[kw]:.2f}x ({100 * t1 / best[kw] / w:.0f} % efficiency)")
 
 
 if __name__ == "__main__":

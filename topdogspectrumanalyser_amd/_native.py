@@ -56,6 +56,11 @@ _SIGNATURES = {
     "tdsa_process_real2": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, C.c_int, _P]),
     "tdsa_get_hold": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int64)]),
     "tdsa_get_avg": (C.c_int, [_P, _P, C.POINTER(C.c_int)]),
+    "tdsa_host_register": (C.c_int, [_P, C.c_size_t]),
+    "tdsa_host_unregister": (C.c_int, [_P]),
+    "tdsa_welch_export": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
+    "tdsa_welch_combine": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_int32), C.c_int, C.c_int, _P, _P]),
+    "tdsa_shader_clock": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "tdsa_get_dc": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "tdsa_set_dc": (C.c_int, [_P, C.c_float, C.c_float]),
     "tdsa_synchronize": (C.c_int, [_P]),

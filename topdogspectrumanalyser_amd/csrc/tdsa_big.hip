@@ -33,6 +33,7 @@ struct BigColsParams {
   unsigned xor_mask;
   float in_off;
   unsigned in_valid;         // complex64 rows: samples from this index on are zeros and are not read (0: the whole row is there)
+  BigWindow win;             // how the window reaches the column threads (WMODE of the kernel = win.mode)
 };
 
 
@@ -47,7 +48,17 @@ __device__ __forceinline__ brsrc_t big_rsrc(const void* base, unsigned bytes) {
 typedef unsigned bu32x2 __attribute__((ext_vector_type(2)));
 
 // One thread per column n2.  X[k1] of the column sits in v[bitrev(k1)] after the in-register DIF.
-template <int LOG2N1>
+// WMODE (BigWindow::mode): 0 = the window is a table [N] (one 4-byte load per sample: 268 MB of L2 hits per 64-segment
+// capture at 2^20 points, +14 us of the column pass, profiles/r04_c5_experiments.txt); 1 = cosine-sum window
+// w[n] = a0 - a1 cos(2 pi n / (N - 1)) - np.hanning / np.hamming / np.ones, every window the reference's sources build
+// (hackrf_samples.py:314-316, rtl_samples.py:199-206) - evaluated in the kernel: with n = i 16384 + n2,
+// theta_i = 2 pi i 16384 / (N - 1) and phi = 2 pi n2 / (N - 1) <= 0.1,
+//   w = (a0 - a1 cos theta_i) + (a1 cos theta_i) (1 - cos phi) + (a1 sin theta_i) sin phi = w0[i] + wa[i] u + wb[i] s:
+// three row constants from the kernel arguments (scalar registers) and (u, s) of the column from one 8-byte load -
+// 3 VALU instructions instead of a load per sample.  The two products are at most 0.1 a1 (rounded to <= 4e-9 a1), w0
+// is rounded once as a table entry is: the kernel's window is within 2^-24 of the table the host verified it against
+// (tdsa_set_window); 2 = one value for every sample (rectangular windows; the all-ones window of the chirp-z path).
+template <int LOG2N1, int WMODE>
 __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
   constexpr int N1 = 1 << LOG2N1;
   const int n2 = blockIdx.x * 256 + threadIdx.x;
@@ -60,6 +71,15 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
   if (p.dc_sub != nullptr) { const c32 s = p.dc_sub[seg]; sub_re = s.x; sub_im = s.y; }
   const brsrc_t wr = big_rsrc(p.window, unsigned(N1) * kRowN * 4u);
   const unsigned wv = unsigned(n2) * 4u;
+  c32 wphi = c32{0.f, 0.f};                               // (1 - cos phi, sin phi) of this column (WMODE 1)
+  if constexpr (WMODE == 1) wphi = p.win.phi[n2];
+  const float4* __restrict__ wrow = p.win.row;            // uniform address, read before any store: scalar loads
+  auto win_value = [&](auto ic) -> float {                // window of sample (row i, this column)
+    constexpr int i = decltype(ic)::value;
+    if constexpr (WMODE == 1) { const float4 r = wrow[i]; return fmaf(r.z, wphi.y, r.y * wphi.x) + r.x; }
+    else if constexpr (WMODE == 2) return p.win.flat;
+    else return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wr, wv, unsigned(i) * kRowN * 4u, 0));
+  };
   // W_N^(n2*k1), k1 = a + 8b, is built from the seeds W^(n2*a) (a < 8) and W^(n2*8b) with at most one product.  The seeds
   // depend on the column only: they come from a per-plan table [seed][n2] (evaluated in double, rounded once) as
   // coalesced 8-byte loads.  Rounds 2-3 rebuilt each from a two-level table exp(-2 pi i m / N) = hi[m >> 10] lo[m & 1023]:
@@ -83,8 +103,9 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
     static_for<0, N1>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       const bu32x2 q = __builtin_amdgcn_raw_buffer_load_b64(ir, unsigned(n2) * 8u, unsigned(i) * kRowN * 8u, 0);
-      const float ww = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wr, wv, unsigned(i) * kRowN * 4u, 0));
+      const float ww = win_value(ic);
       v[i] = c32{((__uint_as_float(q.x) - off) - sub_re) * ww, ((__uint_as_float(q.y) - off) - sub_im) * ww};
+      if constexpr (WMODE == 1 && i % 8 == 7) __builtin_amdgcn_sched_barrier(0);    // (SGPR pressure: see below)
     });
   } else {
     const brsrc_t ir = big_rsrc(p.in + (long long)seg * p.seg_stride, unsigned(N1) * kRowN * 2u);
@@ -92,7 +113,7 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
 #ifndef TDSA_COLS_LOADS_BATCHED   // (-DTDSA_COLS_LOADS_BATCHED: round 2's order, for A/B timing)
     // every load of the thread issued before the first conversion: the 2 N1 results land in the registers v[] will
     // occupy anyway, and the memory latency is paid once instead of once per batch of ~20 the scheduler keeps in flight
-    unsigned ru[N1]; float rw[N1];
+    unsigned ru[N1]; float rw[WMODE == 2 ? 1 : N1];
     static_for<0, N1>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
 #if defined(TDSA_EXP_COLS) && TDSA_EXP_COLS == 7      // timing experiment: no sample loads
@@ -101,28 +122,43 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
       ru[i] = unsigned(__builtin_amdgcn_raw_buffer_load_b16(ir, unsigned(n2) * 2u, unsigned(i) * kRowN * 2u, 2));
 #endif
     });
-    static_for<0, N1>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
+    if constexpr (WMODE == 0) {
+      static_for<0, N1>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
 #if defined(TDSA_EXP_COLS) && TDSA_EXP_COLS == 5      // timing experiment: no window loads
-      rw[i] = 1.0f + float(i);
+        rw[i] = 1.0f + float(i);
 #elif defined(TDSA_EXP_COLS) && TDSA_EXP_COLS == 6    // timing experiment: a quarter of the window loads
-      rw[i] = (i % 4 == 0) ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wr, wv, unsigned(i) * kRowN * 4u, 0)) : float(i);
+        rw[i] = (i % 4 == 0) ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wr, wv, unsigned(i) * kRowN * 4u, 0)) : float(i);
 #else
-      rw[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wr, wv, unsigned(i) * kRowN * 4u, 0));
+        rw[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wr, wv, unsigned(i) * kRowN * 4u, 0));
 #endif
-    });
+      });
+    }
+    if constexpr (WMODE == 1) {
+      // the window values are formed while the sample loads are in flight (in the registers the table's loads would
+      // land in).  The rows' constants arrive through scalar loads, eight rows = 32 SGPRs at a time: hoisted to the top
+      // all 192 of them were live at once and 132 spilled; formed behind the sample loads' wait instead, every batch's
+      // scalar-load latency came on top of it (8-segment captures: 22.2 us against 18.5 with the table)
+      static_for<0, N1>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        rw[i] = win_value(ic);
+        if constexpr (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+      });
+    }
     __builtin_amdgcn_sched_barrier(0);
     static_for<0, N1>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       const unsigned u = ru[i] ^ xm;
-      v[i] = c32{((float(u & 0xffu) - off) - sub_re) * rw[i], ((float((u >> 8) & 0xffu) - off) - sub_im) * rw[i]};
+      float ww;
+      if constexpr (WMODE == 2) ww = win_value(ic); else ww = rw[i];
+      v[i] = c32{((float(u & 0xffu) - off) - sub_re) * ww, ((float((u >> 8) & 0xffu) - off) - sub_im) * ww};
     });
 #else
     static_for<0, N1>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       // read once: non-temporal (aux bit 1), so that the raw bytes do not displace Z from the caches
       const unsigned u = unsigned(__builtin_amdgcn_raw_buffer_load_b16(ir, unsigned(n2) * 2u, unsigned(i) * kRowN * 2u, 2)) ^ xm;
-      const float ww = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wr, wv, unsigned(i) * kRowN * 4u, 0));
+      const float ww = win_value(ic);
       v[i] = c32{((float(u & 0xffu) - off) - sub_re) * ww, ((float((u >> 8) & 0xffu) - off) - sub_im) * ww};
     });
 #endif
@@ -539,6 +575,91 @@ __global__ void __launch_bounds__(256) big_gather_kernel(const float* s, int spl
   }
 }
 
+// ---- Welch partials across GPUs: the running mean of linear power leaves a plan as float32 / float64,
+//      the partials of W plans are combined on ONE device: mean = sum_r c_r m_r / sum_r c_r in double, in rank order
+//      (utils/signal_processing.py:56-59 is the running mean being reassembled), then the finish arithmetic -----------
+template <typename T>
+__global__ void __launch_bounds__(256) welch_export_kernel(const double* __restrict__ src, double div, T* __restrict__ dst,
+                                                           long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = T(src[i] / div);
+}
+
+hipError_t launch_welch_export(const double* src, double div, void* dst, int as_f32, long long n, hipStream_t s) {
+  const dim3 grid(unsigned((n + 255) / 256));
+  if (as_f32) hipLaunchKernelGGL(welch_export_kernel<float>, grid, dim3(256), 0, s, src, div, static_cast<float*>(dst), n);
+  else hipLaunchKernelGGL(welch_export_kernel<double>, grid, dim3(256), 0, s, src, div, static_cast<double*>(dst), n);
+  return hipGetLastError();
+}
+
+struct WelchParts {
+  const void* parts;         // [n_parts] partial means, part_stride bytes apart
+  long long part_stride;
+  int n_parts;
+  int count[kWelchMaxParts]; // segments behind each partial mean (0: not read)
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) welch_combine_kernel(const WelchParts w, long long n, double* sum_out, BigFinishParams fin,
+                                                            int native_db) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double acc = 0.0;
+  for (int r = 0; r < w.n_parts; ++r) {
+    if (w.count[r] == 0) continue;
+    const T* m = reinterpret_cast<const T*>(static_cast<const unsigned char*>(w.parts) + (long long)r * w.part_stride);
+    acc += double(m[i]) * double(w.count[r]);
+  }
+  if (sum_out != nullptr) sum_out[i] = acc;
+  if (!native_db) {
+    big_finish_bin(fin, i, acc);
+  } else {   // LDS-resident sizes: the averager's state is the mean itself, dB as the scan's own rows form it
+    const double mean = acc / double(fin.count);
+    if (fin.mean_out != nullptr) fin.mean_out[i] = mean;
+    float db = fmaf(k10Log10_2, __builtin_amdgcn_logf(float(mean + double(fin.log_floor))), fin.cal_db);
+    if (fin.tare != nullptr) db -= fin.tare[i];
+    if (fin.out_db != nullptr) fin.out_db[i] = db;
+    if (fin.hold_max != nullptr) fin.hold_max[i] = fin.max_first ? ((db != db) ? -500.f : db) : fmaxf(fin.hold_max[i], db);
+    if (fin.hold_min != nullptr) fin.hold_min[i] = fin.min_first ? ((db != db) ? 500.f : db) : fminf(fin.hold_min[i], db);
+  }
+}
+
+hipError_t launch_welch_combine(const void* parts, long long part_stride, const int* counts, int n_parts, int as_f32, long long n,
+                                double* sum_out, double* mean_out, int total, int native_db, int db_mode, float pscale,
+                                float log_floor, float cal_db, const float* tare, float* out_db, float* hold_max,
+                                float* hold_min, int max_first, int min_first, hipStream_t s) {
+  if (n_parts < 1 || n_parts > kWelchMaxParts) return hipErrorInvalidValue;
+  WelchParts w{parts, part_stride, n_parts, {}};
+  for (int r = 0; r < n_parts; ++r) w.count[r] = counts[r];
+  const BigFinishParams fin{nullptr, mean_out, total, db_mode, pscale, log_floor, cal_db, tare, out_db, hold_max, hold_min,
+                            max_first, min_first};
+  const dim3 grid(unsigned((n + 255) / 256));
+  if (as_f32) hipLaunchKernelGGL(welch_combine_kernel<float>, grid, dim3(256), 0, s, w, n, sum_out, fin, native_db);
+  else hipLaunchKernelGGL(welch_combine_kernel<double>, grid, dim3(256), 0, s, w, n, sum_out, fin, native_db);
+  return hipGetLastError();
+}
+
+// ---- shader clock: independent v_add_f32 chains, four waves per SIMD on every CU - the SIMD's saturated VALU rate -----
+__global__ void __launch_bounds__(256) valu_clock_kernel(float* out, int iters, float seed) {
+  float a[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = seed + float(j);
+  const float c = seed * 1.0001f;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int r = 0; r < 64; ++r) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[r % 8]) : "v"(c));
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) sum += a[j];
+  if (sum == 123.456f) out[blockIdx.x] = sum;     // (keeps the chains alive; never true)
+}
+
+hipError_t launch_valu_clock(float* scratch, int n_cu, int iters, hipStream_t s) {
+  hipLaunchKernelGGL(valu_clock_kernel, dim3(unsigned(n_cu) * 4u), dim3(256), 0, s, scratch, iters, 1.0f);
+  return hipGetLastError();
+}
+
 // ---- DC of long frames: exact sums (integers for byte formats), tracker in double ---------------------------
 template <bool IN_C64>
 __global__ void __launch_bounds__(256) big_sums_kernel(const void* in, unsigned xor_mask, long long frame_stride,
@@ -617,7 +738,12 @@ __global__ void __launch_bounds__(256) big_dc_kernel(const double* sums, int n, 
 // ---- host launchers ------------------------------------------------------------------------------------
 template <int L>
 static hipError_t cols_launch(const BigColsParams& p, int n_seg, hipStream_t s) {
-  hipLaunchKernelGGL(big_cols_kernel<L>, dim3(kRowN / 256, n_seg), dim3(256), 0, s, p);
+  const dim3 grid(kRowN / 256, n_seg);
+  switch (p.win.mode) {
+    case 1: hipLaunchKernelGGL((big_cols_kernel<L, 1>), grid, dim3(256), 0, s, p); break;
+    case 2: hipLaunchKernelGGL((big_cols_kernel<L, 2>), grid, dim3(256), 0, s, p); break;
+    default: hipLaunchKernelGGL((big_cols_kernel<L, 0>), grid, dim3(256), 0, s, p); break;
+  }
   return hipGetLastError();
 }
 template <int L>
@@ -628,11 +754,11 @@ static hipError_t gather_launch(const float* src, int split, double* dst, int ad
   return hipGetLastError();
 }
 
-hipError_t launch_big_cols(int log2n, const void* in, int in_c64, long long seg_stride, int n_seg, const float* window,
+hipError_t launch_big_cols(int log2n, const void* in, int in_c64, long long seg_stride, int n_seg, const BigWindow& win,
                            const float2* tw_seed, const float2* dc_sub, float2* z,
                            unsigned xor_mask, float in_off, hipStream_t s, unsigned in_valid) {
-  const BigColsParams p{static_cast<const unsigned char*>(in), in_c64, seg_stride, window, tw_seed, dc_sub, z, xor_mask,
-                        in_off, in_valid};
+  const BigColsParams p{static_cast<const unsigned char*>(in), in_c64, seg_stride, win.table, tw_seed, dc_sub, z, xor_mask,
+                        in_off, in_valid, win};
   switch (log2n - kRowLog2) {
     case 1: return cols_launch<1>(p, n_seg, s);
     case 2: return cols_launch<2>(p, n_seg, s);

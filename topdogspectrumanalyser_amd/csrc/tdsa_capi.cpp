@@ -102,11 +102,18 @@ struct tdsa_plan_s {
   float2* d_z = nullptr;                 // [group][N1][16384] complex64 rows after the column pass
   float* d_acc = nullptr;                // [N1][16384] power sums of the current call (row pass output)
   double* d_sum = nullptr;               // [N] fftshift-ed sums over the segments averaged so far
+  void* d_welch = nullptr;               // staging of tdsa_welch_export (one partial) / tdsa_welch_combine (all of them)
+  size_t welch_bytes = 0;
+  float* d_clock = nullptr;              // scratch of tdsa_shader_clock
+  bool big_mean_in_sum = false;          // Welch calls leave the running mean as d_sum / avg_count; d_avg is formed when someone asks
   double* d_lin64 = nullptr;             // [N] fftshift-ed power of one frame (exp / capped lin averaging)
   double* d_sums64 = nullptr;            // [max_frames][2] exact I / Q sums of the frames of a call
   float2* d_tw_seed = nullptr;           // [big_seed_rows][16384] per-column twiddle seeds of the column pass
   float2* d_tw_row = nullptr;            // W_16384^m : the row pass's twiddle table
   float* d_ones = nullptr;               // [16384] unit window for the row pass
+  BigWindow big_win[3] = {};             // the column pass's window per input format (tdsa_set_window: table, cosine-sum or flat)
+  float2* d_wphi = nullptr;              // [16384] (1 - cos phi, sin phi), phi = 2 pi n2 / (N - 1): cosine-sum windows of long frames
+  float4* d_wrow = nullptr;              // [3][64] per input format and row i of the N1 x 16384 view: (w0, wa, wb, -) of BigWindow
   int avg_wg_min = 128;                  // batches of more frames than this take the workgroup-chunk scan (developer knob TDSA_AVG_WG_MIN)
   bool avg_scan_old = false;             // developer A/B (TDSA_AVG_OLD): chunk aggregates by the scan's own pass over the rows
   int big_group = 64;                    // segments per column-pass / row-pass round (one round for the K = 64 Welch capture)
@@ -240,6 +247,17 @@ static int avg_use_ranges(tdsa_plan p, AvgParams& ap, int n_frames, hipStream_t 
 //     calls since the last reset) are averaged, out_db_dev receives ONE row, the dB of the running mean;
 //   * otherwise one frame per call (n_frames == 1): plain dB, or TraceAverager exp / capped lin on the
 //     float64 state exactly as for the LDS-resident sizes.
+// TraceAverager._buffer of a long-frame plan after Welch calls: the gather leaves the float64 SUM of the segments and the
+// dB row; the mean itself (8 N bytes more per capture) is only formed for whoever reads the state - tdsa_get_avg,
+// tdsa_welch_export, or the capped running mean that takes over once avg_n frames have been seen.
+static int big_materialize_mean(tdsa_plan p) {
+  if (p->big_mean_in_sum && p->avg_count > 0)
+    HIPCHK(launch_big_finish(p->d_sum, (long long)p->nfft, p->d_avg, p->avg_count, TDSA_DB_POW, 1.0f, 1.0f, 0.0f, nullptr,
+                             nullptr, nullptr, nullptr, 0, 0, p->stream));
+  p->big_mean_in_sum = false;
+  return TDSA_OK;
+}
+
 int process_big(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n_frames, float* out_db_dev) {
   const tdsa_mode& m = p->mode;
   const bool averaging = avg_active(m);
@@ -274,7 +292,7 @@ int process_big(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n_f
     const int act = ns < split_max ? ns : split_max;
     if (s0 == 0) split_layout = act;
     HIPCHK(launch_big_cols(p->log2n, static_cast<const unsigned char*>(iq_dev) + (long long)s0 * stride, in_c64, stride, ns,
-                           p->d_window[in_format], p->d_tw_seed, dc_sub ? dc_sub + s0 : nullptr, p->d_z,
+                           p->big_win[in_format], p->d_tw_seed, dc_sub ? dc_sub + s0 : nullptr, p->d_z,
                            xor_mask, in_off, p->stream));
     SpecParams sp{};
     sp.in = p->d_z;
@@ -320,11 +338,13 @@ int process_big(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n_f
   float* const hold_max = hmax ? p->d_hold_max : nullptr;
   float* const hold_min = hmin ? p->d_hold_min : nullptr;
   if (welch) {
-    HIPCHK(launch_big_gather_finish(p->log2n, p->d_acc, split_layout, p->d_sum, p->avg_count > 0, p->d_avg, p->avg_count + n_frames,
+    HIPCHK(launch_big_gather_finish(p->log2n, p->d_acc, split_layout, p->d_sum, p->avg_count > 0, nullptr, p->avg_count + n_frames,
                                     m.db_mode, pscale, m.log_floor, m.cal_offset_db, tare, out_db_dev, hold_max, hold_min,
                                     p->held_max == 0, p->held_min == 0, p->stream));
     p->avg_count += n_frames;
+    p->big_mean_in_sum = true;
   } else if (averaging) {    // TraceAverager exp / capped lin, one frame (signal_processing.py:35-61)
+    { const int rc_m = big_materialize_mean(p); if (rc_m != TDSA_OK) return rc_m; }
     HIPCHK(launch_big_gather(p->log2n, p->d_acc, split_layout, p->d_lin64, 0, p->stream));
     HIPCHK(launch_avg_host_frame(p->d_lin64, p->nfft, p->d_avg, p->avg_count, m.avg_mode, m.avg_n, p->stream));
     if (p->avg_count == 0) p->avg_count = 1;
@@ -359,7 +379,11 @@ int chirp_transform(tdsa_plan p, const void* in, int in_format, long long stride
     const int n1 = M >> kMaxLog2N;
     const long long rowb = (long long)(1 << kMaxLog2N) * sizeof(float2), segb = (long long)M * sizeof(float2);
     if (!p->d_z) HIPCHK(hipMalloc(&p->d_z, size_t(p->max_frames) * M * sizeof(float2)));
-    HIPCHK(launch_big_cols(p->log2m, p->d_u0, 1, segb, n_frames, p->d_ones, p->d_tw_seed, nullptr, p->d_z, 0u, 0.0f, s,
+    BigWindow flat{};                   // the rows are windowed already (chirp_pre): one for every sample
+    flat.mode = 2;
+    flat.table = p->d_ones;
+    flat.flat = 1.0f;
+    HIPCHK(launch_big_cols(p->log2m, p->d_u0, 1, segb, n_frames, flat, p->d_tw_seed, nullptr, p->d_z, 0u, 0.0f, s,
                            unsigned(N)));
 
     SpecParams sp{};
@@ -730,7 +754,7 @@ int tdsa_destroy(tdsa_plan p) {
                   p->d_window_perm[2], p->d_tw, p->d_hold_max, p->d_hold_min,
                   p->d_avg, p->d_lin, p->d_carry, p->d_agg, p->d_agg_w, p->d_chunk_a, p->d_chunk_v, p->d_cplx, p->d_real, p->d_lin1, p->d_db1, p->d_dc_state, p->d_sums, p->d_dc_sub,
                   p->d_tare_base, p->d_tare_acc, p->d_in_stage, p->d_out_stage, p->d_trace_in,
-                  p->d_trace_live, p->d_scratch, p->d_z, p->d_chirp_a, p->d_chirp_b, p->d_u0, p->d_u1, p->d_acc, p->d_sum, p->d_lin64, p->d_sums64, p->d_tw_seed, p->d_tw_row, p->d_ones,
+                  p->d_trace_live, p->d_scratch, p->d_z, p->d_wphi, p->d_wrow, p->d_welch, p->d_clock, p->d_chirp_a, p->d_chirp_b, p->d_u0, p->d_u1, p->d_acc, p->d_sum, p->d_lin64, p->d_sums64, p->d_tw_seed, p->d_tw_row, p->d_ones,
                   p->d_dbg};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -768,6 +792,66 @@ int tdsa_get_info(tdsa_plan p, tdsa_info* out) {
   return TDSA_OK;
 }
 
+// Long frames: the column pass fetches the window sample by sample - one 4-byte load each, 268 MB of L2 hits per
+// 64-segment capture at 2^20 points.  Every window the reference's sources build is a cosine-sum
+// w[n] = a0 - a1 cos(2 pi n / (N - 1)) (np.hanning, np.hamming, np.ones; hackrf_samples.py:314-316 divides np.hanning by
+// its rms, rtl_samples.py:199-206): when the table the caller handed over IS one - a0, a1 by least squares in double,
+// then every sample within one float32 rounding unit (2^-23 of the largest value: the table's own rounding plus the
+// float32 division of the HackRF normalisation) - the column pass evaluates it from three constants per row of the
+// N1 x 16384 view and two values per column instead (BigWindow, tdsa_big.hip); a1 = 0: one value for every sample.
+// Any other table is read as before.
+static int big_window_model(tdsa_plan p, const float* w, const float scale[3]) {
+  const int n = p->nfft, n1 = n >> kMaxLog2N, nrow = 1 << kMaxLog2N;
+  for (int f = 0; f < 3; ++f) {
+    p->big_win[f] = BigWindow{};
+    p->big_win[f].table = p->d_window[f];
+  }
+#ifdef TDSA_DEV
+  if (getenv("TDSA_BIG_WIN_TABLE")) return TDSA_OK;       // developer A/B: always the table
+#endif
+  // least squares for w[n] ~ a0 - a1 c[n], c[n] = cos(2 pi n / (N - 1)), in double
+  const double step = 2.0 * M_PI / double(n - 1);
+  double sc = 0.0, scc = 0.0, sw = 0.0, swc = 0.0, wmax = 0.0;
+  std::vector<double> c(n);
+  for (int i = 0; i < n; ++i) {
+    c[i] = std::cos(step * double(i));
+    sc += c[i]; scc += c[i] * c[i]; sw += double(w[i]); swc += double(w[i]) * c[i];
+    wmax = std::fmax(wmax, std::fabs(double(w[i])));
+  }
+  const double det = double(n) * scc - sc * sc;
+  if (!(det > 0.0) || !(wmax > 0.0) || !std::isfinite(wmax)) return TDSA_OK;
+  const double a0 = (sw * scc - swc * sc) / det, a1 = (sw * sc - swc * double(n)) / det;   // w ~ a0 - a1 c
+  double err = 0.0;
+  for (int i = 0; i < n; ++i) err = std::fmax(err, std::fabs(double(w[i]) - (a0 - a1 * c[i])));
+  if (!(err <= std::ldexp(wmax, -23))) return TDSA_OK;       // not a cosine-sum window: the table
+  const bool flat = std::fabs(a1) <= std::ldexp(wmax, -26);
+  if (!flat && !p->d_wphi) {
+    std::vector<float2> phi(nrow);
+    for (int n2 = 0; n2 < nrow; ++n2) {
+      const double h = std::sin(0.5 * step * double(n2));
+      phi[n2] = float2{float(2.0 * h * h), float(std::sin(step * double(n2)))};
+    }
+    HIPCHK(hipMalloc(&p->d_wphi, size_t(nrow) * sizeof(float2)));
+    HIPCHK(hipMemcpy(p->d_wphi, phi.data(), size_t(nrow) * sizeof(float2), hipMemcpyHostToDevice));
+  }
+  if (!p->d_wrow) HIPCHK(hipMalloc(&p->d_wrow, size_t(3) * 64 * sizeof(float4)));
+  std::vector<float4> rows(size_t(3) * 64, float4{0.f, 0.f, 0.f, 0.f});
+  for (int f = 0; f < 3; ++f) {
+    BigWindow& bw = p->big_win[f];
+    bw.mode = flat ? 2 : 1;
+    bw.phi = p->d_wphi;
+    bw.row = p->d_wrow + size_t(f) * 64;
+    const double sf = double(scale[f]);
+    bw.flat = float(sf * a0);
+    for (int i = 0; i < n1; ++i) {
+      const double th = step * double(i) * double(nrow);
+      rows[size_t(f) * 64 + i] = float4{float(sf * (a0 - a1 * std::cos(th))), float(sf * a1 * std::cos(th)), float(sf * a1 * std::sin(th)), 0.0f};
+    }
+  }
+  HIPCHK(hipMemcpy(p->d_wrow, rows.data(), rows.size() * sizeof(float4), hipMemcpyHostToDevice));
+  return TDSA_OK;
+}
+
 int tdsa_set_window(tdsa_plan p, const float* w_host, int n) {
   if (!p || !w_host) return fail(TDSA_ERR_ARG, "null argument");
   if (n != p->nfft) return fail(TDSA_ERR_ARG, "window length %d != nfft %d", n, p->nfft);
@@ -780,6 +864,10 @@ int tdsa_set_window(tdsa_plan p, const float* w_host, int n) {
     for (int i = 0; i < n; ++i) tmp[i] = w_host[i] * scale[f];
     HIPCHK(hipMemcpy(p->d_window[f], tmp.data(), size_t(n) * sizeof(float), hipMemcpyHostToDevice));
     if (p->d_window_perm[f]) HIPCHK(launch_window_perm(p->log2n, p->d_window[f], p->d_window_perm[f], p->stream));
+  }
+  if (p->big) {
+    const int rc_w = big_window_model(p, w_host, scale);
+    if (rc_w != TDSA_OK) return rc_w;
   }
   p->window_set = true;
   return TDSA_OK;
@@ -1342,10 +1430,115 @@ int tdsa_get_avg(tdsa_plan p, double* avg_linear_host, int* count) {
   if (!p) return fail(TDSA_ERR_ARG, "null plan");
   HIPCHK(hipSetDevice(p->device));
   JOIN(p);
+  if (p->big) { const int rc_m = big_materialize_mean(p); if (rc_m != TDSA_OK) return rc_m; }
   HIPCHK(hipStreamSynchronize(p->stream));
   if (avg_linear_host && p->avg_count > 0)
     HIPCHK(hipMemcpy(avg_linear_host, p->d_avg, size_t(p->nfft) * sizeof(double), hipMemcpyDeviceToHost));
   if (count) *count = p->avg_count;
+  return TDSA_OK;
+}
+
+static int welch_stage(tdsa_plan p, size_t bytes) {
+  if (p->welch_bytes >= bytes) return TDSA_OK;
+  if (p->d_welch) { HIPCHK(hipFree(p->d_welch)); p->d_welch = nullptr; p->welch_bytes = 0; }
+  HIPCHK(hipMalloc(&p->d_welch, bytes));
+  p->welch_bytes = bytes;
+  return TDSA_OK;
+}
+
+int tdsa_host_register(void* host, size_t bytes) {
+  if (!host || bytes == 0) return fail(TDSA_ERR_ARG, "null / empty host range");
+  HIPCHK(hipHostRegister(host, bytes, hipHostRegisterPortable));
+  return TDSA_OK;
+}
+
+int tdsa_host_unregister(void* host) {
+  if (!host) return fail(TDSA_ERR_ARG, "null host pointer");
+  HIPCHK(hipHostUnregister(host));
+  return TDSA_OK;
+}
+
+int tdsa_welch_export(tdsa_plan p, void* mean_host, int as_f32, int* count) {
+  if (!p || !mean_host) return fail(TDSA_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(p->device));
+  JOIN(p);
+  if (count) *count = p->avg_count;
+  if (p->avg_count <= 0) return TDSA_OK;
+  const size_t n = size_t(p->nfft), nb = n * (as_f32 ? sizeof(float) : sizeof(double));
+  const bool from_sum = p->big && p->big_mean_in_sum;
+  if (!as_f32 && !from_sum) {       // the state is the float64 mean already
+    HIPCHK(hipMemcpyAsync(mean_host, p->d_avg, nb, hipMemcpyDeviceToHost, p->stream));
+  } else {
+    { const int rc = welch_stage(p, nb); if (rc != TDSA_OK) return rc; }
+    HIPCHK(launch_welch_export(from_sum ? p->d_sum : p->d_avg, from_sum ? double(p->avg_count) : 1.0, p->d_welch, as_f32,
+                               (long long)n, p->stream));
+    HIPCHK(hipMemcpyAsync(mean_host, p->d_welch, nb, hipMemcpyDeviceToHost, p->stream));
+  }
+  HIPCHK(hipStreamSynchronize(p->stream));
+  return TDSA_OK;
+}
+
+int tdsa_welch_combine(tdsa_plan p, const void* parts_host, size_t part_stride_bytes, const int32_t* counts, int n_parts,
+                       int as_f32, float* out_db_dev, float* out_db_host) {
+  if (!p || !parts_host || !counts) return fail(TDSA_ERR_ARG, "null argument");
+  if (n_parts < 1 || n_parts > kWelchMaxParts) return fail(TDSA_ERR_ARG, "n_parts=%d outside [1, %d]", n_parts, kWelchMaxParts);
+  const tdsa_mode& m = p->mode;
+  const size_t n = size_t(p->nfft), nb = n * (as_f32 ? sizeof(float) : sizeof(double));
+  if (part_stride_bytes < nb) return fail(TDSA_ERR_ARG, "part_stride_bytes=%zu < %zu bytes of one partial", part_stride_bytes, nb);
+  long long total = 0;
+  int cnt[kWelchMaxParts];
+  for (int r = 0; r < n_parts; ++r) {
+    if (counts[r] < 0) return fail(TDSA_ERR_ARG, "counts[%d]=%d", r, counts[r]);
+    cnt[r] = counts[r];
+    total += counts[r];
+  }
+  if (total == 0) return fail(TDSA_ERR_ARG, "no segments behind the partial means");
+  if (!(avg_active(m) && m.avg_mode == TDSA_AVG_LIN && total <= m.avg_n))
+    return fail(TDSA_ERR_STATE, "partial means combine only into an uncapped running mean: avg lin with avg_n >= %lld segments", total);
+  if (p->chirp) return fail(TDSA_ERR_STATE, "not available for chirp-z plans");
+  HIPCHK(hipSetDevice(p->device));
+  JOIN(p);
+  { const int rc = welch_stage(p, nb * size_t(n_parts) + (out_db_host && !out_db_dev ? n * sizeof(float) : 0)); if (rc != TDSA_OK) return rc; }
+  // one strided copy: the parts may sit part_stride_bytes apart in the caller's (pinned, shared) slab
+  HIPCHK(hipMemcpy2DAsync(p->d_welch, nb, parts_host, part_stride_bytes, nb, size_t(n_parts), hipMemcpyHostToDevice, p->stream));
+  float* out_dev = out_db_dev ? out_db_dev
+                              : (out_db_host ? reinterpret_cast<float*>(static_cast<unsigned char*>(p->d_welch) + nb * size_t(n_parts)) : nullptr);
+  const bool hmax = (m.hold_flags & TDSA_HOLD_MAX) != 0, hmin = (m.hold_flags & TDSA_HOLD_MIN) != 0;
+  const float pscale = (p->big && m.db_mode == TDSA_DB_POW) ? m.power_scale : 1.0f;
+  HIPCHK(launch_welch_combine(p->d_welch, (long long)nb, cnt, n_parts, as_f32, (long long)n, p->big ? p->d_sum : nullptr,
+                              p->big ? nullptr : p->d_avg, int(total), p->big ? 0 : 1, m.db_mode, pscale, m.log_floor,
+                              m.cal_offset_db, p->tare_active ? p->d_tare_base : nullptr, out_dev,
+                              hmax ? p->d_hold_max : nullptr, hmin ? p->d_hold_min : nullptr, p->held_max == 0,
+                              p->held_min == 0, p->stream));
+  p->avg_count = int(total);
+  if (p->big) p->big_mean_in_sum = true;
+  if (hmax) p->held_max += 1;
+  if (hmin) p->held_min += 1;
+  if (out_db_host) {
+    HIPCHK(hipMemcpyAsync(out_db_host, out_dev, n * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+  }
+  return TDSA_OK;
+}
+
+int tdsa_shader_clock(tdsa_plan p, float* shader_mhz, float* ns_per_valu) {
+  if (!p) return fail(TDSA_ERR_ARG, "null plan");
+  HIPCHK(hipSetDevice(p->device));
+  JOIN(p);
+  if (!p->d_clock) HIPCHK(hipMalloc(&p->d_clock, size_t(p->num_cu) * 4 * sizeof(float)));
+  const int iters = 4000;                                    // 256 000 instructions per wave: about a millisecond
+  HIPCHK(launch_valu_clock(p->d_clock, p->num_cu, 200, p->stream));
+  HIPCHK(hipEventRecord(p->ev0, p->stream));
+  HIPCHK(launch_valu_clock(p->d_clock, p->num_cu, iters, p->stream));
+  HIPCHK(hipEventRecord(p->ev1, p->stream));
+  HIPCHK(hipEventSynchronize(p->ev1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+  // four waves per SIMD, each 64 * iters instructions: ns per wave-instruction per SIMD; a gfx950 SIMD retires one fp32
+  // wave-instruction per 2 clocks (64 FLOP / clk / SIMD as FMAs: MI355X_MICROARCH.md)
+  const double ns = double(ms) * 1e6 / (double(iters) * 64.0 * 4.0);
+  if (ns_per_valu) *ns_per_valu = float(ns);
+  if (shader_mhz) *shader_mhz = float(2.0e3 / ns);
   return TDSA_OK;
 }
 

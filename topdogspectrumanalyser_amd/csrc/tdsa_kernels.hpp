@@ -197,7 +197,18 @@ constexpr int big_seed_rows(int log2n) {
   const int n1 = 1 << (log2n - 14), na = n1 < 8 ? n1 : 8, nb = n1 / na;
   return (na - 1) + (nb - 1);
 }
-hipError_t launch_big_cols(int log2n, const void* in, int in_c64, long long seg_stride, int n_seg, const float* window,
+// The window as the column threads get it.  mode 0: `table` [N] (window * input scale), one load per sample.  mode 1: a
+// cosine-sum window a0 - a1 cos(2 pi n / (N - 1)) evaluated in the kernel from three constants per row i of the
+// N1 x 16384 view (device table row[i] = (w0, wa, wb, -): w = w0 + wa (1 - cos phi) + wb sin phi, phi = 2 pi n2 / (N - 1);
+// `phi` [16384] holds the column's (1 - cos phi, sin phi)).  mode 2: `flat` for every sample.  tdsa_set_window decides.
+struct BigWindow {
+  int mode;
+  const float* table;
+  const float2* phi;
+  const float4* row;
+  float flat;
+};
+hipError_t launch_big_cols(int log2n, const void* in, int in_c64, long long seg_stride, int n_seg, const BigWindow& win,
                            const float2* tw_seed, const float2* dc_sub, float2* z,
                            unsigned xor_mask, float in_off, hipStream_t s, unsigned in_valid = 0);
 // transposed four-step, second half: R[seg][k1][m2] (row transforms of T[k1][k2] = V[k1 + N1 k2]) -> Y[seg][m] in natural
@@ -224,6 +235,18 @@ hipError_t launch_big_finish(const double* src, long long n, double* mean_out, i
                              float log_floor, float cal_db, const float* tare, float* out_db, float* hold_max,
                              float* hold_min, int max_first, int min_first, hipStream_t s);
 
+// ---- Welch partials across GPUs (tdsa_welch_export / tdsa_welch_combine) ----
+constexpr int kWelchMaxParts = 64;
+// dst[i] = src[i] / div as float32 (as_f32) or float64
+hipError_t launch_welch_export(const double* src, double div, void* dst, int as_f32, long long n, hipStream_t s);
+// sum_r counts[r] * parts[r][i] (double, rank order) -> sum_out (or null), mean -> mean_out (or null), dB row, hold traces;
+// native_db: the dB arithmetic of the LDS-resident sizes' averager (else that of the long-frame finish)
+hipError_t launch_welch_combine(const void* parts, long long part_stride, const int* counts, int n_parts, int as_f32, long long n,
+                                double* sum_out, double* mean_out, int total, int native_db, int db_mode, float pscale,
+                                float log_floor, float cal_db, const float* tare, float* out_db, float* hold_max,
+                                float* hold_min, int max_first, int min_first, hipStream_t s);
+// n_cu * 4 workgroups of 256 threads, each wave 64 * iters independent v_add_f32 (8 chains): the SIMDs' saturated VALU rate
+hipError_t launch_valu_clock(float* scratch, int n_cu, int iters, hipStream_t s);
 
 // ---- frame lengths that are not a power of two, 2 <= N <= 8192 (tdsa_chirp.hip): chirp-z on the frame kernel ----
 constexpr int kChirpMaxN = 1 << 19;      // M = 2^ceil(log2(2N-1)) <= 2^20; M > 16384 runs on the long-frame kernels

@@ -184,6 +184,39 @@ class SpectrumEngine:
         nat.check(nat.lib.tdsa_get_avg(self._h, _ptr(buf), C.byref(cnt)))
         return (buf if cnt.value > 0 else None), cnt.value
 
+    def welch_export(self, dst: np.ndarray) -> int:
+        """The running mean of linear power (TraceAverager._buffer) into `dst` - float32 or float64 [nfft], e.g. a view
+        of a shared-memory slab - and the number of frames behind it (tdsa_welch_export; synchronous)."""
+        if dst.dtype not in (np.float32, np.float64) or dst.size != self.nfft or not dst.flags.c_contiguous:
+            raise ValueError("dst must be a contiguous float32 / float64 array of nfft values")
+        cnt = C.c_int()
+        nat.check(nat.lib.tdsa_welch_export(self._h, _ptr(dst), int(dst.dtype == np.float32), C.byref(cnt)))
+        return cnt.value
+
+    def welch_combine(self, parts: np.ndarray, counts, out_db_dev: Optional[int] = None,
+                      want_host: bool = False) -> Optional[np.ndarray]:
+        """Partial means [n_parts, nfft] (float32 / float64, rows may be strided) + frame counts -> this plan's averager
+        state and the dB row (tdsa_welch_combine): written to the device pointer and / or returned as a host array."""
+        if parts.ndim != 2 or parts.shape[1] != self.nfft or parts.strides[1] != parts.itemsize:
+            raise ValueError("parts must be [n_parts, nfft] with contiguous rows")
+        if parts.dtype not in (np.float32, np.float64):
+            raise TypeError("parts must be float32 or float64")
+        cnt = np.ascontiguousarray(counts, dtype=np.int32)
+        if cnt.size != parts.shape[0]:
+            raise ValueError("one count per partial mean")
+        out = np.empty(self.nfft, dtype=np.float32) if want_host else None
+        nat.check(nat.lib.tdsa_welch_combine(self._h, _ptr(parts), int(parts.strides[0]),
+                                             cnt.ctypes.data_as(C.POINTER(C.c_int32)), int(cnt.size),
+                                             int(parts.dtype == np.float32),
+                                             C.c_void_p(out_db_dev) if out_db_dev else None, _ptr(out)))
+        return out
+
+    def shader_clock(self) -> Tuple[float, float]:
+        """(shader MHz, ns per VALU wave-instruction per SIMD) from a millisecond of saturated v_add_f32 (tdsa_shader_clock)."""
+        mhz, ns = C.c_float(), C.c_float()
+        nat.check(nat.lib.tdsa_shader_clock(self._h, C.byref(mhz), C.byref(ns)))
+        return float(mhz.value), float(ns.value)
+
     @property
     def dc_estimate(self) -> complex:
         re, im = C.c_float(), C.c_float()

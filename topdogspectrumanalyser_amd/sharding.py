@@ -7,7 +7,8 @@ the host: max/min hold with fmax/fmin (associative), Welch / uncapped "lin" aver
 float64 means and frame counts.  The "exp" and capped "lin" recurrences are order dependent: they run
 on one GPU per trace ("replicas only").
 """
-from typing import Sequence, Tuple
+import time
+from typing import Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -45,6 +46,89 @@ def combine_welch(means: Sequence[np.ndarray], counts: Sequence[int]) -> Tuple[n
         if c:
             acc += np.asarray(m, dtype=np.float64) * c
     return acc / total, total
+
+
+class WelchSlab:
+    """Host side of the cross-GPU Welch combine when every GPU has its own PROCESS (bench.py --config c5 --gpus N): a
+    POSIX shared-memory slab every rank maps - `slots` x world partial means of n float32 / float64 values plus the
+    ranks' progress counters - pinned in every process (tdsa_host_register) so that the export and the combine's
+    upload are plain DMA.  No collective and no pickling: rank r's plan writes its partial into slot (step mod slots),
+    publishes the step number, rank 0 waits for all of them, has ITS plan combine the slot on its device
+    (SpectrumEngine.welch_combine) and publishes `done`, which frees the slot for step + slots.
+
+    The protocol is plain stores and loads on x86 (total store order); the payload is complete before the counter moves
+    because tdsa_welch_export returns after its copy has finished."""
+
+    def __init__(self, name: Optional[str], world: int, rank: int, n: int, dtype=np.float32, slots: int = 2,
+                 pin: bool = True):
+        import os
+        import tempfile
+        import uuid
+        self.world, self.rank, self.n, self.slots = int(world), int(rank), int(n), int(slots)
+        self.dtype = np.dtype(dtype)
+        self._hdr = 64 * (self.world + 1)                       # one cache line per counter: ready[rank], then done
+        size = self._hdr + self.slots * self.world * self.n * self.dtype.itemsize
+        self.owner = name is None
+        if self.owner:                                          # a file in shared memory every rank maps
+            base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+            name = os.path.join(base, f"tdsa_welch_{os.getpid()}_{uuid.uuid4().hex[:8]}")
+            with open(name, "wb") as fh:
+                fh.truncate(size)
+        self.name = name
+        self._map = np.memmap(name, dtype=np.uint8, mode="r+", shape=(size,))
+        self._ctr = self._map[: self._hdr].view(np.int64)
+        self.parts = self._map[self._hdr:].view(self.dtype).reshape(self.slots, self.world, self.n)
+        self.pinned = False
+        if pin:
+            try:
+                from . import _native as nat
+                nat.check(nat.lib.tdsa_host_register(self.parts.ctypes.data, self.parts.nbytes))
+                self.pinned = True
+            except Exception:
+                self.pinned = False
+
+    def part(self, step: int) -> np.ndarray:
+        """this rank's partial of `step` (1-based); waits until the slot's previous use has been combined"""
+        while int(self._ctr[8 * self.world]) < step - self.slots:
+            pass
+        return self.parts[step % self.slots, self.rank]
+
+    def publish(self, step: int) -> None:
+        self._ctr[8 * self.rank] = step
+
+    def wait_all(self, step: int, timeout_s: float = 60.0) -> np.ndarray:
+        """rank 0: every rank's partial of `step` -> the slot [world, n]"""
+        t0 = time.perf_counter()
+        for r in range(self.world):
+            while int(self._ctr[8 * r]) < step:
+                if time.perf_counter() - t0 > timeout_s:
+                    raise TimeoutError(f"rank {r} did not deliver its Welch partial of step {step}")
+        return self.parts[step % self.slots]
+
+    def done(self, step: int) -> None:
+        self._ctr[8 * self.world] = step
+
+    def reset(self) -> None:
+        """between timed regions (all ranks at a barrier): counters back to zero"""
+        if self.rank == 0:
+            self._ctr[:] = 0
+
+    def close(self) -> None:
+        import os
+        if self.pinned:
+            try:
+                from . import _native as nat
+                nat.lib.tdsa_host_unregister(self.parts.ctypes.data)
+            except Exception:
+                pass
+            self.pinned = False
+        self._ctr = self.parts = self._map = None
+        if self.owner:
+            try:
+                os.unlink(self.name)
+            except OSError:
+                pass
+            self.owner = False
 
 
 def process_sharded(iq: np.ndarray, nfft: int, hop: int, devices: Sequence[int], window: np.ndarray,
