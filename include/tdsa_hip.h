@@ -159,7 +159,8 @@ int tdsa_process_dev(tdsa_plan p, int in_format, const void* iq_dev, size_t n_sa
  * remover, LDS-resident frame length) all of them leave as ONE persistent launch, which pays the per-launch
  * costs - cold fetch of window and twiddles, hold merge, the ragged last round of frames over the CUs - once
  * per call instead of once per capture; every other mode runs the captures one after the other inside the
- * call.  frames_per_seg <= max_frames; out_db_dev may be NULL. */
+ * call.  frames_per_seg <= max_frames; out_db_dev may be NULL; out_seg_stride_floats = 0 means "captures back to back"
+ * (frames_per_seg * nfft), a smaller non-zero stride - rows of different captures would overlap - is TDSA_ERR_ARG. */
 int tdsa_process_dev_batch(tdsa_plan p, int in_format, const void* iq_dev, size_t seg_stride_bytes,
                            int n_segments, size_t n_samples_per_seg, int hop, int frames_per_seg,
                            float* out_db_dev, size_t out_seg_stride_floats);
@@ -351,7 +352,13 @@ int tdsa_timer_end(tdsa_plan p, float* elapsed_ms); /* records, synchronises, re
 int tdsa_profile_enable(tdsa_plan p, int enable);
 int tdsa_profile_read(tdsa_plan p, int* launches, float* total_ms);
 
-/* ---- developer section (no reference counterpart; used by tools/ only) ---------------------- */
+/* ---- developer section (no reference counterpart; used by tools/ and tests/ only) ---------------------- */
+/* Plan parameters the tools and tests move to reach code paths that otherwise need other hardware or very long
+ * batches (the library reads nothing from the environment): "num_cu" (persistent grids sized for fewer CUs),
+ * "avg_wg_min" (batches of more frames take the workgroup-chunk averager scan), "avg_f64_chunks" (1: always the scan
+ * over fixed 64-frame chunks with float64 aggregates), "overlap_share" (percent of the CUs an overlapped launch is
+ * sized for), "big_group" (long-frame plans: segments per column / row round, 1 .. 64). */
+int tdsa_debug_knob(tdsa_plan p, const char* name, int value);
 /* Phase timeline of workgroup 0 of the frame kernel: allocates the plan's stamp buffer on first call;
  * host_out_2048 != NULL copies 2048 s_memtime stamps back.  Stamps are only written by a library built
  * with -DTDSA_TIMELINE (tools/timeline.py); a production build leaves them zero. */

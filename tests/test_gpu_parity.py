@@ -1220,8 +1220,8 @@ def test_welch_partials_combined_on_one_device(pkg, nfft, k, dtype):
     """tdsa_welch_export / tdsa_welch_combine (what bench.py --config c5 --gpus N does inside every timed
     step): three plans average unequal shares of a capture's segments (one of them none at all), hand out their running
     means as float32 / float64, and a fourth plan reassembles the overall mean ON ITS DEVICE.  The dB row must match the
-    float64 gold of the whole capture, float64 partials must give the row and the state of one plan that saw every
-    segment (the row to float32 rounding of the log, the state to 1e-15), float32 partials move the row by < 1e-6 dB;
+    float64 gold of the whole capture, float64 partials reproduce the host combine (sharding.combine_welch) to 1e-15 and, like float32 ones, the row of ONE
+    plan that saw every segment to 1e-5 dB (the plans group their float32 power sums differently);
     afterwards the combining plan carries the state: one more segment continues the running mean
     (utils/signal_processing.py:56-59)."""
     from topdogspectrumanalyser_amd import sharding
@@ -1255,11 +1255,12 @@ def test_welch_partials_combined_on_one_device(pkg, nfft, k, dtype):
         assert cnt == k
         host_mean, _ = sharding.combine_welch([p.astype(np.float64) for p in parts], counts)
         assert np.max(np.abs(mean - host_mean)) <= 1e-15 * np.max(host_mean) * k
-        if dtype == np.float64:
-            assert np.max(np.abs(mean - mean_one)) <= 4e-15 * np.max(mean_one)
-            assert np.max(np.abs(row - row_one)) <= 2e-6
-        else:
-            assert np.max(np.abs(row - row_one)) <= 1e-6 + 2e-6
+        # against ONE plan that saw every segment: that plan adds the segments' power in float32 inside its row pass
+        # (the LDS-resident sizes: float32 chunk aggregates), the partial plans in other groupings - the states agree to
+        # float32 summation rounding, the rows to a few float32 units of the dB value; float32 partials add 2.6e-7 dB
+        assert np.max(np.abs(mean - mean_one)) <= 1e-6 * np.max(mean_one)
+        d = np.abs(row - row_one)
+        assert np.all(d <= 1e-5), (float(d.max()), float(row_one[np.argmax(d)]))
         # the combining plan carries the state on: segment k + 1 joins the running mean
         nxt = comb.process(iq[2 * nfft * k:], hop=nfft)
         _check(nxt[-1], gold_next, "running mean continued after the combine")
@@ -1450,7 +1451,7 @@ def test_batch_averaging_with_workgroup_chunks(pkg, monkeypatch, avg, nfft, nf):
     the scan's own, the same chain.  Rows,
     hold traces and the averager state must follow the order-dependent recurrence of TraceAverager
     (utils/signal_processing.py:35-61) - against the float64 gold, against the three-pass scan with float64 aggregates
-    (TDSA_AVG_OLD=1) to within what a float32 aggregate can move a row (1e-5 dB), and across a split batch."""
+    (tdsa_debug_knob avg_f64_chunks) to within what a float32 aggregate can move a row (1e-5 dB), and across a split batch."""
     hop = nfft // 2
     iq = so.synth_iq_int8(hop * (nf - 1) + nfft, nfft, seed=71)
     gold, gmax, gmin = so.hackrf_batch(iq, nfft, hop, 20e6, precision="gold", avg=avg)
@@ -1461,11 +1462,13 @@ def test_batch_averaging_with_workgroup_chunks(pkg, monkeypatch, avg, nfft, nf):
         gold_src.power_levels(so.frame(x, nfft, hop, k))
     gold_state = np.asarray(gold_src.averager.buffer, dtype=np.float64)
 
-    def run(split):
+    def run(split, f64_chunks=False):
         with pkg.SpectrumEngine(nfft, max_frames=nf) as e:
             e.set_window(so.hackrf_window(nfft))
             e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=1.0, avg=avg,
                         hold_max=True, hold_min=True)
+            if f64_chunks:
+                e.debug_knob("avg_f64_chunks", 1)
             if split:
                 k0 = 300
                 a = e.process(iq[:2 * (hop * (k0 - 1) + nfft)], hop=hop)
@@ -1485,9 +1488,7 @@ def test_batch_averaging_with_workgroup_chunks(pkg, monkeypatch, avg, nfft, nf):
     assert np.max(np.abs(buf - gold_state)) <= 2e-5 * gold_state.max()        # float32 transform under a float64 average
     out_s, _, _, buf_s, _ = run(True)
     _check(out_s, gold, f"workgroup chunks, split batch {avg}")
-    monkeypatch.setenv("TDSA_AVG_OLD", "1")
-    out_o, mx_o, _, buf_o, _ = run(False)
-    monkeypatch.delenv("TDSA_AVG_OLD")
+    out_o, mx_o, _, buf_o, _ = run(False, f64_chunks=True)
     assert np.max(np.abs(out - out_o)) <= 1e-5, np.max(np.abs(out - out_o))
     assert np.max(np.abs(buf - buf_o)) <= 3e-7 * buf_o.max()
 
@@ -1496,21 +1497,21 @@ def test_batch_averaging_with_workgroup_chunks(pkg, monkeypatch, avg, nfft, nf):
 @pytest.mark.parametrize("nfft,nf", [(1024, 100), (4096, 60), (512, 49)])
 def test_short_averaged_batches_take_the_chunked_scan_too(pkg, monkeypatch, avg, nfft, nf):
     """Up to 4096 points the workgroup-chunk scan takes over from the one-thread-per-bin kernel at 49 frames already
-    (TDSA_AVG_WG_MIN): same rows as the sequential kernel to within a float32 aggregate, and the float64 gold."""
+    (tdsa_debug_knob avg_wg_min): same rows as the sequential kernel to within a float32 aggregate, and the float64 gold."""
     iq = so.synth_iq_int8(nfft * nf, nfft, seed=91)
     gold, _, _ = so.hackrf_batch(iq, nfft, nfft, 20e6, precision="gold", avg=avg)
 
-    def run():
+    def run(wg_min=None):
         with pkg.SpectrumEngine(nfft, max_frames=nf) as e:
             e.set_window(so.hackrf_window(nfft))
             e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=1.0, avg=avg)
+            if wg_min is not None:
+                e.debug_knob("avg_wg_min", wg_min)
             out = e.process(iq, hop=nfft)
             return out, e.averaged()[0]
     out, buf = run()
     _check(out, gold, f"short averaged batch {avg}")
-    monkeypatch.setenv("TDSA_AVG_WG_MIN", "100000")
-    out_s, buf_s = run()
-    monkeypatch.delenv("TDSA_AVG_WG_MIN")
+    out_s, buf_s = run(wg_min=100000)
     assert np.max(np.abs(out - out_s)) <= 1e-5
     assert np.max(np.abs(buf - buf_s)) <= 3e-7 * buf_s.max()
 
@@ -2600,10 +2601,9 @@ def test_batched_captures_full_c3_shape(pkg):
 
 @pytest.mark.parametrize("group", [1, 3, 5])
 def test_long_frame_welch_over_several_rounds(pkg, monkeypatch, group):
-    """The column / row rounds of the long-frame path (TDSA_BIG_GROUP segments each, 64 by default: one round for the
+    """The column / row rounds of the long-frame path (tdsa_debug_knob big_group segments each, 64 by default: one round for the
     C5 capture): with small rounds the row pass's per-workgroup partial rows are ADDED to from round to round (rounds of
     unequal size, fewer workgroups per row in the last one) and the result must not depend on the round size."""
-    monkeypatch.setenv("TDSA_BIG_GROUP", str(group))
     nfft, k, cal = 1 << 16, 8, -0.8087054556396822
     iq = so.synth_iq_int8(nfft * k, nfft, seed=17)
     gold, gold_mean = _welch_gold(iq, nfft, k, cal)
@@ -2611,9 +2611,9 @@ def test_long_frame_welch_over_several_rounds(pkg, monkeypatch, group):
         e.set_window(so.rtl_window("hanning", nfft).astype(np.float32))
         e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=-1.0, avg=("lin", k),
                     cal_offset_db=cal)
+        e.debug_knob("big_group", group)
         out = e.process(iq, hop=nfft)
         mean, cnt = e.averaged()
-    monkeypatch.delenv("TDSA_BIG_GROUP")
     with pkg.SpectrumEngine(nfft, max_frames=k) as e:
         e.set_window(so.rtl_window("hanning", nfft).astype(np.float32))
         e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=-1.0, avg=("lin", k),

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--hold", type=int, default=0)
     ap.add_argument("--state-only", action="store_true", help="no dB rows wanted (out = NULL): only the averager's state")
     ap.add_argument("--ring", type=int, default=4, help="distinct input / output buffers cycled through")
+    ap.add_argument("--f64-chunks", action="store_true", help="tdsa_debug_knob avg_f64_chunks: fixed 64-frame chunks, float64 aggregates")
     a = ap.parse_args()
     n, hop, F = a.nfft, a.hop, a.frames
     ns = hop * (F - 1) + n
@@ -41,6 +42,8 @@ def main():
     avg = (a.avg[0], int(a.avg[1]))
     e.configure(db_mode="pow", power_scale=1.0, log_floor=1e-10, dc_alpha=1.0, avg=avg, hold_max=bool(a.hold & 1),
                 hold_min=bool(a.hold & 2))
+    if a.f64_chunks:
+        e.debug_knob("avg_f64_chunks", 1)
 
     def step(i):
         r = i % a.ring
@@ -54,7 +57,7 @@ def main():
     ms = e.timer_end()
     us = ms / a.steps * 1e3
     algo = F * (2 * hop + 4 * n)
-    print(f"avg={avg} N={n} hop={hop} F={F} hold={a.hold} state_only={int(a.state_only)} old={os.environ.get('TDSA_AVG_OLD', '0')}  step {us:.1f} us  "
+    print(f"avg={avg} N={n} hop={hop} F={F} hold={a.hold} state_only={int(a.state_only)} f64_chunks={int(a.f64_chunks)}  step {us:.1f} us  "
           f"{algo / us / 1e6:.3f} TB/s algorithmic ({algo / us / 1e6 / 8 * 100:.1f} % of 8 TB/s)")
 
 

@@ -104,6 +104,7 @@ _SIGNATURES = {
     "tdsa_timer_begin": (C.c_int, [_P]),
     "tdsa_timer_end": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "tdsa_debug_timeline": (C.c_int, [_P, _P]),
+    "tdsa_debug_knob": (C.c_int, [_P, C.c_char_p, C.c_int]),
 }
 
 

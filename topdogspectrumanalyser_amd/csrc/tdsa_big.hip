@@ -46,19 +46,29 @@ __device__ __forceinline__ brsrc_t big_rsrc(const void* base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, int(bytes), 0x00020000);
 }
 typedef unsigned bu32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned bu32x4 __attribute__((ext_vector_type(4)));
+
+// A buffer store of more than 8 bytes whose data registers are overwritten by the next VALU instruction is a hazard on
+// gfx950 that ROCm 7.2's hazard recognizer pads only when the store's soffset is not a register: in round 3, with
+// `soffset = s4`, the compiler re-used v[78:81] for the next pair of rows right behind the store and rows came out
+// corrupted run to run (1e-6 .. 6e-4 of the frame maximum, only with more than 256 workgroups in flight; two 8-byte
+// stores were always right: tools/ubench/store_hazard.hip, profiles/r03_store_hazard.txt).  Rounds 3-4 kept the row
+// offset in the VGPR offset so that the recognizer padded it; since round 5 the store and its wait states are ONE
+// inline-asm block, whatever the compiler's recognizer thinks (tests/test_kernel_resources.py checks the ISA).
+__device__ __forceinline__ void store16_pinned(bu32x4 data, brsrc_t r, unsigned voff) {
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(data), "v"(voff), "s"(r));
+}
 
 // One thread per column n2.  X[k1] of the column sits in v[bitrev(k1)] after the in-register DIF.
-// WMODE (BigWindow::mode): 0 = the window is a table [N] (one 4-byte load per sample: 268 MB of L2 hits per 64-segment
-// capture at 2^20 points, +14 us of the column pass, profiles/r04_c5_experiments.txt); 1 = cosine-sum window
-// w[n] = a0 - a1 cos(2 pi n / (N - 1)) - np.hanning / np.hamming / np.ones, every window the reference's sources build
-// (hackrf_samples.py:314-316, rtl_samples.py:199-206) - evaluated in the kernel: with n = i 16384 + n2,
-// theta_i = 2 pi i 16384 / (N - 1) and phi = 2 pi n2 / (N - 1) <= 0.1,
-//   w = (a0 - a1 cos theta_i) + (a1 cos theta_i) (1 - cos phi) + (a1 sin theta_i) sin phi = w0[i] + wa[i] u + wb[i] s:
-// three row constants from the kernel arguments (scalar registers) and (u, s) of the column from one 8-byte load -
-// 3 VALU instructions instead of a load per sample.  The two products are at most 0.1 a1 (rounded to <= 4e-9 a1), w0
-// is rounded once as a table entry is: the kernel's window is within 2^-24 of the table the host verified it against
-// (tdsa_set_window); 2 = one value for every sample (rectangular windows; the all-ones window of the chirp-z path).
-template <int LOG2N1, int WMODE>
+// WFLAT: one window value for every sample (BigWindow::flat: rectangular windows, the all-ones window of the chirp-z
+// path) - no window loads; otherwise the window is a table [N], one 4-byte load per sample.  (Round 5 also evaluated
+// cosine-sum windows - every window the reference builds is a0 - a1 cos(2 pi n / (N - 1)) - in the kernel, from three
+// scalar row constants and two values per column, 2 FMAs per sample instead of the load: 249-252 us per 64-segment
+// capture against 231-238 with the table, 50.6 against 47.4 at 8 segments, alternating in one process,
+// profiles/r05_c5_experiments.txt - the pass has no VALU slots to spare; not kept.)
+// DC: the per-segment DC estimate is subtracted (HackRF branch); the RTL branch / BASELINE config 5 has none and its
+// instantiation skips the two subtractions per sample.
+template <int LOG2N1, bool WFLAT, bool DC>
 __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
   constexpr int N1 = 1 << LOG2N1;
   const int n2 = blockIdx.x * 256 + threadIdx.x;
@@ -68,17 +78,12 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
   // left 3e-7 * A_max in the DC bin)
   const float off = p.in_off;
   float sub_re = 0.f, sub_im = 0.f;
-  if (p.dc_sub != nullptr) { const c32 s = p.dc_sub[seg]; sub_re = s.x; sub_im = s.y; }
+  if constexpr (DC) { const c32 s = p.dc_sub[seg]; sub_re = s.x; sub_im = s.y; }
   const brsrc_t wr = big_rsrc(p.window, unsigned(N1) * kRowN * 4u);
   const unsigned wv = unsigned(n2) * 4u;
-  c32 wphi = c32{0.f, 0.f};                               // (1 - cos phi, sin phi) of this column (WMODE 1)
-  if constexpr (WMODE == 1) wphi = p.win.phi[n2];
-  const float4* __restrict__ wrow = p.win.row;            // uniform address, read before any store: scalar loads
-  auto win_value = [&](auto ic) -> float {                // window of sample (row i, this column)
-    constexpr int i = decltype(ic)::value;
-    if constexpr (WMODE == 1) { const float4 r = wrow[i]; return fmaf(r.z, wphi.y, r.y * wphi.x) + r.x; }
-    else if constexpr (WMODE == 2) return p.win.flat;
-    else return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wr, wv, unsigned(i) * kRowN * 4u, 0));
+  auto sample = [&](float re_raw, float im_raw, float ww) -> c32 {
+    if constexpr (DC) return c32{((re_raw - off) - sub_re) * ww, ((im_raw - off) - sub_im) * ww};
+    else return c32{(re_raw - off) * ww, (im_raw - off) * ww};
   };
   // W_N^(n2*k1), k1 = a + 8b, is built from the seeds W^(n2*a) (a < 8) and W^(n2*8b) with at most one product.  The seeds
   // depend on the column only: they come from a per-plan table [seed][n2] (evaluated in double, rounded once) as
@@ -92,10 +97,6 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
   static_for<1, NA>([&](auto ac) { constexpr int a = decltype(ac)::value; seeds[a][threadIdx.x] = p.tw_seed[(a - 1) * kRowN + n2]; });
   static_for<1, NB>([&](auto bc) { constexpr int b = decltype(bc)::value; seeds[NA + b][threadIdx.x] = p.tw_seed[(NA - 1 + b - 1) * kRowN + n2]; });
   c32 v[N1];
-#if defined(TDSA_EXP_COLS) && (TDSA_EXP_COLS == 2 || TDSA_EXP_COLS == 3)   // timing experiments: 2 = stores only (no loads, no arithmetic), 3 = arithmetic + stores, no sample / window loads
-  static_for<0, N1>([&](auto ic) { constexpr int i = decltype(ic)::value; v[i] = c32{float(n2 + i), float(seg)}; });
-  if (false)
-#endif
   if (p.in_c64) {
     // (chirp-z rows: the padding behind the first in_valid samples is implied - the descriptor ends there and a load
     //  past its end returns zeros)
@@ -103,85 +104,45 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
     static_for<0, N1>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       const bu32x2 q = __builtin_amdgcn_raw_buffer_load_b64(ir, unsigned(n2) * 8u, unsigned(i) * kRowN * 8u, 0);
-      const float ww = win_value(ic);
-      v[i] = c32{((__uint_as_float(q.x) - off) - sub_re) * ww, ((__uint_as_float(q.y) - off) - sub_im) * ww};
-      if constexpr (WMODE == 1 && i % 8 == 7) __builtin_amdgcn_sched_barrier(0);    // (SGPR pressure: see below)
+      float ww = p.win.flat;
+      if constexpr (!WFLAT) ww = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wr, wv, unsigned(i) * kRowN * 4u, 0));
+      v[i] = sample(__uint_as_float(q.x), __uint_as_float(q.y), ww);
     });
   } else {
     const brsrc_t ir = big_rsrc(p.in + (long long)seg * p.seg_stride, unsigned(N1) * kRowN * 2u);
     const unsigned xm = p.xor_mask & 0xffffu;
-#ifndef TDSA_COLS_LOADS_BATCHED   // (-DTDSA_COLS_LOADS_BATCHED: round 2's order, for A/B timing)
     // every load of the thread issued before the first conversion: the 2 N1 results land in the registers v[] will
-    // occupy anyway, and the memory latency is paid once instead of once per batch of ~20 the scheduler keeps in flight
-    unsigned ru[N1]; float rw[WMODE == 2 ? 1 : N1];
+    // occupy anyway, and the memory latency is paid once instead of once per batch of ~20 the scheduler keeps in flight.
+    // The samples are read once: non-temporal (aux bit 1), so that the raw bytes do not displace Z from the caches
+    unsigned ru[N1]; float rw[WFLAT ? 1 : N1];
     static_for<0, N1>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-#if defined(TDSA_EXP_COLS) && TDSA_EXP_COLS == 7      // timing experiment: no sample loads
-      ru[i] = unsigned(n2 + i);
-#else
       ru[i] = unsigned(__builtin_amdgcn_raw_buffer_load_b16(ir, unsigned(n2) * 2u, unsigned(i) * kRowN * 2u, 2));
-#endif
     });
-    if constexpr (WMODE == 0) {
+    if constexpr (!WFLAT) {
       static_for<0, N1>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-#if defined(TDSA_EXP_COLS) && TDSA_EXP_COLS == 5      // timing experiment: no window loads
-        rw[i] = 1.0f + float(i);
-#elif defined(TDSA_EXP_COLS) && TDSA_EXP_COLS == 6    // timing experiment: a quarter of the window loads
-        rw[i] = (i % 4 == 0) ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wr, wv, unsigned(i) * kRowN * 4u, 0)) : float(i);
-#else
         rw[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wr, wv, unsigned(i) * kRowN * 4u, 0));
-#endif
-      });
-    }
-    if constexpr (WMODE == 1) {
-      // the window values are formed while the sample loads are in flight (in the registers the table's loads would
-      // land in).  The rows' constants arrive through scalar loads, eight rows = 32 SGPRs at a time: hoisted to the top
-      // all 192 of them were live at once and 132 spilled; formed behind the sample loads' wait instead, every batch's
-      // scalar-load latency came on top of it (8-segment captures: 22.2 us against 18.5 with the table)
-      static_for<0, N1>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        rw[i] = win_value(ic);
-        if constexpr (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);
       });
     }
     __builtin_amdgcn_sched_barrier(0);
     static_for<0, N1>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       const unsigned u = ru[i] ^ xm;
-      float ww;
-      if constexpr (WMODE == 2) ww = win_value(ic); else ww = rw[i];
-      v[i] = c32{((float(u & 0xffu) - off) - sub_re) * ww, ((float((u >> 8) & 0xffu) - off) - sub_im) * ww};
+      float ww = p.win.flat;
+      if constexpr (!WFLAT) ww = rw[i];
+      v[i] = sample(float(u & 0xffu), float((u >> 8) & 0xffu), ww);
     });
-#else
-    static_for<0, N1>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      // read once: non-temporal (aux bit 1), so that the raw bytes do not displace Z from the caches
-      const unsigned u = unsigned(__builtin_amdgcn_raw_buffer_load_b16(ir, unsigned(n2) * 2u, unsigned(i) * kRowN * 2u, 2)) ^ xm;
-      const float ww = win_value(ic);
-      v[i] = c32{((float(u & 0xffu) - off) - sub_re) * ww, ((float((u >> 8) & 0xffu) - off) - sub_im) * ww};
-    });
-#endif
   }
-#if !(defined(TDSA_EXP_COLS) && (TDSA_EXP_COLS == 2 || TDSA_EXP_COLS == 4))   // (4 = loads + stores, no DFT)
   dif<N1, 0, N1>(v);
-#endif
   c32 lo[NA];
   static_for<1, NA>([&](auto ac) { constexpr int a = decltype(ac)::value; lo[a] = seeds[a][threadIdx.x]; });
-#ifdef TDSA_EXP_ZSLOTS   // timing experiment (wrong results): Z of segment s aliased onto slot s mod k, so that Z stays in the Infinity Cache
-  const brsrc_t zr = big_rsrc(p.z + (long long)(seg % TDSA_EXP_ZSLOTS) * N1 * kRowN, unsigned(N1) * kRowN * 8u);
-#else
   const brsrc_t zr = big_rsrc(p.z + (long long)seg * N1 * kRowN, unsigned(N1) * kRowN * 8u);
-#endif
-#ifdef TDSA_COLS_STORE8
-  const unsigned zv = unsigned(n2) * 8u;
-#else
   // 16-byte stores: the two lanes of a pair (columns n2, n2 + 1) exchange one value per pair of rows (k1, k1 + 1), the
   // even lane then stores both columns of row k1, the odd lane both columns of row k1 + 1
   const bool odd = (threadIdx.x & 1) != 0;
   const unsigned zv = (unsigned(n2) & ~1u) * 8u + (odd ? unsigned(kRowN) * 8u : 0u);
   c32 xprev = c32{0.f, 0.f};
-#endif
   static_for<0, NB>([&](auto bc) {
     constexpr int b = decltype(bc)::value;
     c32 hb = c32{1.f, 0.f};
@@ -193,10 +154,6 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
       if constexpr (b == 0 && a > 0) x = cmul(x, lo[a]);
       else if constexpr (b > 0 && a == 0) x = cmul(x, hb);
       else if constexpr (b > 0) x = cmul(x, cmul(hb, lo[a]));
-#ifdef TDSA_COLS_STORE8
-      const bu32x2 pk = {__float_as_uint(x.x), __float_as_uint(x.y)};
-      __builtin_amdgcn_raw_buffer_store_b64(pk, zr, zv, unsigned(k1) * kRowN * 8u, 0);
-#else
       if constexpr (N1 >= 2 && (k1 & 1) == 0) {
         xprev = x;                                  // row k1 (even): wait for row k1 + 1
       } else if constexpr (N1 >= 2) {
@@ -206,21 +163,10 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
         const float rx = __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(sx), 0xB1, 0xf, 0xf, true));
         const float ry = __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(sy), 0xB1, 0xf, 0xf, true));
         const float ox = odd ? x.x : xprev.x, oy = odd ? x.y : xprev.y;          // own value of the row this lane stores
-        typedef unsigned bu32x4 __attribute__((ext_vector_type(4)));
         const bu32x4 pk = {__float_as_uint(odd ? rx : ox), __float_as_uint(odd ? ry : oy),
                            __float_as_uint(odd ? ox : rx), __float_as_uint(odd ? oy : ry)};
-        // The row offset goes into the VGPR offset, NOT into an SGPR soffset: a buffer store of more than 8 bytes
-        // whose data registers are overwritten by the next VALU instruction is a hazard on gfx950, and ROCm 7.2's
-        // hazard recognizer only pads it when soffset is not a register.  With `soffset = s4` the compiler re-used
-        // v[78:81] for the next pair right behind the store and rows came out corrupted run-to-run (1e-6 .. 6e-4 of
-        // the frame maximum, only when more than 256 workgroups were in flight; two 8-byte stores were always right).
-#if defined(TDSA_EXP_COLS) && TDSA_EXP_COLS == 1   // timing experiment: no stores (one store per thread that never happens keeps the work alive)
-        if (pk.x == 0x7fc12345u) __builtin_amdgcn_raw_buffer_store_b128(pk, zr, zv + unsigned(k1 - 1) * kRowN * 8u, 0, 0);
-#else
-        __builtin_amdgcn_raw_buffer_store_b128(pk, zr, zv + unsigned(k1 - 1) * kRowN * 8u, 0, 0);
-#endif
+        store16_pinned(pk, zr, zv + unsigned(k1 - 1) * kRowN * 8u);
       }
-#endif
     });
   });
 }
@@ -316,7 +262,9 @@ __global__ void __launch_bounds__(1024, 4) big_rows_kernel(const BigRowsParams p
     // radix network | 8 middle of its combine | 9 behind its LDS writes | 10 behind the last pass's gather | 11 behind its
     // pre-twiddle | 12 behind its radix network | 13 middle of its combine.   TDSA_ROWS_FA / _FB: loads per position, a
     // leading 1 (keeps the literal decimal) and 7 decimal digits each (positions 0-6 / 7-13).
-#ifndef TDSA_ROWS_FA
+#if !(defined(TDSA_DEV) && defined(TDSA_ROWS_FA))
+#undef TDSA_ROWS_FA
+#undef TDSA_ROWS_FB
 #define TDSA_ROWS_FA 11010110
 #define TDSA_ROWS_FB 11011010
 #endif
@@ -739,11 +687,11 @@ __global__ void __launch_bounds__(256) big_dc_kernel(const double* sums, int n, 
 template <int L>
 static hipError_t cols_launch(const BigColsParams& p, int n_seg, hipStream_t s) {
   const dim3 grid(kRowN / 256, n_seg);
-  switch (p.win.mode) {
-    case 1: hipLaunchKernelGGL((big_cols_kernel<L, 1>), grid, dim3(256), 0, s, p); break;
-    case 2: hipLaunchKernelGGL((big_cols_kernel<L, 2>), grid, dim3(256), 0, s, p); break;
-    default: hipLaunchKernelGGL((big_cols_kernel<L, 0>), grid, dim3(256), 0, s, p); break;
-  }
+  const bool flat = p.win.mode == 2, dc = p.dc_sub != nullptr;
+  if (flat && dc) hipLaunchKernelGGL((big_cols_kernel<L, true, true>), grid, dim3(256), 0, s, p);
+  else if (flat) hipLaunchKernelGGL((big_cols_kernel<L, true, false>), grid, dim3(256), 0, s, p);
+  else if (dc) hipLaunchKernelGGL((big_cols_kernel<L, false, true>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((big_cols_kernel<L, false, false>), grid, dim3(256), 0, s, p);
   return hipGetLastError();
 }
 template <int L>

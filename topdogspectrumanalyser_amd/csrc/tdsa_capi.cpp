@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "../../include/tdsa_hip.h"
@@ -72,7 +73,7 @@ struct tdsa_plan_s {
   float* d_agg_w = nullptr;              // [max_frames] weight of each frame in its workgroup's aggregate
   double* d_chunk_a = nullptr;           // [kAvgMaxWgChunks + 64] per chunk: product of its frames' multipliers
   float* d_chunk_v = nullptr;            // [kAvgMaxWgChunks + 64] per chunk: 1 = has frames
-  long long agg_w_key[5] = {-1, -1, -1, -1, -1};   // (count, mode, n, frames, grid) the weights in d_agg_w were made for
+  long long agg_w_key[7] = {-1, -1, -1, -1, -1, -1, -1};   // (count, mode, n, frames, chunks, frames per unit, path) the weights in d_agg_w were made for
   float2* d_cplx = nullptr;              // [max_frames][N] complex spectra (real-input path)
   float2* d_real = nullptr;              // real-input path: the selected signal(s) as complex streams (two for stereo)
   size_t real_bytes = 0;
@@ -111,13 +112,10 @@ struct tdsa_plan_s {
   float2* d_tw_seed = nullptr;           // [big_seed_rows][16384] per-column twiddle seeds of the column pass
   float2* d_tw_row = nullptr;            // W_16384^m : the row pass's twiddle table
   float* d_ones = nullptr;               // [16384] unit window for the row pass
-  BigWindow big_win[3] = {};             // the column pass's window per input format (tdsa_set_window: table, cosine-sum or flat)
-  float2* d_wphi = nullptr;              // [16384] (1 - cos phi, sin phi), phi = 2 pi n2 / (N - 1): cosine-sum windows of long frames
-  float4* d_wrow = nullptr;              // [3][64] per input format and row i of the N1 x 16384 view: (w0, wa, wb, -) of BigWindow
-  int avg_wg_min = 128;                  // batches of more frames than this take the workgroup-chunk scan (developer knob TDSA_AVG_WG_MIN)
-  bool avg_scan_old = false;             // developer A/B (TDSA_AVG_OLD): chunk aggregates by the scan's own pass over the rows
+  BigWindow big_win[3] = {};             // the column pass's window per input format (tdsa_set_window: table or one value)
+  int avg_wg_min = 128;                  // batches of more frames than this take the workgroup-chunk scan (tdsa_debug_knob "avg_wg_min")
+  bool avg_f64_chunks = false;           // tdsa_debug_knob "avg_f64_chunks": always the scan over fixed 64-frame chunks with float64 aggregates
   int big_group = 64;                    // segments per column-pass / row-pass round (one round for the K = 64 Welch capture)
-  bool big_rows_old = false;             // TDSA_BIG_ROWS_OLD=1: row pass through the frame kernel's ACC instantiation (rounds 2-3)
   // frame lengths that are not a power of two (tdsa_chirp.hip): chirp-z on the m_fft-point frame kernel
   bool chirp = false;
   int m_fft = 0, log2m = 0;              // M = 2^log2m >= 2 nfft - 1
@@ -217,9 +215,13 @@ int launch_spectrum_profiled(tdsa_plan p, int in_c64, const SpecParams& sp, cons
 // takes it from there.  With fixed chunks of 64 frames one thread per bin walked hundreds of chunks in order: 75 of the
 // 169 us of a 19 531-frame batch at N = 1024.  Short batches keep the 64-frame chunks.
 static int avg_use_ranges(tdsa_plan p, AvgParams& ap, int n_frames, hipStream_t s) {
-  if (p->avg_scan_old || n_frames <= 1024 || p->d_carry == nullptr) return TDSA_OK;
+  if (p->avg_f64_chunks || n_frames <= 1024 || p->d_carry == nullptr) return TDSA_OK;
   const int ranges = (n_frames + 63) / 64 < 256 ? (n_frames + 63) / 64 : 256;
   if (size_t(ranges) > p->carry_chunks) return TDSA_OK;
+  // a range's aggregate is a float32 sum: kept to the ~160 frames the workgroup-chunk path allows itself; longer
+  // ranges (batches of more than 40 960 frames here) take the 64-frame chunks with their float64 aggregates - the
+  // reference's TraceAverager is float64 throughout (utils/signal_processing.py:48)
+  if ((n_frames + ranges - 1) / ranges > 160) return TDSA_OK;
   const size_t row = size_t(p->nfft);                  // (rows of the real-input path are shorter: nfft / 2 + 1)
   if (!p->d_agg) {      // (a native plan may also take the workgroup-chunk path on another call: one row per workgroup of its grid)
     const size_t grid_rows = (p->chirp || p->big) ? 0 : size_t(spectrum_geometry(p->log2n, p->max_frames, p->num_cu).grid);
@@ -234,7 +236,7 @@ static int avg_use_ranges(tdsa_plan p, AvgParams& ap, int n_frames, hipStream_t 
   ap.wg_fold = 1;
   ap.agg = p->d_agg;
   ap.agg_w_local = p->d_agg_w;
-  const long long key[5] = {p->avg_count, ap.mode, ap.avg_n, n_frames, ranges};
+  const long long key[7] = {p->avg_count, ap.mode, ap.avg_n, n_frames, ranges, 1, 1};          // path 1: equal ranges of the batch
   if (std::memcmp(key, p->agg_w_key, sizeof(key)) != 0) {
     HIPCHK(launch_avg_weights(ap, p->d_agg_w, p->d_chunk_a, p->d_chunk_v, s));
     std::memcpy(p->agg_w_key, key, sizeof(key));
@@ -294,26 +296,6 @@ int process_big(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n_f
     HIPCHK(launch_big_cols(p->log2n, static_cast<const unsigned char*>(iq_dev) + (long long)s0 * stride, in_c64, stride, ns,
                            p->big_win[in_format], p->d_tw_seed, dc_sub ? dc_sub + s0 : nullptr, p->d_z,
                            xor_mask, in_off, p->stream));
-    SpecParams sp{};
-    sp.in = p->d_z;
-    sp.frame_stride = (long long)N * sizeof(float2);            // segment to segment
-    sp.group = ns;
-    sp.group_stride = (long long)(1 << 14) * sizeof(float2);    // k1 row to k1 row
-    sp.n_frames = n1 * ns;
-    sp.first_frame_index = 1;
-    sp.window = p->d_ones;
-    sp.window_perm = p->d_ones;                                 // all ones: any order
-    sp.tw = p->d_tw_row;
-    sp.in_scale = 1.0f;
-    sp.dc_mode = DC_NONE;
-    sp.db_mode = TDSA_DB_POW;
-    sp.pscale = 1.0f;
-    sp.acc = p->d_acc;
-    sp.acc_split = split_layout;
-    sp.acc_active = act;
-    sp.acc_add = s0 > 0;
-    LaunchGeom g = spectrum_geometry(14, sp.n_frames, p->num_cu);
-    g.grid = n1 * act;                                           // workgroup b = k1 * act + j
     if (p->profiling) {
       if (p->prof_used + 2 > p->prof_events.size()) {
         hipEvent_t a, b;
@@ -324,8 +306,7 @@ int process_big(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n_f
       }
       HIPCHK(hipEventRecord(p->prof_events[p->prof_used], p->stream));
     }
-    if (p->big_rows_old) HIPCHK(launch_spectrum_acc(sp, g, p->stream));    // developer A/B: the frame kernel's ACC instantiation
-    else HIPCHK(launch_big_rows(p->d_z, (long long)N * sizeof(float2), ns, n1, act, p->d_acc, split_layout, s0 > 0, p->d_tw_row,
+    HIPCHK(launch_big_rows(p->d_z, (long long)N * sizeof(float2), ns, n1, act, p->d_acc, split_layout, s0 > 0, p->d_tw_row,
                                 p->stream));
     if (p->profiling) {
       HIPCHK(hipEventRecord(p->prof_events[p->prof_used + 1], p->stream));
@@ -570,19 +551,9 @@ static int plan_init(tdsa_plan p) {
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, device_id));
   p->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  if (const char* c = getenv("TDSA_NUM_CU")) {          // developer knob: persistent grids sized for fewer CUs
-    const int v = atoi(c);
-    if (v >= 1 && v <= p->num_cu) p->num_cu = v;
-  }
-  p->avg_scan_old = getenv("TDSA_AVG_OLD") != nullptr;
   // one thread per bin walking the frames beats the three launches of the chunked scan up to ~48 frames at N <= 4096
   // (N = 1024, 128 frames: 24.5 against 13.9 us) and up to ~128 at the larger sizes (N = 16384: 33.7 against 35.0 us)
   p->avg_wg_min = nfft <= 4096 ? 48 : 128;
-  if (const char* c = getenv("TDSA_AVG_WG_MIN")) { const int v = atoi(c); if (v >= 1) p->avg_wg_min = v; }
-  if (const char* c = getenv("TDSA_OVERLAP_SHARE")) {   // developer knob: CU share (percent) of an overlapped launch
-    const int v = atoi(c);
-    if (v >= 10 && v <= 100) p->overlap_share = v;
-  }
   HIPCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreate(&p->ev0));
   HIPCHK(hipEventCreate(&p->ev1));
@@ -686,11 +657,6 @@ static int plan_init(tdsa_plan p) {
     }
   }
   if (big) {
-    if (const char* o = getenv("TDSA_BIG_ROWS_OLD")) p->big_rows_old = atoi(o) != 0;
-    if (const char* g = getenv("TDSA_BIG_GROUP")) {     // developer knob: segments per column/row round
-      const int v = atoi(g);
-      if (v >= 1 && v <= 64) p->big_group = v;
-    }
     HIPCHK(hipMalloc(&p->d_sum, size_t(nfft) * sizeof(double)));
     HIPCHK(hipMalloc(&p->d_lin64, size_t(nfft) * sizeof(double)));
     {   // per-workgroup partial power sums of the row pass: [N1 * split][16384], split = workgroups per k1 row
@@ -754,7 +720,7 @@ int tdsa_destroy(tdsa_plan p) {
                   p->d_window_perm[2], p->d_tw, p->d_hold_max, p->d_hold_min,
                   p->d_avg, p->d_lin, p->d_carry, p->d_agg, p->d_agg_w, p->d_chunk_a, p->d_chunk_v, p->d_cplx, p->d_real, p->d_lin1, p->d_db1, p->d_dc_state, p->d_sums, p->d_dc_sub,
                   p->d_tare_base, p->d_tare_acc, p->d_in_stage, p->d_out_stage, p->d_trace_in,
-                  p->d_trace_live, p->d_scratch, p->d_z, p->d_wphi, p->d_wrow, p->d_welch, p->d_clock, p->d_chirp_a, p->d_chirp_b, p->d_u0, p->d_u1, p->d_acc, p->d_sum, p->d_lin64, p->d_sums64, p->d_tw_seed, p->d_tw_row, p->d_ones,
+                  p->d_trace_live, p->d_scratch, p->d_z, p->d_welch, p->d_clock, p->d_chirp_a, p->d_chirp_b, p->d_u0, p->d_u1, p->d_acc, p->d_sum, p->d_lin64, p->d_sums64, p->d_tw_seed, p->d_tw_row, p->d_ones,
                   p->d_dbg};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -792,63 +758,16 @@ int tdsa_get_info(tdsa_plan p, tdsa_info* out) {
   return TDSA_OK;
 }
 
-// Long frames: the column pass fetches the window sample by sample - one 4-byte load each, 268 MB of L2 hits per
-// 64-segment capture at 2^20 points.  Every window the reference's sources build is a cosine-sum
-// w[n] = a0 - a1 cos(2 pi n / (N - 1)) (np.hanning, np.hamming, np.ones; hackrf_samples.py:314-316 divides np.hanning by
-// its rms, rtl_samples.py:199-206): when the table the caller handed over IS one - a0, a1 by least squares in double,
-// then every sample within one float32 rounding unit (2^-23 of the largest value: the table's own rounding plus the
-// float32 division of the HackRF normalisation) - the column pass evaluates it from three constants per row of the
-// N1 x 16384 view and two values per column instead (BigWindow, tdsa_big.hip); a1 = 0: one value for every sample.
-// Any other table is read as before.
+// Long frames: the column pass fetches the window sample by sample (one 4-byte load each).  A window that is ONE value
+// throughout - np.ones, rtl_samples.py:203-204 - travels as that value instead (BigWindow::flat); every other table
+// is read.  (The cosine-sum windows the reference builds were also evaluated in the kernel in round 5 - two FMAs per
+// sample from three scalar row constants: slower than the loads, see tdsa_big.hip; not kept.)
 static int big_window_model(tdsa_plan p, const float* w, const float scale[3]) {
-  const int n = p->nfft, n1 = n >> kMaxLog2N, nrow = 1 << kMaxLog2N;
+  bool flat = true;
+  for (int i = 1; i < p->nfft && flat; ++i) flat = w[i] == w[0];
   for (int f = 0; f < 3; ++f) {
-    p->big_win[f] = BigWindow{};
-    p->big_win[f].table = p->d_window[f];
+    p->big_win[f] = BigWindow{flat ? 2 : 0, p->d_window[f], w[0] * scale[f]};
   }
-#ifdef TDSA_DEV
-  if (getenv("TDSA_BIG_WIN_TABLE")) return TDSA_OK;       // developer A/B: always the table
-#endif
-  // least squares for w[n] ~ a0 - a1 c[n], c[n] = cos(2 pi n / (N - 1)), in double
-  const double step = 2.0 * M_PI / double(n - 1);
-  double sc = 0.0, scc = 0.0, sw = 0.0, swc = 0.0, wmax = 0.0;
-  std::vector<double> c(n);
-  for (int i = 0; i < n; ++i) {
-    c[i] = std::cos(step * double(i));
-    sc += c[i]; scc += c[i] * c[i]; sw += double(w[i]); swc += double(w[i]) * c[i];
-    wmax = std::fmax(wmax, std::fabs(double(w[i])));
-  }
-  const double det = double(n) * scc - sc * sc;
-  if (!(det > 0.0) || !(wmax > 0.0) || !std::isfinite(wmax)) return TDSA_OK;
-  const double a0 = (sw * scc - swc * sc) / det, a1 = (sw * sc - swc * double(n)) / det;   // w ~ a0 - a1 c
-  double err = 0.0;
-  for (int i = 0; i < n; ++i) err = std::fmax(err, std::fabs(double(w[i]) - (a0 - a1 * c[i])));
-  if (!(err <= std::ldexp(wmax, -23))) return TDSA_OK;       // not a cosine-sum window: the table
-  const bool flat = std::fabs(a1) <= std::ldexp(wmax, -26);
-  if (!flat && !p->d_wphi) {
-    std::vector<float2> phi(nrow);
-    for (int n2 = 0; n2 < nrow; ++n2) {
-      const double h = std::sin(0.5 * step * double(n2));
-      phi[n2] = float2{float(2.0 * h * h), float(std::sin(step * double(n2)))};
-    }
-    HIPCHK(hipMalloc(&p->d_wphi, size_t(nrow) * sizeof(float2)));
-    HIPCHK(hipMemcpy(p->d_wphi, phi.data(), size_t(nrow) * sizeof(float2), hipMemcpyHostToDevice));
-  }
-  if (!p->d_wrow) HIPCHK(hipMalloc(&p->d_wrow, size_t(3) * 64 * sizeof(float4)));
-  std::vector<float4> rows(size_t(3) * 64, float4{0.f, 0.f, 0.f, 0.f});
-  for (int f = 0; f < 3; ++f) {
-    BigWindow& bw = p->big_win[f];
-    bw.mode = flat ? 2 : 1;
-    bw.phi = p->d_wphi;
-    bw.row = p->d_wrow + size_t(f) * 64;
-    const double sf = double(scale[f]);
-    bw.flat = float(sf * a0);
-    for (int i = 0; i < n1; ++i) {
-      const double th = step * double(i) * double(nrow);
-      rows[size_t(f) * 64 + i] = float4{float(sf * (a0 - a1 * std::cos(th))), float(sf * a1 * std::cos(th)), float(sf * a1 * std::sin(th)), 0.0f};
-    }
-  }
-  HIPCHK(hipMemcpy(p->d_wrow, rows.data(), rows.size() * sizeof(float4), hipMemcpyHostToDevice));
   return TDSA_OK;
 }
 
@@ -1058,7 +977,7 @@ static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size
     const int wg_fold = (g.grid + 255) / 256;
     const int units = (n_frames + g.fpw - 1) / g.fpw;
     const bool wg_chunks = n_frames > p->avg_wg_min && g.grid <= kAvgMaxWgChunks &&
-                           ((units + g.grid - 1) / g.grid) * g.fpw * wg_fold <= 160 && !p->avg_scan_old;
+                           ((units + g.grid - 1) / g.grid) * g.fpw * wg_fold <= 160 && !p->avg_f64_chunks;
     const size_t agg_rows = size_t(spectrum_geometry(p->log2n, p->max_frames, p->num_cu).grid);
     const size_t need_chunks = wg_chunks ? (agg_rows < 256 ? agg_rows : size_t(256))
                                          : (p->max_frames > 128 ? size_t(avg_scan_chunks(p->max_frames)) : 0);
@@ -1094,7 +1013,7 @@ static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size
       ap.agg = p->d_agg;
       // the weights depend on where the averager stands and on the chunking only: in steady state (exp mode, or lin
       // with its count at the cap) consecutive calls of one shape re-use them
-      const long long key[5] = {p->avg_count, m.avg_mode, m.avg_n, n_frames, g.grid};
+      const long long key[7] = {p->avg_count, m.avg_mode, m.avg_n, n_frames, g.grid, g.fpw, 0};    // path 0: the frame kernel's workgroup ranges
       if (std::memcmp(key, p->agg_w_key, sizeof(key)) != 0) {
         HIPCHK(launch_avg_weights(ap, p->d_agg_w, p->d_chunk_a, p->d_chunk_v, p->stream));
         std::memcpy(p->agg_w_key, key, sizeof(key));
@@ -1157,6 +1076,7 @@ int tdsa_process_dev_batch(tdsa_plan p, int in_format, const void* iq_dev, size_
   if (n_segments > 1 && seg_stride_bytes % (bps == 8 ? 8 : 2) != 0)
     return fail(TDSA_ERR_ARG, "seg_stride_bytes=%zu must be a multiple of one sample", seg_stride_bytes);
   if (frames_per_seg < 0) return fail(TDSA_ERR_ARG, "frames_per_seg=%d", frames_per_seg);
+  if (out_seg_stride_floats == 0) out_seg_stride_floats = size_t(frames_per_seg) * size_t(p->nfft);   // captures back to back
   // the captures' rows must not overlap: with a stride below one capture's rows the one-launch path would have
   // several workgroups write the same rows concurrently (which capture survives would not be deterministic)
   if (n_segments > 1 && out_db_dev != nullptr && !p->big &&
@@ -1777,6 +1697,40 @@ int tdsa_memcpy_h2d(int device_id, void* dst_dev, const void* src_host, size_t b
 int tdsa_memcpy_d2h(int device_id, void* dst_host, const void* src_dev, size_t bytes) {
   HIPCHK(hipSetDevice(device_id));
   HIPCHK(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+  return TDSA_OK;
+}
+
+// developer hook: plan parameters the tools and the tests move to reach code paths that otherwise need other hardware
+// or very long batches (rounds 1-4 read them from the environment at plan creation: ADVICE r4)
+int tdsa_debug_knob(tdsa_plan p, const char* name, int value) {
+  if (!p || !name) return fail(TDSA_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(p->device));
+  JOIN(p);
+  HIPCHK(hipStreamSynchronize(p->stream));
+  const std::string k(name);
+  if (k == "num_cu") {                       // persistent grids sized for fewer CUs
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, p->device));
+    (void)prop;
+    if (value < 1 || value > p->num_cu) return fail(TDSA_ERR_ARG, "num_cu=%d outside [1, %d] (it can only shrink: buffers are sized for it)", value, p->num_cu);
+    p->num_cu = value;
+    p->agg_w_key[0] = -1;
+  } else if (k == "avg_wg_min") {            // batches of more frames than this take the workgroup-chunk scan
+    if (value < 1) return fail(TDSA_ERR_ARG, "avg_wg_min=%d", value);
+    p->avg_wg_min = value;
+  } else if (k == "avg_f64_chunks") {        // 1: always the scan over fixed 64-frame chunks with float64 aggregates
+    p->avg_f64_chunks = value != 0;
+    p->agg_w_key[0] = -1;
+  } else if (k == "overlap_share") {         // percent of the CUs an overlapped launch is sized for
+    if (value < 10 || value > 100) return fail(TDSA_ERR_ARG, "overlap_share=%d outside [10, 100]", value);
+    p->overlap_share = value;
+  } else if (k == "big_group") {             // long-frame plans: segments per column / row round (<= the 64 the plan was made for)
+    if (!p->big || value < 1 || value > 64) return fail(TDSA_ERR_ARG, "big_group=%d (long-frame plans, 1 .. 64)", value);
+    if (p->d_z && value > p->big_group) return fail(TDSA_ERR_STATE, "big_group can only shrink once the plan has run");
+    p->big_group = value;
+  } else {
+    return fail(TDSA_ERR_ARG, "unknown knob '%s'", name);
+  }
   return TDSA_OK;
 }
 

@@ -58,18 +58,6 @@ struct SpecParams {
   float cal_db;              // calibration offset added to dB
   int hold_flags;            // bit0 max, bit1 min
   unsigned long long* dbg;   // developer timeline buffer (TDSA_TIMELINE builds only), else null
-  // ---- row pass of the N1 x 16384 big-FFT path (tdsa_big.hip): complex64 rows Z[seg][k1][n2] ----
-  // frame f reads from  in + (f % group) * frame_stride + (f / group) * group_stride  and its linear power |X|^2
-  // (bin in natural order, no dB, no fftshift) joins the sum of its group (the K Welch segments of one k1).
-  // Workgroup b = k1 * acc_active + j owns a contiguous share of group k1's frames: the sum stays in registers and
-  // leaves once, as the workgroup's own row of P - plain stores, summed over j by the gather kernel (round 2 added
-  // 4 M float atomics per launch here: 8 us, and results that changed from run to run)
-  int group;
-  long long group_stride;
-  float* acc;                // ACC: partial power sums P[k1 * acc_split + j][bin], one row per workgroup (no atomics)
-  int acc_split;             // rows of P per k1 (layout; the first round of a call fixes it)
-  int acc_active;            // workgroups per k1 in THIS launch (<= acc_split): grid = N1 * acc_active
-  int acc_add;               // 0: the row is overwritten (first round of a call), 1: added to what the row holds
   // ---- several captures ("segments") in one launch (tdsa_process_dev_batch) ----
   // frame f belongs to segment s = floor(f / seg_frames) = umulhi(f, seg_magic), frame fi = f - s * seg_frames of it:
   // it reads from in + s * seg_in_stride + fi * frame_stride and its row goes to out + (s * seg_out_stride + fi * N)
@@ -197,15 +185,12 @@ constexpr int big_seed_rows(int log2n) {
   const int n1 = 1 << (log2n - 14), na = n1 < 8 ? n1 : 8, nb = n1 / na;
   return (na - 1) + (nb - 1);
 }
-// The window as the column threads get it.  mode 0: `table` [N] (window * input scale), one load per sample.  mode 1: a
-// cosine-sum window a0 - a1 cos(2 pi n / (N - 1)) evaluated in the kernel from three constants per row i of the
-// N1 x 16384 view (device table row[i] = (w0, wa, wb, -): w = w0 + wa (1 - cos phi) + wb sin phi, phi = 2 pi n2 / (N - 1);
-// `phi` [16384] holds the column's (1 - cos phi, sin phi)).  mode 2: `flat` for every sample.  tdsa_set_window decides.
+// The window as the column threads get it.  mode 0: `table` [N] (window * input scale), one load per sample.
+// mode 2: `flat` for every sample (rectangular windows, the chirp-z path's all-ones window): no loads at all.
+// tdsa_set_window decides (tdsa_capi.cpp).
 struct BigWindow {
   int mode;
   const float* table;
-  const float2* phi;
-  const float4* row;
   float flat;
 };
 hipError_t launch_big_cols(int log2n, const void* in, int in_c64, long long seg_stride, int n_seg, const BigWindow& win,
@@ -219,9 +204,7 @@ hipError_t launch_big_cols_out(int log2m, const float2* r, long long seg_stride,
 hipError_t launch_big_dc(const void* in, int in_c64, unsigned xor_mask, long long frame_stride, int n, int n_frames,
                          double alpha, double in_off, double in_scale, double* sums, float2* dc_state, float2* dc_res,
                          hipStream_t s);
-// row pass: the 16384-point frame kernel on complex64 rows, power summed per group into p.acc
-hipError_t launch_spectrum_acc(const SpecParams& p, const LaunchGeom& g, hipStream_t s);
-// the same as a kernel of its own (round 4): split fetch of the next row, see tdsa_big.hip
+// row pass: 16384-point transforms of the rows, power summed per workgroup (tdsa_big.hip)
 hipError_t launch_big_rows(const float2* z, long long seg_stride, int group, int n1, int act, float* acc, int acc_split,
                            int acc_add, const float2* tw, hipStream_t s);
 // P[k1 * split + j][k2] float partial sums -> dst[(k1 + N1*k2) ^ N/2] double (overwrite or accumulate)

@@ -19,7 +19,4 @@ template <>
 hipError_t perm_size<TDSA_LOG2N>(const float* w, float* wp, hipStream_t s) {
   return perm_for<TDSA_LOG2N>(w, wp, s);
 }
-#if TDSA_LOG2N == 14
-hipError_t launch_spectrum_acc(const SpecParams& p, const LaunchGeom& g, hipStream_t s) { return launch_acc<14>(p, g, s); }
-#endif
 }  // namespace tdsa

@@ -28,6 +28,10 @@
 //   * a workgroup processes a CONTIGUOUS range of frames (overlapping frames re-read their shared half from the
 //     same XCD's L2, not from HBM); the dB rows leave with non-temporal stores.
 #pragma once
+#ifndef TDSA_DEV          // the two developer builds left (tools/build_variants.sh dev "-DTDSA_DEV -DTDSA_TIMELINE"):
+#undef TDSA_TIMELINE      //   s_memtime stamps of workgroup 0 at the phase boundaries (tdsa_debug_timeline, tools/timeline.py)
+#undef TDSA_DYN_PRIO      //   falling issue priorities through a barrier phase (profiles/r03_c3_timeline_dynprio.txt)
+#endif
 #include "tdsa_fft.hpp"
 #include "tdsa_kernels.hpp"
 
@@ -44,11 +48,7 @@ struct Cfg {
   static constexpr int H = A / 2;                         // first-pass radix done inside one lane (even / odd row split)
   // INL: pass 1 entirely inside a lane (see the kernel); R1 = in-lane radix of pass 1, CPT = adjacent columns
   // (samples) per row read of a half-thread
-#ifdef TDSA_NO_INL    // developer A/B: the even / odd row split at every size, as in rounds 1-2
-  static constexpr bool INL = false;
-#else
   static constexpr bool INL = (M >= 8) && (NPASS == 3);
-#endif
   static constexpr int R1 = INL ? A : H;
   static constexpr int CPT = INL ? M / 2 : M;
   static constexpr int WGT = TPF > 256 ? TPF : 256;       // threads per workgroup
@@ -166,27 +166,23 @@ constexpr int kRowStorePolicy = 2;
 constexpr float k10Log10_2 = 3.01029995663981195214f;   // 10*log10(2)
 constexpr float kMagExactBelow = 1e-8f;                  // |X|^2 below this: the 1e-12 floor is visible
 
-// developer ablation builds (-DTDSA_ABLATE=mask): 1 no barriers, 2 no LDS exchange, 4 no dB stores,
-// 16 no middle-pass table reads, 32 no half-wave swaps, 64 no log, 128 no last pre-twiddle, 256 no
-// middle pre-twiddle, 512 no last radix-16, 2048 no global loads inside the frame loop (bytes and window of the first frame stay), 4096 / 8192 / 16384 only 1 / 2 / 3 waves per SIMD stay.  Results are
-// wrong by construction; timing only.
-#ifndef TDSA_ABLATE
-#define TDSA_ABLATE 0
-#endif
+// (The timing-only ablation switches of rounds 2-4 - no barriers / LDS exchange / stores / swaps / log / twiddles, fewer
+//  waves, the DIF network, unfused twiddles and window, staggered workgroups - went out with round 5: what they measured is
+//  in profiles/r03_c3_ablation.txt, r03_c3_experiments.txt, r04_c3_proto.txt and profiles/HISTORY.md; the tree at the
+//  round-4 verdict (git: 2ece423) still builds them.  tests/test_isa_frozen.py pins the instruction streams they
+//  were taken out of.)
 // Phase boundary inside the frame loop.  When a frame lives inside one wave (N <= 1024) everything the
 // phases exchange through LDS is private to that wave: its DS operations execute in order, so only the
 // compiler has to be kept from reordering across the boundary and the waves of a workgroup run free of
 // each other.  Larger frames span several waves and need the workgroup barrier.
 #define TDSA_SYNC()                                                        \
   do {                                                                     \
-    if constexpr ((TDSA_ABLATE & 1) == 0) {                                \
-      if constexpr (C::TPF <= 64) {                                        \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");             \
-        __builtin_amdgcn_wave_barrier();                                   \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");             \
-      } else {                                                             \
-        __syncthreads();                                                   \
-      }                                                                    \
+    if constexpr (C::TPF <= 64) {                                          \
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");               \
+      __builtin_amdgcn_wave_barrier();                                     \
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");               \
+    } else {                                                               \
+      __syncthreads();                                                     \
     }                                                                      \
   } while (0)
 
@@ -233,14 +229,10 @@ __device__ __forceinline__ void swap_halves(c32& a, c32& b) {
 }
 
 // In-register radix network of the passes: decimation in time with the twiddles folded into FMAs
-// (tdsa_fft.hpp: 6 instructions per general butterfly instead of 8); -DTDSA_DIF restores the DIF network.
+// (tdsa_fft.hpp: 6 instructions per general butterfly instead of 8).
 template <int R, int BASE, int TOT>
 __device__ __forceinline__ void radix(c32 (&v)[TOT]) {
-#ifdef TDSA_DIF
-  dif<R, BASE, TOT>(v);
-#else
   dit<R, BASE, TOT>(v);
-#endif
 }
 
 // radix-2 combine  (E, O) -> (E + w O, E - w O)  in six FMAs (second output as 2E - first)
@@ -255,30 +247,13 @@ __device__ __forceinline__ void combine(c32& e, c32& o, c32 w) {
 template <int U, bool EXACT = false>
 __device__ __forceinline__ void combine32(c32& e, c32& o, bool odd_half) {
   const c32 orot = c32{odd_half ? o.y : o.x, odd_half ? -o.x : o.y};
-#ifdef TDSA_DIF
-  const c32 t = mul_w<U, 32>(orot);
-  o = csub(e, t);
-  e = cadd(e, t);
-#else
   o = orot;
   bf_w<U, 32, EXACT>(e, o);
-#endif
 }
 template <int K, int R, bool EXACT = false>   // compile-time twiddle W_R^K
 __device__ __forceinline__ void combine_const(c32& e, c32& o) {
-#ifdef TDSA_DIF
-  const c32 t = mul_w<K, R>(o);
-  o = csub(e, t);
-  e = cadd(e, t);
-#else
   bf_w<K, R, EXACT>(e, o);
-#endif
 }
-// developer experiment (-DTDSA_EXACT_MASK=m): the difference output of the cross-lane combine of pass 1 (bit 0) / of the
-// middle pass (bit 1) formed with its own FMAs as in the last pass (parity soak: does the worst deep bin move?)
-#ifndef TDSA_EXACT_MASK
-#define TDSA_EXACT_MASK 0
-#endif
 
 // Thread layout: a wave owns 32 consecutive butterfly rows; lane l < 32 is the EVEN half-thread of row
 // (l & 31), lane l + 32 the ODD half-thread of the same row.  Every radix-R pass is done as two
@@ -288,7 +263,7 @@ __device__ __forceinline__ void combine_const(c32& e, c32& o) {
 // halves do full butterflies and no lane idles.  16 points per thread keeps the kernel under 128 VGPRs:
 // 4 waves per SIMD, which is what it takes to keep the VALU fed (one wave issues at most one VALU op
 // every 4 clocks; the SIMD retires one every 2).
-template <int LOG2N, bool IN_C64, int HOLD, bool ACC = false>   // HOLD: bit0 = max trace, bit1 = min trace; 4 = AGG (see below)
+template <int LOG2N, bool IN_C64, int HOLD>   // HOLD: bit0 = max trace, bit1 = min trace; 4 = AGG (see below)
 __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const SpecParams p) {
   using C = Cfg<LOG2N>;
   constexpr int N = C::N, SG = C::SG, A = C::A, M = C::M, H = C::H, FPW = C::FPW, NPAD = C::NPAD;
@@ -300,7 +275,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   // 2048 -2.3 %, but 8192 (4-byte reads) +1.4 %, 256 +2.9 %, 128 +-0.  M = 2 (N = 16384, 512) would need 2-byte
   // loads into twice the registers (gfx950's d16 loads do not preserve the other half with SRAM ECC on), M = 1 is
   // one radix-32 butterfly per row: all of those keep the even / odd row split with the swap + combine stage.
-  constexpr bool INL = C::INL;                    // (the row pass ACC only exists at N = 16384, where INL is off)
+  constexpr bool INL = C::INL;
   constexpr int R1 = C::R1;                       // radix done inside one lane in pass 1
   constexpr int LR1 = ilog2(R1);
   constexpr int CPT = C::CPT;                     // adjacent columns (samples) per row read of a half-thread
@@ -322,10 +297,6 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
 #ifdef TDSA_TIMELINE
   const unsigned long long tl_entry = __builtin_amdgcn_s_memtime();     // launch-level stamps of workgroup 0
 #endif
-  // timing-only developer ablations (with 1|2|4: no barriers, no LDS exchange, no stores): k waves per SIMD
-  if constexpr ((TDSA_ABLATE & 4096) != 0) { if (wave >= 4) return; }
-  if constexpr ((TDSA_ABLATE & 8192) != 0) { if (wave >= 8) return; }
-  if constexpr ((TDSA_ABLATE & 16384) != 0) { if (wave >= 12) return; }
   const int h = (tid >> 5) & 1;                              // 0: even half-thread, 1: odd half-thread
   const int g = wave * 32 + (tid & 31);                      // row inside the workgroup
   // UNI: a frame is made of whole waves (N >= 1024), so its slot - and with it the frame index, the frame's base
@@ -346,23 +317,6 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   const unsigned upw = unsigned(n_units) / gridDim.x, urem = unsigned(n_units) - upw * gridDim.x;
   int u0 = int(blockIdx.x * upw + blockIdx.x * urem / gridDim.x);
   int u1 = int((blockIdx.x + 1) * upw + (blockIdx.x + 1) * urem / gridDim.x);
-#ifdef TDSA_STAGGER   // developer experiment: workgroups with one unit less than the others start k/4 frame periods late
-  if (!ACC && urem != 0 && u1 - u0 == int(upw)) {
-    const unsigned k = (blockIdx.x * 2654435761u) >> 30;
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)k * TDSA_STAGGER) __builtin_amdgcn_s_sleep(8);
-  }
-#endif
-  if constexpr (ACC) {
-    // row pass of the long-frame path: workgroup b = k1 * acc_active + j takes the j-th share of group k1's frames,
-    // so that everything it sums belongs to ONE row of the result (its own row of P, no atomics)
-    const int k1 = int(blockIdx.x) / p.acc_active, j = int(blockIdx.x) - k1 * p.acc_active;
-    const int chunk = (p.group + p.acc_active - 1) / p.acc_active;
-    const int s0 = min(p.group, j * chunk), s1 = min(p.group, s0 + chunk);
-    u0 = k1 * p.group + s0;
-    u1 = k1 * p.group + s1;
-  }
-
   // frame of this slot in workgroup-unit `unit`: every FPW-th frame of the workgroup's range - or, where the averager's
   // chunk aggregate is formed (HOLD == 4), the slot's own run of consecutive frames
   auto frame_of = [&](int unit) -> int {
@@ -375,7 +329,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   float* win_lds = reinterpret_cast<float*>(smem + C::LDS_BYTES - C::WIN_BYTES);
   // TWF_LDS: the last pass's per-thread twiddles W_N^(t (8a + h)), W_N^(2 t j) are re-read from LDS every frame instead
   // of living in 14 VGPRs (see Cfg::TWF_BYTES)
-  constexpr bool TWF_LDS = C::TWF_BYTES != 0 && HOLD == 3 && !IN_C64 && !ACC;
+  constexpr bool TWF_LDS = C::TWF_BYTES != 0 && HOLD == 3 && !IN_C64;
   c32* twf_tab = reinterpret_cast<c32*>(smem + C::LDS_BYTES - C::WIN_BYTES - C::TWF_BYTES);    // [3][SG] lo, then [4][TPF] hi
   if constexpr (TWF_LDS) {
     if (slot == 0) {
@@ -391,8 +345,6 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   // table (window_perm_kernel below): every load instruction of a wave covers 2 x 512 contiguous bytes
   const unsigned win_voff = (unsigned(h) * SG + unsigned(t)) * 16u;
   const bool odd_half = h != 0;   // upper half-wave: its radix-32 combine twiddle is W_32^(u+8) = -i * W_32^u
-  float pacc[ACC ? 16 : 1];                 // ACC: linear power summed over the frames of one group
-  static_for<0, (ACC ? 16 : 1)>([&](auto ic) { pacc[decltype(ic)::value] = 0.f; });
   // AGG (HOLD == 4: linear-power rows for the TraceAverager, one frame per workgroup slot): the workgroup also forms the
   // chunk aggregate the chained scan of tdsa_trace.hip needs for ITS frames [u0, u1) - the averager's recurrence
   // s <- a_f s + b_f P_f (utils/signal_processing.py:35-61) run from a zero state, which is the dot product
@@ -405,7 +357,6 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   // Several frames per workgroup (N <= 2048): slot s takes the s-th run of consecutive frames of the workgroup's range
   // (frame_of below) instead of every FPW-th one, the weights are those of the workgroup's whole range, and the slots'
   // partial sums are added through LDS at the end - one aggregate row per workgroup as at the larger sizes.
-  static_assert(!AGG || !ACC, "chunk aggregates: frame instantiations only");
   float agg[AGG ? 16 : 1];
   static_for<0, (AGG ? 16 : 1)>([&](auto ic) { agg[decltype(ic)::value] = 0.f; });
   float hmax[(HOLD & 1) ? 16 : 1], hmin[(HOLD & 2) ? 16 : 1];
@@ -503,30 +454,6 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     }
   };
   if (u0 < u1) load_frame_raw(frame_of(u0));
-  // ACC (row pass of the long-frame path): no window, no raw bytes, no hold traces - the registers they
-  // would take hold the NEXT frame's complex64 samples instead, fetched while this frame is transformed
-  c32 vnext[ACC ? 16 : 1];
-  auto load_frame_c64 = [&](int frame) {
-    if constexpr (ACC) {
-      const int fg = frame / p.group;
-#ifdef TDSA_EXP_ZSLOTS   // timing experiment (wrong results): see tdsa_big.hip
-      const unsigned char* fb = static_cast<const unsigned char*>(p.in) + (long long)((frame - fg * p.group) % TDSA_EXP_ZSLOTS) * p.frame_stride +
-                                (long long)fg * p.group_stride;
-#else
-      const unsigned char* fb = static_cast<const unsigned char*>(p.in) + (long long)(frame - fg * p.group) * p.frame_stride +
-                                (long long)fg * p.group_stride;
-#endif
-      static_for<0, 16>([&](auto ic) {
-        constexpr int idx = decltype(ic)::value;
-        constexpr int jj = idx / H, i = idx % H;
-        const c32* row = reinterpret_cast<const c32*>(fb + 2 * i * (N / A) * 8 + lane_in_off);
-        // last use of the column pass's rows: non-temporal (together with the non-temporal raw loads of the
-        // column pass: C5 302 -> 290 us per 64 segments)
-        { const lds_v2 q = __builtin_nontemporal_load(reinterpret_cast<const lds_v2*>(&row[jj])); vnext[idx] = c32{q.x, q.y}; }
-      });
-    }
-  };
-  if constexpr (ACC) { if (u0 < u1) load_frame_c64(u0 * FPW + slot); }
   // order of the cold fetches: the first frame's bytes (the DC sums need them first), the twiddles (the
   // middle-pass table goes through registers into LDS, which waits for everything issued before it), the
   // window slice last (64 KiB per workgroup, not needed before the first barrier has been passed)
@@ -541,7 +468,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       twm[tid] = p.tw[ka * b * (N / (32 * A))];
     }
   }
-  if constexpr (!C::WIN_LDS && !ACC) load_window();
+  if constexpr (!C::WIN_LDS) load_window();
 
 #ifdef TDSA_TIMELINE
   if (p.dbg != nullptr && blockIdx.x == 0 && (tid & 63) == 0) {
@@ -558,9 +485,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     float sub_re = p.in_off, sub_im = p.in_off;
     float res_re = 0.f, res_im = 0.f;     // DC_TRACKED: the estimate as a small residual on top of in_off (see below)
     // ---- frame sums for DC removal ---------------------------------------------------------------
-    if constexpr (ACC) {
-      static_for<0, 16>([&](auto ic) { constexpr int idx = decltype(ic)::value; v[idx] = vnext[idx]; });
-    } else if constexpr (IN_C64) {
+    if constexpr (IN_C64) {
       const unsigned char* fb = static_cast<const unsigned char*>(p.in) + in_byte_off(frame);
       static_for<0, 16>([&](auto ic) {
         constexpr int idx = decltype(ic)::value;
@@ -714,19 +639,13 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     // FUSE_WIN: the window multiply rides the first butterfly layer of pass 1 (pairs r, r + R1/2 of every radix-R1
     // group):  (e we + o wo, e we - o wo)  as  mul, fma, fma  per component instead of  mul, mul, add, sub  -
     // 16 instructions less per thread and frame; here the samples are only unpacked and DC-freed
-#if defined(TDSA_UNFUSED_WIN) || defined(TDSA_DIF)
-    constexpr bool FUSE_WIN = false;
-#else
-    constexpr bool FUSE_WIN = !ACC && R1 >= 2;
-#endif
+    constexpr bool FUSE_WIN = R1 >= 2;
     auto put = [&](auto ic, float xr, float xi) {          // sample idx, DC-free -> v[idx] (windowed unless fused)
       constexpr int idx = decltype(ic)::value;
       if constexpr (FUSE_WIN) v[idx] = c32{xr, xi};
       else v[idx] = c32{xr * win[idx], xi * win[idx]};
     };
-    if constexpr (ACC) {
-      // rows arrive windowed, DC-free and pre-twiddled from the column pass
-    } else if constexpr (IN_C64) {
+    if constexpr (IN_C64) {
       static_for<0, 16>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         put(ic, v[i].x - sub_re, v[i].y - sub_im);
@@ -783,7 +702,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
         });
       });
     }
-    if constexpr (!ACC && !IN_C64) {
+    if constexpr (!IN_C64) {
       // Tracked DC remover: x - in_off above is exact (small integers / halves), the estimate follows as its own
       // term, v -= dc * w, instead of one float32 "128 + dc" whose 2^-17 LSB of resolution would add up coherently
       // in the DC bin (it was worth up to 3.8 rounding units of A_max there).  Wave-uniform branch, this mode only.
@@ -810,7 +729,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     }
     TDSA_STAMP(3);
     // raw registers are free again: start the next frame's HBM read now, it lands during the FFT
-    if ((TDSA_ABLATE & 2048) == 0 && unit + 1 < u1) load_frame_raw(frame_of(unit + 1));
+    if (unit + 1 < u1) load_frame_raw(frame_of(unit + 1));
     TDSA_PRIO(2);
 
     // ---- pass 1: per lane CPT radix-R1 DFTs; INL: that is the whole pass, else (even / odd input rows per
@@ -822,7 +741,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       static_for<0, 16>([&](auto ec) {
         constexpr int e = decltype(ec)::value;
         constexpr int g = e / A, k = e % A;
-        if constexpr ((TDSA_ABLATE & 2) == 0) lds_st(&buf[wr1_base + e], v[g * A + bitrev(k, LR1)]);
+        lds_st(&buf[wr1_base + e], v[g * A + bitrev(k, LR1)]);
       });
     } else {
     TDSA_PRIO(1);
@@ -831,15 +750,14 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       if constexpr (u == 4) TDSA_PRIO(0);
       constexpr int jj0 = u / H, k0 = u % H, jj1 = (u + 8) / H, k1 = (u + 8) % H;
       constexpr int re = jj0 * H + bitrev(k0, LH), ro = jj1 * H + bitrev(k1, LH);
-      if constexpr ((TDSA_ABLATE & 32) == 0) swap_halves(v[re], v[ro]);   // v[re] = E of unit u + 8h, v[ro] = O
-      if constexpr (A == 32) combine32<u, (TDSA_EXACT_MASK & 1) != 0>(v[re], v[ro], odd_half);
-      else combine_const<k0, A, (TDSA_EXACT_MASK & 1) != 0>(v[re], v[ro]);               // (u + 8h) % H == u % H for H <= 8
+      swap_halves(v[re], v[ro]);   // v[re] = E of unit u + 8h, v[ro] = O
+      if constexpr (A == 32) combine32<u>(v[re], v[ro], odd_half);
+      else combine_const<k0, A>(v[re], v[ro]);               // (u + 8h) % H == u % H for H <= 8
       constexpr int li = jj0 * A + k0;                       // + lane offset folded into wr1_base
-      if constexpr ((TDSA_ABLATE & 2) == 0) { lds_st(&buf[wr1_base + li], v[re]); lds_st(&buf[wr1_base + li + H], v[ro]); }
+      { lds_st(&buf[wr1_base + li], v[re]); lds_st(&buf[wr1_base + li + H], v[ro]); }
     });
     }
     TDSA_STAMP(4);
-    if constexpr (ACC) { if ((TDSA_ABLATE & 2048) == 0 && unit + 1 < u1) load_frame_c64((unit + 1) * FPW + slot); }
     TDSA_SYNC();
     TDSA_PRIO(3);
     TDSA_STAMP(5);
@@ -849,12 +767,11 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     if constexpr (C::NPASS == 3) {
       static_for<0, 16>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        if constexpr ((TDSA_ABLATE & 2) == 0) v[i] = lds_ld(&buf[rdA + i * 2 * rd_stride]);
+        v[i] = lds_ld(&buf[rdA + i * 2 * rd_stride]);
       });
       int tw_o = h * A + ka_mid;
       asm volatile("" : "+v"(tw_o));                        // keep the table reads inside the loop
       // two batches of eight table reads, each issued back to back and waited for once
-#ifndef TDSA_UNFUSED_TW   // (-DTDSA_UNFUSED_TW: the separate pre-twiddle of rounds 1-2, kept for A/B timing)
       // batch k serves the pairs (i, i + 8), i = 4k .. 4k + 3, of the radix-16's first layer: the pre-twiddle rides
       // that layer's butterflies (bf_tw: 10 instead of 12 instructions per pair)
       static_for<0, 2>([&](auto bc) {
@@ -876,32 +793,13 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       TDSA_PRIO(2);
       dit_rest<16, 0, 16>(v);
       TDSA_PRIO(1);
-#else
-      static_for<0, 2>([&](auto bc) {
-        constexpr int b0 = decltype(bc)::value * 8;
-        c32 tw8[8];
-        static_for<0, 8>([&](auto ic) {
-          constexpr int i = b0 + decltype(ic)::value;
-          if constexpr ((TDSA_ABLATE & 16) == 0) tw8[i - b0] = twm[tw_o + i * 2 * A];
-          else tw8[i - b0] = twf_hi[i & 3];
-        });
-        __builtin_amdgcn_sched_barrier(0);
-        static_for<0, 8>([&](auto ic) {
-          constexpr int i = b0 + decltype(ic)::value;
-          if constexpr ((TDSA_ABLATE & 256) == 0) v[i] = cmul(v[i], tw8[i - b0]);
-        });
-        __builtin_amdgcn_sched_barrier(0);
-      });
-      TDSA_STAMP(6);
-      radix<16, 0, 16>(v);
-#endif
       static_for<0, 8>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
         if constexpr (u == 4) TDSA_PRIO(0);
         constexpr int re = bitrev(u, 4), ro = bitrev(u + 8, 4);
-        if constexpr ((TDSA_ABLATE & 32) == 0) swap_halves(v[re], v[ro]);
-        combine32<u, (TDSA_EXACT_MASK & 2) != 0>(v[re], v[ro], odd_half);                // outputs kb = u + 8h and kb + 16
-        if constexpr ((TDSA_ABLATE & 2) == 0) {
+        swap_halves(v[re], v[ro]);
+        combine32<u>(v[re], v[ro], odd_half);                // outputs kb = u + 8h and kb + 16
+        {
           lds_st(&buf[wrM + u * rd_stride], v[re]);
           lds_st(&buf[wrM + (u + 16) * rd_stride], v[ro]);
         }
@@ -912,7 +810,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       TDSA_STAMP(8);
       static_for<0, 16>([&](auto ic) {                       // element c = 2i + h of row (kb, ka)
         constexpr int i = decltype(ic)::value;
-        if constexpr ((TDSA_ABLATE & 2) == 0) v[i] = lds_ld(&buf[rd3A + 2 * i * A + ((2 * i * A) >> 5)]);
+        v[i] = lds_ld(&buf[rd3A + 2 * i * A + ((2 * i * A) >> 5)]);
       });
     } else {
       static_for<0, 16>([&](auto ic) {
@@ -929,7 +827,6 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       static_for<0, 3>([&](auto ic) { opaque(twf_lo[decltype(ic)::value]); });
       static_for<0, 4>([&](auto ic) { opaque(twf_hi[decltype(ic)::value]); });
     }
-#ifndef TDSA_UNFUSED_TW   // (-DTDSA_UNFUSED_TW: the separate pre-twiddle of rounds 1-2, kept for A/B timing)
     static_for<0, 8>([&](auto ic) {                          // pre-twiddle W_N^(t*(2i+h)), i = 4a + j, fused with the
       constexpr int i = decltype(ic)::value;                 // radix-16's first layer: pairs (i, i + 8) = (a, a + 2)
       constexpr int a = i >> 2, j = i & 3;
@@ -939,20 +836,10 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     });
     TDSA_PRIO(2);
     dit_rest<16, 0, 16>(v);
-#else
-    static_for<0, 16>([&](auto ic) {                         // pre-twiddle W_N^(t*(2i+h)), i = 4a + j
-      constexpr int i = decltype(ic)::value;
-      constexpr int a = i >> 2, j = i & 3;
-      if constexpr ((TDSA_ABLATE & 128) != 0) { /* dev ablation: skip the last pre-twiddle */ }
-      else if constexpr (j == 0) v[i] = cmul(v[i], twf_hi[a]);
-      else v[i] = cmul(v[i], cmul(twf_hi[a], twf_lo[j - 1]));
-    });
-    if constexpr ((TDSA_ABLATE & 512) == 0) radix<16, 0, 16>(v);
-#endif
     static_for<0, 8>([&](auto uc) {
       constexpr int u = decltype(uc)::value;
       constexpr int re = bitrev(u, 4), ro = bitrev(u + 8, 4);
-      if constexpr ((TDSA_ABLATE & 32) == 0) swap_halves(v[re], v[ro]);
+      swap_halves(v[re], v[ro]);
       combine32<u, true>(v[re], v[ro], odd_half);            // bins kc = u + 8h (v[re]) and kc + 16 (v[ro])
     });
     TDSA_PRIO(1);
@@ -960,17 +847,6 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
 
     // ---- epilogue: |X|^2 -> dB -> hold ; bin k = t + kc*SG lands at k ^ N/2 (fftshift) -----------
     // this thread's 16 bins: q < 8: kc = q + 8h (register bitrev(q)), q >= 8: kc = q + 8 + 8h (bitrev(q))
-    if constexpr (ACC) {
-      // row pass of the big-FFT path: |X|^2 of bin k = t + kc*SG (natural order) joins the group's sum;
-      // the sums leave the registers (one float atomic per bin) when the group ends or this workgroup does
-      if (active) {
-        static_for<0, 16>([&](auto ic) {
-          constexpr int q = decltype(ic)::value;
-          const c32 X = v[bitrev(q, 4)];
-          pacc[q] = fmaf(X.x, X.x, fmaf(X.y, X.y, pacc[q]));
-        });
-      }
-    } else
     if (active) {
       if (p.out_cplx != nullptr) {            // real-input path: hand the complex bins to the fold kernel
         if constexpr (!C::WIN_LDS) load_window();
@@ -1051,8 +927,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
         } else {
           static_for<0, 16>([&](auto ic) {
             constexpr int q = decltype(ic)::value;
-            if constexpr ((TDSA_ABLATE & 64) == 0) db[q] = fmaf(k10Log10_2, __builtin_amdgcn_logf(fmaf(db[q], ps_v, fl_v)), cal_v);
-            else db[q] = fmaf(k10Log10_2, fmaf(db[q], ps_v, fl_v), cal_v);
+            db[q] = fmaf(k10Log10_2, __builtin_amdgcn_logf(fmaf(db[q], ps_v, fl_v)), cal_v);
           });
         }
         if (p.tare != nullptr) {
@@ -1065,21 +940,12 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
             db[q] -= __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(tr, out_voff, kcs * SG * 4u, 0));
           });
         }
-        if constexpr (!C::WIN_LDS && (TDSA_ABLATE & 2048) == 0) load_window();     // next frame's window, ahead of this frame's stores
+        if constexpr (!C::WIN_LDS) load_window();     // next frame's window, ahead of this frame's stores
         TDSA_PRIO(0);
-        if ((TDSA_ABLATE & 4) == 0 && p.out_db != nullptr) {
+        if (p.out_db != nullptr) {
           float* orow = p.out_db + out_elem_off(frame);
           if constexpr (UNI) {
             const rsrc_t r = make_rsrc(orow, N * 4u);
-            if constexpr ((TDSA_ABLATE & 1024) != 0) {
-              // timing experiment only (wrong layout): the same 64 KiB as four 16-byte stores per lane
-              static_for<0, 4>([&](auto gc) {
-                constexpr int g4 = decltype(gc)::value;
-                const u32x4 pk = {__float_as_uint(db[4 * g4]), __float_as_uint(db[4 * g4 + 1]),
-                                  __float_as_uint(db[4 * g4 + 2]), __float_as_uint(db[4 * g4 + 3])};
-                __builtin_amdgcn_raw_buffer_store_b128(pk, r, unsigned(tid) * 16u + g4 * 16384u, 0, kRowStorePolicy);   // (row offset in the VGPR: see tdsa_big.hip on the soffset hazard)
-              });
-            } else
             static_for<0, 16>([&](auto ic) {
               constexpr int q = decltype(ic)::value;
               constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
@@ -1119,24 +985,6 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   if (p.dbg != nullptr && blockIdx.x == 0)
     for (int i = tid; i < 8 * 16 * 16; i += C::WGT) p.dbg[i] = tl[i];
 #endif
-  if constexpr (ACC) {
-    // the workgroup's share of its group's power sum leaves as its own row of P (a workgroup without frames
-    // contributes zeros in the first round of a call and nothing afterwards)
-    if (u1 > u0 || p.acc_add == 0) {
-      int tid_a = threadIdx.x;
-      asm volatile("" : "+v"(tid_a));
-      const int h_a = (tid_a >> 5) & 1, t_a = (tid_a >> 6) * 32 + (tid_a & 31);
-      const int k1 = int(blockIdx.x) / p.acc_active, j = int(blockIdx.x) - k1 * p.acc_active;
-      float* arow = p.acc + (long long)(k1 * p.acc_split + j) * N + t_a + 8 * h_a * SG;
-      static_for<0, 16>([&](auto ic) {
-        constexpr int q = decltype(ic)::value;
-        constexpr int kc = (q < 8 ? q : q + 8);
-        float v = pacc[q];
-        if (p.acc_add != 0) v += arow[kc * SG];
-        arow[kc * SG] = v;
-      });
-    }
-  }
   // fold this workgroup's register-resident hold traces straight into the plan's traces with
   // integer-punned float atomics (max/min are associative; the traces start at -inf / +inf).
   // (Issuing the bulk of them before the last frame to hide the tail was tried: the extra live state
@@ -1318,17 +1166,6 @@ hipError_t launch_n(int in_c64, const SpecParams& p, const LaunchGeom& g, hipStr
     case 2: return launch_one<LOG2N, false, 2>(p, g, s);
     default: return launch_one<LOG2N, false, 3>(p, g, s);
   }
-}
-
-// row pass of the big-FFT path: complex64 rows in, power sums out (size 14 only)
-template <int LOG2N>
-inline hipError_t launch_acc(const SpecParams& p, const LaunchGeom& g, hipStream_t s) {
-  auto k = spectrum_kernel<LOG2N, true, 0, true>;
-  static std::atomic<unsigned long long> attr_done{0};
-  const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), int(g.lds_bytes), attr_done);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k, dim3(g.grid), dim3(g.block), g.lds_bytes, s, p);
-  return hipGetLastError();
 }
 
 // one translation unit per size (tdsa_spectrum_inst.hip, -DTDSA_LOG2N=k) provides these

@@ -233,6 +233,10 @@ class SpectrumEngine:
         nat.check(nat.lib.tdsa_get_info(self._h, C.byref(inf)))
         return inf
 
+    def debug_knob(self, name: str, value: int) -> None:
+        """developer hook (tdsa_debug_knob): num_cu, avg_wg_min, avg_f64_chunks, overlap_share, big_group"""
+        nat.check(nat.lib.tdsa_debug_knob(self._h, name.encode(), int(value)))
+
     def profile_enable(self, on: bool = True) -> None:
         nat.check(nat.lib.tdsa_profile_enable(self._h, int(bool(on))))
 
