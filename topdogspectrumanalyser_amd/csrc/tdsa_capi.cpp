@@ -115,6 +115,7 @@ struct tdsa_plan_s {
   BigWindow big_win[3] = {};             // the column pass's window per input format (tdsa_set_window: table or one value)
   int avg_wg_min = 128;                  // batches of more frames than this take the workgroup-chunk scan (tdsa_debug_knob "avg_wg_min")
   bool avg_f64_chunks = false;           // tdsa_debug_knob "avg_f64_chunks": always the scan over fixed 64-frame chunks with float64 aggregates
+  int big_pre_wgs = 0;                   // tdsa_debug_knob "big_pre_wgs": empty workgroups launched ahead of every column pass
   int big_group = 64;                    // segments per column-pass / row-pass round (one round for the K = 64 Welch capture)
   // frame lengths that are not a power of two (tdsa_chirp.hip): chirp-z on the m_fft-point frame kernel
   bool chirp = false;
@@ -293,6 +294,7 @@ int process_big(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n_f
     const int ns = n_frames - s0 < group ? n_frames - s0 : group;
     const int act = ns < split_max ? ns : split_max;
     if (s0 == 0) split_layout = act;
+    if (p->big_pre_wgs > 0) HIPCHK(launch_xcd_shift(p->big_pre_wgs, p->stream));
     HIPCHK(launch_big_cols(p->log2n, static_cast<const unsigned char*>(iq_dev) + (long long)s0 * stride, in_c64, stride, ns,
                            p->big_win[in_format], p->d_tw_seed, dc_sub ? dc_sub + s0 : nullptr, p->d_z,
                            xor_mask, in_off, p->stream));
@@ -1728,6 +1730,9 @@ int tdsa_debug_knob(tdsa_plan p, const char* name, int value) {
     if (!p->big || value < 1 || value > 64) return fail(TDSA_ERR_ARG, "big_group=%d (long-frame plans, 1 .. 64)", value);
     if (p->d_z && value > p->big_group) return fail(TDSA_ERR_STATE, "big_group can only shrink once the plan has run");
     p->big_group = value;
+  } else if (k == "big_pre_wgs") {           // long-frame plans: empty workgroups ahead of every column pass (XCD phase)
+    if (value < 0 || value > 64) return fail(TDSA_ERR_ARG, "big_pre_wgs=%d outside [0, 64]", value);
+    p->big_pre_wgs = value;
   } else {
     return fail(TDSA_ERR_ARG, "unknown knob '%s'", name);
   }
