@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Turns what tools/prof_round5.sh left under gpurun_out/prof_r05 into the committed summaries under profiles/r05_*: bench
+lines, rocprofv3 kernel stats per configuration / submission mode, concurrency of the overlapped C3 mode, per-launch HBM bytes
+(FETCH_SIZE / WRITE_SIZE, separate --pmc passes; every r05_*_pmc.json names the script and the command that produced it),
+the emulated strong-scaling table of C5."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import prof_collect3 as pc3  # noqa: E402
+
+SRC = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r05"
+TAG = sys.argv[2] if len(sys.argv) > 2 else "r05"
+DST = "profiles"
+pc3.SRC, pc3.TAG = SRC, TAG
+ALGO = {"c3": 2440 * 81920, "c3b": 8 * 2440 * 81920, "c2": 4096 * 24576, "c4": 65536 * 49152, "c5": 64 * 2162688}
+CMD = {"c3": "tools/devbench.py --steps 9 --warmup 2 --hold 1", "c3b": "tools/devbench.py --steps 24 --warmup 8 --batch 8 --hold 1",
+       "c2": "tools/devbench.py --nfft 4096 --hop 4096 --frames 4096 --mode pow --hold 1",
+       "c4": "tools/devbench.py --nfft 8192 --hop 8192 --frames 65536 --steps 5 --hold 1",
+       "c5": "bench.py --config c5 --steps 2 --warmup 1 --reps 1 --min-region-s 0.05 --preroll-seconds 0 --no-cpu-baseline --no-parity"}
+
+
+def main():
+    for c in ("c2", "c3", "c4", "c5", "c5_2ranks", "c5_2ranks_captures", "c3_2ranks", "c4_2ranks"):
+        src = os.path.join(SRC, f"bench_{c}.json")
+        if os.path.exists(src) and os.path.getsize(src) > 10:
+            shutil.copy(src, os.path.join(DST, f"{TAG}_{c}_bench.json"))
+    names = {"c3_serial": f"{TAG}_c3_kernel_stats.csv", "c3_batch": f"{TAG}_c3_batch8_kernel_stats.csv",
+             "c3_value": f"{TAG}_c3_value_kernel_stats.csv", "c2": f"{TAG}_c2_batch8_kernel_stats.csv",
+             "c4": f"{TAG}_c4_kernel_stats.csv", "c5": f"{TAG}_c5_kernel_stats.csv"}
+    for k, dst in names.items():
+        f = pc3.newest(f"stats_{k}/**/*kernel_stats.csv")
+        if f:
+            shutil.copy(f, os.path.join(DST, dst))
+    conc = {k: pc3.trace_summary(k) for k in ("c3_serial", "c3_batch", "c3_value")}
+    json.dump({"what": "frame-kernel dispatches of `rocprofv3 --kernel-trace -- python bench.py --legs <mode> ...` (tools/prof_round5.sh), "
+                       "steady-state part of each run: duration per dispatch and how many dispatches are in flight at once",
+               "c3_serial": conc["c3_serial"], "c3_batch8_serial": conc["c3_batch"], "c3_value_batch8_3streams": conc["c3_value"]},
+              open(os.path.join(DST, f"{TAG}_c3_concurrency.json"), "w"), indent=1)
+    lines = [f"# rocprofv3 --pmc passes, {TAG} (tools/prof_round5.sh; FETCH_SIZE and WRITE_SIZE in separate passes)",
+             "# FETCH_SIZE is reported in KB and counts 64 B per 128-B request on gfx950 for wide coalesced reads",
+             "# (MI355X_MICROARCH.md): the upper bound doubles it; WRITE_SIZE (KB) is 1:1 (calibrated in round 1)."]
+    for c in ("c2", "c3", "c3b", "c4", "c5"):
+        rd, nrd = pc3.counters(f"{c}_rd")
+        wr, nwr = pc3.counters(f"{c}_wr")
+        if not rd or not wr:
+            continue
+        per_step = {}
+        if c == "c5":
+            ng = max(1, nrd.get("gather", 1))
+            launches = {"cols": nrd.get("cols", 0) / ng, "rows": nrd.get("rows", 0) / ng, "gather": 1}
+            fetch = sum(rd.get(k, {}).get("FETCH_SIZE", 0.0) * n for k, n in launches.items()) * 1024
+            write = sum(wr.get(k, {}).get("WRITE_SIZE", 0.0) * n for k, n in launches.items()) * 1024
+            per_step = {k: {"fetch_kb_per_launch": rd.get(k, {}).get("FETCH_SIZE"),
+                            "write_kb_per_launch": wr.get(k, {}).get("WRITE_SIZE"), "launches_per_step": n}
+                        for k, n in launches.items()}
+        else:
+            fetch = rd["frame"]["FETCH_SIZE"] * 1024
+            write = wr["frame"]["WRITE_SIZE"] * 1024
+        out = {"config": c, "kernel": "spectrum_kernel" if c != "c5" else "cols + rows + gather (one 64-segment step)",
+               "fetch_bytes_raw": fetch, "fetch_bytes_upper": 2 * fetch, "write_bytes": write,
+               "algorithmic_bytes": ALGO[c], "traffic_over_algorithmic": (2 * fetch + write) / ALGO[c],
+               "dispatches_averaged": {"read_pass": nrd, "write_pass": nwr}, "per_kernel": per_step,
+               "collected_by": "tools/prof_round5.sh + tools/prof_collect5.py",
+               "command": f"rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python {CMD[c]}",
+               "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), median dispatch"}
+        json.dump(out, open(os.path.join(DST, f"{TAG}_{c}_pmc.json"), "w"), indent=1)
+        lines.append(f"{c}: FETCH_SIZE {fetch/1e6:8.1f} MB raw (<= {2*fetch/1e6:8.1f} MB)  WRITE_SIZE {write/1e6:8.1f} MB  "
+                     f"algorithmic {ALGO[c]/1e6:8.1f} MB  -> traffic / algorithmic <= {(2*fetch+write)/ALGO[c]:.2f}")
+    open(os.path.join(DST, f"{TAG}_pmc.txt"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+    # ---- C5 strong scaling: the K-segment captures a rank of a W-GPU run gets, measured on one GPU, + the combine's cost
+    sc = os.path.join(SRC, "c5_scaling.txt")
+    if os.path.exists(sc):
+        best = {}
+        for ln in open(sc):
+            if ln.startswith("K="):
+                k = int(ln.split(":")[0][2:])
+                us = float(ln.split(":")[1].split("us")[0])
+                best[k] = min(best.get(k, 1e9), us)
+        comb = None
+        two = os.path.join(SRC, "bench_c5_2ranks.json")
+        if os.path.exists(two) and os.path.getsize(two) > 10:
+            comb = json.load(open(two))["welch"]
+        out = ["# C5 (2^20 points, Welch average of 64 segments): the strong-scaling curve emulated on ONE MI355X",
+               "# tools/c5_scaling.py (gpurun_out/prof_r05/c5_scaling.txt): a capture of K segments is what a rank of a W = 64 / K GPU run",
+               "# averages when the segments of one capture are sharded (bench.py --config c5 --c5-shard segments)", ""]
+        out += [ln.rstrip() for ln in open(sc)]
+        out.append("")
+        if 64 in best:
+            out.append("W GPUs | segments per rank | compute per capture | speed-up (compute only) | efficiency")
+            for w in (1, 2, 4, 8):
+                k = 64 // w
+                if k in best:
+                    out.append(f"{w:6d} | {k:17d} | {best[k]:16.1f} us | {best[64] / best[k]:22.2f}x | {100 * best[64] / best[k] / w:8.0f} %")
+            if comb:
+                c_ms = comb["combine_ms"]
+                out += ["", f"Cross-rank combine measured with 2 ranks on this one GPU (profiles/{TAG}_c5_2ranks_bench.json): {c_ms * 1e3:.0f} us per step",
+                        f"(rank 0: wait for the partials {comb['rank0_wait_for_partials_ms'] * 1e3:.0f} us, upload of {2} x 4 MiB + combine kernel "
+                        f"{comb['rank0_upload_combine_ms'] * 1e3:.0f} us; every rank: export of its 4 MiB float32 partial mean).  Model per step at W ranks:",
+                        "  t(W) = compute(64 / W) + export (4 MiB device -> pinned host, ~90 us) + upload on rank 0 (W x 4 MiB host -> device at ~50 GB/s:"
+                        " ~85 us x W) + combine kernel (~10 us)"]
+                out.append("W GPUs | end to end per capture (model) | speed-up end to end")
+                for w in (2, 4, 8):
+                    k = 64 // w
+                    if k in best:
+                        t = best[k] + 90.0 + 85.0 * w + 10.0
+                        out.append(f"{w:6d} | {t:27.0f} us | {best[64] / t:18.2f}x")
+                out += ["-> sharding the segments of ONE capture never wins end to end over host memory: the partial means (4 MiB per rank and",
+                        "   capture) cost more to move than the capture costs to compute.  --c5-shard captures (every rank whole captures,",
+                        "   nothing to combine) scales like C3: W x 1 GPU's rate."]
+        open(os.path.join(DST, f"{TAG}_c5_strong_scaling.txt"), "w").write("\n".join(out) + "\n")
+        print("\n".join(out[-22:]))
+
+
+if __name__ == "__main__":
+    main()
