@@ -901,11 +901,61 @@ def test_c4_shape_independence_and_parseval(pkg):
     assert np.max(np.abs(energy_freq / energy_time - 1.0)) < 1e-5
 
 
+_C4_SHARE = {}
+
+
+def _c4_share_iq():
+    """the 8192 frames x 8192 points one GPU of eight gets of BASELINE config 4 (synthesised once per session: 25 s)"""
+    if "iq" not in _C4_SHARE:
+        nfft, chunk = 8192, 1024
+        _C4_SHARE["iq"] = np.concatenate([so.synth_iq_int8(nfft * chunk, nfft, seed=40 + c) for c in range(8)])
+    return _C4_SHARE["iq"]
+
+
+def test_c4_full_waterfall_properties(pkg):
+    """BASELINE config 4 as named, on ONE GPU: the whole waterfall of 65 536 frames x 8192 points in one call (1 GiB of int8
+    IQ in, 2 GiB of dB rows out: what bench.py --config c4 times per step; displays/waterfall.py:163-180 is the layout the
+    rows have).  The capture is the 8192-frame share eight times, each copy rotated by another odd number of samples (as
+    bench.py builds it).  Max hold == column maximum of all 65 536 rows bit for bit, Parseval on the frames of every
+    eighth block of 1024, frames at the copies' seams and ends against the float64 gold and against the same frame
+    processed alone."""
+    nfft, nf, chunk = 8192, 65536, 1024
+    share = _c4_share_iq()
+    iq = np.concatenate([share if k == 0 else np.roll(share, 2 * 977 * k) for k in range(8)])
+    assert iq.size == 2 * nfft * nf
+    w = so.hackrf_window(nfft)
+    with pkg.SpectrumEngine(nfft, max_frames=nf) as e:
+        e.set_window(w)
+        e.configure(db_mode="pow", power_scale=1.0, log_floor=0.0, dc_alpha=1.0, hold_max=True)
+        out = e.process(iq, hop=nfft)
+        mx, _ = e.hold()
+        assert out.shape == (nf, nfft)
+        assert np.array_equal(mx, out.max(axis=0))
+        e.reset()
+        picks = (0, 8191, 8192, 8193, 30000, 57343, 57344, nf - 1)
+        for k in picks:
+            alone = e.process(iq[2 * k * nfft: 2 * (k + 1) * nfft], hop=nfft, n_frames=1)
+            assert np.array_equal(alone[0], out[k]), k
+    w64 = w.astype(np.float64)
+    worst = 0.0
+    for c in range(0, nf // chunk, 8):                # sum_k |X_k|^2 = N sum_n |w_n (x_n - mean)|^2, frame by frame
+        x = so.unpack_iq_int8(iq[2 * c * chunk * nfft: 2 * (c + 1) * chunk * nfft]).astype(np.complex128).reshape(chunk, nfft)
+        xw = (x - x.mean(axis=1, keepdims=True)) * w64
+        energy_time = nfft * (xw.real ** 2 + xw.imag ** 2).sum(axis=1)
+        energy_freq = (10.0 ** (out[c * chunk:(c + 1) * chunk].astype(np.float64) / 10.0)).sum(axis=1)
+        worst = max(worst, float(np.max(np.abs(energy_freq / energy_time - 1.0))))
+    assert worst < 1e-5, worst
+    br = so.HackrfBranchOracle(nfft, 20e6, precision="gold")
+    for k in picks:
+        gold = br.power_levels(so.unpack_iq_int8(iq[2 * k * nfft: 2 * (k + 1) * nfft]))
+        _check(out[k], gold, f"C4 waterfall frame {k}")
+
+
 def test_c4_full_share_properties(pkg):
-    """C4 at the size one GPU gets: 64k frames / 8 GPUs = 8192 frames x 8192 points (hop = N), one launch.
+    """C4 at the size one GPU of eight gets: 64k frames / 8 GPUs = 8192 frames x 8192 points (hop = N), one launch.
     Parseval on every frame, frame independence, max hold == column max, sampled rows against the gold oracle."""
     nfft, nf, chunk = 8192, 8192, 1024
-    iq = np.concatenate([so.synth_iq_int8(nfft * chunk, nfft, seed=40 + c) for c in range(nf // chunk)])
+    iq = _c4_share_iq()
     w = so.hackrf_window(nfft)
     with pkg.SpectrumEngine(nfft, max_frames=nf) as e:
         e.set_window(w)

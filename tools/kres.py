@@ -40,7 +40,7 @@ def main():
         reps = dict(zip(sizes, ex.map(lambda k: report(k, extra), sizes)))
     for k in sizes:
         for name, r in sorted(reps[k].items()):
-            m = re.search(r"spectrum_kernelILi(\d+)ELb(\d)ELi(\d)ELb(\d)", name)
+            m = re.search(r"spectrum_kernelILi(\d+)ELb(\d)ELi(\d)E()", name)
             if not m:
                 continue
             print(f"N=2^{m.group(1):>2} c64={m.group(2)} hold={m.group(3)} acc={m.group(4)}  VGPRs {r['VGPRs']:>3}  "

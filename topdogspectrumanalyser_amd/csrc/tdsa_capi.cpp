@@ -123,6 +123,8 @@ struct tdsa_plan_s {
   bool chirp_big = false;                // M > 16384: the two M-point transforms run on the long-frame kernels (N1 x 16384)
   float2* d_chirp_a = nullptr;           // [nfft] a[n] = exp(-i pi n^2 / nfft)
   float2* d_chirp_b = nullptr;           // [M]    FFT_M of conj(a) wrapped around M
+  float2* d_chirp_aw[3] = {nullptr, nullptr, nullptr};   // [nfft] window * input scale * a[n] per input format (M <= 16384: the
+                                         // unpack / window / chirp pass rides the first transform's loads)
   float2* d_u0 = nullptr;                // [max_frames][M] work rows (allocated on first use)
   float2* d_u1 = nullptr;
   void* d_scratch = nullptr;             // grows on demand: results of tdsa_rows_stats / tdsa_rows_top_peaks
@@ -347,14 +349,31 @@ int process_big(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n_f
 
 // Chirp-z core of a plan whose frame length is not a power of two: frames at `in` (stride bytes apart) ->
 // p->d_u0[f][k] = M * conj(convolution), k < nfft (tdsa_chirp.hip steps 1-3), on the main stream.
+// the transforms can carry the element-wise passes: M <= 16384 and frames made of whole waves (the fused instantiations
+// address their rows through wave-uniform descriptors)
+static bool chirp_fusable(tdsa_plan p) { return p->chirp && !p->chirp_big && p->log2m >= 10; }
+
+// post (fusable plans only): what the second transform's stores turn the bins into - the dB / power rows and hold traces
+// of tdsa_chirp.hip's step 4 - instead of leaving complex rows in d_u0 for chirp_post_kernel; null: complex rows
+struct ChirpPost {
+  int first_frame_index, db_mode;
+  float pscale, log_floor, cal_db;
+  const float* tare;
+  float* out_db;
+  float* out_lin;
+  float* hold_max;
+  float* hold_min;
+};
 int chirp_transform(tdsa_plan p, const void* in, int in_format, long long stride, int n_frames, const float2* dc_sub,
-                    unsigned xor_mask, float in_off) {
+                    unsigned xor_mask, float in_off, const ChirpPost* post = nullptr) {
   const int N = p->nfft, M = p->m_fft;
   hipStream_t s = p->stream;
-  if (!p->d_u0) HIPCHK(hipMalloc(&p->d_u0, size_t(p->max_frames) * M * sizeof(float2)));
+  const bool fused = chirp_fusable(p) && post != nullptr;  // both element-wise passes ride the transforms
+  if (!p->d_u0 && !fused) HIPCHK(hipMalloc(&p->d_u0, size_t(p->max_frames) * M * sizeof(float2)));
   if (!p->d_u1) HIPCHK(hipMalloc(&p->d_u1, size_t(p->max_frames) * M * sizeof(float2)));
-  HIPCHK(launch_chirp_pre(in, in_format == TDSA_IN_C64, stride, N, M, n_frames, p->d_window[in_format], p->d_chirp_a, dc_sub,
-                          xor_mask, in_off, p->d_u0, s));
+  if (!fused)
+    HIPCHK(launch_chirp_pre(in, in_format == TDSA_IN_C64, stride, N, M, n_frames, p->d_window[in_format], p->d_chirp_a, dc_sub,
+                            xor_mask, in_off, p->d_u0, s));
   if (p->chirp_big) {
     // M = N1 x 16384: first transform as for a native long frame (column pass -> rows through the frame kernel, which
     // stores conj(X B) in its own [k1][k2] order); second transform transposed (rows first, then the per-column N1-point
@@ -411,13 +430,41 @@ int chirp_transform(tdsa_plan p, const void* in, int in_format, long long stride
   sp.out_cplx = p->d_u1;
   sp.out_mul = p->d_chirp_b;          // the first transform stores conj(FFT_M(U) * B)
   sp.in_valid = N;                    // rows of U: N samples, the padding up to M is neither written nor read
+  if (fused) {                        // ... and U itself is never stored: the raw frames are unpacked on load
+    sp.in = in;
+    sp.pre_raw = in;
+    sp.pre_stride = stride;
+    sp.pre_aw = p->d_chirp_aw[in_format];
+    sp.pre_c64 = in_format == TDSA_IN_C64;
+    sp.dc_sub = dc_sub;
+    sp.pre_xor = xor_mask;
+    sp.pre_off = in_off;
+  }
   { const int rc = launch_spectrum_profiled(p, 1, sp, g); if (rc != TDSA_OK) return rc; }
   sp.in = p->d_u1;
+  sp.pre_raw = nullptr;
+  sp.dc_sub = nullptr;
   sp.out_cplx = p->d_u0;
   sp.out_mul = nullptr;
   sp.in_valid = 0;
   sp.out_valid = N;                   // only bins k < N of the convolution are needed
+  if (fused) {                        // ... and leave as the dB / power rows themselves
+    sp.out_cplx = nullptr;
+    sp.out_valid = 0;
+    sp.post_n = N;
+    sp.post_inv_m = 1.0f / float(M);
+    sp.first_frame_index = post->first_frame_index;
+    sp.db_mode = post->db_mode;
+    sp.pscale = post->pscale;
+    sp.log_floor = post->log_floor;
+    sp.cal_db = post->cal_db;
+    sp.tare = post->tare;
+    sp.out_db = post->out_db;
+    sp.out_lin = post->out_lin;
+  }
   { const int rc = launch_spectrum_profiled(p, 1, sp, g); if (rc != TDSA_OK) return rc; }
+  if (fused && post->out_lin == nullptr && (post->hold_max || post->hold_min))
+    HIPCHK(launch_chirp_hold(post->out_db, N, n_frames, post->first_frame_index, post->hold_max, post->hold_min, s));
   return TDSA_OK;
 }
 
@@ -447,18 +494,36 @@ int process_chirp(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n
       dc_sub = p->d_dc_sub;
     }
   }
-  { const int rc = chirp_transform(p, iq_dev, in_format, stride, n_frames, dc_sub, xor_mask, in_off); if (rc != TDSA_OK) return rc; }
   const float pscale = m.db_mode == TDSA_DB_POW ? m.power_scale : 1.0f;
   float* const tare = p->tare_active ? p->d_tare_base : nullptr;
   const int first = p->frames_seen > 0 ? 1 : 0;
+  if (averaging && !p->d_lin) HIPCHK(hipMalloc(&p->d_lin, size_t(p->max_frames) * N * sizeof(float)));
+  // M <= 16384: the power / dB rows leave the second transform directly (linear rows for the averager's scan, else dB
+  // rows + hold traces); longer frames: complex rows in d_u0, chirp_post below
+  const bool fusable = chirp_fusable(p);
+  const bool holding = (m.hold_flags & (TDSA_HOLD_MAX | TDSA_HOLD_MIN)) != 0;
+  float* rows = out_db_dev;
+  if (fusable && !averaging && rows == nullptr && holding) {   // only the hold traces are wanted: the rows go to scratch
+    if (!p->d_u0) HIPCHK(hipMalloc(&p->d_u0, size_t(p->max_frames) * M * sizeof(float2)));
+    rows = reinterpret_cast<float*>(p->d_u0);
+  }
+  if (fusable && !averaging && rows == nullptr) {              // nothing to produce (no rows, no hold, no averaging)
+    p->frames_seen += n_frames;
+    return TDSA_OK;
+  }
+  const ChirpPost post{first, m.db_mode, pscale, m.log_floor, m.cal_offset_db, averaging ? nullptr : tare,
+                       averaging ? nullptr : rows, averaging ? p->d_lin : nullptr,
+                       (!averaging && (m.hold_flags & TDSA_HOLD_MAX)) ? p->d_hold_max : nullptr,
+                       (!averaging && (m.hold_flags & TDSA_HOLD_MIN)) ? p->d_hold_min : nullptr};
+  { const int rc = chirp_transform(p, iq_dev, in_format, stride, n_frames, dc_sub, xor_mask, in_off, fusable ? &post : nullptr); if (rc != TDSA_OK) return rc; }
   if (averaging) {
-    if (!p->d_lin) HIPCHK(hipMalloc(&p->d_lin, size_t(p->max_frames) * N * sizeof(float)));
     if (!p->d_carry && p->max_frames > 128) {
       HIPCHK(hipMalloc(&p->d_carry, size_t(avg_scan_chunks(p->max_frames)) * N * sizeof(double)));
       p->carry_chunks = size_t(avg_scan_chunks(p->max_frames));
     }
-    HIPCHK(launch_chirp_post(p->d_u0, N, M, n_frames, first, m.db_mode, pscale, m.log_floor,
-                             m.cal_offset_db, nullptr, nullptr, p->d_lin, nullptr, nullptr, s));
+    if (!fusable)
+      HIPCHK(launch_chirp_post(p->d_u0, N, M, n_frames, first, m.db_mode, pscale, m.log_floor,
+                               m.cal_offset_db, nullptr, nullptr, p->d_lin, nullptr, nullptr, s));
     AvgParams ap{};
     ap.lin = p->d_lin;
     ap.n_frames = n_frames;
@@ -481,7 +546,7 @@ int process_chirp(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n
     } else {
       p->avg_count = 1;
     }
-  } else {
+  } else if (!fusable) {
     HIPCHK(launch_chirp_post(p->d_u0, N, M, n_frames, first, m.db_mode, pscale, m.log_floor,
                              m.cal_offset_db, tare, out_db_dev, nullptr,
                              (m.hold_flags & TDSA_HOLD_MAX) ? p->d_hold_max : nullptr,
@@ -722,7 +787,7 @@ int tdsa_destroy(tdsa_plan p) {
                   p->d_window_perm[2], p->d_tw, p->d_hold_max, p->d_hold_min,
                   p->d_avg, p->d_lin, p->d_carry, p->d_agg, p->d_agg_w, p->d_chunk_a, p->d_chunk_v, p->d_cplx, p->d_real, p->d_lin1, p->d_db1, p->d_dc_state, p->d_sums, p->d_dc_sub,
                   p->d_tare_base, p->d_tare_acc, p->d_in_stage, p->d_out_stage, p->d_trace_in,
-                  p->d_trace_live, p->d_scratch, p->d_z, p->d_welch, p->d_clock, p->d_chirp_a, p->d_chirp_b, p->d_u0, p->d_u1, p->d_acc, p->d_sum, p->d_lin64, p->d_sums64, p->d_tw_seed, p->d_tw_row, p->d_ones,
+                  p->d_trace_live, p->d_scratch, p->d_z, p->d_welch, p->d_clock, p->d_chirp_aw[0], p->d_chirp_aw[1], p->d_chirp_aw[2], p->d_chirp_a, p->d_chirp_b, p->d_u0, p->d_u1, p->d_acc, p->d_sum, p->d_lin64, p->d_sums64, p->d_tw_seed, p->d_tw_row, p->d_ones,
                   p->d_dbg};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -789,6 +854,20 @@ int tdsa_set_window(tdsa_plan p, const float* w_host, int n) {
   if (p->big) {
     const int rc_w = big_window_model(p, w_host, scale);
     if (rc_w != TDSA_OK) return rc_w;
+  }
+  if (chirp_fusable(p)) {
+    // window x input scale x chirp a[n] = exp(-i pi n^2 / N) (phase from n^2 mod 2N in integers), product in double,
+    // rounded once: the first transform multiplies the unpacked samples by it on load
+    std::vector<float2> aw(n);
+    for (int f = 0; f < 3; ++f) {
+      for (int i = 0; i < n; ++i) {
+        const long long q = ((long long)i * i) % (2ll * n);
+        const double ang = -M_PI * double(q) / double(n), wv = double(w_host[i]) * double(scale[f]);
+        aw[i] = float2{float(wv * std::cos(ang)), float(wv * std::sin(ang))};
+      }
+      if (!p->d_chirp_aw[f]) HIPCHK(hipMalloc(&p->d_chirp_aw[f], size_t(n) * sizeof(float2)));
+      HIPCHK(hipMemcpy(p->d_chirp_aw[f], aw.data(), size_t(n) * sizeof(float2), hipMemcpyHostToDevice));
+    }
   }
   p->window_set = true;
   return TDSA_OK;

@@ -21,9 +21,13 @@
 // pass + rows through the frame kernel, which leaves conj(X B) in its own [k1][k2] order (B is stored in that order),
 // (3) transposed: rows first, then big_cols_out_kernel's per-column N1-point DFT, which leaves natural order.
 //
-// Cost: two M-point complex-to-complex transforms and two element-wise passes over [F][M] complex64 rows - about
-// ten times the time of a native size of similar length; the point of this path is that every size the reference
-// accepts has a device path, not its speed.
+// M <= 16384 and frames of whole waves (M >= 1024), round 5: steps (1) and (4) ride the transforms - the first
+// transform unpacks the raw samples and multiplies them by window x a[n] on load, the second stores the dB / power rows
+// of the N wanted bins itself (instantiations spectrum_kernel<L, true, 0, 1 | 2>); the rows U and the complex result
+// are never stored; hold traces are folded from the finished rows (chirp_hold_kernel).
+//
+// Cost: two M-point complex-to-complex transforms (plus, for M < 1024 or M > 16384, two element-wise passes over
+// [F][M] complex64 rows); the point of this path is that every size the reference accepts has a device path.
 #include "tdsa_fft.hpp"
 #include "tdsa_kernels.hpp"
 
@@ -229,6 +233,35 @@ hipError_t launch_chirp_post(const float2* y, int n, int m, int n_frames, int fi
                     tare, out_db, out_lin, hold_max, hold_min};
   const int gy = (n_frames + kChirpFramesPerBlock - 1) / kChirpFramesPerBlock;
   hipLaunchKernelGGL(chirp_post_kernel, dim3((n + 255) / 256, gy), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+// Hold traces from finished dB rows [F][n] (plans with M <= 16384, whose second transform stores the rows itself):
+// column max / min over blocks of frames, one atomic per bin and block where the trace moves.
+__global__ void __launch_bounds__(256) chirp_hold_kernel(const float* rows, int n, int n_frames, int first_frame_index,
+                                                         float* hold_max, float* hold_min) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  float hmax = -INFINITY, hmin = INFINITY;
+  const int f0 = blockIdx.y * kChirpFramesPerBlock;
+  const int f1 = f0 + kChirpFramesPerBlock < n_frames ? f0 + kChirpFramesPerBlock : n_frames;
+#pragma unroll 4
+  for (int f = f0; f < f1; ++f) {
+    const float db = rows[(long long)f * n + j];
+    float dmx = db, dmn = db;
+    if (first_frame_index + f == 0 && db != db) { dmx = -500.f; dmn = 500.f; }     // _nan_safe, first frame ever
+    hmax = fmaxf(hmax, dmx);                 // a NaN operand is ignored, as by np.fmax
+    hmin = fminf(hmin, dmn);
+  }
+  if (hold_max != nullptr && hmax > hold_max[j]) chirp_atomic_fmax(hold_max + j, hmax);
+  if (hold_min != nullptr && hmin < hold_min[j]) chirp_atomic_fmin(hold_min + j, hmin);
+}
+
+hipError_t launch_chirp_hold(const float* rows, int n, int n_frames, int first_frame_index, float* hold_max, float* hold_min,
+                             hipStream_t s) {
+  const int gy = (n_frames + kChirpFramesPerBlock - 1) / kChirpFramesPerBlock;
+  hipLaunchKernelGGL(chirp_hold_kernel, dim3((n + 255) / 256, gy), dim3(256), 0, s, rows, n, n_frames, first_frame_index,
+                     hold_max, hold_min);
   return hipGetLastError();
 }
 

@@ -70,6 +70,19 @@ struct SpecParams {
   unsigned seg_frames;
   long long seg_in_stride;   // bytes
   long long seg_out_stride;  // output elements
+  // ---- chirp-z plans with M <= 16384 (tdsa_chirp.hip; complex64 instantiation without hold): the two element-wise passes
+  //      of the convolution ride the two transforms (appended in round 5: the offsets of everything above stay) ----
+  const void* pre_raw;       // FIRST transform: the raw frames (bytes, or complex64 if pre_c64) - sample n of frame f is
+                             // unpacked, DC-freed (dc_sub[f], or null) and multiplied by pre_aw[n] on load; `in` is not read.
+                             // null: `in` holds complex64 rows
+  long long pre_stride;      // bytes between raw frames
+  const float2* pre_aw;      // [in_valid] window * input scale * chirp a[n] (made in double, rounded once)
+  int pre_c64;
+  unsigned pre_xor;          // 0x8080 for int8 (-> offset binary), 0 for uint8
+  float pre_off;             // 128 / 127.5 / 0: the raw format's zero level (in_off / xor_mask above stay those of complex64 rows)
+  int post_n;                // SECOND transform: > 0: bins k < post_n leave as |X / M|^2 -> power (out_lin) or dB (out_db, tare,
+                             // part_max / part_min) rows of post_n values, bin k at (k + post_n / 2) mod post_n; out_cplx is not written
+  float post_inv_m;          // 1 / M
 };
 
 struct LaunchGeom {
@@ -244,6 +257,9 @@ hipError_t launch_chirp_pre(const void* in, int in_c64, long long frame_stride, 
 hipError_t launch_chirp_post(const float2* y, int n, int m, int n_frames, int first_frame_index,
                              int db_mode, float pscale, float log_floor, float cal_db, const float* tare, float* out_db,
                              float* out_lin, float* hold_max, float* hold_min, hipStream_t s);
+// hold traces folded from finished dB rows [F][n] (chirp-z plans whose second transform stores the rows itself)
+hipError_t launch_chirp_hold(const float* rows, int n, int n_frames, int first_frame_index, float* hold_max, float* hold_min,
+                             hipStream_t s);
 // real-input frames: one-sided linear power rows in the layout of launch_real_fold
 hipError_t launch_chirp_post_real(const float2* y, int n, int m, int n_frames, int rows_per_frame, int row, float pscale,
                                   float* lin, hipStream_t s);

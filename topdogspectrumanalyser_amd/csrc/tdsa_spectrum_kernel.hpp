@@ -263,7 +263,11 @@ __device__ __forceinline__ void combine_const(c32& e, c32& o) {
 // halves do full butterflies and no lane idles.  16 points per thread keeps the kernel under 128 VGPRs:
 // 4 waves per SIMD, which is what it takes to keep the VALU fed (one wave issues at most one VALU op
 // every 4 clocks; the SIMD retires one every 2).
-template <int LOG2N, bool IN_C64, int HOLD>   // HOLD: bit0 = max trace, bit1 = min trace; 4 = AGG (see below)
+// CHIRP (complex64 input, no hold, frames of whole waves only): 1 = first transform of a chirp-z plan (raw samples unpacked,
+// DC-freed and multiplied by window x chirp on load; conj(X B) stored), 2 = its second transform (dB / power rows of the
+// N wanted bins stored): tdsa_chirp.hip's two element-wise passes folded into the transforms, in instantiations of their own -
+// as run-time branches of the plain complex64 kernel they cost it 68 - 83 spilled registers
+template <int LOG2N, bool IN_C64, int HOLD, int CHIRP = 0>   // HOLD: bit0 = max trace, bit1 = min trace; 4 = AGG (see below)
 __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const SpecParams p) {
   using C = Cfg<LOG2N>;
   constexpr int N = C::N, SG = C::SG, A = C::A, M = C::M, H = C::H, FPW = C::FPW, NPAD = C::NPAD;
@@ -486,6 +490,43 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     float res_re = 0.f, res_im = 0.f;     // DC_TRACKED: the estimate as a small residual on top of in_off (see below)
     // ---- frame sums for DC removal ---------------------------------------------------------------
     if constexpr (IN_C64) {
+      if constexpr (CHIRP == 1) {
+        static_assert(HOLD == 0 && UNI, "fused chirp transforms: complex64 instantiation without hold, whole waves per frame");
+        {
+          // chirp-z plans (tdsa_chirp.hip): the frame's RAW samples, unpacked, DC-freed and multiplied by window x chirp
+          // on the way in - step 1 folded into this load, the rows U[f][M] are neither written nor read.  The frame is
+          // wave-uniform here: SGPR descriptors, and samples from in_valid on (the implied zero padding) come back as zeros
+          // from the table's descriptor, which ends there.
+          const unsigned char* rb = static_cast<const unsigned char*>(p.pre_raw) + (long long)frame * p.pre_stride;
+          const unsigned nv = active ? unsigned(p.in_valid) : 0u;
+          const rsrc_t ar = make_rsrc(p.pre_aw, nv * 8u);
+          float dcx = 0.f, dcy = 0.f;
+          if (active && p.dc_sub != nullptr) { const float2 d = p.dc_sub[frame]; dcx = d.x; dcy = d.y; }
+          const unsigned xm = p.pre_xor & 0xffffu;
+          if (p.pre_c64) {
+            const rsrc_t rr = make_rsrc(rb, nv * 8u);
+            static_for<0, 16>([&](auto ic) {
+              constexpr int idx = decltype(ic)::value;
+              constexpr int jj = idx / R1, i = idx % R1;
+              const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(rr, lane_in_off + jj * 8u, RSTEP * i * (N / A) * 8, 0);
+              const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(ar, lane_in_off + jj * 8u, RSTEP * i * (N / A) * 8, 0);
+              v[idx] = cmul(c32{__uint_as_float(q.x) - dcx, __uint_as_float(q.y) - dcy}, c32{__uint_as_float(w.x), __uint_as_float(w.y)});
+            });
+          } else {
+            const rsrc_t rr = make_rsrc(rb, nv * 2u);
+            const unsigned roff = lane_in_off >> 2;          // 2 bytes per raw sample against 8 per complex64 one
+            static_for<0, 16>([&](auto ic) {
+              constexpr int idx = decltype(ic)::value;
+              constexpr int jj = idx / R1, i = idx % R1;
+              const unsigned u = unsigned(__builtin_amdgcn_raw_buffer_load_b16(rr, roff + jj * 2u, RSTEP * i * (N / A) * 2, 0)) ^ xm;
+              const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(ar, lane_in_off + jj * 8u, RSTEP * i * (N / A) * 8, 0);
+              // (x - pre_off is exact: small integers / halves; a sample past in_valid meets a zero of the table)
+              v[idx] = cmul(c32{(float(u & 0xffu) - p.pre_off) - dcx, (float((u >> 8) & 0xffu) - p.pre_off) - dcy},
+                            c32{__uint_as_float(w.x), __uint_as_float(w.y)});
+            });
+          }
+        }
+      } else {
       const unsigned char* fb = static_cast<const unsigned char*>(p.in) + in_byte_off(frame);
       static_for<0, 16>([&](auto ic) {
         constexpr int idx = decltype(ic)::value;
@@ -501,6 +542,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
           v[idx] = active ? row[jj] : c32{0.f, 0.f};
         }
       });
+      }
     } else {
       static_for<0, NRAW>([&](auto ic) { raw[decltype(ic)::value] ^= xm_v; });   // int8 -> offset binary
     }
@@ -847,6 +889,74 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
 
     // ---- epilogue: |X|^2 -> dB -> hold ; bin k = t + kc*SG lands at k ^ N/2 (fftshift) -----------
     // this thread's 16 bins: q < 8: kc = q + 8h (register bitrev(q)), q >= 8: kc = q + 8 + 8h (bitrev(q))
+    if constexpr (CHIRP == 2) {
+      static_assert(IN_C64 && HOLD == 0 && UNI, "fused chirp transforms: complex64 instantiation without hold, whole waves per frame");
+      if (active) {
+        // chirp-z plans, second transform: X[k] = a[k] conj(.) / M with |a[k]| = 1 - only |X|^2 of the bins k < post_n is
+        // wanted: power / dB rows of post_n values, fftshift-ed as np.fft.fftshift does for any N, hold traces through
+        // integer-punned atomics issued only where a trace moves (tdsa_chirp.hip step 4 folded into these stores; the
+        // frame is wave-uniform: one SGPR descriptor per row, stores past its end - bins k >= post_n - are dropped)
+        if constexpr (!C::WIN_LDS) load_window();
+        const int pn = p.post_n, half = pn / 2;
+        // bin k = t + 8 h SG + kc SG of this thread -> byte offset of its fftshift-ed position, or past the row's end
+        auto bin_off = [&](int kc) -> unsigned {
+          const int k = t + 8 * h * SG + kc * SG;
+          int j = k + half;
+          if (j >= pn) j -= pn;
+          return k < pn ? unsigned(j) * 4u : 0xfffffff0u;
+        };
+        const float inv_m2 = p.post_inv_m * p.post_inv_m;
+        if (p.out_lin != nullptr) {
+          const rsrc_t lr = make_rsrc(p.out_lin + (long long)frame * pn, unsigned(pn) * 4u);
+          const float sc = inv_m2 * p.pscale;
+          static_for<0, 16>([&](auto ic) {
+            constexpr int q = decltype(ic)::value;
+            constexpr int kc = (q < 8 ? q : q + 8);
+            const c32 X = v[bitrev(q, 4)];
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((X.x * X.x + X.y * X.y) * sc), lr, bin_off(kc), 0, 0);
+          });
+        } else {
+          // dB rows (the hold traces of a chirp-z plan are folded from these rows by chirp_hold_kernel: atomics in this
+          // epilogue cost the instantiation 70 - 100 spilled registers)
+          const bool mag = p.db_mode == 0;
+          const rsrc_t orr = make_rsrc(p.out_db + (long long)frame * pn, unsigned(pn) * 4u);
+          const rsrc_t tr = make_rsrc(p.tare, p.tare != nullptr ? unsigned(pn) * 4u : 0u);   // (no tare: zero records, loads return 0)
+          float db[16];
+          static_for<0, 16>([&](auto ic) {
+            constexpr int q = decltype(ic)::value;
+            const c32 X = v[bitrev(q, 4)];
+            db[q] = (X.x * X.x + X.y * X.y) * inv_m2;
+          });
+          static_for<0, 16>([&](auto ic) {
+            constexpr int q = decltype(ic)::value;
+            constexpr int kc = (q < 8 ? q : q + 8);
+            const unsigned off = bin_off(kc);
+            if (mag) db[q] = fmaf(2.0f * k10Log10_2, __builtin_amdgcn_logf(__builtin_amdgcn_sqrtf(db[q]) + p.log_floor), p.cal_db);
+            else db[q] = fmaf(k10Log10_2, __builtin_amdgcn_logf(fmaf(db[q], p.pscale, p.log_floor)), p.cal_db);
+            db[q] -= __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(tr, off, 0, 0));
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(db[q]), orr, off, 0, 0);
+          });
+        }
+      }
+    }
+    else if constexpr (CHIRP == 1) {
+      // first transform of a chirp-z plan: the spectrum leaves multiplied by the chirp filter's spectrum and conjugated,
+      // ready for the inverse transform
+      if (active) {
+        if constexpr (!C::WIN_LDS) load_window();
+        c32* crow = p.out_cplx + out_elem_off(frame) + t + 8 * h * SG;
+        const c32* brow = p.out_mul + t + 8 * h * SG;
+        static_for<0, 16>([&](auto ic) {
+          constexpr int q = decltype(ic)::value;
+          constexpr int kc = (q < 8 ? q : q + 8);
+          const c32 z = cmul(v[bitrev(q, 4)], brow[kc * SG]);
+          crow[kc * SG] = c32{z.x, -z.y};
+        });
+      } else {
+        if constexpr (!C::WIN_LDS) load_window();
+      }
+    }
+    else
     if (active) {
       if (p.out_cplx != nullptr) {            // real-input path: hand the complex bins to the fold kernel
         if constexpr (!C::WIN_LDS) load_window();
@@ -1137,9 +1247,9 @@ inline LaunchGeom geom_for(int n_frames, int num_cu) {
   return g;
 }
 
-template <int LOG2N, bool IN_C64, int HOLD>
+template <int LOG2N, bool IN_C64, int HOLD, int CHIRP = 0>
 inline hipError_t launch_one(const SpecParams& p, const LaunchGeom& g, hipStream_t s) {
-  auto k = spectrum_kernel<LOG2N, IN_C64, HOLD>;
+  auto k = spectrum_kernel<LOG2N, IN_C64, HOLD, CHIRP>;
   static std::atomic<unsigned long long> attr_done{0};
   const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), int(g.lds_bytes), attr_done);
   if (e != hipSuccess) return e;
@@ -1152,6 +1262,10 @@ hipError_t launch_n(int in_c64, const SpecParams& p, const LaunchGeom& g, hipStr
   const int hold = p.out_lin == nullptr ? (p.hold_flags & 3) : 0;
   if (p.out_lin != nullptr && p.agg_out != nullptr)
     return in_c64 ? launch_one<LOG2N, true, 4>(p, g, s) : launch_one<LOG2N, false, 4>(p, g, s);
+  if constexpr (Cfg<LOG2N>::TPF >= 64) {       // chirp-z plans: the transforms that carry the element-wise passes
+    if (in_c64 && p.pre_raw != nullptr) return launch_one<LOG2N, true, 0, 1>(p, g, s);
+    if (in_c64 && p.post_n != 0) return launch_one<LOG2N, true, 0, 2>(p, g, s);
+  }
   if (in_c64) {
     switch (hold) {
       case 0: return launch_one<LOG2N, true, 0>(p, g, s);
