@@ -78,13 +78,17 @@ def test_every_instantiation_is_free_of_scratch(reports, log2n, in_c64, hold):
 
 
 @pytest.mark.parametrize("log2n", [10, 11, 12, 13, 14])
-@pytest.mark.parametrize("chirp", [1, 2])
+@pytest.mark.parametrize("chirp", [1, 2, 3])
 def test_chirp_transform_instantiations_are_free_of_scratch(reports, log2n, chirp):
-    """The two transforms of a chirp-z plan that carry its element-wise passes (tdsa_chirp.hip; complex64 in, no hold,
-    M = 1024 ... 16384): no scratch at four waves per SIMD - as run-time branches of the plain complex64 kernel the same
-    code spilled 68 - 98 registers."""
+    """The instantiations that carry a chirp-z plan's element-wise passes (tdsa_chirp.hip; complex64 in, no hold,
+    M = 1024 ... 16384): 3 = the whole convolution of a frame in one pass through its workgroup, 1 / 2 = its two transforms as
+    two launches.  No scratch at four waves per SIMD - as run-time branches of the plain complex64 kernel the same code
+    spilled 68 - 98 registers.  One exception, stated: the one-launch instantiation at 16384 points (1024 threads, 136 KB
+    of LDS: no room for a twiddle table, no fifth wave) keeps 7 dwords in scratch; it still beats its two-launch
+    alternative by 26 % (profiles/r05_chirp.txt)."""
     k = _kernel(reports, log2n, True, 0, chirp)
-    assert int(k["ScratchSize [bytes/lane]"]) == 0 and int(k["VGPRs Spill"]) == 0, k
+    allowed = 32 if (log2n, chirp) == (14, 3) else 0
+    assert int(k["ScratchSize [bytes/lane]"]) <= allowed and int(k["VGPRs Spill"]) <= allowed // 4, k
     assert int(k["VGPRs"]) <= 128 and int(k["Occupancy [waves/SIMD]"]) >= 4, k
 
 

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="captures per call (tdsa_process_dev_batch), distinct buffers")
     ap.add_argument("--streams", type=int, default=1)
     ap.add_argument("--fmt", default="i8", choices=["i8", "c64"])
+    ap.add_argument("--knob", action="append", default=[], help="name=value for tdsa_debug_knob (repeatable)")
     a = ap.parse_args()
     n, hop, F = a.nfft, (a.hop or a.nfft // 2), a.frames
     ns = hop * (F - 1) + n
@@ -47,6 +48,9 @@ def main():
     w = np.hanning(n).astype(np.float32)
     e.set_window(w)
     e.configure(db_mode=a.mode, log_floor=1e-12, dc_alpha=1.0, hold_max=bool(a.hold & 1), hold_min=bool(a.hold & 2))
+    for kv in a.knob:
+        k, v = kv.split("=")
+        e.debug_knob(k, int(v))
     out_ptr = None if a.nodb else dev_out.value
     e.set_overlap(a.streams)
 
@@ -74,7 +78,7 @@ def main():
     fps = F / (per * 1e-3)
     bytes_per_frame = sb * hop + 4 * n
     inf = e.info()
-    print(f"lib={os.path.basename(nat.LIB_PATH)} fmt={a.fmt} N={n} hop={hop} F={F} batch={B} streams={a.streams} hold={a.hold} grid={inf.grid}x{inf.block} lds={inf.lds_bytes} "
+    print(f"lib={os.path.basename(nat.LIB_PATH)} {' '.join(a.knob)} fmt={a.fmt} N={n} hop={hop} F={F} batch={B} streams={a.streams} hold={a.hold} grid={inf.grid}x{inf.block} lds={inf.lds_bytes} "
           f"step={per*1e3:.1f} us  {fps/1e6:.3f} Mframes/s  {fps*bytes_per_frame/1e12:.3f} TB/s algorithmic "
           f"({fps*bytes_per_frame/8e12*100:.1f}% of 8 TB/s)  host wall {((t1-t0)/(calls*B))*1e6:.1f} us/step")
 

@@ -115,6 +115,7 @@ struct tdsa_plan_s {
   BigWindow big_win[3] = {};             // the column pass's window per input format (tdsa_set_window: table or one value)
   int avg_wg_min = 128;                  // batches of more frames than this take the workgroup-chunk scan (tdsa_debug_knob "avg_wg_min")
   bool avg_f64_chunks = false;           // tdsa_debug_knob "avg_f64_chunks": always the scan over fixed 64-frame chunks with float64 aggregates
+  int chirp_single = 1;                  // tdsa_debug_knob "chirp_single": 0 = the fusable chirp-z plans run their two transforms as two launches
   int big_pre_wgs = 0;                   // tdsa_debug_knob "big_pre_wgs": empty workgroups launched ahead of every column pass
   int big_group = 64;                    // segments per column-pass / row-pass round (one round for the K = 64 Welch capture)
   // frame lengths that are not a power of two (tdsa_chirp.hip): chirp-z on the m_fft-point frame kernel
@@ -370,7 +371,7 @@ int chirp_transform(tdsa_plan p, const void* in, int in_format, long long stride
   hipStream_t s = p->stream;
   const bool fused = chirp_fusable(p) && post != nullptr;  // both element-wise passes ride the transforms
   if (!p->d_u0 && !fused) HIPCHK(hipMalloc(&p->d_u0, size_t(p->max_frames) * M * sizeof(float2)));
-  if (!p->d_u1) HIPCHK(hipMalloc(&p->d_u1, size_t(p->max_frames) * M * sizeof(float2)));
+  if (!p->d_u1 && !(fused && p->chirp_single)) HIPCHK(hipMalloc(&p->d_u1, size_t(p->max_frames) * M * sizeof(float2)));
   if (!fused)
     HIPCHK(launch_chirp_pre(in, in_format == TDSA_IN_C64, stride, N, M, n_frames, p->d_window[in_format], p->d_chirp_a, dc_sub,
                             xor_mask, in_off, p->d_u0, s));
@@ -440,15 +441,7 @@ int chirp_transform(tdsa_plan p, const void* in, int in_format, long long stride
     sp.pre_xor = xor_mask;
     sp.pre_off = in_off;
   }
-  { const int rc = launch_spectrum_profiled(p, 1, sp, g); if (rc != TDSA_OK) return rc; }
-  sp.in = p->d_u1;
-  sp.pre_raw = nullptr;
-  sp.dc_sub = nullptr;
-  sp.out_cplx = p->d_u0;
-  sp.out_mul = nullptr;
-  sp.in_valid = 0;
-  sp.out_valid = N;                   // only bins k < N of the convolution are needed
-  if (fused) {                        // ... and leave as the dB / power rows themselves
+  const auto set_post = [&] {         // what the second transform's stores turn the bins into
     sp.out_cplx = nullptr;
     sp.out_valid = 0;
     sp.post_n = N;
@@ -461,7 +454,25 @@ int chirp_transform(tdsa_plan p, const void* in, int in_format, long long stride
     sp.tare = post->tare;
     sp.out_db = post->out_db;
     sp.out_lin = post->out_lin;
+  };
+  if (fused && p->chirp_single) {
+    // the whole convolution of a frame in one pass through its workgroup (spectrum_kernel<L, true, 0, 3>): transform,
+    // x B, conjugate, through LDS back into sample order, transform, dB rows - the complex64 intermediate never leaves the CU
+    set_post();
+    { const int rc = launch_spectrum_profiled(p, 1, sp, g); if (rc != TDSA_OK) return rc; }
+    if (post->out_lin == nullptr && (post->hold_max || post->hold_min))
+      HIPCHK(launch_chirp_hold(post->out_db, N, n_frames, post->first_frame_index, post->hold_max, post->hold_min, s));
+    return TDSA_OK;
   }
+  { const int rc = launch_spectrum_profiled(p, 1, sp, g); if (rc != TDSA_OK) return rc; }
+  sp.in = p->d_u1;
+  sp.pre_raw = nullptr;
+  sp.dc_sub = nullptr;
+  sp.out_cplx = p->d_u0;
+  sp.out_mul = nullptr;
+  sp.in_valid = 0;
+  sp.out_valid = N;                   // only bins k < N of the convolution are needed
+  if (fused) set_post();              // ... and leave as the dB / power rows themselves
   { const int rc = launch_spectrum_profiled(p, 1, sp, g); if (rc != TDSA_OK) return rc; }
   if (fused && post->out_lin == nullptr && (post->hold_max || post->hold_min))
     HIPCHK(launch_chirp_hold(post->out_db, N, n_frames, post->first_frame_index, post->hold_max, post->hold_min, s));
@@ -865,8 +876,8 @@ int tdsa_set_window(tdsa_plan p, const float* w_host, int n) {
         const double ang = -M_PI * double(q) / double(n), wv = double(w_host[i]) * double(scale[f]);
         aw[i] = float2{float(wv * std::cos(ang)), float(wv * std::sin(ang))};
       }
-      if (!p->d_chirp_aw[f]) HIPCHK(hipMalloc(&p->d_chirp_aw[f], size_t(n) * sizeof(float2)));
-      HIPCHK(hipMemcpy(p->d_chirp_aw[f], aw.data(), size_t(n) * sizeof(float2), hipMemcpyHostToDevice));
+      if (!p->d_chirp_aw[f]) HIPCHK(hipMalloc(&p->d_chirp_aw[f], aw.size() * sizeof(float2)));
+      HIPCHK(hipMemcpy(p->d_chirp_aw[f], aw.data(), aw.size() * sizeof(float2), hipMemcpyHostToDevice));
     }
   }
   p->window_set = true;
@@ -1809,6 +1820,8 @@ int tdsa_debug_knob(tdsa_plan p, const char* name, int value) {
     if (!p->big || value < 1 || value > 64) return fail(TDSA_ERR_ARG, "big_group=%d (long-frame plans, 1 .. 64)", value);
     if (p->d_z && value > p->big_group) return fail(TDSA_ERR_STATE, "big_group can only shrink once the plan has run");
     p->big_group = value;
+  } else if (k == "chirp_single") {          // fusable chirp-z plans: 1 = one launch per call (default), 0 = two transforms, two launches
+    p->chirp_single = value != 0;
   } else if (k == "big_pre_wgs") {           // long-frame plans: empty workgroups ahead of every column pass (XCD phase)
     if (value < 0 || value > 64) return fail(TDSA_ERR_ARG, "big_pre_wgs=%d outside [0, 64]", value);
     p->big_pre_wgs = value;

@@ -263,9 +263,10 @@ __device__ __forceinline__ void combine_const(c32& e, c32& o) {
 // halves do full butterflies and no lane idles.  16 points per thread keeps the kernel under 128 VGPRs:
 // 4 waves per SIMD, which is what it takes to keep the VALU fed (one wave issues at most one VALU op
 // every 4 clocks; the SIMD retires one every 2).
-// CHIRP (complex64 input, no hold, frames of whole waves only): 1 = first transform of a chirp-z plan (raw samples unpacked,
-// DC-freed and multiplied by window x chirp on load; conj(X B) stored), 2 = its second transform (dB / power rows of the
-// N wanted bins stored): tdsa_chirp.hip's two element-wise passes folded into the transforms, in instantiations of their own -
+// CHIRP (complex64 input, no hold, frames of whole waves only): 3 = the whole chirp-z convolution of a frame in one pass
+// through the workgroup (raw samples in, dB / power rows of the N wanted bins out); 1 = its first transform alone (raw samples
+// unpacked, DC-freed and multiplied by window x chirp on load; conj(X B) stored), 2 = its second transform alone (dB / power
+// rows stored): tdsa_chirp.hip's two element-wise passes folded into the transforms, in instantiations of their own -
 // as run-time branches of the plain complex64 kernel they cost it 68 - 83 spilled registers
 template <int LOG2N, bool IN_C64, int HOLD, int CHIRP = 0>   // HOLD: bit0 = max trace, bit1 = min trace; 4 = AGG (see below)
 __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const SpecParams p) {
@@ -413,7 +414,9 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   // reload is unconditional (the last one is simply unused) so that the old values are dead in between.
   float win[16];                       // win[c*R1 + r] = w[a(r)*(N/A) + t*M + c (+ h*CPT if INL)], a(r) = r (INL) or 2r + h
   auto load_window = [&] {
-    if constexpr (C::WIN_LDS) {
+    if constexpr (CHIRP != 0) {
+      // (the transforms of a chirp-z plan carry no window: it is part of the table the samples meet on load)
+    } else if constexpr (C::WIN_LDS) {
       static_for<0, R1>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         static_for<0, CPT>([&](auto jc) {
@@ -462,7 +465,10 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   // middle-pass table goes through registers into LDS, which waits for everything issued before it), the
   // window slice last (64 KiB per workgroup, not needed before the first barrier has been passed)
   c32 twf_lo[3], twf_hi[4];   // last pass: W_N^(t*(2i+h)), i = 4a + j  ->  hi[a] = W^(t(8a+h)), lo[j-1] = W^(2tj)
-  if constexpr (!TWF_LDS) {
+  // TWF_RELOAD: the one-launch chirp-z instantiations of 2048 and 16384 points have no 14 registers to keep them in across
+  // the frame loop (1 / 18 spilled dwords) and the LDS no room for a table: re-read from the L2-resident table per transform
+  constexpr bool TWF_RELOAD = CHIRP == 3 && (LOG2N == 11 || LOG2N == 14);
+  if constexpr (!TWF_LDS && !TWF_RELOAD) {
     static_for<0, 3>([&](auto ic) { constexpr int j = decltype(ic)::value; twf_lo[j] = p.tw[t * 2 * (j + 1)]; });
     static_for<0, 4>([&](auto ic) { constexpr int a = decltype(ic)::value; twf_hi[a] = p.tw[t * (8 * a + h)]; });
   }
@@ -490,7 +496,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     float res_re = 0.f, res_im = 0.f;     // DC_TRACKED: the estimate as a small residual on top of in_off (see below)
     // ---- frame sums for DC removal ---------------------------------------------------------------
     if constexpr (IN_C64) {
-      if constexpr (CHIRP == 1) {
+      if constexpr (CHIRP == 1 || CHIRP == 3) {
         static_assert(HOLD == 0 && UNI, "fused chirp transforms: complex64 instantiation without hold, whole waves per frame");
         {
           // chirp-z plans (tdsa_chirp.hip): the frame's RAW samples, unpacked, DC-freed and multiplied by window x chirp
@@ -546,350 +552,46 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     } else {
       static_for<0, NRAW>([&](auto ic) { raw[decltype(ic)::value] ^= xm_v; });   // int8 -> offset binary
     }
-    if constexpr (!IN_C64 && SG >= 32) {
-      // byte formats, whole waves per frame: exact integer sums, DPP wave reduce, one int2 per wave
-      int* redi = reinterpret_cast<int*>(red);
-      if (p.dc_mode == DC_FRAME_MEAN) {
-        unsigned si = 0, sq = 0;
-        static_for<0, NRAW>([&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          si = __builtin_amdgcn_udot4(raw[i], 0x00010001u, si, false);
-          sq = __builtin_amdgcn_udot4(raw[i], 0x01000100u, sq, false);
-        });
-        const int wi = dpp_wave_sum(int(si)), wq = dpp_wave_sum(int(sq));
-        if constexpr (HOLD >= 3) {
-          // both hold traces (or the averager's chunk aggregate) in registers: the slot address of this one-lane store is rebuilt from the (scalar) wave
-          // index per frame - kept in a VGPR across the loop it was the dword that got spilled at N = 16384, and its
-          // reload at the frame top waited (vmcnt(0)) for all of the previous frame's row stores
-          int ws = __builtin_amdgcn_readfirstlane(wave);
-          asm volatile("" : "+s"(ws));
-          if ((tid & 63) == 63) *reinterpret_cast<int2*>(&redi[ws * 2]) = int2{wi, wq};
-        } else {
-          if ((tid & 63) == 63) *reinterpret_cast<int2*>(&redi[wave * 2]) = int2{wi, wq};
-        }
+    // One transform (DC, window, three radix passes: v[] in sample order -> v[] in bin order) - or, CHIRP == 3, the whole
+    // chirp-z convolution of a frame without leaving the workgroup: transform, times the chirp filter's spectrum,
+    // conjugate, back through LDS into sample order, transform again (the complex64 intermediate of the two-launch version -
+    // 16 bytes per point written and read - never reaches memory).
+    if constexpr (CHIRP != 3) {
+#include "tdsa_spectrum_passes.inc"
+    } else {
+      {
+#include "tdsa_spectrum_passes.inc"
       }
-      TDSA_STAMP(1);
-      TDSA_SYNC();       // also the WAR fence between the previous frame's LDS reads and our writes
-      TDSA_PRIO(3);
-      TDSA_STAMP(2);
-      if (p.dc_mode == DC_FRAME_MEAN) {
-        const int w0 = slot * C::WPF;
-        // lane (l mod WPF) fetches one wave's partial (a single conflict-free ds_read_b64 per wave),
-        // the WPF partials are then summed inside the 16-lane row with DPP adds
-        const int2 q = *reinterpret_cast<const int2*>(&redi[(w0 + (tid & (C::WPF - 1))) * 2]);
-        int ti = q.x, tq = q.y;
-        if constexpr (C::WPF >= 2) {
-          ti += __builtin_amdgcn_update_dpp(0, ti, 0xB1, 0xf, 0xf, false);
-          tq += __builtin_amdgcn_update_dpp(0, tq, 0xB1, 0xf, 0xf, false);
-        }
-        if constexpr (C::WPF >= 4) {
-          ti += __builtin_amdgcn_update_dpp(0, ti, 0x4E, 0xf, 0xf, false);
-          tq += __builtin_amdgcn_update_dpp(0, tq, 0x4E, 0xf, 0xf, false);
-        }
-        if constexpr (C::WPF >= 8) {
-          ti += __builtin_amdgcn_update_dpp(0, ti, 0x141, 0xf, 0xf, false);
-          tq += __builtin_amdgcn_update_dpp(0, tq, 0x141, 0xf, 0xf, false);
-        }
-        if constexpr (C::WPF >= 16) {
-          ti += __builtin_amdgcn_update_dpp(0, ti, 0x140, 0xf, 0xf, false);
-          tq += __builtin_amdgcn_update_dpp(0, tq, 0x140, 0xf, 0xf, false);
-        }
-        sub_re = float(ti) * (1.0f / N);     // exact: sums < 2^24, N a power of two
-        sub_im = float(tq) * (1.0f / N);
-        if (p.dc_state != nullptr && frame == p.n_frames - 1 && t == 0 && h == 0)
-          *p.dc_state = c32{(sub_re - p.in_off) * p.in_scale, (sub_im - p.in_off) * p.in_scale};
-      } else if (p.dc_mode == DC_TRACKED && active) {
-        const c32 sv = p.dc_sub[frame]; res_re = sv.x; res_im = sv.y;
-      }
-    } else if (!IN_C64 && p.dc_mode == DC_FRAME_MEAN) {
-      // byte formats, several frames per wave (N < 1024): exact integer sums again, reduced over the
-      // SG rows of the frame inside one 16-lane DPP row, then across the two half-threads
-      unsigned si = 0, sq = 0;
-      static_for<0, NRAW>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        si = __builtin_amdgcn_udot4(raw[i], 0x00010001u, si, false);
-        sq = __builtin_amdgcn_udot4(raw[i], 0x01000100u, sq, false);
+    {
+      // conj(X B) in natural bin order into LDS (element i at i + (i >> 5)), then the second transform's pass-1 inputs
+      const rsrc_t br = make_rsrc(p.out_mul, N * 8u);
+      TDSA_SYNC();                                          // every thread has gathered its last-pass inputs
+      static_for<0, 16>([&](auto ic) {
+        constexpr int q = decltype(ic)::value;
+        constexpr int kc = (q < 8 ? q : q + 8);
+        const int k = t + 8 * h * SG + kc * SG;
+        const u32x2 bq = __builtin_amdgcn_raw_buffer_load_b64(br, (unsigned(t) + 8u * unsigned(h) * SG) * 8u, kc * SG * 8u, 0);
+        const c32 w = cmul(v[bitrev(q, 4)], c32{__uint_as_float(bq.x), __uint_as_float(bq.y)});
+        lds_st(&buf[k + (k >> 5)], c32{w.x, -w.y});
       });
-      int ti = int(si), tq = int(sq);
-      if constexpr (SG >= 2) {
-        ti += __builtin_amdgcn_update_dpp(0, ti, 0xB1, 0xf, 0xf, false);
-        tq += __builtin_amdgcn_update_dpp(0, tq, 0xB1, 0xf, 0xf, false);
-      }
-      if constexpr (SG >= 4) {
-        ti += __builtin_amdgcn_update_dpp(0, ti, 0x4E, 0xf, 0xf, false);
-        tq += __builtin_amdgcn_update_dpp(0, tq, 0x4E, 0xf, 0xf, false);
-      }
-      if constexpr (SG >= 8) {
-        ti += __builtin_amdgcn_update_dpp(0, ti, 0x141, 0xf, 0xf, false);
-        tq += __builtin_amdgcn_update_dpp(0, tq, 0x141, 0xf, 0xf, false);
-      }
-      if constexpr (SG >= 16) {
-        ti += __builtin_amdgcn_update_dpp(0, ti, 0x140, 0xf, 0xf, false);
-        tq += __builtin_amdgcn_update_dpp(0, tq, 0x140, 0xf, 0xf, false);
-      }
-      ti += __shfl_xor(ti, 32);
-      tq += __shfl_xor(tq, 32);
       TDSA_SYNC();
-      sub_re = float(ti) * (1.0f / N);     // exact: sums < 2^24, N a power of two
-      sub_im = float(tq) * (1.0f / N);
-      if (p.dc_state != nullptr && frame == p.n_frames - 1 && t == 0 && h == 0)
-        *p.dc_state = c32{(sub_re - p.in_off) * p.in_scale, (sub_im - p.in_off) * p.in_scale};
-    } else if (p.dc_mode == DC_FRAME_MEAN) {
-      // complex64 input: double sums, shuffles
-      double s_re = 0.0, s_im = 0.0;
       static_for<0, 16>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        s_re += double(v[i].x); s_im += double(v[i].y);
+        constexpr int idx = decltype(ic)::value;
+        constexpr int jj = idx / R1, i = idx % R1;
+        const int n_idx = INL ? i * (N / A) + t * M + h * CPT + jj : (2 * i) * (N / A) + h * (N / A) + t * M + jj;
+        v[idx] = lds_ld(&buf[n_idx + (n_idx >> 5)]);
       });
-      constexpr int W = SG < 32 ? SG : 32;                  // rows of this frame inside the half-wave
-      s_re = seg_sum<W>(s_re); s_im = seg_sum<W>(s_im);
-      s_re += __shfl_xor(s_re, 32); s_im += __shfl_xor(s_im, 32);   // the other half-thread's rows
-      if constexpr (SG > 32) {
-        if constexpr (HOLD >= 3) {          // (scalar wave index rebuilt per frame: see the byte path above)
-          int ws = __builtin_amdgcn_readfirstlane(wave);
-          asm volatile("" : "+s"(ws));
-          if ((tid & 63) == 0) { red[ws * 2] = s_re; red[ws * 2 + 1] = s_im; }
-        } else {
-          if ((tid & 63) == 0) { red[wave * 2] = s_re; red[wave * 2 + 1] = s_im; }
-        }
-      }
-      TDSA_SYNC();
-      if constexpr (SG > 32) {
-        const int w0 = slot * C::WPF;
-        s_re = 0.0; s_im = 0.0;
-#pragma unroll
-        for (int i = 0; i < C::WPF; ++i) { s_re += red[(w0 + i) * 2]; s_im += red[(w0 + i) * 2 + 1]; }
-      }
-      sub_re = float(s_re * (1.0 / N));
-      sub_im = float(s_im * (1.0 / N));
-      if (p.dc_state != nullptr && frame == p.n_frames - 1 && t == 0 && h == 0)
-        *p.dc_state = c32{(sub_re - p.in_off) * p.in_scale, (sub_im - p.in_off) * p.in_scale};
-    } else {
-      TDSA_SYNC();
-      if (p.dc_mode == DC_TRACKED && active) {
-        const c32 s = p.dc_sub[frame];
-        if constexpr (IN_C64) { sub_re = s.x; sub_im = s.y; }    // in_off = 0: the estimate IS the subtract value
-        else { res_re = s.x; res_im = s.y; }
+    }
+      {
+#include "tdsa_spectrum_passes.inc"
       }
     }
-    sub_re = in_vgpr(sub_re);
-    sub_im = in_vgpr(sub_im);
-    if constexpr (C::WIN_LDS) load_window();
-
-    // ---- unpack + DC removal + window ------------------------------------------------------------
-    // v[c*R1 + r] = sample of row read r (input row a(r)), column c of this half-thread (c < CPT).
-    // FUSE_WIN: the window multiply rides the first butterfly layer of pass 1 (pairs r, r + R1/2 of every radix-R1
-    // group):  (e we + o wo, e we - o wo)  as  mul, fma, fma  per component instead of  mul, mul, add, sub  -
-    // 16 instructions less per thread and frame; here the samples are only unpacked and DC-freed
-    constexpr bool FUSE_WIN = R1 >= 2;
-    auto put = [&](auto ic, float xr, float xi) {          // sample idx, DC-free -> v[idx] (windowed unless fused)
-      constexpr int idx = decltype(ic)::value;
-      if constexpr (FUSE_WIN) v[idx] = c32{xr, xi};
-      else v[idx] = c32{xr * win[idx], xi * win[idx]};
-    };
-    if constexpr (IN_C64) {
-      static_for<0, 16>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        put(ic, v[i].x - sub_re, v[i].y - sub_im);
-      });
-    } else if constexpr (M == 1) {
-      static_for<0, 16>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        const uint32_t u = raw[i];
-        put(ic, float(u & 0xffu) - sub_re, float((u >> 8) & 0xffu) - sub_im);
-      });
-    } else if constexpr (FUSE_WIN) {
-      // pair by pair (row reads r and r + R1/2 of the same butterfly), so that raw bytes and window values die as they
-      // are used
-      auto pair = [&](auto ac, float exr, float exi, float oxr, float oxi) {
-        constexpr int a = decltype(ac)::value, b = a + R1 / 2;
-        const float er = (exr - sub_re) * win[a], ei = (exi - sub_im) * win[a];
-        const float orr = oxr - sub_re, oi = oxi - sub_im;
-        v[a] = c32{fmaf(orr, win[b], er), fmaf(oi, win[b], ei)};
-        v[b] = c32{fmaf(-orr, win[b], er), fmaf(-oi, win[b], ei)};
-      };
-      static_for<0, R1 / 2>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        static_for<0, DW>([&](auto dc) {
-          constexpr int d = decltype(dc)::value;
-          const uint32_t ue = raw[i * DW + d], uo = raw[(i + R1 / 2) * DW + d];
-          pair(std::integral_constant<int, (2 * d) * R1 + i>{}, float(ue & 0xffu), float((ue >> 8) & 0xffu),
-               float(uo & 0xffu), float((uo >> 8) & 0xffu));
-          pair(std::integral_constant<int, (2 * d + 1) * R1 + i>{}, float((ue >> 16) & 0xffu), float(ue >> 24),
-               float((uo >> 16) & 0xffu), float(uo >> 24));
-        });
-      });
-    } else {
-      static_for<0, R1>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        static_for<0, DW>([&](auto dc) {
-          constexpr int d = decltype(dc)::value;
-          const uint32_t u = raw[i * DW + d];
-          constexpr int i0 = (2 * d) * R1 + i, i1 = (2 * d + 1) * R1 + i;
-          put(std::integral_constant<int, i0>{}, float(u & 0xffu) - sub_re, float((u >> 8) & 0xffu) - sub_im);
-          put(std::integral_constant<int, i1>{}, float((u >> 16) & 0xffu) - sub_re, float(u >> 24) - sub_im);
-        });
-      });
-    }
-    if constexpr (FUSE_WIN && (IN_C64 || M == 1)) {
-      // first layer of every radix-R1 group with the window folded in (the byte path above did it on the way)
-      static_for<0, CPT>([&](auto jc) {
-        constexpr int jj = decltype(jc)::value;
-        static_for<0, R1 / 2>([&](auto ic) {
-          constexpr int a = jj * R1 + decltype(ic)::value, b = a + R1 / 2;
-          const float er = v[a].x * win[a], ei = v[a].y * win[a];
-          const float orr = v[b].x, oi = v[b].y;
-          v[a] = c32{fmaf(orr, win[b], er), fmaf(oi, win[b], ei)};
-          v[b] = c32{fmaf(-orr, win[b], er), fmaf(-oi, win[b], ei)};
-        });
-      });
-    }
-    if constexpr (!IN_C64) {
-      // Tracked DC remover: x - in_off above is exact (small integers / halves), the estimate follows as its own
-      // term, v -= dc * w, instead of one float32 "128 + dc" whose 2^-17 LSB of resolution would add up coherently
-      // in the DC bin (it was worth up to 3.8 rounding units of A_max there).  Wave-uniform branch, this mode only.
-      // Behind the fused first layer the term of a pair (a, b) is dc (w_a + w_b) on the sum and dc (w_a - w_b) on
-      // the difference.
-      if (p.dc_mode == DC_TRACKED) {
-        if constexpr (FUSE_WIN) {
-          static_for<0, CPT>([&](auto jc) {
-            constexpr int jj = decltype(jc)::value;
-            static_for<0, R1 / 2>([&](auto ic) {
-              constexpr int a = jj * R1 + decltype(ic)::value, b = a + R1 / 2;
-              const float ws = win[a] + win[b], wd = win[a] - win[b];
-              v[a] = c32{fmaf(-res_re, ws, v[a].x), fmaf(-res_im, ws, v[a].y)};
-              v[b] = c32{fmaf(-res_re, wd, v[b].x), fmaf(-res_im, wd, v[b].y)};
-            });
-          });
-        } else {
-          static_for<0, 16>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            v[i] = c32{fmaf(-res_re, win[i], v[i].x), fmaf(-res_im, win[i], v[i].y)};
-          });
-        }
-      }
-    }
-    TDSA_STAMP(3);
-    // raw registers are free again: start the next frame's HBM read now, it lands during the FFT
-    if (unit + 1 < u1) load_frame_raw(frame_of(unit + 1));
-    TDSA_PRIO(2);
-
-    // ---- pass 1: per lane CPT radix-R1 DFTs; INL: that is the whole pass, else (even / odd input rows per
-    //      half-thread) the cross-lane combine follows ------------------------------------------------
-    if constexpr (FUSE_WIN) static_for<0, CPT>([&](auto jc) { dit_rest<R1, decltype(jc)::value * R1, 16>(v); });
-    else static_for<0, CPT>([&](auto jc) { radix<R1, decltype(jc)::value * R1, 16>(v); });
-    if constexpr (INL) {
-      // butterfly g of this half-thread is butterfly h*CPT + g of the row: X[k] -> element (h*CPT + g)*A + k
-      static_for<0, 16>([&](auto ec) {
-        constexpr int e = decltype(ec)::value;
-        constexpr int g = e / A, k = e % A;
-        lds_st(&buf[wr1_base + e], v[g * A + bitrev(k, LR1)]);
-      });
-    } else {
-    TDSA_PRIO(1);
-    static_for<0, 8>([&](auto uc) {
-      constexpr int u = decltype(uc)::value;
-      if constexpr (u == 4) TDSA_PRIO(0);
-      constexpr int jj0 = u / H, k0 = u % H, jj1 = (u + 8) / H, k1 = (u + 8) % H;
-      constexpr int re = jj0 * H + bitrev(k0, LH), ro = jj1 * H + bitrev(k1, LH);
-      swap_halves(v[re], v[ro]);   // v[re] = E of unit u + 8h, v[ro] = O
-      if constexpr (A == 32) combine32<u>(v[re], v[ro], odd_half);
-      else combine_const<k0, A>(v[re], v[ro]);               // (u + 8h) % H == u % H for H <= 8
-      constexpr int li = jj0 * A + k0;                       // + lane offset folded into wr1_base
-      { lds_st(&buf[wr1_base + li], v[re]); lds_st(&buf[wr1_base + li + H], v[ro]); }
-    });
-    }
-    TDSA_STAMP(4);
-    TDSA_SYNC();
-    TDSA_PRIO(3);
-    TDSA_STAMP(5);
-
-    // ---- middle radix-32 pass (3-pass sizes), IN PLACE: a row's two half-threads own the 32 slots
-    //      they gather, so no barrier separates the gather from the scatter ----------------------------
-    if constexpr (C::NPASS == 3) {
-      static_for<0, 16>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        v[i] = lds_ld(&buf[rdA + i * 2 * rd_stride]);
-      });
-      int tw_o = h * A + ka_mid;
-      asm volatile("" : "+v"(tw_o));                        // keep the table reads inside the loop
-      // two batches of eight table reads, each issued back to back and waited for once
-      // batch k serves the pairs (i, i + 8), i = 4k .. 4k + 3, of the radix-16's first layer: the pre-twiddle rides
-      // that layer's butterflies (bf_tw: 10 instead of 12 instructions per pair)
-      static_for<0, 2>([&](auto bc) {
-        constexpr int b0 = decltype(bc)::value * 4;
-        c32 tw8[8];
-        static_for<0, 8>([&](auto ic) {
-          constexpr int q = decltype(ic)::value;
-          constexpr int i = b0 + (q & 3) + 8 * (q >> 2);
-          tw8[q] = twm[tw_o + i * 2 * A];
-        });
-        __builtin_amdgcn_sched_barrier(0);
-        static_for<0, 4>([&](auto ic) {
-          constexpr int q = decltype(ic)::value;
-          bf_tw(v[b0 + q], v[b0 + q + 8], tw8[q], tw8[q + 4]);
-        });
-        __builtin_amdgcn_sched_barrier(0);
-      });
-      TDSA_STAMP(6);
-      TDSA_PRIO(2);
-      dit_rest<16, 0, 16>(v);
-      TDSA_PRIO(1);
-      static_for<0, 8>([&](auto uc) {
-        constexpr int u = decltype(uc)::value;
-        if constexpr (u == 4) TDSA_PRIO(0);
-        constexpr int re = bitrev(u, 4), ro = bitrev(u + 8, 4);
-        swap_halves(v[re], v[ro]);
-        combine32<u>(v[re], v[ro], odd_half);                // outputs kb = u + 8h and kb + 16
-        {
-          lds_st(&buf[wrM + u * rd_stride], v[re]);
-          lds_st(&buf[wrM + (u + 16) * rd_stride], v[ro]);
-        }
-      });
-      TDSA_STAMP(7);
-      TDSA_SYNC();
-      TDSA_PRIO(3);
-      TDSA_STAMP(8);
-      static_for<0, 16>([&](auto ic) {                       // element c = 2i + h of row (kb, ka)
-        constexpr int i = decltype(ic)::value;
-        v[i] = lds_ld(&buf[rd3A + 2 * i * A + ((2 * i * A) >> 5)]);
-      });
-    } else {
-      static_for<0, 16>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        if constexpr (SG % 32 == 0) v[i] = lds_ld(&buf[rdA + i * 2 * rd_stride]);
-        else { const int e = t + (2 * i + h) * SG; v[i] = lds_ld(&buf[e + (e >> 5)]); }
-      });
-    }
-    TDSA_STAMP(9);
-    if constexpr (TWF_LDS) {
-      static_for<0, 3>([&](auto ic) { constexpr int j = decltype(ic)::value; twf_lo[j] = lds_ld(&twf_tab[j * SG + t]); });
-      static_for<0, 4>([&](auto ic) { constexpr int a = decltype(ic)::value; twf_hi[a] = lds_ld(&twf_tab[3 * SG + a * C::TPF + h * SG + t]); });
-    } else {
-      static_for<0, 3>([&](auto ic) { opaque(twf_lo[decltype(ic)::value]); });
-      static_for<0, 4>([&](auto ic) { opaque(twf_hi[decltype(ic)::value]); });
-    }
-    static_for<0, 8>([&](auto ic) {                          // pre-twiddle W_N^(t*(2i+h)), i = 4a + j, fused with the
-      constexpr int i = decltype(ic)::value;                 // radix-16's first layer: pairs (i, i + 8) = (a, a + 2)
-      constexpr int a = i >> 2, j = i & 3;
-      c32 te = twf_hi[a], to = twf_hi[a + 2];
-      if constexpr (j != 0) { te = cmul(te, twf_lo[j - 1]); to = cmul(to, twf_lo[j - 1]); }
-      bf_tw(v[i], v[i + 8], te, to);
-    });
-    TDSA_PRIO(2);
-    dit_rest<16, 0, 16>(v);
-    static_for<0, 8>([&](auto uc) {
-      constexpr int u = decltype(uc)::value;
-      constexpr int re = bitrev(u, 4), ro = bitrev(u + 8, 4);
-      swap_halves(v[re], v[ro]);
-      combine32<u, true>(v[re], v[ro], odd_half);            // bins kc = u + 8h (v[re]) and kc + 16 (v[ro])
-    });
     TDSA_PRIO(1);
     TDSA_STAMP(10);
 
     // ---- epilogue: |X|^2 -> dB -> hold ; bin k = t + kc*SG lands at k ^ N/2 (fftshift) -----------
     // this thread's 16 bins: q < 8: kc = q + 8h (register bitrev(q)), q >= 8: kc = q + 8 + 8h (bitrev(q))
-    if constexpr (CHIRP == 2) {
+    if constexpr (CHIRP == 2 || CHIRP == 3) {
       static_assert(IN_C64 && HOLD == 0 && UNI, "fused chirp transforms: complex64 instantiation without hold, whole waves per frame");
       if (active) {
         // chirp-z plans, second transform: X[k] = a[k] conj(.) / M with |a[k]| = 1 - only |X|^2 of the bins k < post_n is
@@ -920,7 +622,6 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
           // epilogue cost the instantiation 70 - 100 spilled registers)
           const bool mag = p.db_mode == 0;
           const rsrc_t orr = make_rsrc(p.out_db + (long long)frame * pn, unsigned(pn) * 4u);
-          const rsrc_t tr = make_rsrc(p.tare, p.tare != nullptr ? unsigned(pn) * 4u : 0u);   // (no tare: zero records, loads return 0)
           float db[16];
           static_for<0, 16>([&](auto ic) {
             constexpr int q = decltype(ic)::value;
@@ -929,12 +630,21 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
           });
           static_for<0, 16>([&](auto ic) {
             constexpr int q = decltype(ic)::value;
-            constexpr int kc = (q < 8 ? q : q + 8);
-            const unsigned off = bin_off(kc);
             if (mag) db[q] = fmaf(2.0f * k10Log10_2, __builtin_amdgcn_logf(__builtin_amdgcn_sqrtf(db[q]) + p.log_floor), p.cal_db);
             else db[q] = fmaf(k10Log10_2, __builtin_amdgcn_logf(fmaf(db[q], p.pscale, p.log_floor)), p.cal_db);
-            db[q] -= __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(tr, off, 0, 0));
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(db[q]), orr, off, 0, 0);
+          });
+          if (p.tare != nullptr) {
+            const rsrc_t tr = make_rsrc(p.tare, unsigned(pn) * 4u);
+            static_for<0, 16>([&](auto ic) {
+              constexpr int q = decltype(ic)::value;
+              constexpr int kc = (q < 8 ? q : q + 8);
+              db[q] -= __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(tr, bin_off(kc), 0, 0));
+            });
+          }
+          static_for<0, 16>([&](auto ic) {
+            constexpr int q = decltype(ic)::value;
+            constexpr int kc = (q < 8 ? q : q + 8);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(db[q]), orr, bin_off(kc), 0, 0);
           });
         }
       }
@@ -1263,6 +973,7 @@ hipError_t launch_n(int in_c64, const SpecParams& p, const LaunchGeom& g, hipStr
   if (p.out_lin != nullptr && p.agg_out != nullptr)
     return in_c64 ? launch_one<LOG2N, true, 4>(p, g, s) : launch_one<LOG2N, false, 4>(p, g, s);
   if constexpr (Cfg<LOG2N>::TPF >= 64) {       // chirp-z plans: the transforms that carry the element-wise passes
+    if (in_c64 && p.pre_raw != nullptr && p.post_n != 0) return launch_one<LOG2N, true, 0, 3>(p, g, s);
     if (in_c64 && p.pre_raw != nullptr) return launch_one<LOG2N, true, 0, 1>(p, g, s);
     if (in_c64 && p.post_n != 0) return launch_one<LOG2N, true, 0, 2>(p, g, s);
   }
