@@ -90,12 +90,13 @@ int tdsa_device_count(int* count);
 /* One plan = (device, FFT size, batch capacity).  Replaces _allocate_fft_resources
  * (datasources/hackrf_samples.py:311-324) + the per-source TraceAverager (datasources/base.py:59)
  * + the hold buffers mw.max_power_levels / mw.min_power_levels (main.py:70-105).
- * nfft: any power of two from 64 to 2^20, and ANY size from 2 to 2^19 (HackrfSamplesDataSource.set_num_samples
+ * nfft: ANY size from 2 to 2^20 (HackrfSamplesDataSource.set_num_samples
  * is unbounded and np.fft.fft takes any N, hackrf_samples.py:392-405, :370): powers of two 64 .. 16384 run as ONE
  * LDS-resident kernel; 2^15 .. 2^20 as N1 x 16384 in two passes (in-register column DFT kernel + a 16384-point
  * row pass); every other size as a chirp-z convolution on the power-of-two kernels, M = 2^ceil(log2(2 nfft - 1))
- * (tdsa_chirp.hip: same modes, state and outputs, one row per frame, 7-8x slower per frame; M > 16384 - sizes above
- * 8192 - through the long-frame kernels; fftshift by nfft / 2 as np.fft.fftshift does for odd sizes).  A plan of
+ * (tdsa_chirp.hip: same modes, state and outputs, one row per frame; M <= 16384 - sizes up to 8192 - as ONE kernel per
+ * call, about 5x the time of a native size; larger M through the long-frame kernels; sizes above 2^19 as four half-length
+ * sub-convolutions of 2^20 points; fftshift by nfft / 2 as np.fft.fftshift does for odd sizes).  A plan of
  * 2^15 .. 2^20 points (a power of two: "long-frame plan") takes one
  * frame per call, or - with avg_mode lin and avg_n >= the frames seen since the last reset - a batch of K
  * segments whose Welch average comes back as ONE dB row. */

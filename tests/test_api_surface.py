@@ -158,11 +158,11 @@ def test_unsupported_fft_size_never_raises():
                                     device_factory=lambda: ReplayHackRF(iq))
     h.start()
     try:
-        h.set_num_samples(600000)                # not a power of two and above 2^19: the library has no plan for it
+        h.set_num_samples(1500000)               # above 2^20: the library has no plan for it
         p, f = h.get_power_levels()
-        assert p.shape == (600000,) and not p.any() and f.shape == (600000,)
-        assert abs((f[1] - f[0]) - 20e6 / 600000) < 1e-6
+        assert p.shape == (1500000,) and not p.any() and f.shape == (1500000,)
+        assert abs((f[1] - f[0]) - 20e6 / 1500000) < 1e-6
         p2, _ = h.get_power_levels()             # and again (the failure is remembered, not re-raised)
-        assert p2.shape == (600000,) and not p2.any()
+        assert p2.shape == (1500000,) and not p2.any()
     finally:
         h.stop()

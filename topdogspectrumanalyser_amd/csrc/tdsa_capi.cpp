@@ -122,6 +122,10 @@ struct tdsa_plan_s {
   bool chirp = false;
   int m_fft = 0, log2m = 0;              // M = 2^log2m >= 2 nfft - 1
   bool chirp_big = false;                // M > 16384: the two M-point transforms run on the long-frame kernels (N1 x 16384)
+  int chirp_split = 0;                   // frames above 2^19 points: H = ceil(N / 2); the convolution runs as four half-length
+                                         // sub-convolutions of M = 2^20 points on rows [2F][M] (tdsa_chirp.hip)
+  float2* d_chirp_bm = nullptr;          // [M] spectra of the filter segments b[m - H], b[m + H] (d_chirp_b: b[m]), split plans only
+  float2* d_chirp_bp = nullptr;
   float2* d_chirp_a = nullptr;           // [nfft] a[n] = exp(-i pi n^2 / nfft)
   float2* d_chirp_b = nullptr;           // [M]    FFT_M of conj(a) wrapped around M
   float2* d_chirp_aw[3] = {nullptr, nullptr, nullptr};   // [nfft] window * input scale * a[n] per input format (M <= 16384: the
@@ -370,28 +374,31 @@ int chirp_transform(tdsa_plan p, const void* in, int in_format, long long stride
   const int N = p->nfft, M = p->m_fft;
   hipStream_t s = p->stream;
   const bool fused = chirp_fusable(p) && post != nullptr;  // both element-wise passes ride the transforms
-  if (!p->d_u0 && !fused) HIPCHK(hipMalloc(&p->d_u0, size_t(p->max_frames) * M * sizeof(float2)));
-  if (!p->d_u1 && !(fused && p->chirp_single)) HIPCHK(hipMalloc(&p->d_u1, size_t(p->max_frames) * M * sizeof(float2)));
+  const int H = p->chirp_split;                            // > 0: two half-length rows per frame
+  const size_t rows_max = size_t(p->max_frames) * (H ? 2 : 1);
+  const int n_rows = n_frames * (H ? 2 : 1);
+  if (!p->d_u0 && !fused) HIPCHK(hipMalloc(&p->d_u0, rows_max * M * sizeof(float2)));
+  if (!p->d_u1 && !(fused && p->chirp_single)) HIPCHK(hipMalloc(&p->d_u1, rows_max * M * sizeof(float2)));
   if (!fused)
     HIPCHK(launch_chirp_pre(in, in_format == TDSA_IN_C64, stride, N, M, n_frames, p->d_window[in_format], p->d_chirp_a, dc_sub,
-                            xor_mask, in_off, p->d_u0, s));
+                            xor_mask, in_off, p->d_u0, s, H));
   if (p->chirp_big) {
     // M = N1 x 16384: first transform as for a native long frame (column pass -> rows through the frame kernel, which
     // stores conj(X B) in its own [k1][k2] order); second transform transposed (rows first, then the per-column N1-point
     // DFT that leaves natural order): tdsa_big.hip
     const int n1 = M >> kMaxLog2N;
     const long long rowb = (long long)(1 << kMaxLog2N) * sizeof(float2), segb = (long long)M * sizeof(float2);
-    if (!p->d_z) HIPCHK(hipMalloc(&p->d_z, size_t(p->max_frames) * M * sizeof(float2)));
+    if (!p->d_z) HIPCHK(hipMalloc(&p->d_z, rows_max * M * sizeof(float2)));
     BigWindow flat{};                   // the rows are windowed already (chirp_pre): one for every sample
     flat.mode = 2;
     flat.table = p->d_ones;
     flat.flat = 1.0f;
-    HIPCHK(launch_big_cols(p->log2m, p->d_u0, 1, segb, n_frames, flat, p->d_tw_seed, nullptr, p->d_z, 0u, 0.0f, s,
-                           unsigned(N)));
+    HIPCHK(launch_big_cols(p->log2m, p->d_u0, 1, segb, n_rows, flat, p->d_tw_seed, nullptr, p->d_z, 0u, 0.0f, s,
+                           unsigned(H ? H : N)));
 
     SpecParams sp{};
     sp.frame_stride = rowb;
-    sp.n_frames = n_frames * n1;
+    sp.n_frames = n_rows * n1;
     sp.first_frame_index = 1;
     sp.window = p->d_ones;
     sp.window_perm = p->d_ones;
@@ -403,16 +410,18 @@ int chirp_transform(tdsa_plan p, const void* in, int in_format, long long stride
     const LaunchGeom g = spectrum_geometry(kMaxLog2N, sp.n_frames, p->num_cu);
     sp.in = p->d_z;
     sp.out_cplx = p->d_u1;
-    sp.out_mul = p->d_chirp_b;          // [k1][k2] order, row k1 = frame mod N1
-    sp.out_mul_rows = n1;
+    sp.out_mul = H ? nullptr : p->d_chirp_b;       // [k1][k2] order, row k1 = frame mod N1
+    sp.out_mul_rows = H ? 0 : n1;
     { const int rc = launch_spectrum_profiled(p, 1, sp, g); if (rc != TDSA_OK) return rc; }
+    if (H)    // split plans: the two half-rows' spectra meet the three filter segments: conj(UA B0 + UB Bm), conj(UA Bp + UB B0)
+      HIPCHK(launch_chirp_split_combine(p->d_u1, (long long)M, n_frames, p->d_chirp_b, p->d_chirp_bm, p->d_chirp_bp, s));
     sp.in = p->d_u1;
     sp.out_cplx = p->d_z;
     sp.out_mul = nullptr;
     sp.out_mul_rows = 0;
     { const int rc = launch_spectrum_profiled(p, 1, sp, g); if (rc != TDSA_OK) return rc; }
 
-    HIPCHK(launch_big_cols_out(p->log2m, p->d_z, segb, n_frames, p->d_tw_seed, p->d_u0, unsigned(N), s));
+    HIPCHK(launch_big_cols_out(p->log2m, p->d_z, segb, n_rows, p->d_tw_seed, p->d_u0, unsigned(H ? H : N), s));
     return TDSA_OK;
   }
   SpecParams sp{};
@@ -534,7 +543,7 @@ int process_chirp(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n
     }
     if (!fusable)
       HIPCHK(launch_chirp_post(p->d_u0, N, M, n_frames, first, m.db_mode, pscale, m.log_floor,
-                               m.cal_offset_db, nullptr, nullptr, p->d_lin, nullptr, nullptr, s));
+                               m.cal_offset_db, nullptr, nullptr, p->d_lin, nullptr, nullptr, s, p->chirp_split));
     AvgParams ap{};
     ap.lin = p->d_lin;
     ap.n_frames = n_frames;
@@ -561,7 +570,7 @@ int process_chirp(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n
     HIPCHK(launch_chirp_post(p->d_u0, N, M, n_frames, first, m.db_mode, pscale, m.log_floor,
                              m.cal_offset_db, tare, out_db_dev, nullptr,
                              (m.hold_flags & TDSA_HOLD_MAX) ? p->d_hold_max : nullptr,
-                             (m.hold_flags & TDSA_HOLD_MIN) ? p->d_hold_min : nullptr, s));
+                             (m.hold_flags & TDSA_HOLD_MIN) ? p->d_hold_min : nullptr, s, p->chirp_split));
   }
   if (m.hold_flags & TDSA_HOLD_MAX) p->held_max += n_frames;
   if (m.hold_flags & TDSA_HOLD_MIN) p->held_min += n_frames;
@@ -608,7 +617,12 @@ int tdsa_create(int device_id, int nfft, int max_frames, tdsa_plan* out) {
   p->chirp = chirp;
   if (chirp) {
     int m = 1 << kMinLog2N;
-    while (m < 2 * nfft - 1) m <<= 1;
+    if (nfft > (1 << 19)) {                  // 2^21 would be needed: split into half-length sub-convolutions of 2^20
+      p->chirp_split = (nfft + 1) / 2;
+      m = 1 << kBigMaxLog2N;
+    } else {
+      while (m < 2 * nfft - 1) m <<= 1;
+    }
     p->m_fft = m;
     p->log2m = ilog2i(m);
     p->chirp_big = p->log2m > kMaxLog2N;
@@ -671,15 +685,6 @@ static int plan_init(tdsa_plan p) {
       const double ang = -M_PI * double(q) / double(nfft);
       ar[n] = std::cos(ang);
       ai[n] = std::sin(ang);
-      br[n] = ar[n];
-      bi[n] = -ai[n];
-      if (n > 0) { br[M - n] = ar[n]; bi[M - n] = -ai[n]; }
-    }
-    for (int i = 1, j = 0; i < M; ++i) {        // bit reversal
-      int bit = M >> 1;
-      for (; j & bit; bit >>= 1) j ^= bit;
-      j ^= bit;
-      if (i < j) { std::swap(br[i], br[j]); std::swap(bi[i], bi[j]); }
     }
     std::vector<double> twc(M / 2), tws(M / 2);      // exp(-2 pi i k / M), k < M / 2: one table for every stage
     for (int k = 0; k < M / 2; ++k) {
@@ -687,36 +692,69 @@ static int plan_init(tdsa_plan p) {
       twc[k] = std::cos(ang);
       tws[k] = std::sin(ang);
     }
-    for (int len = 2; len <= M; len <<= 1) {
-      const int step = M / len;
-      for (int i = 0; i < M; i += len) {
-        for (int k = 0; k < len / 2; ++k) {
-          const double wr = twc[k * step], wi = tws[k * step];
-          const double xr = br[i + k + len / 2] * wr - bi[i + k + len / 2] * wi;
-          const double xi = br[i + k + len / 2] * wi + bi[i + k + len / 2] * wr;
-          br[i + k + len / 2] = br[i + k] - xr;
-          bi[i + k + len / 2] = bi[i + k] - xi;
-          br[i + k] += xr;
-          bi[i + k] += xi;
+    // FFT_M, in double, of the filter segment  h[m mod M] = b[m + shift] = conj(a[|m + shift|])  for lo <= m <= hi, 0 elsewhere
+    const auto filter_spectrum = [&](int shift, int lo, int hi) {
+      std::fill(br.begin(), br.end(), 0.0);
+      std::fill(bi.begin(), bi.end(), 0.0);
+      for (int mm = lo; mm <= hi; ++mm) {
+        const int idx = mm + shift < 0 ? -(mm + shift) : mm + shift;
+        const int pos = mm < 0 ? M + mm : mm;
+        br[pos] = ar[idx];
+        bi[pos] = -ai[idx];
+      }
+      for (int i = 1, j = 0; i < M; ++i) {        // bit reversal
+        int bit = M >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { std::swap(br[i], br[j]); std::swap(bi[i], bi[j]); }
+      }
+      for (int len = 2; len <= M; len <<= 1) {
+        const int step = M / len;
+        for (int i = 0; i < M; i += len) {
+          for (int k = 0; k < len / 2; ++k) {
+            const double wr = twc[k * step], wi = tws[k * step];
+            const double xr = br[i + k + len / 2] * wr - bi[i + k + len / 2] * wi;
+            const double xi = br[i + k + len / 2] * wi + bi[i + k + len / 2] * wr;
+            br[i + k + len / 2] = br[i + k] - xr;
+            bi[i + k + len / 2] = bi[i + k] - xi;
+            br[i + k] += xr;
+            bi[i + k] += xi;
+          }
         }
       }
+    };
+    // ... rounded once, in the order the first transform leaves its bins in ([k1][k2] on the long-frame kernels)
+    const auto upload_spectrum = [&](float2** dst) -> int {
+      std::vector<float2> b32(M);
+      if (p->chirp_big) {
+        const int n1 = M >> kMaxLog2N, n2 = 1 << kMaxLog2N;
+        for (int k1 = 0; k1 < n1; ++k1)
+          for (int k2 = 0; k2 < n2; ++k2) b32[size_t(k1) * n2 + k2] = float2{float(br[k1 + n1 * k2]), float(bi[k1 + n1 * k2])};
+      } else {
+        for (int k = 0; k < M; ++k) b32[k] = float2{float(br[k]), float(bi[k])};
+      }
+      HIPCHK(hipMalloc(dst, size_t(M) * sizeof(float2)));
+      HIPCHK(hipMemcpy(*dst, b32.data(), size_t(M) * sizeof(float2), hipMemcpyHostToDevice));
+      return TDSA_OK;
+    };
+    const int H = p->chirp_split;
+    if (H == 0) {
+      filter_spectrum(0, -(nfft - 1), nfft - 1);           // b[n] = b[M - n] = conj(a[n]) for n < N
+      { const int rc = upload_spectrum(&p->d_chirp_b); if (rc != TDSA_OK) return rc; }
+    } else {                                               // (tdsa_chirp.hip: the three segments of the split convolution)
+      filter_spectrum(0, -(H - 1), H - 1);
+      { const int rc = upload_spectrum(&p->d_chirp_b); if (rc != TDSA_OK) return rc; }
+      filter_spectrum(-H, -(nfft - H - 1), H - 1);         // b[m - H], m = k - n' in (-(N - H), H)
+      { const int rc = upload_spectrum(&p->d_chirp_bm); if (rc != TDSA_OK) return rc; }
+      filter_spectrum(H, -(H - 1), nfft - H - 1);          // b[m + H], m = k' - n in (-H, N - H)
+      { const int rc = upload_spectrum(&p->d_chirp_bp); if (rc != TDSA_OK) return rc; }
     }
-    std::vector<float2> a32(nfft), b32(M);
+    std::vector<float2> a32(nfft);
     for (int n = 0; n < nfft; ++n) a32[n] = float2{float(ar[n]), float(ai[n])};
-    if (p->chirp_big) {
-      // the first transform's row pass leaves bin k = k1 + N1 k2 at [k1][k2]: B in that order, one row of 16384 per k1
-      const int n1 = M >> kMaxLog2N, n2 = 1 << kMaxLog2N;
-      for (int k1 = 0; k1 < n1; ++k1)
-        for (int k2 = 0; k2 < n2; ++k2) b32[size_t(k1) * n2 + k2] = float2{float(br[k1 + n1 * k2]), float(bi[k1 + n1 * k2])};
-    } else {
-      for (int k = 0; k < M; ++k) b32[k] = float2{float(br[k]), float(bi[k])};
-    }
     HIPCHK(hipMalloc(&p->d_chirp_a, size_t(nfft) * sizeof(float2)));
-    HIPCHK(hipMalloc(&p->d_chirp_b, size_t(M) * sizeof(float2)));
     HIPCHK(hipMalloc(&p->d_ones, size_t(M) * sizeof(float)));
     std::vector<float> ones(M, 1.0f);
     HIPCHK(hipMemcpy(p->d_chirp_a, a32.data(), size_t(nfft) * sizeof(float2), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(p->d_chirp_b, b32.data(), size_t(M) * sizeof(float2), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(p->d_ones, ones.data(), size_t(M) * sizeof(float), hipMemcpyHostToDevice));
     if (p->chirp_big) {   // the M-point transforms' column-pass seeds (as for a native long frame of M points)
       const int nrow = 1 << kMaxLog2N, n1 = M >> kMaxLog2N, na = n1 < 8 ? n1 : 8;
@@ -798,7 +836,7 @@ int tdsa_destroy(tdsa_plan p) {
                   p->d_window_perm[2], p->d_tw, p->d_hold_max, p->d_hold_min,
                   p->d_avg, p->d_lin, p->d_carry, p->d_agg, p->d_agg_w, p->d_chunk_a, p->d_chunk_v, p->d_cplx, p->d_real, p->d_lin1, p->d_db1, p->d_dc_state, p->d_sums, p->d_dc_sub,
                   p->d_tare_base, p->d_tare_acc, p->d_in_stage, p->d_out_stage, p->d_trace_in,
-                  p->d_trace_live, p->d_scratch, p->d_z, p->d_welch, p->d_clock, p->d_chirp_aw[0], p->d_chirp_aw[1], p->d_chirp_aw[2], p->d_chirp_a, p->d_chirp_b, p->d_u0, p->d_u1, p->d_acc, p->d_sum, p->d_lin64, p->d_sums64, p->d_tw_seed, p->d_tw_row, p->d_ones,
+                  p->d_trace_live, p->d_scratch, p->d_z, p->d_welch, p->d_clock, p->d_chirp_aw[0], p->d_chirp_aw[1], p->d_chirp_aw[2], p->d_chirp_bm, p->d_chirp_bp, p->d_chirp_a, p->d_chirp_b, p->d_u0, p->d_u1, p->d_acc, p->d_sum, p->d_lin64, p->d_sums64, p->d_tw_seed, p->d_tw_row, p->d_ones,
                   p->d_dbg};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -1358,6 +1396,7 @@ int tdsa_process_real2(tdsa_plan p, const float* lr_host, size_t n_samples, int 
   float2* const za = p->d_real;
   float2* const zb = p->d_real + need;
   HIPCHK(launch_real_select(lr_dev, need, channel, za, zb, p->stream));
+  if (p->chirp_split) return fail(TDSA_ERR_STATE, "the real-input path has no plan for frames above 2^19 points that are not a power of two");
   for (int sig = 0; sig < n_sig; ++sig) {
     if (p->chirp) {
       // a size that is not a power of two: signal + 0i through the chirp-z core, mean removed (exact sums), and

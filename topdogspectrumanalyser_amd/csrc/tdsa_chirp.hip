@@ -124,6 +124,8 @@ struct ChirpPreParams {
   unsigned xor_mask;
   float in_off;
   float2* u;                 // [F][m]
+  int split_h;               // > 0 (frames of more than 2^19 points): sample i goes to row 2f + (i >= split_h), index i mod split_h,
+                             // of the rows [2F][m]; the second row is zero-filled up to split_h
 };
 
 // two consecutive samples per thread: 4 / 16 bytes in (frame starts are only sample aligned: packed loads),
@@ -162,14 +164,25 @@ __global__ void __launch_bounds__(256) chirp_pre_kernel(const ChirpPreParams p) 
       o0 = cmul(c32{r0 * w0, i0 * w0}, a0);
       if (in1) o1 = cmul(c32{r1 * w1, i1 * w1}, a1);
     }
-    *reinterpret_cast<float4*>(p.u + (long long)f * p.m + i) = float4{o0.x, o0.y, o1.x, o1.y};
+    if (p.split_h == 0) {
+      *reinterpret_cast<float4*>(p.u + (long long)f * p.m + i) = float4{o0.x, o0.y, o1.x, o1.y};
+    } else {
+      // two half-length rows per frame (an odd split_h: a pair may straddle the halves - element by element)
+      float2* rows = p.u + (long long)(2 * f) * p.m;
+      const int h = p.split_h;
+      rows[i < h ? i : p.m + i - h] = float2{o0.x, o0.y};
+      if (in1) rows[i + 1 < h ? i + 1 : p.m + i + 1 - h] = float2{o1.x, o1.y};
+      if (i + 2 >= p.n) {                       // the thread that holds the frame's end pads the second row up to split_h
+        for (int z = p.n - h; z < h; ++z) rows[p.m + z] = float2{0.f, 0.f};
+      }
+    }
   }
 }
 
 hipError_t launch_chirp_pre(const void* in, int in_c64, long long frame_stride, int n, int m, int n_frames,
                             const float* window, const float2* chirp, const float2* dc_sub, unsigned xor_mask,
-                            float in_off, float2* u, hipStream_t s) {
-  ChirpPreParams p{in, in_c64, frame_stride, n, m, n_frames, window, chirp, dc_sub, xor_mask, in_off, u};
+                            float in_off, float2* u, hipStream_t s, int split_h) {
+  ChirpPreParams p{in, in_c64, frame_stride, n, m, n_frames, window, chirp, dc_sub, xor_mask, in_off, u, split_h};
   const int gy = n_frames < 2048 ? n_frames : 2048;
   hipLaunchKernelGGL(chirp_pre_kernel, dim3(((n + 1) / 2 + 255) / 256, gy), dim3(256), 0, s, p);
   return hipGetLastError();
@@ -187,6 +200,7 @@ struct ChirpPostParams {
   float* out_lin;            // [F][n] linear power * pscale (averaging modes) or null
   float* hold_max;           // [n] or null
   float* hold_min;
+  int split_h;               // > 0: y holds [2F][m] rows, bin k of frame f at row 2f + (k >= split_h), index k mod split_h
 };
 
 constexpr int kChirpFramesPerBlock = 8;    // one hold atomic (when the trace moves) per bin and this many frames
@@ -203,7 +217,8 @@ __global__ void __launch_bounds__(256) chirp_post_kernel(const ChirpPostParams p
 #pragma unroll 4
   for (int f = f0; f < f1; ++f) {
     // X[k] = a[k] * conj(w) / M with |a[k]| = 1: only |X|^2 is needed, the last chirp factor drops out
-    const c32 w = p.y[(long long)f * p.m + k];
+    const c32 w = p.split_h == 0 ? p.y[(long long)f * p.m + k]
+                                 : p.y[(long long)(2 * f + (k >= p.split_h ? 1 : 0)) * p.m + (k >= p.split_h ? k - p.split_h : k)];
     const float xr = w.x * p.inv_m, xi = w.y * p.inv_m;
     const float pw = xr * xr + xi * xi;
     if (p.out_lin != nullptr) {
@@ -228,11 +243,44 @@ __global__ void __launch_bounds__(256) chirp_post_kernel(const ChirpPostParams p
 
 hipError_t launch_chirp_post(const float2* y, int n, int m, int n_frames, int first_frame_index,
                              int db_mode, float pscale, float log_floor, float cal_db, const float* tare, float* out_db,
-                             float* out_lin, float* hold_max, float* hold_min, hipStream_t s) {
+                             float* out_lin, float* hold_max, float* hold_min, hipStream_t s, int split_h) {
   ChirpPostParams p{y, n, m, n_frames, first_frame_index, 1.0f / float(m), db_mode, pscale, log_floor, cal_db,
-                    tare, out_db, out_lin, hold_max, hold_min};
+                    tare, out_db, out_lin, hold_max, hold_min, split_h};
   const int gy = (n_frames + kChirpFramesPerBlock - 1) / kChirpFramesPerBlock;
   hipLaunchKernelGGL(chirp_post_kernel, dim3((n + 255) / 256, gy), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+// Frames of more than 2^19 points that are not a power of two: M = 2^ceil(log2(2N - 1)) would be 2^21, more than the
+// long-frame kernels transform.  The convolution is split instead - samples into halves A = [0, H), B = [H, N), bins into
+// K0 = [0, H), K1 = [H, N), H = ceil(N / 2) - into four sub-convolutions of H inputs and H outputs, each of which fits a
+// circular convolution of 2^20 points (2 H - 1 <= 2^20):
+//   y[k]     = sum_A u[n] b[k - n]     + sum_B u[H + n'] b[k - n' - H]        k  in K0
+//   y[H + k'] = sum_A u[n] b[k' - n + H] + sum_B u[H + n'] b[k' - n']         k' in [0, N - H)
+// i.e. with the spectra of the two half-rows UA, UB and of three filter segments B0 (b[m]), Bm (b[m - H]), Bp (b[m + H]):
+//   Y0 = UA B0 + UB Bm,   Y1 = UA Bp + UB B0  - two forward and two inverse 2^20-point transforms per frame.
+// This kernel forms conj(Y0), conj(Y1) in place of UA, UB (rows 2f, 2f + 1 of [2F][m], any element order: the tables are
+// stored in the order the first transform leaves its bins in).
+__global__ void __launch_bounds__(256) chirp_split_combine_kernel(float2* u, long long m, int n_frames, const float2* b0,
+                                                                  const float2* bm, const float2* bp) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  const c32 f0 = b0[i], fm = bm[i], fp = bp[i];
+  for (int f = blockIdx.y; f < n_frames; f += gridDim.y) {
+    float2* ra = u + (long long)(2 * f) * m;
+    float2* rb = ra + m;
+    const c32 ua = ra[i], ub = rb[i];
+    const c32 y0 = cadd(cmul(ua, f0), cmul(ub, fm));
+    const c32 y1 = cadd(cmul(ua, fp), cmul(ub, f0));
+    ra[i] = float2{y0.x, -y0.y};
+    rb[i] = float2{y1.x, -y1.y};
+  }
+}
+
+hipError_t launch_chirp_split_combine(float2* u, long long m, int n_frames, const float2* b0, const float2* bm,
+                                      const float2* bp, hipStream_t s) {
+  const int gy = n_frames < 64 ? n_frames : 64;
+  hipLaunchKernelGGL(chirp_split_combine_kernel, dim3(unsigned((m + 255) / 256), gy), dim3(256), 0, s, u, m, n_frames, b0, bm, bp);
   return hipGetLastError();
 }
 

@@ -246,17 +246,21 @@ hipError_t launch_xcd_shift(int wgs, hipStream_t s);
 hipError_t launch_valu_clock(float* scratch, int n_cu, int iters, hipStream_t s);
 
 // ---- frame lengths that are not a power of two, 2 <= N <= 8192 (tdsa_chirp.hip): chirp-z on the frame kernel ----
-constexpr int kChirpMaxN = 1 << 19;      // M = 2^ceil(log2(2N-1)) <= 2^20; M > 16384 runs on the long-frame kernels
+constexpr int kChirpMaxN = (1 << 20) - 1; // M = 2^ceil(log2(2N-1)) <= 2^20 up to N = 2^19 (M > 16384: the long-frame kernels); longer
+                                         // frames as four half-length sub-convolutions of 2^20 points (tdsa_chirp.hip)
 // res[f] = frame mean minus the format's zero level, raw units (twice_zero: 256 int8 after the xor, 255 uint8, 0 c64)
 // dc_state (or null): receives the last frame's mean in units of x - the per-frame mean mode needs no tracker pass
 hipError_t launch_chirp_sums(const void* in, int in_c64, unsigned xor_mask, long long frame_stride, int n, int n_frames,
                              int twice_zero, float2* res, float2* dc_state, float in_scale, hipStream_t s);
 hipError_t launch_chirp_pre(const void* in, int in_c64, long long frame_stride, int n, int m, int n_frames,
                             const float* window, const float2* chirp, const float2* dc_sub, unsigned xor_mask,
-                            float in_off, float2* u, hipStream_t s);
+                            float in_off, float2* u, hipStream_t s, int split_h = 0);
 hipError_t launch_chirp_post(const float2* y, int n, int m, int n_frames, int first_frame_index,
                              int db_mode, float pscale, float log_floor, float cal_db, const float* tare, float* out_db,
-                             float* out_lin, float* hold_max, float* hold_min, hipStream_t s);
+                             float* out_lin, float* hold_max, float* hold_min, hipStream_t s, int split_h = 0);
+// split convolution of frames above 2^19 points: rows (2f, 2f + 1) of u[2F][m] <- conj(UA b0 + UB bm), conj(UA bp + UB b0)
+hipError_t launch_chirp_split_combine(float2* u, long long m, int n_frames, const float2* b0, const float2* bm,
+                                      const float2* bp, hipStream_t s);
 // hold traces folded from finished dB rows [F][n] (chirp-z plans whose second transform stores the rows itself)
 hipError_t launch_chirp_hold(const float* rows, int n, int n_frames, int first_frame_index, float* hold_max, float* hold_min,
                              hipStream_t s);

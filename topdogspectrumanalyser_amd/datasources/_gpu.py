@@ -24,7 +24,7 @@ class GpuSpectrumMixin:
 
     def _gpu_engine(self, nfft: int) -> SpectrumEngine:
         if not gpu_fft_size_supported(nfft):
-            raise ValueError(f"FFT size {nfft}: the device library plans any size up to 2^19 and powers of two up to 2^20")
+            raise ValueError(f"FFT size {nfft}: the device library plans any size from 2 to 2^20")
         if self._engine is None or self._engine_n != nfft:
             # the DC estimate is a property of the source, not of an FFT size (the reference keeps
             # self._dc_estimate across set_num_samples): it moves to the new plan

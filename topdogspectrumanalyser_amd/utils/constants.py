@@ -44,11 +44,12 @@ class FFTSize(IntEnum):
 
 GPU_MIN_FFT = 64
 GPU_MAX_FFT = 1 << 20      # 64 .. 16384 in one LDS-resident pass, 2^15 .. 2^20 as N1 x 16384 (two passes)
-GPU_MAX_ANY_FFT = 1 << 19  # any size from 2 up to here, power of two or not: chirp-z on the power-of-two kernels, M = 2^ceil(log2(2N-1)) <= 2^20
+GPU_MAX_ANY_FFT = 1 << 20  # any size from 2 up to here, power of two or not: chirp-z on the power-of-two kernels (above 2^19 as four
+                           # half-length sub-convolutions of 2^20 points)
 
 
 def gpu_fft_size_supported(nfft: int) -> bool:
-    """Sizes the device library has a plan for: every N in [2, 2^19], every power of two up to 2^20."""
+    """Sizes the device library has a plan for: every N in [2, 2^20]."""
     nfft = int(nfft)
     if 2 <= nfft <= GPU_MAX_ANY_FFT:
         return True
