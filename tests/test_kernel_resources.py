@@ -92,6 +92,13 @@ def test_chirp_transform_instantiations_are_free_of_scratch(reports, log2n, chir
     assert int(k["VGPRs"]) <= 128 and int(k["Occupancy [waves/SIMD]"]) >= 4, k
 
 
+def test_long_chirp_row_pass_instantiation_is_free_of_scratch(reports):
+    """spectrum_kernel<14, true, 0, 4>: the row passes of a long chirp-z frame's two transforms in one kernel."""
+    k = _kernel(reports, 14, True, 0, 4)
+    assert int(k["ScratchSize [bytes/lane]"]) == 0 and int(k["VGPRs Spill"]) == 0, k
+    assert int(k["VGPRs"]) <= 128 and int(k["Occupancy [waves/SIMD]"]) >= 4, k
+
+
 def test_byte_input_hot_instantiations_keep_four_waves(reports):
     """C2 (4096), C4 (8192), C3 (16384): int8 / uint8 frames, no hold / max hold - the BASELINE shapes - at <= 128 VGPRs."""
     for log2n in (12, 13, 14):

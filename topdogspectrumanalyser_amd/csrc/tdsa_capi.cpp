@@ -412,6 +412,15 @@ int chirp_transform(tdsa_plan p, const void* in, int in_format, long long stride
     sp.out_cplx = p->d_u1;
     sp.out_mul = H ? nullptr : p->d_chirp_b;       // [k1][k2] order, row k1 = frame mod N1
     sp.out_mul_rows = H ? 0 : n1;
+    if (!H && p->chirp_single) {
+      // the row pass of the first transform and the row pass of the transposed second one work on the SAME row k1 (its
+      // bins k1 + N1 k2 over k2): one pass through the workgroup does both, with the filter multiply between them
+      // (spectrum_kernel<14, true, 0, 4>) - the rows are written once and read once less
+      sp.rows_twice = 1;
+      { const int rc = launch_spectrum_profiled(p, 1, sp, g); if (rc != TDSA_OK) return rc; }
+      HIPCHK(launch_big_cols_out(p->log2m, p->d_u1, segb, n_rows, p->d_tw_seed, p->d_u0, unsigned(N), s));
+      return TDSA_OK;
+    }
     { const int rc = launch_spectrum_profiled(p, 1, sp, g); if (rc != TDSA_OK) return rc; }
     if (H)    // split plans: the two half-rows' spectra meet the three filter segments: conj(UA B0 + UB Bm), conj(UA Bp + UB B0)
       HIPCHK(launch_chirp_split_combine(p->d_u1, (long long)M, n_frames, p->d_chirp_b, p->d_chirp_bm, p->d_chirp_bp, s));

@@ -83,6 +83,8 @@ struct SpecParams {
   int post_n;                // SECOND transform: > 0: bins k < post_n leave as |X / M|^2 -> power (out_lin) or dB (out_db, tare,
                              // part_max / part_min) rows of post_n values, bin k at (k + post_n / 2) mod post_n; out_cplx is not written
   float post_inv_m;          // 1 / M
+  int rows_twice;            // long chirp-z frames (size 14 only): the row passes of the first and of the (transposed) second
+                             // transform run back to back on each row: X -> conj(X out_mul) -> through LDS -> transform -> out_cplx
 };
 
 struct LaunchGeom {

@@ -266,7 +266,8 @@ __device__ __forceinline__ void combine_const(c32& e, c32& o) {
 // CHIRP (complex64 input, no hold, frames of whole waves only): 3 = the whole chirp-z convolution of a frame in one pass
 // through the workgroup (raw samples in, dB / power rows of the N wanted bins out); 1 = its first transform alone (raw samples
 // unpacked, DC-freed and multiplied by window x chirp on load; conj(X B) stored), 2 = its second transform alone (dB / power
-// rows stored): tdsa_chirp.hip's two element-wise passes folded into the transforms, in instantiations of their own -
+// rows stored); 4 = the two row passes of a LONG chirp-z frame's transforms in one (16384-point rows: transform, x the
+// filter spectrum's row, conjugate, through LDS, transform; complex64 rows in and out): tdsa_chirp.hip's two element-wise passes folded into the transforms, in instantiations of their own -
 // as run-time branches of the plain complex64 kernel they cost it 68 - 83 spilled registers
 template <int LOG2N, bool IN_C64, int HOLD, int CHIRP = 0>   // HOLD: bit0 = max trace, bit1 = min trace; 4 = AGG (see below)
 __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const SpecParams p) {
@@ -467,7 +468,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   c32 twf_lo[3], twf_hi[4];   // last pass: W_N^(t*(2i+h)), i = 4a + j  ->  hi[a] = W^(t(8a+h)), lo[j-1] = W^(2tj)
   // TWF_RELOAD: the one-launch chirp-z instantiations of 2048 and 16384 points have no 14 registers to keep them in across
   // the frame loop (1 / 18 spilled dwords) and the LDS no room for a table: re-read from the L2-resident table per transform
-  constexpr bool TWF_RELOAD = CHIRP == 3 && (LOG2N == 11 || LOG2N == 14);
+  constexpr bool TWF_RELOAD = (CHIRP == 3 || CHIRP == 4) && (LOG2N == 11 || LOG2N == 14);
   if constexpr (!TWF_LDS && !TWF_RELOAD) {
     static_for<0, 3>([&](auto ic) { constexpr int j = decltype(ic)::value; twf_lo[j] = p.tw[t * 2 * (j + 1)]; });
     static_for<0, 4>([&](auto ic) { constexpr int a = decltype(ic)::value; twf_hi[a] = p.tw[t * (8 * a + h)]; });
@@ -556,7 +557,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     // chirp-z convolution of a frame without leaving the workgroup: transform, times the chirp filter's spectrum,
     // conjugate, back through LDS into sample order, transform again (the complex64 intermediate of the two-launch version -
     // 16 bytes per point written and read - never reaches memory).
-    if constexpr (CHIRP != 3) {
+    if constexpr (CHIRP != 3 && CHIRP != 4) {
 #include "tdsa_spectrum_passes.inc"
     } else {
       {
@@ -564,7 +565,8 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       }
     {
       // conj(X B) in natural bin order into LDS (element i at i + (i >> 5)), then the second transform's pass-1 inputs
-      const rsrc_t br = make_rsrc(p.out_mul, N * 8u);
+      // (CHIRP == 4, rows of a long chirp-z frame: the filter spectrum has one row of N per k1 = frame mod out_mul_rows)
+      const rsrc_t br = make_rsrc(p.out_mul + (CHIRP == 4 && p.out_mul_rows > 1 ? (long long)(frame % p.out_mul_rows) * N : 0ll), N * 8u);
       TDSA_SYNC();                                          // every thread has gathered its last-pass inputs
       static_for<0, 16>([&](auto ic) {
         constexpr int q = decltype(ic)::value;
@@ -672,7 +674,7 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
         if constexpr (!C::WIN_LDS) load_window();
         c32* crow = p.out_cplx + out_elem_off(frame) + t + 8 * h * SG;
         bool plain = true;
-        if constexpr (IN_C64 && HOLD == 0) {
+        if constexpr (IN_C64 && HOLD == 0 && CHIRP != 4) {
           // chirp-z plans (tdsa_chirp.hip): the spectrum leaves multiplied by the chirp filter's spectrum and
           // conjugated, ready for the inverse transform - one pass over the rows less
           if (p.out_mul != nullptr) {
@@ -973,6 +975,9 @@ hipError_t launch_n(int in_c64, const SpecParams& p, const LaunchGeom& g, hipStr
   if (p.out_lin != nullptr && p.agg_out != nullptr)
     return in_c64 ? launch_one<LOG2N, true, 4>(p, g, s) : launch_one<LOG2N, false, 4>(p, g, s);
   if constexpr (Cfg<LOG2N>::TPF >= 64) {       // chirp-z plans: the transforms that carry the element-wise passes
+    if constexpr (LOG2N == 14) {
+      if (in_c64 && p.rows_twice != 0) return launch_one<LOG2N, true, 0, 4>(p, g, s);
+    }
     if (in_c64 && p.pre_raw != nullptr && p.post_n != 0) return launch_one<LOG2N, true, 0, 3>(p, g, s);
     if (in_c64 && p.pre_raw != nullptr) return launch_one<LOG2N, true, 0, 1>(p, g, s);
     if (in_c64 && p.post_n != 0) return launch_one<LOG2N, true, 0, 2>(p, g, s);
