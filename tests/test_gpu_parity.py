@@ -2294,7 +2294,8 @@ def call_sequence_trial(pkg, trial, report=None, any_size=False):
                 rel = max(p[0] for p in pairs)
                 if report is not None and (units > 2.0 or rel > REL_TOL):
                     report(f"trial {trial} pos {pos} k {k}: nfft {nfft} hop {hop} psd {psd} dc {dc_alpha} avg "
-                           f"{br.averager.mode},{br.averager.n} cal {cal} tare {tare is not None}: {units:.2f} units, rel {rel:.1e}")
+                           f"{br.averager.mode},{br.averager.n} cal {cal} tare {tare is not None}: {units:.2f} units, rel {rel:.1e} "
+                           f"(rows {pairs[0][1] / 1e-3:.2f}, max hold {pairs[1][1] / 1e-3:.2f}, min hold {pairs[2][1] / 1e-3:.2f})")
                 worst_units, worst_rel, calls = max(worst_units, units), max(worst_rel, rel), calls + 1
                 pos += k
     return worst_units, worst_rel, calls
