@@ -121,6 +121,59 @@ def test_long_frames_that_are_not_a_power_of_two(pkg, nfft, branch):
         _check(out, gold, f"RTL exp N={nfft}")
 
 
+@pytest.mark.parametrize("nfft", [1000, 6000, 20000, 100003, 600000])
+@pytest.mark.parametrize("fmt", ["i8", "u8", "c64"])
+def test_chirp_plans_every_input_format_and_both_code_paths(pkg, nfft, fmt):
+    """The chirp-z plans carry their element-wise passes inside the transforms (M <= 16384: one launch) or inside the
+    long-frame column passes (M > 16384) - raw frames of each of the three input formats are unpacked by those loads.
+    The alternatives the debug knobs keep for A/B (two launches; the passes as kernels of their own) must give rows
+    within the same bounds, and the hold traces must be the folds of the rows whichever path made them."""
+    nf = 3
+    hop = (2 * nfft) // 3
+    rng = np.random.default_rng(nfft)
+    n = hop * (nf - 1) + nfft
+    if fmt == "i8":
+        iq = so.synth_iq_int8(n, 4096, seed=nfft % 997)
+        x = so.unpack_iq_int8(iq)
+        feed = iq
+    elif fmt == "u8":
+        feed = rng.integers(0, 256, size=2 * n, dtype=np.uint8)
+        t = np.arange(n)
+        feed[0::2] = np.clip(127.5 + 100 * np.cos(2 * np.pi * 0.123 * t) + rng.normal(0, 3, n), 0, 255).astype(np.uint8)
+        feed[1::2] = np.clip(127.5 + 100 * np.sin(2 * np.pi * 0.123 * t) + rng.normal(0, 3, n), 0, 255).astype(np.uint8)
+        x = so.unpack_iq_uint8_rtl(feed)
+    else:
+        iq = so.synth_iq_int8(n, 4096, seed=nfft % 991)
+        x = so.unpack_iq_int8(iq)
+        feed = x
+    br = so.HackrfBranchOracle(nfft, 20e6, precision="gold")
+    gold = np.stack([br.power_levels(x[k * hop:k * hop + nfft]) for k in range(nf)])
+    for knobs in ({}, {"chirp_single": 0}, {"chirp_fuse_big": 0}):
+        with _hackrf_engine(pkg, nfft, nf, hold_max=True, hold_min=True) as e:
+            for k, v in knobs.items():
+                e.debug_knob(k, v)
+            out = e.process(feed, hop=hop, n_frames=nf)
+            mx, mn = e.hold()
+        _check(out, gold, f"N={nfft} {fmt} {knobs}")
+        assert np.array_equal(mx, out.max(axis=0)) and np.array_equal(mn, out.min(axis=0))
+        # hold traces only (no rows asked for): the same traces
+        with _hackrf_engine(pkg, nfft, nf, hold_max=True, hold_min=True) as e:
+            for k, v in knobs.items():
+                e.debug_knob(k, v)
+            assert e.process(feed, hop=hop, n_frames=nf, want_db=False) is None
+            mx2, mn2 = e.hold()
+        assert np.array_equal(mx2, mx) and np.array_equal(mn2, mn)
+        # linear averaging over the three frames (the averager's scan on the power rows the transforms leave)
+        ga = so.HackrfBranchOracle(nfft, 20e6, precision="gold")
+        ga.averager.set_mode("lin", 3)
+        gavg = np.stack([np.array(ga.power_levels(x[k * hop:k * hop + nfft])) for k in range(nf)])
+        with _hackrf_engine(pkg, nfft, nf, avg=("lin", 3)) as e:
+            for k, v in knobs.items():
+                e.debug_knob(k, v)
+            out = e.process(feed, hop=hop, n_frames=nf)
+        _check(out, gavg, f"N={nfft} {fmt} {knobs} lin avg")
+
+
 @pytest.mark.parametrize("nfft", [64, 1024, 4096, 16384])
 def test_hackrf_plain_c64(pkg, nfft):
     nf = 3

@@ -121,7 +121,7 @@ def test_long_frame_column_pass_keeps_three_waves_and_no_vmem_wait_between_its_s
     # four instantiations per size: the window from a table / one value for every sample, with / without DC removal
     for flat in (0, 1):
         for dc in (0, 1):
-            name = f"_ZN4tdsa15big_cols_kernelILi6ELb{flat}ELb{dc}EEEvNS_13BigColsParamsE"
+            name = f"_ZN4tdsa15big_cols_kernelILi6ELb{flat}ELb{dc}ELb0EEEvNS_13BigColsParamsE"
             rep, on = {}, False
             for ln in r.stderr.splitlines():
                 m = re.search(r"Function Name: (\S+)", ln)
@@ -152,6 +152,20 @@ def test_long_frame_column_pass_keeps_three_waves_and_no_vmem_wait_between_its_s
             assert all(body[i + 1].startswith("s_nop 1") for i in stores), [body[i + 1] for i in stores]
             loads = sum(ln.startswith("buffer_load_dword ") for ln in body)       # the table's 4-byte window loads
             assert (loads >= 64) == (flat == 0), (flat, loads)
+
+    # the long chirp-z frames' instantiations (raw frames in, times window x chirp; power / dB rows out): no scratch
+    for name in ("_ZN4tdsa15big_cols_kernelILi6ELb1ELb0ELb1EEEvNS_13BigColsParamsE",
+                 "_ZN4tdsa19big_cols_out_kernelILi6EEEvNS_16BigColsOutParamsE"):
+        rep, on = {}, False
+        for ln in r.stderr.splitlines():
+            m = re.search(r"Function Name: (\S+)", ln)
+            if m:
+                on = m.group(1) == name
+                continue
+            m = re.search(r"remark:\s+([A-Za-z \[\]/]+?):\s+(\S+)\s+\[-Rpass", ln)
+            if m and on:
+                rep[m.group(1).strip()] = m.group(2)
+        assert int(rep["ScratchSize [bytes/lane]"]) == 0 and int(rep["SGPRs Spill"]) == 0, (name, rep)
 
     # row pass (big_rows_kernel): 128 VGPRs / 4 waves per SIMD without scratch, and the fetch of the next row spread over
     # the row's work - eight 16-byte loads, one at a time, each behind a stretch of arithmetic (bursts cost 13 %)

@@ -34,6 +34,7 @@ struct BigColsParams {
   float in_off;
   unsigned in_valid;         // complex64 rows: samples from this index on are zeros and are not read (0: the whole row is there)
   BigWindow win;             // how the window reaches the column threads (WMODE of the kernel = win.mode)
+  BigChirpPre pre;           // long chirp-z frames: raw samples in, unpacked and multiplied by window x chirp on load (pre.aw != null)
 };
 
 
@@ -68,7 +69,9 @@ __device__ __forceinline__ void store16_pinned(bu32x4 data, brsrc_t r, unsigned 
 // profiles/r05_c5_experiments.txt - the pass has no VALU slots to spare; not kept.)
 // DC: the per-segment DC estimate is subtracted (HackRF branch); the RTL branch / BASELINE config 5 has none and its
 // instantiation skips the two subtractions per sample.
-template <int LOG2N1, bool WFLAT, bool DC>
+// PRE: long chirp-z frames - raw samples in, times window x chirp (BigChirpPre); its own instantiation, the Welch path's
+// register count (3 waves per SIMD at 2^20 points) is not to move.
+template <int LOG2N1, bool WFLAT, bool DC, bool PRE = false>
 __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
   constexpr int N1 = 1 << LOG2N1;
   const int n2 = blockIdx.x * 256 + threadIdx.x;
@@ -97,6 +100,36 @@ __global__ void __launch_bounds__(256) big_cols_kernel(const BigColsParams p) {
   static_for<1, NA>([&](auto ac) { constexpr int a = decltype(ac)::value; seeds[a][threadIdx.x] = p.tw_seed[(a - 1) * kRowN + n2]; });
   static_for<1, NB>([&](auto bc) { constexpr int b = decltype(bc)::value; seeds[NA + b][threadIdx.x] = p.tw_seed[(NA - 1 + b - 1) * kRowN + n2]; });
   c32 v[N1];
+  if constexpr (PRE) {
+    // long chirp-z frames (tdsa_chirp.hip): step 1 - unpack, DC, window x chirp a[n] - folded into this load: the raw frame
+    // is read instead of rows U[f][M] (never written).  Split plans (frames above 2^19 points): segment 2f + s is the half
+    // [s H, s H + valid) of frame f.  Samples past `valid` meet the table's descriptor end: zeros.
+    const int fr = p.pre.split_h ? seg >> 1 : seg, sh = p.pre.split_h ? (seg & 1) * p.pre.split_h : 0;
+    const unsigned valid = p.pre.split_h ? unsigned((seg & 1) ? p.pre.n - p.pre.split_h : p.pre.split_h) : unsigned(p.pre.n);
+    const unsigned char* rb = p.in + (long long)fr * p.seg_stride + (long long)sh * (p.pre.c64 ? 8 : 2);
+    const brsrc_t ar = big_rsrc(p.pre.aw + sh, valid * 8u);
+    float dcx = 0.f, dcy = 0.f;
+    if (p.dc_sub != nullptr) { const c32 d = p.dc_sub[fr]; dcx = d.x; dcy = d.y; }
+    const unsigned xm = p.xor_mask & 0xffffu;
+    if (p.pre.c64) {
+      const brsrc_t ir = big_rsrc(rb, valid * 8u);
+      static_for<0, N1>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const bu32x2 q = __builtin_amdgcn_raw_buffer_load_b64(ir, unsigned(n2) * 8u, unsigned(i) * kRowN * 8u, 0);
+        const bu32x2 w = __builtin_amdgcn_raw_buffer_load_b64(ar, unsigned(n2) * 8u, unsigned(i) * kRowN * 8u, 0);
+        v[i] = cmul(c32{__uint_as_float(q.x) - dcx, __uint_as_float(q.y) - dcy}, c32{__uint_as_float(w.x), __uint_as_float(w.y)});
+      });
+    } else {
+      const brsrc_t ir = big_rsrc(rb, valid * 2u);
+      static_for<0, N1>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const unsigned u = unsigned(__builtin_amdgcn_raw_buffer_load_b16(ir, unsigned(n2) * 2u, unsigned(i) * kRowN * 2u, 0)) ^ xm;
+        const bu32x2 w = __builtin_amdgcn_raw_buffer_load_b64(ar, unsigned(n2) * 8u, unsigned(i) * kRowN * 8u, 0);
+        v[i] = cmul(c32{(float(u & 0xffu) - off) - dcx, (float((u >> 8) & 0xffu) - off) - dcy},
+                    c32{__uint_as_float(w.x), __uint_as_float(w.y)});
+      });
+    }
+  } else
   if (p.in_c64) {
     // (chirp-z rows: the padding behind the first in_valid samples is implied - the descriptor ends there and a load
     //  past its end returns zeros)
@@ -394,6 +427,7 @@ struct BigColsOutParams {
   const float2* tw_seed;     // the column pass's table for this M
   float2* y;                 // [seg][N1 * 16384] natural order
   unsigned out_valid;        // bins wanted (0: all)
+  BigChirpPost post;         // long chirp-z frames: the wanted bins leave as power / dB rows instead (post.n != 0; y is not written)
 };
 
 template <int LOG2N1>
@@ -420,6 +454,38 @@ __global__ void __launch_bounds__(256) big_cols_out_kernel(const BigColsOutParam
     else v[k1] = cmul(v[k1], cmul(hi[b], lo[a]));
   });
   dif<N1, 0, N1>(v);                                     // Y[m1] in v[bitrev(m1)]
+  if (p.post.n != 0) {
+    // long chirp-z frames (tdsa_chirp.hip): step 4 - |X / M|^2, fftshift by n / 2, dB + cal - tare (or linear power rows for
+    // the averager) - folded into these stores: bin k of frame f sits in this segment at m = k - s H (split plans: segment
+    // 2f + s holds the bins [s H, s H + valid)) and lands at (k + n / 2) mod n of row f.  Hold traces: chirp_hold_kernel.
+    const int n = p.post.n, half = n / 2;
+    const int fr = p.post.split_h ? seg >> 1 : seg, kb = p.post.split_h ? (seg & 1) * p.post.split_h : 0;
+    const int valid = p.post.split_h ? ((seg & 1) ? n - p.post.split_h : p.post.split_h) : n;
+    float* lrow = p.post.out_lin ? p.post.out_lin + (long long)fr * n : nullptr;
+    float* drow = p.post.out_db ? p.post.out_db + (long long)fr * n : nullptr;
+    static_for<0, N1>([&](auto mc) {
+      constexpr int m1 = decltype(mc)::value;
+      const int m = m1 * kRowN + m2;
+      if (m < valid) {
+        int j = m + kb + half;
+        if (j >= n) j -= n;
+        const c32 x = v[bitrev(m1, LOG2N1)];
+        const float xr = x.x * p.post.inv_m, xi = x.y * p.post.inv_m;
+        const float pw = xr * xr + xi * xi;
+        if (lrow != nullptr) {
+          lrow[j] = pw * p.post.pscale;
+        } else {
+          float db;
+          constexpr float kTenLog10Of2 = 3.01029995663981195214f;   // as chirp_post_kernel, operation for operation
+          if (p.post.db_mode == 0) db = fmaf(2.0f * kTenLog10Of2, __builtin_amdgcn_logf(__builtin_amdgcn_sqrtf(pw) + p.post.log_floor), p.post.cal_db);
+          else db = fmaf(kTenLog10Of2, __builtin_amdgcn_logf(fmaf(pw, p.post.pscale, p.post.log_floor)), p.post.cal_db);
+          if (p.post.tare != nullptr) db -= p.post.tare[j];
+          drow[j] = db;
+        }
+      }
+    });
+    return;
+  }
   const unsigned nvalid = p.out_valid ? p.out_valid : unsigned(N1) * kRowN;
   // the descriptor ends behind the last wanted bin: stores past it are dropped by the hardware
   const brsrc_t yr = big_rsrc(reinterpret_cast<unsigned char*>(p.y) + (long long)seg * p.seg_stride, nvalid * 8u);
@@ -438,8 +504,8 @@ static hipError_t cols_out_launch(const BigColsOutParams& p, int n_seg, hipStrea
 }
 
 hipError_t launch_big_cols_out(int log2m, const float2* r, long long seg_stride, int n_seg, const float2* tw_seed, float2* y,
-                               unsigned out_valid, hipStream_t s) {
-  const BigColsOutParams p{r, seg_stride, tw_seed, y, out_valid};
+                               unsigned out_valid, hipStream_t s, const BigChirpPost* post) {
+  const BigColsOutParams p{r, seg_stride, tw_seed, y, out_valid, post ? *post : BigChirpPost{}};
   switch (log2m - kRowLog2) {
     case 1: return cols_out_launch<1>(p, n_seg, s);
     case 2: return cols_out_launch<2>(p, n_seg, s);
@@ -696,7 +762,8 @@ template <int L>
 static hipError_t cols_launch(const BigColsParams& p, int n_seg, hipStream_t s) {
   const dim3 grid(kRowN / 256, n_seg);
   const bool flat = p.win.mode == 2, dc = p.dc_sub != nullptr;
-  if (flat && dc) hipLaunchKernelGGL((big_cols_kernel<L, true, true>), grid, dim3(256), 0, s, p);
+  if (p.pre.aw != nullptr) hipLaunchKernelGGL((big_cols_kernel<L, true, false, true>), grid, dim3(256), 0, s, p);
+  else if (flat && dc) hipLaunchKernelGGL((big_cols_kernel<L, true, true>), grid, dim3(256), 0, s, p);
   else if (flat) hipLaunchKernelGGL((big_cols_kernel<L, true, false>), grid, dim3(256), 0, s, p);
   else if (dc) hipLaunchKernelGGL((big_cols_kernel<L, false, true>), grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL((big_cols_kernel<L, false, false>), grid, dim3(256), 0, s, p);
@@ -712,9 +779,9 @@ static hipError_t gather_launch(const float* src, int split, double* dst, int ad
 
 hipError_t launch_big_cols(int log2n, const void* in, int in_c64, long long seg_stride, int n_seg, const BigWindow& win,
                            const float2* tw_seed, const float2* dc_sub, float2* z,
-                           unsigned xor_mask, float in_off, hipStream_t s, unsigned in_valid) {
+                           unsigned xor_mask, float in_off, hipStream_t s, unsigned in_valid, const BigChirpPre* pre) {
   const BigColsParams p{static_cast<const unsigned char*>(in), in_c64, seg_stride, win.table, tw_seed, dc_sub, z, xor_mask,
-                        in_off, in_valid, win};
+                        in_off, in_valid, win, pre ? *pre : BigChirpPre{}};
   switch (log2n - kRowLog2) {
     case 1: return cols_launch<1>(p, n_seg, s);
     case 2: return cols_launch<2>(p, n_seg, s);

@@ -115,6 +115,7 @@ struct tdsa_plan_s {
   BigWindow big_win[3] = {};             // the column pass's window per input format (tdsa_set_window: table or one value)
   int avg_wg_min = 128;                  // batches of more frames than this take the workgroup-chunk scan (tdsa_debug_knob "avg_wg_min")
   bool avg_f64_chunks = false;           // tdsa_debug_knob "avg_f64_chunks": always the scan over fixed 64-frame chunks with float64 aggregates
+  int chirp_fuse_big = 1;                // tdsa_debug_knob "chirp_fuse_big": 0 = long chirp-z frames run chirp_pre / chirp_post as their own passes
   int chirp_single = 1;                  // tdsa_debug_knob "chirp_single": 0 = the fusable chirp-z plans run their two transforms as two launches
   int big_pre_wgs = 0;                   // tdsa_debug_knob "big_pre_wgs": empty workgroups launched ahead of every column pass
   int big_group = 64;                    // segments per column-pass / row-pass round (one round for the K = 64 Welch capture)
@@ -356,7 +357,8 @@ int process_big(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n_f
 // p->d_u0[f][k] = M * conj(convolution), k < nfft (tdsa_chirp.hip steps 1-3), on the main stream.
 // the transforms can carry the element-wise passes: M <= 16384 and frames made of whole waves (the fused instantiations
 // address their rows through wave-uniform descriptors)
-static bool chirp_fusable(tdsa_plan p) { return p->chirp && !p->chirp_big && p->log2m >= 10; }
+// (M > 16384: the column passes of tdsa_big.hip carry them instead, BigChirpPre / BigChirpPost)
+static bool chirp_fusable(tdsa_plan p) { return p->chirp && p->log2m >= 10 && (!p->chirp_big || p->chirp_fuse_big); }
 
 // post (fusable plans only): what the second transform's stores turn the bins into - the dB / power rows and hold traces
 // of tdsa_chirp.hip's step 4 - instead of leaving complex rows in d_u0 for chirp_post_kernel; null: complex rows
@@ -374,11 +376,12 @@ int chirp_transform(tdsa_plan p, const void* in, int in_format, long long stride
   const int N = p->nfft, M = p->m_fft;
   hipStream_t s = p->stream;
   const bool fused = chirp_fusable(p) && post != nullptr;  // both element-wise passes ride the transforms
+  const bool bfused = fused && p->chirp_big;
   const int H = p->chirp_split;                            // > 0: two half-length rows per frame
   const size_t rows_max = size_t(p->max_frames) * (H ? 2 : 1);
   const int n_rows = n_frames * (H ? 2 : 1);
   if (!p->d_u0 && !fused) HIPCHK(hipMalloc(&p->d_u0, rows_max * M * sizeof(float2)));
-  if (!p->d_u1 && !(fused && p->chirp_single)) HIPCHK(hipMalloc(&p->d_u1, rows_max * M * sizeof(float2)));
+  if (!p->d_u1 && !(fused && p->chirp_single && !p->chirp_big)) HIPCHK(hipMalloc(&p->d_u1, rows_max * M * sizeof(float2)));
   if (!fused)
     HIPCHK(launch_chirp_pre(in, in_format == TDSA_IN_C64, stride, N, M, n_frames, p->d_window[in_format], p->d_chirp_a, dc_sub,
                             xor_mask, in_off, p->d_u0, s, H));
@@ -393,8 +396,22 @@ int chirp_transform(tdsa_plan p, const void* in, int in_format, long long stride
     flat.mode = 2;
     flat.table = p->d_ones;
     flat.flat = 1.0f;
-    HIPCHK(launch_big_cols(p->log2m, p->d_u0, 1, segb, n_rows, flat, p->d_tw_seed, nullptr, p->d_z, 0u, 0.0f, s,
-                           unsigned(H ? H : N)));
+    if (bfused) {                       // ... or are never stored: the raw frames are unpacked by the column pass itself
+      const BigChirpPre pre{p->d_chirp_aw[in_format], N, in_format == TDSA_IN_C64, H};
+      HIPCHK(launch_big_cols(p->log2m, in, 1, stride, n_rows, flat, p->d_tw_seed, dc_sub, p->d_z, xor_mask, in_off, s, 0u, &pre));
+    } else {
+      HIPCHK(launch_big_cols(p->log2m, p->d_u0, 1, segb, n_rows, flat, p->d_tw_seed, nullptr, p->d_z, 0u, 0.0f, s,
+                             unsigned(H ? H : N)));
+    }
+    // the last column pass turns the bins into the dB / power rows (fused plans); hold traces from the finished rows
+    const BigChirpPost bpost = bfused ? BigChirpPost{N, H, 1.0f / float(M), post->db_mode, post->pscale, post->log_floor,
+                                                     post->cal_db, post->tare, post->out_db, post->out_lin}
+                                      : BigChirpPost{};
+    const auto hold_rows = [&]() -> int {
+      if (bfused && post->out_lin == nullptr && (post->hold_max || post->hold_min))
+        HIPCHK(launch_chirp_hold(post->out_db, N, n_frames, post->first_frame_index, post->hold_max, post->hold_min, s));
+      return TDSA_OK;
+    };
 
     SpecParams sp{};
     sp.frame_stride = rowb;
@@ -418,8 +435,8 @@ int chirp_transform(tdsa_plan p, const void* in, int in_format, long long stride
       // (spectrum_kernel<14, true, 0, 4>) - the rows are written once and read once less
       sp.rows_twice = 1;
       { const int rc = launch_spectrum_profiled(p, 1, sp, g); if (rc != TDSA_OK) return rc; }
-      HIPCHK(launch_big_cols_out(p->log2m, p->d_u1, segb, n_rows, p->d_tw_seed, p->d_u0, unsigned(N), s));
-      return TDSA_OK;
+      HIPCHK(launch_big_cols_out(p->log2m, p->d_u1, segb, n_rows, p->d_tw_seed, p->d_u0, unsigned(N), s, bfused ? &bpost : nullptr));
+      return hold_rows();
     }
     { const int rc = launch_spectrum_profiled(p, 1, sp, g); if (rc != TDSA_OK) return rc; }
     if (H)    // split plans: the two half-rows' spectra meet the three filter segments: conj(UA B0 + UB Bm), conj(UA Bp + UB B0)
@@ -430,8 +447,8 @@ int chirp_transform(tdsa_plan p, const void* in, int in_format, long long stride
     sp.out_mul_rows = 0;
     { const int rc = launch_spectrum_profiled(p, 1, sp, g); if (rc != TDSA_OK) return rc; }
 
-    HIPCHK(launch_big_cols_out(p->log2m, p->d_z, segb, n_rows, p->d_tw_seed, p->d_u0, unsigned(H ? H : N), s));
-    return TDSA_OK;
+    HIPCHK(launch_big_cols_out(p->log2m, p->d_z, segb, n_rows, p->d_tw_seed, p->d_u0, unsigned(H ? H : N), s, bfused ? &bpost : nullptr));
+    return hold_rows();
   }
   SpecParams sp{};
   sp.frame_stride = (long long)M * sizeof(float2);
@@ -527,13 +544,13 @@ int process_chirp(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n
   float* const tare = p->tare_active ? p->d_tare_base : nullptr;
   const int first = p->frames_seen > 0 ? 1 : 0;
   if (averaging && !p->d_lin) HIPCHK(hipMalloc(&p->d_lin, size_t(p->max_frames) * N * sizeof(float)));
-  // M <= 16384: the power / dB rows leave the second transform directly (linear rows for the averager's scan, else dB
-  // rows + hold traces); longer frames: complex rows in d_u0, chirp_post below
+  // the power / dB rows leave the second transform directly (linear rows for the averager's scan, else dB rows + hold
+  // traces); frames below 1024 points (and the A/B knobs): complex rows in d_u0, chirp_post below
   const bool fusable = chirp_fusable(p);
   const bool holding = (m.hold_flags & (TDSA_HOLD_MAX | TDSA_HOLD_MIN)) != 0;
   float* rows = out_db_dev;
   if (fusable && !averaging && rows == nullptr && holding) {   // only the hold traces are wanted: the rows go to scratch
-    if (!p->d_u0) HIPCHK(hipMalloc(&p->d_u0, size_t(p->max_frames) * M * sizeof(float2)));
+    if (!p->d_u0) HIPCHK(hipMalloc(&p->d_u0, size_t(p->max_frames) * (p->chirp_split ? 2 : 1) * M * sizeof(float2)));
     rows = reinterpret_cast<float*>(p->d_u0);
   }
   if (fusable && !averaging && rows == nullptr) {              // nothing to produce (no rows, no hold, no averaging)
@@ -913,15 +930,21 @@ int tdsa_set_window(tdsa_plan p, const float* w_host, int n) {
     const int rc_w = big_window_model(p, w_host, scale);
     if (rc_w != TDSA_OK) return rc_w;
   }
-  if (chirp_fusable(p)) {
+  if (p->chirp && p->log2m >= 10) {
     // window x input scale x chirp a[n] = exp(-i pi n^2 / N) (phase from n^2 mod 2N in integers), product in double,
     // rounded once: the first transform multiplies the unpacked samples by it on load
     std::vector<float2> aw(n);
+    std::vector<double> ca(n), sa(n);
+    for (int i = 0; i < n; ++i) {
+      const long long q = ((long long)i * i) % (2ll * n);
+      const double ang = -M_PI * double(q) / double(n);
+      ca[i] = std::cos(ang);
+      sa[i] = std::sin(ang);
+    }
     for (int f = 0; f < 3; ++f) {
       for (int i = 0; i < n; ++i) {
-        const long long q = ((long long)i * i) % (2ll * n);
-        const double ang = -M_PI * double(q) / double(n), wv = double(w_host[i]) * double(scale[f]);
-        aw[i] = float2{float(wv * std::cos(ang)), float(wv * std::sin(ang))};
+        const double wv = double(w_host[i]) * double(scale[f]);
+        aw[i] = float2{float(wv * ca[i]), float(wv * sa[i])};
       }
       if (!p->d_chirp_aw[f]) HIPCHK(hipMalloc(&p->d_chirp_aw[f], aw.size() * sizeof(float2)));
       HIPCHK(hipMemcpy(p->d_chirp_aw[f], aw.data(), aw.size() * sizeof(float2), hipMemcpyHostToDevice));
@@ -1868,6 +1891,8 @@ int tdsa_debug_knob(tdsa_plan p, const char* name, int value) {
     if (!p->big || value < 1 || value > 64) return fail(TDSA_ERR_ARG, "big_group=%d (long-frame plans, 1 .. 64)", value);
     if (p->d_z && value > p->big_group) return fail(TDSA_ERR_STATE, "big_group can only shrink once the plan has run");
     p->big_group = value;
+  } else if (k == "chirp_fuse_big") {        // long chirp-z frames: 1 = element-wise passes inside the column passes (default)
+    p->chirp_fuse_big = value != 0;
   } else if (k == "chirp_single") {          // fusable chirp-z plans: 1 = one launch per call (default), 0 = two transforms, two launches
     p->chirp_single = value != 0;
   } else if (k == "big_pre_wgs") {           // long-frame plans: empty workgroups ahead of every column pass (XCD phase)

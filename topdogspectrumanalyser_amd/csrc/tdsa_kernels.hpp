@@ -208,13 +208,33 @@ struct BigWindow {
   const float* table;
   float flat;
 };
+// long chirp-z frames: the column pass reads the RAW frames (seg_stride = bytes between frames, dc_sub per FRAME) and
+// multiplies the unpacked samples by aw[n] = window x input scale x chirp on load
+struct BigChirpPre {
+  const float2* aw;          // [n] or null (off)
+  int n;                     // samples per frame
+  int c64;                   // raw samples are complex64
+  int split_h;               // > 0: segment 2f + s is the half [s H, ...) of frame f (frames above 2^19 points)
+};
+// ... and the transposed transform's column pass writes the wanted bins as power / dB rows [F][n]
+struct BigChirpPost {
+  int n;                     // bins per frame, 0: off
+  int split_h;
+  float inv_m;
+  int db_mode;
+  float pscale, log_floor, cal_db;
+  const float* tare;
+  float* out_db;
+  float* out_lin;
+};
 hipError_t launch_big_cols(int log2n, const void* in, int in_c64, long long seg_stride, int n_seg, const BigWindow& win,
                            const float2* tw_seed, const float2* dc_sub, float2* z,
-                           unsigned xor_mask, float in_off, hipStream_t s, unsigned in_valid = 0);
+                           unsigned xor_mask, float in_off, hipStream_t s, unsigned in_valid = 0,
+                           const BigChirpPre* pre = nullptr);
 // transposed four-step, second half: R[seg][k1][m2] (row transforms of T[k1][k2] = V[k1 + N1 k2]) -> Y[seg][m] in natural
 // order, M = N1 * 16384 points; bins from out_valid on are not stored (tdsa_big.hip)
 hipError_t launch_big_cols_out(int log2m, const float2* r, long long seg_stride, int n_seg, const float2* tw_seed, float2* y,
-                               unsigned out_valid, hipStream_t s);
+                               unsigned out_valid, hipStream_t s, const BigChirpPost* post = nullptr);
 // exact per-frame sums + DC tracker in double; dc_res[f] = DC estimate in raw units MINUS in_off (small)
 hipError_t launch_big_dc(const void* in, int in_c64, unsigned xor_mask, long long frame_stride, int n, int n_frames,
                          double alpha, double in_off, double in_scale, double* sums, float2* dc_state, float2* dc_res,
