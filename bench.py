@@ -21,8 +21,10 @@ Three ways of submitting the same K steps are timed, all in the line:
   value_serial   one second per launch, strictly serial full-chip launches
 Results are bit-identical in all three (tests/test_gpu_parity.py::test_batched_captures_*).
 
-The default run (C3, one GPU) then appends SHORT legs of the other three GPU configurations of BASELINE.json - C2, C4
-as named (65 536 frames x 8192 points) and C5 - each with its own parity block, under `roofline.other_configs`, and the
+The default run (C3) then appends SHORT legs of the other three GPU configurations of BASELINE.json - C2, C4 as named
+(65 536 frames x 8192 points) and C5 - each with its own parity block, under `roofline.other_configs`; at N > 1 they are
+sharded over the same ranks (C4's frames and C5's segments split over the world - with the cross-rank Welch combine inside
+every step - plus C5 with whole captures per rank): one driver run per N carries every configuration's curve.  Also the
 shader clock the kernels ran at (`roofline.shader_clock_mhz`: a millisecond of saturated v_add_f32 right after the
 kernel-alone pass - the frame kernel is VALU-issue bound, so kernel time x clock is what compares across boxes).
 
@@ -983,6 +985,8 @@ def main() -> None:
                          "for C4 and the short legs of the default run")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default run only: skip the short C2 / C4 / C5 legs appended under roofline.other_configs")
+    ap.add_argument("--dry-other-configs", action="store_true",
+                    help="with --dry-run: also walk the short C2 / C4 / C5 legs (tests of the multi-rank plumbing)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: exercise spawn / barrier / aggregation with a stand-in engine (no perf meaning)")
     args = ap.parse_args()
@@ -1007,7 +1011,8 @@ def main() -> None:
         saved_fd, null_fd = os.dup(1), os.open(os.devnull, os.O_WRONLY)
         os.dup2(null_fd, 1)
         try:
-            dist.init_process_group(backend="gloo")
+            import datetime
+            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(minutes=15))
             dist.barrier()
         finally:
             sys.stdout.flush()
@@ -1020,39 +1025,59 @@ def main() -> None:
     result = run_config(args, comm, torch)
 
     # ---- the default run: short legs of the other GPU configurations, one driver run for all four (round-4 verdict) ----
-    if args.config == "c3" and world == 1 and not args.dry_run and not args.no_other_configs and args.legs == "all":
+    # At N > 1 the same legs run sharded over the ranks - C4 as named (its 65 536 frames split over the world), C5 both ways
+    # (the segments of one capture over the ranks with the cross-rank combine inside each step = the strong-scaling curve
+    # north_star names, and whole captures per rank) - so that one driver run per N yields every configuration's curve.
+    want_others = (args.config == "c3" and not args.no_other_configs and args.legs == "all"
+                   and (not args.dry_run or args.dry_other_configs))
+    if want_others:
         others = {}
-        for name in ("c2", "c4", "c5"):
+        leg_list = [("c2", "c2", None), ("c4", "c4", None), ("c5", "c5", "segments")]
+        if world > 1:
+            leg_list.append(("c5_captures", "c5", "captures"))
+        for key, name, shard in leg_list:
             a = copy.copy(args)
             a.config, a.short_leg = name, True
+            if shard is not None:
+                a.c5_shard = shard
             a.reps, a.min_region_s, a.legs = 3, 0.2, "value"
             a.steps, a.warmup, a.preroll_seconds = 40, 8, 0.1
             a.no_cpu_baseline, a.no_cpu_pool = True, True
             t0 = time.perf_counter()
             try:
                 r = run_config(a, comm, torch)
-                pb = r.get("parity", {})
-                others[name] = {"workload": r["config"]["workload"], "value": r["value"], "unit": r["unit"],
-                                "ms_per_step": r["ms_per_step"], "frames_per_step": r["config"]["frames_per_step_all_gpus"],
-                                "steps_per_call": r["config"]["steps_per_call"], "streams": r["config"]["streams_per_gpu"],
-                                "frac": r["roofline"]["frac"], "achieved": r["roofline"]["achieved"],
-                                "kernel": r["roofline"]["kernel"], "kernel_avg_us": r["roofline"]["kernel_avg_us"],
-                                "algorithmic_bytes_per_launch": r["roofline"]["algorithmic_bytes_per_launch"],
-                                "shader_clock_mhz": r["roofline"]["shader_clock_mhz"],
-                                "traffic": r["roofline"]["traffic"], "traffic_source": r["roofline"]["traffic_source"],
-                                "parity": {k: pb.get(k) for k in ("pass", "north_star_pass", "survey_8d_strict_pass",
-                                                                   "max_rel_power_err", "max_db_err_top100dB", "hold_trace_pass",
-                                                                   "checked")},
-                                "timing": {"repetitions": r["timing"]["repetitions"], "min_region_s": r["timing"]["min_region_s"],
-                                           "region_ms": r["timing"]["region_ms"]},
-                                "data": r["data"], "leg_wall_s": time.perf_counter() - t0}
-                result["roofline"]["quoted_files"].update(r["roofline"]["quoted_files"])
+                if r is None:                          # (ranks other than 0 took part; rank 0 holds the result)
+                    continue
+                pb, rf, cf, tm = r.get("parity", {}), r["roofline"], r["config"], r.get("timing", {})
+                others[key] = {"workload": cf["workload"], "value": r["value"], "unit": r["unit"], "n_gpus": r["n_gpus"],
+                               "scaling": r["scaling"], "ms_per_step": r["ms_per_step"],
+                               "frames_per_step": cf["frames_per_step_all_gpus"],
+                               "steps_per_call": cf["steps_per_call"], "streams": cf["streams_per_gpu"],
+                               "frac": rf.get("frac"), "achieved": rf.get("achieved"),
+                               "kernel": rf.get("kernel"), "kernel_avg_us": rf.get("kernel_avg_us"),
+                               "algorithmic_bytes_per_launch": rf.get("algorithmic_bytes_per_launch"),
+                               "shader_clock_mhz": rf.get("shader_clock_mhz"),
+                               "traffic": rf.get("traffic"), "traffic_source": rf.get("traffic_source"),
+                               "parity": {k: pb.get(k) for k in ("pass", "north_star_pass", "survey_8d_strict_pass",
+                                                                  "max_rel_power_err", "max_db_err_top100dB", "hold_trace_pass",
+                                                                  "checked")},
+                               "timing": {"repetitions": tm.get("repetitions"), "min_region_s": tm.get("min_region_s"),
+                                          "region_ms": tm.get("region_ms")},
+                               "data": r["data"], "leg_wall_s": time.perf_counter() - t0}
+                for k in ("value_compute_only", "ms_per_step_compute_only", "welch"):
+                    if k in r:
+                        others[key][k] = r[k]
+                if "frames_per_step_per_rank" in cf:
+                    others[key]["frames_per_step_per_rank"] = cf["frames_per_step_per_rank"]
+                result["roofline"].setdefault("quoted_files", {}).update(rf.get("quoted_files") or {})
             except Exception as exc:                   # a reported extra, never a reason to lose the C3 line
-                others[name] = {"error": f"{type(exc).__name__}: {exc}"}
-        result["roofline"]["other_configs"] = others
-        result["roofline"]["other_configs_are"] = ("short legs of the same bench (`value` submission mode, 3 repetitions of "
-                                                   ">= 0.2 s, parity block each, no CPU legs): python bench.py --config cX "
-                                                   "is the full run of each")
+                others[key] = {"error": f"{type(exc).__name__}: {exc}"}
+        if result is not None:
+            result["roofline"]["other_configs"] = others
+            result["roofline"]["other_configs_are"] = ("short legs of the same bench (`value` submission mode, 3 repetitions of "
+                                                       ">= 0.2 s, parity block each, no CPU legs; at N > 1 sharded over the "
+                                                       "ranks like the main line): python bench.py --config cX is the full "
+                                                       "run of each")
     if rank == 0:
         result["wall_s"] = time.perf_counter() - t_run0
         print(json.dumps(result), flush=True)

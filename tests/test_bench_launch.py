@@ -112,6 +112,31 @@ def test_bench_c4_is_the_named_waterfall_sharded_over_the_ranks(n):
     assert "sharded over" in d["config"]["parallelism"] and "no collective" in d["config"]["parallelism"]
 
 
+@pytest.mark.parametrize("n", [1, 2, 8])
+def test_default_run_carries_the_other_configurations_at_every_world_size(n):
+    """The default run (C3) appends short legs of the other GPU configurations under roofline.other_configs - at N > 1
+    sharded over the same ranks: C2 (every rank its own captures), C4 as named (65 536 frames split over the world), C5
+    with the segments of one capture split (strong; cross-rank combine inside the step) and with whole captures per rank
+    (weak) - so that one driver run per N yields every configuration's curve."""
+    d = _run([sys.executable, "bench.py", "--gpus", str(n), "--steps", "40", "--warmup", "3", "--reps", "3", "--dry-run",
+              "--dry-other-configs", "--min-region-s", "0.05"])
+    _check_line(d, n)
+    oc = d["roofline"]["other_configs"]
+    assert set(oc) == ({"c2", "c4", "c5"} | ({"c5_captures"} if n > 1 else set())), oc.keys()
+    for k, v in oc.items():
+        assert "error" not in v, (k, v)
+        assert v["n_gpus"] == n and v["value"] > 0
+    assert oc["c2"]["scaling"] == "weak" and oc["c2"]["frames_per_step"] == 4096 * n
+    assert oc["c4"]["scaling"] == "strong" and oc["c4"]["frames_per_step"] == 65536
+    assert oc["c4"]["frames_per_step_per_rank"] == [65536 // n] * n
+    assert oc["c5"]["scaling"] == "strong" and oc["c5"]["frames_per_step"] == 64
+    assert oc["c5"]["welch"]["shard"] == "segments" and sum(oc["c5"]["welch"]["segments_per_rank"]) == 64
+    if n > 1:
+        assert oc["c5"]["welch"]["combine_ms"] >= 0.0 and "value_compute_only" in oc["c5"]
+        assert oc["c5_captures"]["scaling"] == "weak" and oc["c5_captures"]["frames_per_step"] == 64 * n
+        assert oc["c5_captures"]["welch"]["shard"] == "captures"
+
+
 def test_bench_workers_are_all_reaped_when_one_fails(tmp_path):
     """a failing worker must not leave the others parked in the gloo barrier - every worker is waited
     for (or terminated) and the first non-zero exit code comes back."""
