@@ -388,15 +388,38 @@ def run_config(args, comm: Comm, torch) -> dict:
 
     # ---- cross-rank Welch combine (C5, --c5-shard segments, more than one rank): part of every step ----------------
     combine_state = {"n": 0, "t_wait": 0.0, "t_comb": 0.0}
+    peer = False                                      # the partial means stay in device memory, read in place by rank 0
     if combine:
-        from topdogspectrumanalyser_amd.sharding import WelchSlab
+        from topdogspectrumanalyser_amd.sharding import WelchPeerSlab, WelchSlab
         bins = _DryEngine.DRY_BINS if args.dry_run else nfft
         part_dtype = np.float64 if args.c5_partials == "f64" else np.float32
-        if rank == 0:
-            slab = WelchSlab(None, world, 0, bins, dtype=part_dtype, pin=not args.dry_run)
-        name = comm.bcast(slab.name if rank == 0 else None)
-        if rank != 0:
-            slab = WelchSlab(name, world, rank, bins, dtype=part_dtype, pin=not args.dry_run)
+        if args.c5_combine in ("auto", "peer") and not args.dry_run:
+            # device-resident partials (HIP IPC + peer reads over xGMI); any rank that cannot -> everybody falls back
+            try:
+                pslab = WelchPeerSlab(None, world, 0, bins, dev_index, dtype=part_dtype) if rank == 0 else None
+                name = comm.bcast(pslab.name if rank == 0 else None)
+                if rank != 0:
+                    pslab = WelchPeerSlab(name, world, rank, bins, dev_index, dtype=part_dtype)
+                pslab.allocate()
+                host_barrier()
+                pslab.connect()
+                host_barrier()
+                if pslab.ok:
+                    slab, peer = pslab, True
+                else:
+                    pslab.close()
+            except Exception as exc:                   # (same on every rank: the verdict is rank 0's)
+                if args.c5_combine == "peer":
+                    raise
+                sys.stderr.write(f"[bench] rank {rank}: no peer buffers ({exc}); Welch partials go through host memory\n")
+            if not peer and args.c5_combine == "peer":
+                sys.exit("--c5-combine peer: the ranks' buffers could not be mapped on rank 0's device")
+        if not peer:
+            if rank == 0:
+                slab = WelchSlab(None, world, 0, bins, dtype=part_dtype, pin=not args.dry_run)
+            name = comm.bcast(slab.name if rank == 0 else None)
+            if rank != 0:
+                slab = WelchSlab(name, world, rank, bins, dtype=part_dtype, pin=not args.dry_run)
         host_barrier()
         dry_combined = {}
 
@@ -406,12 +429,11 @@ def run_config(args, comm: Comm, torch) -> dict:
             c = combine_state["n"] + 1
             combine_state["n"] = c
             step(i)
-            if counts[rank]:
-                dst = slab.part(c)
-                if args.dry_run:
-                    eng.welch_export(dst)
+            if counts[rank]:                               # (synchronous: the payload is complete when this returns)
+                if peer:
+                    eng.welch_export_dev(slab.part_ptr(c), as_f32=part_dtype == np.float32)
                 else:
-                    eng.welch_export(dst)                  # synchronous: the payload is complete when this returns
+                    eng.welch_export(slab.part(c))
             slab.publish(c)
             if rank == 0:
                 t0 = time.perf_counter()
@@ -419,6 +441,10 @@ def run_config(args, comm: Comm, torch) -> dict:
                 t1 = time.perf_counter()
                 if args.dry_run:
                     dry_combined["mean"] = _DryEngine.welch_combine(parts, counts)
+                elif peer:
+                    eng.welch_combine_dev(parts, counts, as_f32=part_dtype == np.float32,
+                                          out_db_dev=out_ring[i % ring].data_ptr())
+                    eng.synchronize()                      # the kernel has read the slots: they may be written again
                 else:
                     eng.welch_combine(parts, counts, out_db_dev=out_ring[i % ring].data_ptr())
                     eng.synchronize()                      # the upload has read the slot: it may be written again
@@ -591,15 +617,21 @@ def run_config(args, comm: Comm, torch) -> dict:
                 e2e_ms = head["med"] / steps_timed * 1e3
                 comp_ms = compute_only["med"] / compute_only["steps"] * 1e3
                 welch_block = {"shard": "segments", "segments_per_rank": counts, "segments_total": int(sum(counts)),
-                               "partials": f"{slab.dtype.name} means through a {'pinned ' if slab.pinned else ''}shared-memory "
-                                           f"slab ({slab.slots} slots x {world} ranks x {slab.n} bins), no pickling, no collective",
-                               "combined_on": "rank 0's device: tdsa_welch_combine (count-weighted mean in float64, rank order, "
-                                              "then 10*log10(mean + floor) + calibration offset), inside the timed region",
+                               "exchange": "peer" if peer else "host",
+                               "partials": (f"{slab.dtype.name} means left in device buffers of the ranks' own GPUs "
+                                            f"({slab.slots} slots x {slab.n} bins each), mapped on rank 0's device through HIP IPC "
+                                            "handles and read in place by its combine kernel (other GPUs': over xGMI); no "
+                                            "host copy, no pickling, no collective, no RCCL") if peer else
+                                           (f"{slab.dtype.name} means through a {'pinned ' if slab.pinned else ''}shared-memory "
+                                            f"slab ({slab.slots} slots x {world} ranks x {slab.n} bins), no pickling, no collective"),
+                               "combined_on": f"rank 0's device: tdsa_welch_combine{'_dev' if peer else ''} (count-weighted mean in "
+                                              "float64, rank order, then 10*log10(mean + floor) + calibration offset), inside "
+                                              "the timed region",
                                "combine_ms": max(0.0, e2e_ms - comp_ms),
                                "combine_ms_is": "ms_per_step (end to end) - ms_per_step_compute_only",
                                "rank0_wait_for_partials_ms": head["comb_wait_s"] / n_steps * 1e3,
                                "rank0_upload_combine_ms": head["comb_s"] / n_steps * 1e3,
-                               "ms_per_step_compute_only": comp_ms, "pinned": bool(slab.pinned)}
+                               "ms_per_step_compute_only": comp_ms, "pinned": bool(getattr(slab, "pinned", False))}
                 if args.dry_run:
                     welch_block["mean_of_means"] = float(np.mean(dry_combined["mean"]))
                 else:
@@ -939,7 +971,11 @@ def run_config(args, comm: Comm, torch) -> dict:
                     result["cpu_baseline_pool"] = {"value": None, "error": str(exc)}
     if slab is not None:
         host_barrier()
+        if peer and rank != 0:                        # rank 0 unmaps the other ranks' buffers before their owners free them
+            host_barrier()
         slab.close()
+        if peer and rank == 0:
+            host_barrier()
     if not args.dry_run:
         eng.close()
         del in_ring, out_ring
@@ -977,6 +1013,10 @@ def main() -> None:
     ap.add_argument("--c5-shard", default="segments", choices=["segments", "captures"],
                     help="--config c5 on several GPUs: shard the 64 segments of ONE capture (strong scaling; every step pays "
                          "the cross-GPU combine) or give every GPU whole captures (weak scaling, no combine)")
+    ap.add_argument("--c5-combine", default="auto", choices=["auto", "peer", "host"],
+                    help="C5 at N > 1, segments sharded: where the ranks' partial means meet - peer = they stay in device "
+                         "buffers rank 0 reads in place (HIP IPC, over xGMI), host = pinned shared memory; auto = peer when "
+                         "every buffer can be mapped, else host")
     ap.add_argument("--c5-partials", default="f32", choices=["f32", "f64"],
                     help="precision the ranks' partial Welch means travel in (f32: 4 MiB per rank and step; the row moves < 1e-6 dB)")
     ap.add_argument("--synth", default="auto", choices=["auto", "numpy", "device"],

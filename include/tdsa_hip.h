@@ -208,6 +208,21 @@ int tdsa_welch_export(tdsa_plan p, void* mean_host, int as_f32, int* count);
  * pointer, asynchronous) and / or out_db_host (then the call synchronises); either may be NULL. */
 int tdsa_welch_combine(tdsa_plan p, const void* parts_host, size_t part_stride_bytes, const int32_t* counts, int n_parts,
                        int as_f32, float* out_db_dev, float* out_db_host);
+/* The same exchange without the detour through host memory, for ranks on GPUs of one node: every rank keeps its partial
+ * mean in a device buffer the other processes can map (HIP IPC: tdsa_peer_alloc hands out the 64-byte handle, which
+ * travels through any host channel; tdsa_peer_open maps it on the combining rank's device, refusing devices without peer
+ * access), tdsa_welch_export_dev writes the running mean there (synchronous: the values have landed when it returns) and
+ * tdsa_welch_combine_dev reads all partials IN PLACE - its own from HBM, the others' over xGMI, each over its own link -
+ * with the arithmetic, state and outputs of tdsa_welch_combine.  Still no collective and no RCCL: one kernel on one
+ * device loading through mapped peer pointers.  owner_device_id < 0 skips the peer-access check. */
+#define TDSA_PEER_HANDLE_BYTES 64
+int tdsa_peer_alloc(int device_id, size_t bytes, void** dev_ptr, unsigned char* handle64);
+int tdsa_peer_free(int device_id, void* dev_ptr);
+int tdsa_peer_open(int device_id, const unsigned char* handle64, int owner_device_id, void** dev_ptr);
+int tdsa_peer_close(int device_id, void* dev_ptr);
+int tdsa_welch_export_dev(tdsa_plan p, void* mean_dev, int as_f32, int* count);
+int tdsa_welch_combine_dev(tdsa_plan p, const void* const* parts_dev, const int32_t* counts, int n_parts, int as_f32,
+                           float* out_db_dev, float* out_db_host);
 
 /* Saturated VALU rate of the SIMDs right now - independent v_add_f32 chains, four waves per SIMD on every CU, about a
  * millisecond, timed with events on the plan's stream: *ns_per_valu = ns per wave-instruction per SIMD,

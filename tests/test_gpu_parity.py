@@ -1349,6 +1349,30 @@ def test_welch_partials_combined_on_one_device(pkg, nfft, k, dtype):
                 e.process(iq[2 * f0 * nfft: 2 * f1 * nfft], hop=nfft, want_db=False)
             counts.append(e.welch_export(parts[r]))
     assert counts == [f1 - f0 for f0, f1 in shares]
+    # the same partials left in device buffers (tdsa_peer_alloc) and combined in place: the same bits as through the host
+    import ctypes as C
+    nat = pkg._native
+    bufs, handle = [], (C.c_ubyte * 64)()
+    try:
+        for r, (f0, f1) in enumerate(shares):
+            ptr = C.c_void_p()
+            nat.check(nat.lib.tdsa_peer_alloc(0, nfft * np.dtype(dtype).itemsize, C.byref(ptr), handle))
+            bufs.append(int(ptr.value))
+            with plan(f1 - f0) as e:
+                if f1 > f0:
+                    e.process(iq[2 * f0 * nfft: 2 * f1 * nfft], hop=nfft, want_db=False)
+                assert e.welch_export_dev(bufs[r], as_f32=dtype == np.float32) == f1 - f0
+        with plan(1) as comb:
+            row_dev = comb.welch_combine_dev(bufs, counts, as_f32=dtype == np.float32, want_host=True)
+            mean_dev, _ = comb.averaged()
+        with plan(1) as comb:
+            assert np.array_equal(row_dev, comb.welch_combine(parts, counts, want_host=True))
+            assert np.array_equal(mean_dev, comb.averaged()[0])
+            with pytest.raises(nat.TdsaError):                   # a part that counts needs a pointer
+                comb.welch_combine_dev([bufs[0], None, None], counts[:1] + [1, 1], as_f32=dtype == np.float32)
+    finally:
+        for b in bufs:
+            nat.lib.tdsa_peer_free(0, C.c_void_p(b))
     with plan(k) as one:                                         # the reference: one plan, every segment
         row_one = one.process(iq[: 2 * nfft * k], hop=nfft)
         row_one = row_one[-1] if row_one.ndim == 2 else row_one
@@ -1374,6 +1398,29 @@ def test_welch_partials_combined_on_one_device(pkg, nfft, k, dtype):
         bad.configure(avg=("lin", k - 1))
         with pytest.raises(pkg._native.TdsaError):
             bad.welch_combine(parts, counts, want_host=True)
+
+
+def test_welch_partials_read_in_place_from_another_process(pkg):
+    """Ranks on GPUs of one node leave their partial means in device buffers (tdsa_peer_alloc), rank 0 maps them through
+    HIP IPC handles (tdsa_peer_open) and tdsa_welch_combine_dev reads them in place - here: two bench.py ranks sharing this
+    box's one GPU, the 64 segments of the C5 capture split 32 / 32; the combined dB row passes the bench's parity block
+    against the float64 Welch gold and the line says which exchange ran."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29547", "bench.py", "--gpus", "2", "--config", "c5",
+                          "--c5-combine", "peer", "--steps", "10", "--warmup", "2", "--reps", "2", "--min-region-s", "0.1"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["welch"]["exchange"] == "peer" and d["welch"]["segments_per_rank"] == [32, 32]
+    assert d["parity"]["pass"] is True, d["parity"]
+    assert d["welch"]["combine_ms"] < 5.0
 
 
 def test_shader_clock_is_plausible(pkg):

@@ -87,3 +87,21 @@ def test_combine_helpers():
     assert c == 4 and np.allclose(m, [3.25, 6.5])
     with pytest.raises(ValueError):
         sharding.combine_welch([np.zeros(2)], [0])
+
+
+def test_welch_peer_slab_reports_failure_instead_of_raising():
+    """sharding.WelchPeerSlab on a box where the device buffers cannot be had (no GPU here): allocate() records the
+    failure, connect() turns it into ok == False on every rank - bench.py then takes the host-memory slab."""
+    from topdogspectrumanalyser_amd.sharding import WelchPeerSlab
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the buffers can be had (tests/test_gpu_parity.py covers that side)")
+    slab = WelchPeerSlab(None, 1, 0, 1024, device=0)
+    try:
+        slab.allocate()
+        slab.connect()
+        assert slab.ok is False
+    finally:
+        name = slab.name
+        slab.close()
+    assert not os.path.exists(name)

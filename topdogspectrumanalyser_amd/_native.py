@@ -60,6 +60,12 @@ _SIGNATURES = {
     "tdsa_host_unregister": (C.c_int, [_P]),
     "tdsa_welch_export": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
     "tdsa_welch_combine": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_int32), C.c_int, C.c_int, _P, _P]),
+    "tdsa_peer_alloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(_P), _P]),
+    "tdsa_peer_free": (C.c_int, [C.c_int, _P]),
+    "tdsa_peer_open": (C.c_int, [C.c_int, _P, C.c_int, C.POINTER(_P)]),
+    "tdsa_peer_close": (C.c_int, [C.c_int, _P]),
+    "tdsa_welch_export_dev": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
+    "tdsa_welch_combine_dev": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int32), C.c_int, C.c_int, _P, _P]),
     "tdsa_shader_clock": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "tdsa_get_dc": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "tdsa_set_dc": (C.c_int, [_P, C.c_float, C.c_float]),

@@ -607,10 +607,10 @@ hipError_t launch_welch_export(const double* src, double div, void* dst, int as_
 }
 
 struct WelchParts {
-  const void* parts;         // [n_parts] partial means, part_stride bytes apart
-  long long part_stride;
+  const void* part[kWelchMaxParts];   // the partial means: this device's staging copy of a host slab, or the ranks' own
+                                      // buffers read in place over xGMI (tdsa_peer_open)
   int n_parts;
-  int count[kWelchMaxParts]; // segments behind each partial mean (0: not read)
+  int count[kWelchMaxParts];          // segments behind each partial mean (0: not read)
 };
 
 template <typename T>
@@ -621,8 +621,7 @@ __global__ void __launch_bounds__(256) welch_combine_kernel(const WelchParts w, 
   double acc = 0.0;
   for (int r = 0; r < w.n_parts; ++r) {
     if (w.count[r] == 0) continue;
-    const T* m = reinterpret_cast<const T*>(static_cast<const unsigned char*>(w.parts) + (long long)r * w.part_stride);
-    acc += double(m[i]) * double(w.count[r]);
+    acc += double(static_cast<const T*>(w.part[r])[i]) * double(w.count[r]);
   }
   if (sum_out != nullptr) sum_out[i] = acc;
   if (!native_db) {
@@ -638,13 +637,17 @@ __global__ void __launch_bounds__(256) welch_combine_kernel(const WelchParts w, 
   }
 }
 
-hipError_t launch_welch_combine(const void* parts, long long part_stride, const int* counts, int n_parts, int as_f32, long long n,
+hipError_t launch_welch_combine(const void* const* parts, const int* counts, int n_parts, int as_f32, long long n,
                                 double* sum_out, double* mean_out, int total, int native_db, int db_mode, float pscale,
                                 float log_floor, float cal_db, const float* tare, float* out_db, float* hold_max,
                                 float* hold_min, int max_first, int min_first, hipStream_t s) {
   if (n_parts < 1 || n_parts > kWelchMaxParts) return hipErrorInvalidValue;
-  WelchParts w{parts, part_stride, n_parts, {}};
-  for (int r = 0; r < n_parts; ++r) w.count[r] = counts[r];
+  WelchParts w{};
+  w.n_parts = n_parts;
+  for (int r = 0; r < n_parts; ++r) {
+    w.part[r] = parts[r];
+    w.count[r] = counts[r];
+  }
   const BigFinishParams fin{nullptr, mean_out, total, db_mode, pscale, log_floor, cal_db, tare, out_db, hold_max, hold_min,
                             max_first, min_first};
   const dim3 grid(unsigned((n + 255) / 256));

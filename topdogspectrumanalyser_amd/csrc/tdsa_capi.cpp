@@ -1561,13 +1561,82 @@ int tdsa_welch_export(tdsa_plan p, void* mean_host, int as_f32, int* count) {
   return TDSA_OK;
 }
 
-int tdsa_welch_combine(tdsa_plan p, const void* parts_host, size_t part_stride_bytes, const int32_t* counts, int n_parts,
-                       int as_f32, float* out_db_dev, float* out_db_host) {
-  if (!p || !parts_host || !counts) return fail(TDSA_ERR_ARG, "null argument");
+int tdsa_welch_export_dev(tdsa_plan p, void* mean_dev, int as_f32, int* count) {
+  if (!p || !mean_dev) return fail(TDSA_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(p->device));
+  JOIN(p);
+  if (count) *count = p->avg_count;
+  if (p->avg_count <= 0) return TDSA_OK;
+  const bool from_sum = p->big && p->big_mean_in_sum;
+  HIPCHK(launch_welch_export(from_sum ? p->d_sum : p->d_avg, from_sum ? double(p->avg_count) : 1.0, mean_dev, as_f32,
+                             (long long)p->nfft, p->stream));
+  HIPCHK(hipStreamSynchronize(p->stream));     // the caller tells the combining process next: the values must have landed
+  return TDSA_OK;
+}
+
+// ---- device buffers another process of the node can read in place (HIP IPC; peer reads go over xGMI) ----
+int tdsa_peer_alloc(int device_id, size_t bytes, void** dev_ptr, unsigned char* handle64) {
+  if (!dev_ptr || !handle64 || bytes == 0) return fail(TDSA_ERR_ARG, "null / empty argument");
+  static_assert(sizeof(hipIpcMemHandle_t) == TDSA_PEER_HANDLE_BYTES, "handle size");
+  *dev_ptr = nullptr;
+  HIPCHK(hipSetDevice(device_id));
+  void* d = nullptr;
+  HIPCHK(hipMalloc(&d, bytes));
+  hipIpcMemHandle_t h;
+  const hipError_t e = hipIpcGetMemHandle(&h, d);
+  if (e != hipSuccess) {
+    (void)hipFree(d);
+    return fail(TDSA_ERR_HIP, "hipIpcGetMemHandle: %s", hipGetErrorString(e));
+  }
+  HIPCHK(hipMemset(d, 0, bytes));
+  std::memcpy(handle64, &h, sizeof(h));
+  *dev_ptr = d;
+  return TDSA_OK;
+}
+
+int tdsa_peer_free(int device_id, void* dev_ptr) {
+  if (!dev_ptr) return TDSA_OK;
+  HIPCHK(hipSetDevice(device_id));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipFree(dev_ptr));
+  return TDSA_OK;
+}
+
+int tdsa_peer_open(int device_id, const unsigned char* handle64, int owner_device_id, void** dev_ptr) {
+  if (!dev_ptr || !handle64) return fail(TDSA_ERR_ARG, "null argument");
+  *dev_ptr = nullptr;
+  HIPCHK(hipSetDevice(device_id));
+  if (owner_device_id >= 0 && owner_device_id != device_id) {
+    int can = 0;
+    HIPCHK(hipDeviceCanAccessPeer(&can, device_id, owner_device_id));
+    if (!can) return fail(TDSA_ERR_STATE, "device %d cannot read device %d's memory", device_id, owner_device_id);
+  }
+  hipIpcMemHandle_t h;
+  std::memcpy(&h, handle64, sizeof(h));
+  void* d = nullptr;
+  HIPCHK(hipIpcOpenMemHandle(&d, h, hipIpcMemLazyEnablePeerAccess));
+  *dev_ptr = d;
+  return TDSA_OK;
+}
+
+int tdsa_peer_close(int device_id, void* dev_ptr) {
+  if (!dev_ptr) return TDSA_OK;
+  HIPCHK(hipSetDevice(device_id));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipIpcCloseMemHandle(dev_ptr));
+  return TDSA_OK;
+}
+
+// parts_host != null: the partial means sit part_stride_bytes apart in host memory and are staged on this device first;
+// else parts_dev[r] are device pointers this device can read (its own memory or tdsa_peer_open'ed buffers of other ranks)
+static int welch_combine_impl(tdsa_plan p, const void* parts_host, size_t part_stride_bytes, const void* const* parts_dev,
+                              const int32_t* counts, int n_parts, int as_f32, float* out_db_dev, float* out_db_host) {
+  if (!p || !(parts_host || parts_dev) || !counts) return fail(TDSA_ERR_ARG, "null argument");
   if (n_parts < 1 || n_parts > kWelchMaxParts) return fail(TDSA_ERR_ARG, "n_parts=%d outside [1, %d]", n_parts, kWelchMaxParts);
   const tdsa_mode& m = p->mode;
   const size_t n = size_t(p->nfft), nb = n * (as_f32 ? sizeof(float) : sizeof(double));
-  if (part_stride_bytes < nb) return fail(TDSA_ERR_ARG, "part_stride_bytes=%zu < %zu bytes of one partial", part_stride_bytes, nb);
+  if (parts_host && part_stride_bytes < nb)
+    return fail(TDSA_ERR_ARG, "part_stride_bytes=%zu < %zu bytes of one partial", part_stride_bytes, nb);
   long long total = 0;
   int cnt[kWelchMaxParts];
   for (int r = 0; r < n_parts; ++r) {
@@ -1581,14 +1650,24 @@ int tdsa_welch_combine(tdsa_plan p, const void* parts_host, size_t part_stride_b
   if (p->chirp) return fail(TDSA_ERR_STATE, "not available for chirp-z plans");
   HIPCHK(hipSetDevice(p->device));
   JOIN(p);
-  { const int rc = welch_stage(p, nb * size_t(n_parts) + (out_db_host && !out_db_dev ? n * sizeof(float) : 0)); if (rc != TDSA_OK) return rc; }
-  // one strided copy: the parts may sit part_stride_bytes apart in the caller's (pinned, shared) slab
-  HIPCHK(hipMemcpy2DAsync(p->d_welch, nb, parts_host, part_stride_bytes, nb, size_t(n_parts), hipMemcpyHostToDevice, p->stream));
+  const size_t staged = parts_host ? nb * size_t(n_parts) : 0;
+  { const int rc = welch_stage(p, staged + (out_db_host && !out_db_dev ? n * sizeof(float) : 0)); if (rc != TDSA_OK) return rc; }
+  const void* part[kWelchMaxParts];
+  if (parts_host) {
+    // one strided copy: the parts may sit part_stride_bytes apart in the caller's (pinned, shared) slab
+    HIPCHK(hipMemcpy2DAsync(p->d_welch, nb, parts_host, part_stride_bytes, nb, size_t(n_parts), hipMemcpyHostToDevice, p->stream));
+    for (int r = 0; r < n_parts; ++r) part[r] = static_cast<const unsigned char*>(p->d_welch) + nb * size_t(r);
+  } else {
+    for (int r = 0; r < n_parts; ++r) {
+      if (cnt[r] != 0 && !parts_dev[r]) return fail(TDSA_ERR_ARG, "parts_dev[%d] is null", r);
+      part[r] = parts_dev[r];
+    }
+  }
   float* out_dev = out_db_dev ? out_db_dev
-                              : (out_db_host ? reinterpret_cast<float*>(static_cast<unsigned char*>(p->d_welch) + nb * size_t(n_parts)) : nullptr);
+                              : (out_db_host ? reinterpret_cast<float*>(static_cast<unsigned char*>(p->d_welch) + staged) : nullptr);
   const bool hmax = (m.hold_flags & TDSA_HOLD_MAX) != 0, hmin = (m.hold_flags & TDSA_HOLD_MIN) != 0;
   const float pscale = (p->big && m.db_mode == TDSA_DB_POW) ? m.power_scale : 1.0f;
-  HIPCHK(launch_welch_combine(p->d_welch, (long long)nb, cnt, n_parts, as_f32, (long long)n, p->big ? p->d_sum : nullptr,
+  HIPCHK(launch_welch_combine(part, cnt, n_parts, as_f32, (long long)n, p->big ? p->d_sum : nullptr,
                               p->big ? nullptr : p->d_avg, int(total), p->big ? 0 : 1, m.db_mode, pscale, m.log_floor,
                               m.cal_offset_db, p->tare_active ? p->d_tare_base : nullptr, out_dev,
                               hmax ? p->d_hold_max : nullptr, hmin ? p->d_hold_min : nullptr, p->held_max == 0,
@@ -1602,6 +1681,18 @@ int tdsa_welch_combine(tdsa_plan p, const void* parts_host, size_t part_stride_b
     HIPCHK(hipStreamSynchronize(p->stream));
   }
   return TDSA_OK;
+}
+
+int tdsa_welch_combine(tdsa_plan p, const void* parts_host, size_t part_stride_bytes, const int32_t* counts, int n_parts,
+                       int as_f32, float* out_db_dev, float* out_db_host) {
+  if (!parts_host) return fail(TDSA_ERR_ARG, "null argument");
+  return welch_combine_impl(p, parts_host, part_stride_bytes, nullptr, counts, n_parts, as_f32, out_db_dev, out_db_host);
+}
+
+int tdsa_welch_combine_dev(tdsa_plan p, const void* const* parts_dev, const int32_t* counts, int n_parts, int as_f32,
+                           float* out_db_dev, float* out_db_host) {
+  if (!parts_dev) return fail(TDSA_ERR_ARG, "null argument");
+  return welch_combine_impl(p, nullptr, 0, parts_dev, counts, n_parts, as_f32, out_db_dev, out_db_host);
 }
 
 int tdsa_shader_clock(tdsa_plan p, float* shader_mhz, float* ns_per_valu) {

@@ -259,7 +259,7 @@ constexpr int kWelchMaxParts = 64;
 hipError_t launch_welch_export(const double* src, double div, void* dst, int as_f32, long long n, hipStream_t s);
 // sum_r counts[r] * parts[r][i] (double, rank order) -> sum_out (or null), mean -> mean_out (or null), dB row, hold traces;
 // native_db: the dB arithmetic of the LDS-resident sizes' averager (else that of the long-frame finish)
-hipError_t launch_welch_combine(const void* parts, long long part_stride, const int* counts, int n_parts, int as_f32, long long n,
+hipError_t launch_welch_combine(const void* const* parts, const int* counts, int n_parts, int as_f32, long long n,
                                 double* sum_out, double* mean_out, int total, int native_db, int db_mode, float pscale,
                                 float log_floor, float cal_db, const float* tare, float* out_db, float* hold_max,
                                 float* hold_min, int max_first, int min_first, hipStream_t s);

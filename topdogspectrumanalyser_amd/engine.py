@@ -211,6 +211,27 @@ class SpectrumEngine:
                                              C.c_void_p(out_db_dev) if out_db_dev else None, _ptr(out)))
         return out
 
+    def welch_export_dev(self, dst_dev: int, as_f32: bool = True) -> int:
+        """The running mean into a DEVICE buffer (e.g. a slot of a sharding.WelchPeerSlab other ranks read in place);
+        returns the number of frames behind it (tdsa_welch_export_dev; synchronous)."""
+        cnt = C.c_int()
+        nat.check(nat.lib.tdsa_welch_export_dev(self._h, C.c_void_p(int(dst_dev)), int(bool(as_f32)), C.byref(cnt)))
+        return cnt.value
+
+    def welch_combine_dev(self, parts_dev, counts, as_f32: bool = True, out_db_dev: Optional[int] = None,
+                          want_host: bool = False) -> Optional[np.ndarray]:
+        """welch_combine on partial means that sit in device memory this plan's GPU can read - its own or other ranks'
+        buffers mapped with tdsa_peer_open (read over xGMI, no staging): tdsa_welch_combine_dev."""
+        cnt = np.ascontiguousarray(counts, dtype=np.int32)
+        if cnt.size != len(parts_dev):
+            raise ValueError("one count per partial mean")
+        ptrs = (C.c_void_p * len(parts_dev))(*[C.c_void_p(int(p)) if p else None for p in parts_dev])
+        out = np.empty(self.nfft, dtype=np.float32) if want_host else None
+        nat.check(nat.lib.tdsa_welch_combine_dev(self._h, ptrs, cnt.ctypes.data_as(C.POINTER(C.c_int32)), int(cnt.size),
+                                                 int(bool(as_f32)), C.c_void_p(out_db_dev) if out_db_dev else None,
+                                                 _ptr(out)))
+        return out
+
     def shader_clock(self) -> Tuple[float, float]:
         """(shader MHz, ns per VALU wave-instruction per SIMD) from a millisecond of saturated v_add_f32 (tdsa_shader_clock)."""
         mhz, ns = C.c_float(), C.c_float()

@@ -131,6 +131,133 @@ class WelchSlab:
             self.owner = False
 
 
+class WelchPeerSlab:
+    """The same exchange with the partial means left in DEVICE memory (ranks on GPUs of one node): every rank keeps
+    `slots` partials of n values in a buffer of its own GPU that other processes can map (tdsa_peer_alloc: HIP IPC),
+    the 64-byte handles and the progress counters travel through a small shared-memory file, rank 0 maps every other
+    rank's buffer on its device (tdsa_peer_open: refused without peer access) and its combine kernel reads them in
+    place - over xGMI, each rank's over its own link - instead of W uploads through rank 0's one PCIe link.  No
+    collective, no RCCL.  `ok` is False on every rank when any rank could not allocate or rank 0 could not map a
+    buffer: the caller then falls back to WelchSlab (host memory).
+
+    Header of the file, one 64-byte line each: ready[rank] ..., done, verdict, then per rank: status (int64), device
+    (int64), handle (64 bytes)."""
+
+    def __init__(self, name: Optional[str], world: int, rank: int, n: int, device: int, dtype=np.float32,
+                 slots: int = 2, timeout_s: float = 60.0):
+        import os
+        import tempfile
+        import uuid
+        from . import _native as nat
+        self._nat = nat
+        self.world, self.rank, self.n, self.slots, self.device = int(world), int(rank), int(n), int(slots), int(device)
+        self.dtype = np.dtype(dtype)
+        self._ctr_lines = self.world + 2
+        size = 64 * self._ctr_lines + 128 * self.world
+        self.owner = name is None
+        if self.owner:
+            base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+            name = os.path.join(base, f"tdsa_welch_peer_{os.getpid()}_{uuid.uuid4().hex[:8]}")
+            with open(name, "wb") as fh:
+                fh.truncate(size)
+        self.name = name
+        self._map = np.memmap(name, dtype=np.uint8, mode="r+", shape=(size,))
+        self._ctr = self._map[: 64 * self._ctr_lines].view(np.int64)
+        self._info = self._map[64 * self._ctr_lines:].reshape(self.world, 128)
+        self._mine = None                      # this rank's device buffer [slots][n]
+        self._peers = [None] * self.world      # rank 0: every rank's buffer as mapped on ITS device
+        self.ok = False
+        self._timeout = float(timeout_s)
+
+    # -- set-up: two phases with the caller's barrier between them ------------------------------------------------
+    def allocate(self) -> None:
+        """phase 1, every rank: its buffer and the handle into the file"""
+        import ctypes as C
+        nat = self._nat
+        ptr, handle = C.c_void_p(), (C.c_ubyte * 64)()
+        line = self._info[self.rank]
+        try:
+            nat.check(nat.lib.tdsa_peer_alloc(self.device, self.slots * self.n * self.dtype.itemsize, C.byref(ptr), handle))
+            self._mine = int(ptr.value)
+            line[16:80] = np.frombuffer(bytes(handle), dtype=np.uint8)
+            line[8:16].view(np.int64)[0] = self.device
+            line[0:8].view(np.int64)[0] = 1
+        except Exception:
+            line[0:8].view(np.int64)[0] = -1
+
+    def connect(self) -> None:
+        """phase 2 (after a barrier), rank 0: map every other rank's buffer; the verdict for everybody"""
+        import ctypes as C
+        nat = self._nat
+        verdict = self._ctr[8 * (self.world + 1): 8 * (self.world + 1) + 1]
+        if self.rank == 0:
+            good = all(int(self._info[r][0:8].view(np.int64)[0]) == 1 for r in range(self.world))
+            if good:
+                self._peers[0] = self._mine
+                for r in range(1, self.world):
+                    line = self._info[r]
+                    handle = (C.c_ubyte * 64).from_buffer_copy(bytes(line[16:80]))
+                    ptr = C.c_void_p()
+                    owner = int(line[8:16].view(np.int64)[0])
+                    try:
+                        nat.check(nat.lib.tdsa_peer_open(self.device, handle, owner, C.byref(ptr)))
+                        self._peers[r] = int(ptr.value)
+                    except Exception:
+                        good = False
+                        break
+            verdict[0] = 1 if good else -1
+        t0 = time.perf_counter()
+        while int(verdict[0]) == 0:
+            if time.perf_counter() - t0 > self._timeout:
+                raise TimeoutError("rank 0 did not report on the peer buffers")
+        self.ok = int(verdict[0]) == 1
+
+    # -- per step ---------------------------------------------------------------------------------------------------
+    def part_ptr(self, step: int) -> int:
+        """device pointer of this rank's partial of `step` (1-based); waits until the slot's previous use is combined"""
+        while int(self._ctr[8 * self.world]) < step - self.slots:
+            pass
+        return self._mine + (step % self.slots) * self.n * self.dtype.itemsize
+
+    def publish(self, step: int) -> None:
+        self._ctr[8 * self.rank] = step
+
+    def wait_all(self, step: int):
+        """rank 0: every rank's partial of `step` as device pointers on rank 0's GPU"""
+        t0 = time.perf_counter()
+        for r in range(self.world):
+            while int(self._ctr[8 * r]) < step:
+                if time.perf_counter() - t0 > self._timeout:
+                    raise TimeoutError(f"rank {r} did not deliver its Welch partial of step {step}")
+        off = (step % self.slots) * self.n * self.dtype.itemsize
+        return [p + off for p in self._peers]
+
+    def done(self, step: int) -> None:
+        self._ctr[8 * self.world] = step
+
+    def reset(self) -> None:
+        if self.rank == 0:
+            self._ctr[: 8 * (self.world + 1)] = 0
+
+    def close(self) -> None:
+        import os
+        nat = self._nat
+        for r in range(1, self.world):
+            if self._peers[r]:
+                nat.lib.tdsa_peer_close(self.device, self._peers[r])
+        self._peers = [None] * self.world
+        if self._mine:
+            nat.lib.tdsa_peer_free(self.device, self._mine)
+            self._mine = None
+        self._ctr = self._info = self._map = None
+        if self.owner:
+            try:
+                os.unlink(self.name)
+            except OSError:
+                pass
+            self.owner = False
+
+
 def process_sharded(iq: np.ndarray, nfft: int, hop: int, devices: Sequence[int], window: np.ndarray,
                     hold: str = "", **configure):
     """One capture over several GPUs from ONE process: a thread and a SpectrumEngine per entry of `devices`
