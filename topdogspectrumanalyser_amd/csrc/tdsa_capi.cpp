@@ -1615,6 +1615,13 @@ int tdsa_peer_open(int device_id, const unsigned char* handle64, int owner_devic
   std::memcpy(&h, handle64, sizeof(h));
   void* d = nullptr;
   HIPCHK(hipIpcOpenMemHandle(&d, h, hipIpcMemLazyEnablePeerAccess));
+  // probe: a mapping this device cannot read must show up here as an error code, not later as a fault inside a kernel
+  unsigned probe = 0;
+  const hipError_t e = hipMemcpy(&probe, d, sizeof(probe), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) {
+    (void)hipIpcCloseMemHandle(d);
+    return fail(TDSA_ERR_HIP, "mapped peer buffer is not readable: %s", hipGetErrorString(e));
+  }
   *dev_ptr = d;
   return TDSA_OK;
 }
