@@ -116,7 +116,8 @@ struct tdsa_plan_s {
   int avg_wg_min = 128;                  // batches of more frames than this take the workgroup-chunk scan (tdsa_debug_knob "avg_wg_min")
   bool avg_f64_chunks = false;           // tdsa_debug_knob "avg_f64_chunks": always the scan over fixed 64-frame chunks with float64 aggregates
   int chirp_fuse_big = 1;                // tdsa_debug_knob "chirp_fuse_big": 0 = long chirp-z frames run chirp_pre / chirp_post as their own passes
-  int chirp_single = 1;                  // tdsa_debug_knob "chirp_single": 0 = the fusable chirp-z plans run their two transforms as two launches
+  int chirp_single = 1;                  // tdsa_debug_knob "chirp_single": 0 = chirp-z plans run chirp_pre / two transforms / chirp_post as separate
+                                         // kernels (M <= 16384; developer builds: two launches that carry the passes), separate row passes (M > 16384)
   int big_pre_wgs = 0;                   // tdsa_debug_knob "big_pre_wgs": empty workgroups launched ahead of every column pass
   int big_group = 64;                    // segments per column-pass / row-pass round (one round for the K = 64 Welch capture)
   // frame lengths that are not a power of two (tdsa_chirp.hip): chirp-z on the m_fft-point frame kernel
@@ -358,7 +359,15 @@ int process_big(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n_f
 // the transforms can carry the element-wise passes: M <= 16384 and frames made of whole waves (the fused instantiations
 // address their rows through wave-uniform descriptors)
 // (M > 16384: the column passes of tdsa_big.hip carry them instead, BigChirpPre / BigChirpPost)
-static bool chirp_fusable(tdsa_plan p) { return p->chirp && p->log2m >= 10 && (!p->chirp_big || p->chirp_fuse_big); }
+#ifdef TDSA_DEV
+constexpr bool kChirpTwoLaunches = true;    // spectrum_kernel<L, true, 0, 1 | 2>: each transform carries one element-wise pass
+#else
+constexpr bool kChirpTwoLaunches = false;   // shipped: one launch, or (tdsa_debug_knob chirp_single 0) the passes as kernels of their own
+#endif
+static bool chirp_fusable(tdsa_plan p) {
+  if (!p->chirp || p->log2m < 10) return false;
+  return p->chirp_big ? p->chirp_fuse_big != 0 : (p->chirp_single != 0 || kChirpTwoLaunches);
+}
 
 // post (fusable plans only): what the second transform's stores turn the bins into - the dB / power rows and hold traces
 // of tdsa_chirp.hip's step 4 - instead of leaving complex rows in d_u0 for chirp_post_kernel; null: complex rows
@@ -1991,7 +2000,7 @@ int tdsa_debug_knob(tdsa_plan p, const char* name, int value) {
     p->big_group = value;
   } else if (k == "chirp_fuse_big") {        // long chirp-z frames: 1 = element-wise passes inside the column passes (default)
     p->chirp_fuse_big = value != 0;
-  } else if (k == "chirp_single") {          // fusable chirp-z plans: 1 = one launch per call (default), 0 = two transforms, two launches
+  } else if (k == "chirp_single") {          // chirp-z plans: 1 = one launch per call (default), 0 = the separate passes
     p->chirp_single = value != 0;
   } else if (k == "big_pre_wgs") {           // long-frame plans: empty workgroups ahead of every column pass (XCD phase)
     if (value < 0 || value > 64) return fail(TDSA_ERR_ARG, "big_pre_wgs=%d outside [0, 64]", value);

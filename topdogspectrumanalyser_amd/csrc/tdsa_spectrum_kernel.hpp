@@ -979,9 +979,12 @@ hipError_t launch_n(int in_c64, const SpecParams& p, const LaunchGeom& g, hipStr
       if (in_c64 && p.rows_twice != 0) return launch_one<LOG2N, true, 0, 4>(p, g, s);
     }
     if (in_c64 && p.pre_raw != nullptr && p.post_n != 0) return launch_one<LOG2N, true, 0, 3>(p, g, s);
+#ifdef TDSA_DEV   // the two transforms as two launches, each carrying one element-wise pass: developer builds only (A/B)
     if (in_c64 && p.pre_raw != nullptr) return launch_one<LOG2N, true, 0, 1>(p, g, s);
     if (in_c64 && p.post_n != 0) return launch_one<LOG2N, true, 0, 2>(p, g, s);
+#endif
   }
+  if (p.pre_raw != nullptr || p.post_n != 0 || p.rows_twice != 0) return hipErrorInvalidValue;   // no such instantiation
   if (in_c64) {
     switch (hold) {
       case 0: return launch_one<LOG2N, true, 0>(p, g, s);
