@@ -373,9 +373,11 @@ int tdsa_profile_read(tdsa_plan p, int* launches, float* total_ms);
  * batches (the library reads nothing from the environment): "num_cu" (persistent grids sized for fewer CUs),
  * "avg_wg_min" (batches of more frames take the workgroup-chunk averager scan), "avg_f64_chunks" (1: always the scan
  * over fixed 64-frame chunks with float64 aggregates), "overlap_share" (percent of the CUs an overlapped launch is
- * sized for), "big_group" (long-frame plans: segments per column / row round, 1 .. 64), "big_pre_wgs" (empty workgroups
- * ahead of every column pass), "chirp_single" (chirp-z plans: 0 = the passes of the convolution as separate kernels instead of one launch), "chirp_fuse_big" (chirp-z plans with
- * M > 16384: 0 = the unpack / window / chirp and the power / dB passes as kernels of their own). */
+ * sized for), "big_group" (long-frame plans: segments per column / row round, 1 .. 64), "chirp_single" (chirp-z plans:
+ * 0 = the passes of the convolution as separate kernels instead of one launch), "chirp_fuse_big" (chirp-z plans with
+ * M > 16384: 0 = the unpack / window / chirp and the power / dB passes as kernels of their own); a library built with
+ * -DTDSA_DEV also knows "big_pre_wgs" (empty workgroups ahead of every column pass: tools/c5_xcd_phase.py).
+ * Unknown names are an error. */
 int tdsa_debug_knob(tdsa_plan p, const char* name, int value);
 /* Phase timeline of workgroup 0 of the frame kernel: allocates the plan's stamp buffer on first call;
  * host_out_2048 != NULL copies 2048 s_memtime stamps back.  Stamps are only written by a library built

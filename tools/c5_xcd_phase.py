@@ -4,6 +4,8 @@ process" (116 or 122 us per 64 segments, the row pass trading the other way).  I
 dispatcher hands workgroups to the eight XCDs round robin and every launch of the chain has a multiple of eight of them,
 so the phase a process starts with stays.  Here k = 0 .. 8 empty workgroups are launched ahead of every column pass
 (tdsa_debug_knob big_pre_wgs) inside ONE process, alternating; the row-pass time comes from the plan's profiling events.
+Needs a developer build of the library (tools/build_variants.sh dev "-DTDSA_DEV", TDSA_HIP_LIB=...): the shipped one has no
+such knob.
 python tools/c5_xcd_phase.py [--steps 120] [--rounds 3]"""
 import argparse
 import ctypes as C

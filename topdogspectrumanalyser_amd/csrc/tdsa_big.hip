@@ -656,6 +656,7 @@ hipError_t launch_welch_combine(const void* const* parts, const int* counts, int
   return hipGetLastError();
 }
 
+#ifdef TDSA_DEV
 // developer hook (tdsa_debug_knob "big_pre_wgs"): k empty workgroups ahead of the column pass - the dispatcher hands
 // workgroups to the eight XCDs round robin, so this moves the XCD every workgroup of the following launches lands on
 __global__ void __launch_bounds__(64) xcd_shift_kernel() {}
@@ -663,6 +664,7 @@ hipError_t launch_xcd_shift(int wgs, hipStream_t s) {
   hipLaunchKernelGGL(xcd_shift_kernel, dim3(unsigned(wgs)), dim3(64), 0, s);
   return hipGetLastError();
 }
+#endif
 
 // ---- shader clock: independent v_add_f32 chains, four waves per SIMD on every CU - the SIMD's saturated VALU rate -----
 __global__ void __launch_bounds__(256) valu_clock_kernel(float* out, int iters, float seed) {

@@ -118,7 +118,7 @@ struct tdsa_plan_s {
   int chirp_fuse_big = 1;                // tdsa_debug_knob "chirp_fuse_big": 0 = long chirp-z frames run chirp_pre / chirp_post as their own passes
   int chirp_single = 1;                  // tdsa_debug_knob "chirp_single": 0 = chirp-z plans run chirp_pre / two transforms / chirp_post as separate
                                          // kernels (M <= 16384; developer builds: two launches that carry the passes), separate row passes (M > 16384)
-  int big_pre_wgs = 0;                   // tdsa_debug_knob "big_pre_wgs": empty workgroups launched ahead of every column pass
+  int big_pre_wgs = 0;                   // developer builds, tdsa_debug_knob "big_pre_wgs": empty workgroups launched ahead of every column pass
   int big_group = 64;                    // segments per column-pass / row-pass round (one round for the K = 64 Welch capture)
   // frame lengths that are not a power of two (tdsa_chirp.hip): chirp-z on the m_fft-point frame kernel
   bool chirp = false;
@@ -303,7 +303,9 @@ int process_big(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n_f
     const int ns = n_frames - s0 < group ? n_frames - s0 : group;
     const int act = ns < split_max ? ns : split_max;
     if (s0 == 0) split_layout = act;
+#ifdef TDSA_DEV
     if (p->big_pre_wgs > 0) HIPCHK(launch_xcd_shift(p->big_pre_wgs, p->stream));
+#endif
     HIPCHK(launch_big_cols(p->log2n, static_cast<const unsigned char*>(iq_dev) + (long long)s0 * stride, in_c64, stride, ns,
                            p->big_win[in_format], p->d_tw_seed, dc_sub ? dc_sub + s0 : nullptr, p->d_z,
                            xor_mask, in_off, p->stream));
@@ -2002,9 +2004,11 @@ int tdsa_debug_knob(tdsa_plan p, const char* name, int value) {
     p->chirp_fuse_big = value != 0;
   } else if (k == "chirp_single") {          // chirp-z plans: 1 = one launch per call (default), 0 = the separate passes
     p->chirp_single = value != 0;
+#ifdef TDSA_DEV
   } else if (k == "big_pre_wgs") {           // long-frame plans: empty workgroups ahead of every column pass (XCD phase)
     if (value < 0 || value > 64) return fail(TDSA_ERR_ARG, "big_pre_wgs=%d outside [0, 64]", value);
     p->big_pre_wgs = value;
+#endif
   } else {
     return fail(TDSA_ERR_ARG, "unknown knob '%s'", name);
   }

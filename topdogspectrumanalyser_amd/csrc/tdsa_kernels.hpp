@@ -263,7 +263,9 @@ hipError_t launch_welch_combine(const void* const* parts, const int* counts, int
                                 double* sum_out, double* mean_out, int total, int native_db, int db_mode, float pscale,
                                 float log_floor, float cal_db, const float* tare, float* out_db, float* hold_max,
                                 float* hold_min, int max_first, int min_first, hipStream_t s);
+#ifdef TDSA_DEV
 hipError_t launch_xcd_shift(int wgs, hipStream_t s);
+#endif
 // n_cu * 4 workgroups of 256 threads, each wave 64 * iters independent v_add_f32 (8 chains): the SIMDs' saturated VALU rate
 hipError_t launch_valu_clock(float* scratch, int n_cu, int iters, hipStream_t s);
 
