@@ -542,9 +542,11 @@ int process_chirp(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n
     // frame means as residuals (exact sums); 0 <= alpha < 1: the tracker of the native path fed with them
     // directly (n = 1, zero level 0)
     const bool tracked = m.dc_alpha < 1.0f;
+    if (chirp_sum_chunks(N) > 1 && !p->d_sums64)      // long frames: several workgroups per frame leave partial sums here
+      HIPCHK(hipMalloc(&p->d_sums64, size_t(p->max_frames) * chirp_sum_chunks(N) * 2 * sizeof(double)));
     HIPCHK(launch_chirp_sums(iq_dev, in_c64, xor_mask, stride, N, n_frames,
                              in_format == TDSA_IN_I8 ? 256 : (in_c64 ? 0 : 255), p->d_sums,
-                             tracked ? nullptr : p->d_dc_state, in_scale, s));
+                             tracked ? nullptr : p->d_dc_state, in_scale, s, p->d_sums64));
     dc_sub = p->d_sums;                   // dc_alpha >= 1: the frame's own mean
     if (tracked) {
       HIPCHK(launch_dc_track(p->d_sums, 1, n_frames, m.dc_alpha, 0.0f, in_scale, p->d_dc_state, p->d_dc_sub, s));
@@ -1446,7 +1448,9 @@ int tdsa_process_real2(tdsa_plan p, const float* lr_host, size_t n_samples, int 
       // the one-sided power straight from the full spectrum
       const float2* zin = sig == 0 ? za : zb;
       const long long stride = (long long)hop * sizeof(float2);
-      HIPCHK(launch_chirp_sums(zin, 1, 0u, stride, n, n_frames, 0, p->d_sums, nullptr, 1.0f, p->stream));
+      if (chirp_sum_chunks(n) > 1 && !p->d_sums64)
+        HIPCHK(hipMalloc(&p->d_sums64, size_t(p->max_frames) * chirp_sum_chunks(n) * 2 * sizeof(double)));
+      HIPCHK(launch_chirp_sums(zin, 1, 0u, stride, n, n_frames, 0, p->d_sums, nullptr, 1.0f, p->stream, p->d_sums64));
       { const int rc = chirp_transform(p, zin, TDSA_IN_C64, stride, n_frames, p->d_sums, 0u, 0.0f); if (rc != TDSA_OK) return rc; }
       HIPCHK(launch_chirp_post_real(p->d_u0, n, p->m_fft, n_frames, n_sig, sig, m.power_scale, p->d_lin1, p->stream));
       continue;

@@ -53,12 +53,20 @@ __device__ __forceinline__ void chirp_atomic_fmin(float* addr, float v) {
 // res[f] = mean of the frame's raw samples MINUS the format's zero level (128 / 127.5 / 0), raw units.  Byte
 // formats: integer sums (exact), the small numerator sum - zero * n formed in integers, one division in double -
 // a float32 "sum / n - 128" would cancel to ~1e-5 LSB, visible in the DC bin.
+// Long frames (part != null): gridDim.y workgroups per frame, kChirpSumChunk samples each, leave their partial sums in
+// part[f][chunk][2] and chirp_sums_finish_kernel adds them in chunk order (one workgroup per frame read a 10^6-point frame at
+// 48 GB/s: 420 of the 780 us of a ten-frame call).
+constexpr int kChirpSumChunk = 32768;
 template <bool IN_C64>
-__global__ void __launch_bounds__(256) chirp_sums_kernel(const void* in, unsigned xor_mask, long long frame_stride, int n,
-                                                         int twice_zero, float2* res, float2* dc_state, float in_scale) {
+__global__ void __launch_bounds__(256) chirp_sums_kernel(const void* in, unsigned xor_mask, long long frame_stride, int n_all,
+                                                         int twice_zero, float2* res, float2* dc_state, float in_scale,
+                                                         double* part) {
   __shared__ double red[8];
   const int f = blockIdx.x;
-  const unsigned char* fb = static_cast<const unsigned char*>(in) + (long long)f * frame_stride;
+  const int i0 = part != nullptr ? int(blockIdx.y) * kChirpSumChunk : 0;
+  const int n = part != nullptr ? (n_all - i0 < kChirpSumChunk ? n_all - i0 : kChirpSumChunk) : n_all;   // this workgroup's samples
+  const unsigned char* fb = static_cast<const unsigned char*>(in) + (long long)f * frame_stride +
+                            (long long)i0 * (IN_C64 ? 8 : 2);
   double sr = 0.0, si = 0.0;
   if constexpr (IN_C64) {
     const float2* x = reinterpret_cast<const float2*>(fb);
@@ -92,6 +100,12 @@ __global__ void __launch_bounds__(256) chirp_sums_kernel(const void* in, unsigne
   __syncthreads();
   if (threadIdx.x == 0) {
     const double tr = red[0] + red[2] + red[4] + red[6], ti = red[1] + red[3] + red[5] + red[7];
+    if (part != nullptr) {
+      double* o = part + ((long long)f * gridDim.y + blockIdx.y) * 2;
+      o[0] = tr;
+      o[1] = ti;
+      return;
+    }
     // (2 sum - twice_zero n) / (2 n): integer-valued numerator for the byte formats
     const double dn = double(n), tz = double(twice_zero);
     const float2 r = float2{float((2.0 * tr - tz * dn) / (2.0 * dn)), float((2.0 * ti - tz * dn) / (2.0 * dn))};
@@ -101,14 +115,49 @@ __global__ void __launch_bounds__(256) chirp_sums_kernel(const void* in, unsigne
   }
 }
 
+// one wave per frame: the partial sums are fetched side by side, thread 0 adds them in chunk order (reproducible; exact for
+// the byte formats: integers)
+__global__ void __launch_bounds__(64) chirp_sums_finish_kernel(const double* part, int chunks, int n, int n_frames,
+                                                               int twice_zero, float2* res, float2* dc_state, float in_scale) {
+  __shared__ double pr[64], pi[64];
+  const int f = blockIdx.x;
+  double tr = 0.0, ti = 0.0;
+  for (int c0 = 0; c0 < chunks; c0 += 64) {
+    const int c = c0 + int(threadIdx.x);
+    if (c < chunks) {
+      pr[threadIdx.x] = part[((long long)f * chunks + c) * 2];
+      pi[threadIdx.x] = part[((long long)f * chunks + c) * 2 + 1];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int nc = chunks - c0 < 64 ? chunks - c0 : 64;
+      for (int u = 0; u < nc; ++u) { tr += pr[u]; ti += pi[u]; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  const double dn = double(n), tz = double(twice_zero);
+  const float2 r = float2{float((2.0 * tr - tz * dn) / (2.0 * dn)), float((2.0 * ti - tz * dn) / (2.0 * dn))};
+  res[f] = r;
+  if (dc_state != nullptr && f == n_frames - 1) *dc_state = float2{r.x * in_scale, r.y * in_scale};
+}
+
+int chirp_sum_chunks(int n) { return n > 2 * kChirpSumChunk ? (n + kChirpSumChunk - 1) / kChirpSumChunk : 1; }
+
 hipError_t launch_chirp_sums(const void* in, int in_c64, unsigned xor_mask, long long frame_stride, int n, int n_frames,
-                             int twice_zero, float2* res, float2* dc_state, float in_scale, hipStream_t s) {
+                             int twice_zero, float2* res, float2* dc_state, float in_scale, hipStream_t s, double* part) {
+  const int chunks = part != nullptr ? chirp_sum_chunks(n) : 1;
+  double* const pp = chunks > 1 ? part : nullptr;
+  const dim3 grid(n_frames, chunks);
   if (in_c64)
-    hipLaunchKernelGGL(chirp_sums_kernel<true>, dim3(n_frames), dim3(256), 0, s, in, xor_mask, frame_stride, n, twice_zero,
-                       res, dc_state, in_scale);
+    hipLaunchKernelGGL(chirp_sums_kernel<true>, grid, dim3(256), 0, s, in, xor_mask, frame_stride, n, twice_zero,
+                       res, dc_state, in_scale, pp);
   else
-    hipLaunchKernelGGL(chirp_sums_kernel<false>, dim3(n_frames), dim3(256), 0, s, in, xor_mask, frame_stride, n, twice_zero,
-                       res, dc_state, in_scale);
+    hipLaunchKernelGGL(chirp_sums_kernel<false>, grid, dim3(256), 0, s, in, xor_mask, frame_stride, n, twice_zero,
+                       res, dc_state, in_scale, pp);
+  if (pp != nullptr)
+    hipLaunchKernelGGL(chirp_sums_finish_kernel, dim3(n_frames), dim3(64), 0, s, pp, chunks, n, n_frames,
+                       twice_zero, res, dc_state, in_scale);
   return hipGetLastError();
 }
 

@@ -274,8 +274,11 @@ constexpr int kChirpMaxN = (1 << 20) - 1; // M = 2^ceil(log2(2N-1)) <= 2^20 up t
                                          // frames as four half-length sub-convolutions of 2^20 points (tdsa_chirp.hip)
 // res[f] = frame mean minus the format's zero level, raw units (twice_zero: 256 int8 after the xor, 255 uint8, 0 c64)
 // dc_state (or null): receives the last frame's mean in units of x - the per-frame mean mode needs no tracker pass
+// part: scratch of n_frames * chirp_sum_chunks(n) * 2 doubles (frames long enough to be summed by several workgroups) or null
+int chirp_sum_chunks(int n);
 hipError_t launch_chirp_sums(const void* in, int in_c64, unsigned xor_mask, long long frame_stride, int n, int n_frames,
-                             int twice_zero, float2* res, float2* dc_state, float in_scale, hipStream_t s);
+                             int twice_zero, float2* res, float2* dc_state, float in_scale, hipStream_t s,
+                             double* part = nullptr);
 hipError_t launch_chirp_pre(const void* in, int in_c64, long long frame_stride, int n, int m, int n_frames,
                             const float* window, const float2* chirp, const float2* dc_sub, unsigned xor_mask,
                             float in_off, float2* u, hipStream_t s, int split_h = 0);
