@@ -71,3 +71,18 @@ def test_missing_library_is_an_import_error(tmp_path, monkeypatch):
         for k in [k for k in sys.modules if k.startswith("topdogspectrumanalyser_amd")]:
             sys.modules.pop(k)
         sys.modules.update(saved)
+
+
+def test_peer_buffer_entry_points_refuse_bad_arguments_without_touching_a_device():
+    """tdsa_peer_* / tdsa_welch_*_dev (the cross-GPU Welch exchange through device buffers): null pointers and empty sizes
+    are argument errors, reported before any HIP call - no GPU needed to see that."""
+    import ctypes as C
+    from topdogspectrumanalyser_amd import _native as nat
+    ptr, handle = C.c_void_p(), (C.c_ubyte * 64)()
+    assert nat.lib.tdsa_peer_alloc(0, 0, C.byref(ptr), handle) == -1
+    assert nat.lib.tdsa_peer_alloc(0, 4096, None, handle) == -1
+    assert nat.lib.tdsa_peer_open(0, None, -1, C.byref(ptr)) == -1
+    assert nat.lib.tdsa_peer_free(0, None) == 0 and nat.lib.tdsa_peer_close(0, None) == 0      # nothing to release
+    assert nat.lib.tdsa_welch_export_dev(None, None, 1, None) == -1
+    assert nat.lib.tdsa_welch_combine_dev(None, None, None, 1, 1, None, None) == -1
+    assert b"null" in nat.lib.tdsa_last_error_string()
