@@ -621,7 +621,18 @@ __global__ void __launch_bounds__(256) welch_combine_kernel(const WelchParts w, 
   double acc = 0.0;
   for (int r = 0; r < w.n_parts; ++r) {
     if (w.count[r] == 0) continue;
-    acc += double(static_cast<const T*>(w.part[r])[i]) * double(w.count[r]);
+    // system-scope loads: a part may live in another GPU's memory, rewritten by that GPU's process between two launches of
+    // this kernel - nothing this device cached of it earlier may be served again
+    T m;
+    if constexpr (sizeof(T) == 4) {
+      const unsigned u = __hip_atomic_load(static_cast<const unsigned*>(w.part[r]) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      m = __uint_as_float(u);
+    } else {
+      const unsigned long long u = __hip_atomic_load(static_cast<const unsigned long long*>(w.part[r]) + i, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_SYSTEM);
+      m = __longlong_as_double((long long)u);
+    }
+    acc += double(m) * double(w.count[r]);
   }
   if (sum_out != nullptr) sum_out[i] = acc;
   if (!native_db) {
