@@ -25,7 +25,7 @@ CMD = {"c3": "tools/devbench.py --steps 9 --warmup 2 --hold 1", "c3b": "tools/de
 
 
 def main():
-    for c in ("c2", "c3", "c4", "c5", "c5_2ranks", "c5_2ranks_captures", "c3_2ranks", "c4_2ranks"):
+    for c in ("c2", "c3", "c4", "c5", "c5_2ranks", "c5_2ranks_peer", "c5_2ranks_captures", "c3_2ranks", "c4_2ranks"):
         src = os.path.join(SRC, f"bench_{c}.json")
         if os.path.exists(src) and os.path.getsize(src) > 10:
             shutil.copy(src, os.path.join(DST, f"{TAG}_{c}_bench.json"))
@@ -113,8 +113,87 @@ def main():
                 out += ["-> sharding the segments of ONE capture never wins end to end over host memory: the partial means (4 MiB per rank and",
                         "   capture) cost more to move than the capture costs to compute.  --c5-shard captures (every rank whole captures,",
                         "   nothing to combine) scales like C3: W x 1 GPU's rate."]
+            peer = os.path.join(SRC, "bench_c5_2ranks_peer.json")
+            if comb and os.path.exists(peer) and os.path.getsize(peer) > 10:
+                pj = json.load(open(peer))
+                pw = pj["welch"]
+                out += ["", "## peer exchange (bench.py --c5-combine auto | peer; sharding.WelchPeerSlab, tdsa_peer_*, tdsa_welch_export_dev / _combine_dev)",
+                        "The partial means stay in device buffers of the ranks' own GPUs; rank 0 maps them through HIP IPC handles and its combine kernel",
+                        "reads them in place (other GPUs': over xGMI, each over its own link).  Two ranks on this one GPU, same box as the host-exchange",
+                        f"line above (profiles/{TAG}_c5_2ranks_peer_bench.json):",
+                        f"  peer: combine {pw['combine_ms']:.3f} ms per step (rank 0: wait {pw['rank0_wait_for_partials_ms']:.3f}, combine kernel "
+                        f"{pw['rank0_upload_combine_ms']:.3f}), end to end {pj['ms_per_step']:.3f} ms per capture = {pj['value'] / 1e3:.0f} k segments/s, "
+                        f"parity.pass {pj['parity'].get('pass')}",
+                        f"  host: combine {comb['combine_ms']:.3f} ms per step (rank 0: wait {comb['rank0_wait_for_partials_ms']:.3f}, upload + kernel "
+                        f"{comb['rank0_upload_combine_ms']:.3f})",
+                        f"  compute only: {pw['ms_per_step_compute_only']:.3f} ms per capture",
+                        "Model per step at W ranks with the peer exchange: compute(64 / W) + the measured export + combine of the same-GPU case, with the",
+                        "xGMI reads ASSUMED to add 10-15 us ((W - 1) x 4 MiB over W - 1 links at once; the links' 153 GB/s peak would allow 27 us in all;",
+                        "not measured - one GPU per box here):",
+                        "W GPUs | end to end per capture (model) | speed-up end to end"]
+                ex = pw["combine_ms"] * 1e3 + 12.0
+                for w in (2, 4, 8):
+                    k = 64 // w
+                    if k in best:
+                        t = best[k] + ex
+                        out.append(f"{w:6d} | {t:27.0f} us | {best[64] / t:18.2f}x")
+                for n in (3, 4, 8):
+                    f = os.path.join(SRC, f"bench_c5_{n}ranks_peer.json")
+                    if os.path.exists(f) and os.path.getsize(f) > 10:
+                        j = json.load(open(f))
+                        out.append(f"plumbing, {n} ranks sharing this GPU: segments {j['welch']['segments_per_rank']}, exchange {j['welch']['exchange']}, "
+                                   f"parity.pass {j['parity'].get('pass')} (max dB error {j['parity'].get('max_db_err_top100dB'):.2e}), combine "
+                                   f"{j['welch']['combine_ms']:.3f} ms per step (processes time-slicing one GPU: not a scaling figure)")
         open(os.path.join(DST, f"{TAG}_c5_strong_scaling.txt"), "w").write("\n".join(out) + "\n")
-        print("\n".join(out[-22:]))
+        print("\n".join(out[-30:]))
+    chirp_stats()
+
+
+def chirp_stats():
+    """profiles/<TAG>_chirp_kernel_stats.txt: per-kernel time per call and HBM traffic of three chirp-z plans"""
+    import collections
+    cfg = {"n1000": "N = 1000, 4096 frames per call (M = 2048: one launch per call)",
+           "n20000": "N = 20 000, 512 frames per call (M = 65536: columns, rows of both transforms in one kernel, columns out)",
+           "n1000000": "N = 1 000 000, 10 frames per call (split plan: four half-length sub-convolutions of 2^20 points)"}
+    out = ["# rocprofv3 --kernel-trace --stats around tools/devbench.py (tools/prof_round5.sh), per-kernel average duration per call;",
+           "# one devbench step = one tdsa_process_dev call with --hold 1 (max-hold trace folded)"]
+    for n in cfg:
+        f = pc3.newest(f"stats_chirp_{n}/**/*kernel_stats.csv")
+        if not f:
+            continue
+        out.append(f"\n## {cfg[n]}")
+        rows = [r for r in csv.DictReader(open(f)) if "tdsa" in r["Name"] and "fill_kernel" not in r["Name"]]
+        steps = min(int(r["Calls"]) for r in rows)
+        tot = 0.0
+        for r in rows:
+            per = float(r["TotalDurationNs"]) / steps / 1e3
+            tot += per
+            out.append(f"  {r['Name'].split('(')[0][:62]:62s} {int(r['Calls']) // steps} x {float(r['AverageNs']) / 1e3:7.1f} us = {per:7.1f} us per call")
+        out.append(f"  sum of kernels {tot:7.1f} us per call")
+    out.append("\n## HBM traffic per call (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; KB units; FETCH_SIZE counts 64 B per 128-B "
+               "request for wide reads: the upper bound doubles it)")
+    for n, algo in (("n1000", 4096 * 6 * 1000), ("n20000", 512 * 6 * 20000)):
+        tot = {}
+        for kind, ctr in (("rd", "FETCH_SIZE"), ("wr", "WRITE_SIZE")):
+            f = pc3.newest(f"pmc_chirp_{n}_{kind}/**/*counter_collection.csv")
+            if not f:
+                continue
+            per = collections.defaultdict(list)
+            for r in csv.DictReader(open(f)):
+                if r.get("Counter_Name") == ctr:
+                    per[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+            s = 0.0
+            for k, v in per.items():
+                if "fill" in k or "rocclr" in k:
+                    continue
+                v = sorted(v)
+                s += v[len(v) // 2]
+            tot[kind] = s * 1024
+        if len(tot) == 2:
+            out.append(f"  {n}: FETCH_SIZE {tot['rd'] / 1e6:7.1f} MB raw (<= {2 * tot['rd'] / 1e6:7.1f})  WRITE_SIZE {tot['wr'] / 1e6:7.1f} MB   "
+                       f"algorithmic (2 N in + 4 N out per frame) {algo / 1e6:7.1f} MB")
+    if len(out) > 3:
+        open(os.path.join(DST, f"{TAG}_chirp_kernel_stats.txt"), "w").write("\n".join(out) + "\n")
 
 
 if __name__ == "__main__":

@@ -7,7 +7,11 @@ OUT=gpurun_out/prof_r05
 rm -rf $OUT && mkdir -p $OUT && export TMPDIR=/tmp
 ( time python bench.py > $OUT/bench_c3.json 2> $OUT/bench.err ) 2> $OUT/bench_c3_time.txt
 for c in c2 c4 c5; do python bench.py --config $c > $OUT/bench_$c.json 2>> $OUT/bench.err; done
-python bench.py --config c5 --gpus 2 > $OUT/bench_c5_2ranks.json 2>> $OUT/bench.err
+python bench.py --config c5 --gpus 2 --c5-combine host > $OUT/bench_c5_2ranks.json 2>> $OUT/bench.err
+python bench.py --config c5 --gpus 2 --c5-combine peer > $OUT/bench_c5_2ranks_peer.json 2>> $OUT/bench.err
+for n in 3 4 8; do   # plumbing + parity of the peer exchange at more ranks (all on this one GPU)
+  python bench.py --gpus $n --config c5 --c5-combine peer --reps 2 --min-region-s 0.1 --no-cpu-baseline > $OUT/bench_c5_${n}ranks_peer.json 2>> $OUT/bench.err
+done
 python bench.py --config c5 --gpus 2 --c5-shard captures > $OUT/bench_c5_2ranks_captures.json 2>> $OUT/bench.err
 python bench.py --gpus 2 > $OUT/bench_c3_2ranks.json 2>> $OUT/bench.err
 python bench.py --config c4 --gpus 2 > $OUT/bench_c4_2ranks.json 2>> $OUT/bench.err
@@ -35,5 +39,14 @@ pmc c4_wr WRITE_SIZE $DEV --nfft 8192 --hop 8192 --frames 65536 --steps 5
 C5="python bench.py --config c5 --steps 2 --warmup 1 --reps 1 --min-region-s 0.05 --preroll-seconds 0 --no-cpu-baseline --no-parity"
 pmc c5_rd FETCH_SIZE $C5
 pmc c5_wr WRITE_SIZE $C5
+# chirp-z plans: kernel stats and traffic of three sizes (one launch; long-frame kernels; split plan)
+CH="python tools/devbench.py --hold 1"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_chirp_n1000 -- $CH --nfft 1000 --hop 1000 --frames 4096 --steps 200 --warmup 20 > $OUT/stats_chirp_n1000.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_chirp_n20000 -- $CH --nfft 20000 --hop 20000 --frames 512 --steps 100 --warmup 10 > $OUT/stats_chirp_n20000.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_chirp_n1000000 -- $CH --nfft 1000000 --hop 1000000 --frames 10 --steps 50 --warmup 5 > $OUT/stats_chirp_n1000000.log 2>&1
+pmc chirp_n1000_rd FETCH_SIZE $CH --nfft 1000 --hop 1000 --frames 4096 --steps 5 --warmup 2
+pmc chirp_n1000_wr WRITE_SIZE $CH --nfft 1000 --hop 1000 --frames 4096 --steps 5 --warmup 2
+pmc chirp_n20000_rd FETCH_SIZE $CH --nfft 20000 --hop 20000 --frames 512 --steps 5 --warmup 2
+pmc chirp_n20000_wr WRITE_SIZE $CH --nfft 20000 --hop 20000 --frames 512 --steps 5 --warmup 2
 find $OUT -name "*kernel_stats.csv" | head -10
 find $OUT -name "*.db" -delete; find $OUT -name "*kernel_trace.csv" -size +20M -delete
