@@ -709,6 +709,7 @@ __global__ void __launch_bounds__(256) big_sums_kernel(const void* in, unsigned 
   double sr = 0.0, si = 0.0;
   if constexpr (IN_C64) {
     const float2* x = reinterpret_cast<const float2*>(fb);
+#pragma unroll 8
     for (int i = i0 + threadIdx.x; i < i0 + per; i += 256) { sr += double(x[i].x); si += double(x[i].y); }
   } else {
     // eight samples (16 bytes) per lane and load, eight loads in flight (segment starts are only sample aligned).  The
@@ -850,7 +851,8 @@ hipError_t launch_big_dc(const void* in, int in_c64, unsigned xor_mask, long lon
                          hipStream_t s) {
   hipError_t e = hipMemsetAsync(sums, 0, size_t(n_frames) * 2 * sizeof(double), s);
   if (e != hipSuccess) return e;
-  const dim3 grid(n / 16384, n_frames);
+  // a workgroup per 16384 samples; a call of few frames (one per GUI tick) spreads each over four times as many
+  const dim3 grid(n / (n_frames >= 8 ? 16384 : 4096), n_frames);
   if (in_c64) hipLaunchKernelGGL(big_sums_kernel<true>, grid, dim3(256), 0, s, in, xor_mask, frame_stride, n, sums);
   else hipLaunchKernelGGL(big_sums_kernel<false>, grid, dim3(256), 0, s, in, xor_mask, frame_stride, n, sums);
   hipLaunchKernelGGL(big_dc_kernel, dim3(1), dim3(256), 0, s, sums, n, n_frames, alpha, in_off, in_scale, dc_state,

@@ -192,7 +192,7 @@ int chirp_sum_chunks(int n) { return n > 2 * kChirpSumChunk ? (n + kChirpSumChun
 
 hipError_t launch_chirp_sums(const void* in, int in_c64, unsigned xor_mask, long long frame_stride, int n, int n_frames,
                              int twice_zero, float2* res, float2* dc_state, float in_scale, hipStream_t s, double* part) {
-  if (n <= kChirpSumWaveMax) {
+  if (n <= kChirpSumWaveMax && n_frames >= 256) {   // (few frames - a GUI tick has one - keep a workgroup each: latency)
     const dim3 grid((n_frames + 3) / 4);
     if (in_c64)
       hipLaunchKernelGGL(chirp_sums_wave_kernel<true>, grid, dim3(256), 0, s, in, xor_mask, frame_stride, n, n_frames,
