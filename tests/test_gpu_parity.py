@@ -1423,6 +1423,25 @@ def test_welch_partials_read_in_place_from_another_process(pkg):
     assert d["welch"]["combine_ms"] < 5.0
 
 
+def test_debug_knobs_named_in_the_header_exist_and_unknown_names_are_errors(pkg):
+    """tdsa_debug_knob: the library reads nothing from the environment; every name the header's developer section lists is
+    accepted, anything else - the developer-build-only "big_pre_wgs" included - is an error, not a silent no-op."""
+    import re
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    txt = open(os.path.join(root, "include", "tdsa_hip.h")).read()
+    sec = txt[txt.index("developer section"):txt.index("int tdsa_debug_knob")]
+    names = re.findall(r'"([a-z0-9_]+)"', sec)
+    shipped = [n for n in names if n != "big_pre_wgs"]
+    assert set(shipped) >= {"num_cu", "avg_wg_min", "avg_f64_chunks", "overlap_share", "big_group", "chirp_single", "chirp_fuse_big"}
+    values = {"num_cu": 128, "overlap_share": 50, "big_group": 16}
+    with pkg.SpectrumEngine(1 << 15, max_frames=4) as e:
+        for n in shipped:
+            e.debug_knob(n, values.get(n, 1))
+        for bad in ("big_pre_wgs", "no_such_knob", ""):
+            with pytest.raises(pkg._native.TdsaError):
+                e.debug_knob(bad, 1)
+
+
 def test_shader_clock_is_plausible(pkg):
     with pkg.SpectrumEngine(1024, max_frames=1) as e:
         mhz, ns = e.shader_clock()
