@@ -20,7 +20,11 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--plans", type=int, default=2)
+    ap.add_argument("--masks", default="", help="developer build only (TDSA_HIP_LIB=libtdsa_dev.so): one CU mask per plan, "
+                                                "eight hex words each (a:b:c:d:e:f:g:h), separated by commas")
+    ap.add_argument("--num-cu", type=int, default=0, help="tdsa_debug_knob num_cu on every plan (persistent grids)")
     a = ap.parse_args()
+    masks = a.masks.split(",") if a.masks else []
     n, K = 1 << 20, 64
     ns = n * K
     iq = np.random.default_rng(0).integers(-100, 100, size=2 * ns, dtype=np.int8)
@@ -31,8 +35,12 @@ def main():
     for r in range(ring):
         nat.check(nat.lib.tdsa_memcpy_h2d(0, C.c_void_p(di.value + r * iq.nbytes), iq.ctypes.data_as(C.c_void_p), iq.nbytes))
     engs = []
-    for _ in range(a.plans):
+    for k in range(a.plans):
+        if masks:
+            os.environ["TDSA_DEV_CU_MASK"] = masks[k % len(masks)]
         e = SpectrumEngine(n, max_frames=K)
+        if a.num_cu:
+            e.debug_knob("num_cu", a.num_cu)
         e.set_window(np.hanning(n).astype(np.float32))
         e.configure(db_mode="pow", power_scale=1.0, log_floor=1e-12, dc_alpha=-1.0, avg=("lin", K), cal_offset_db=-0.8087)
         engs.append(e)

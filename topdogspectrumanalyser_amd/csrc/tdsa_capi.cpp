@@ -685,6 +685,14 @@ static int plan_init(tdsa_plan p) {
   // one thread per bin walking the frames beats the three launches of the chunked scan up to ~48 frames at N <= 4096
   // (N = 1024, 128 frames: 24.5 against 13.9 us) and up to ~128 at the larger sizes (N = 16384: 33.7 against 35.0 us)
   p->avg_wg_min = nfft <= 4096 ? 48 : 128;
+#ifdef TDSA_DEV
+  // developer experiment (tools/c5_two_plans.py): the plan's stream confined to a set of CUs, TDSA_DEV_CU_MASK = eight hex words
+  if (const char* m = std::getenv("TDSA_DEV_CU_MASK")) {
+    uint32_t mask[8] = {0};
+    std::sscanf(m, "%x:%x:%x:%x:%x:%x:%x:%x", &mask[0], &mask[1], &mask[2], &mask[3], &mask[4], &mask[5], &mask[6], &mask[7]);
+    HIPCHK(hipExtStreamCreateWithCUMask(&p->stream, 8, mask));
+  } else
+#endif
   HIPCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreate(&p->ev0));
   HIPCHK(hipEventCreate(&p->ev1));
