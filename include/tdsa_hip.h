@@ -376,7 +376,8 @@ int tdsa_profile_read(tdsa_plan p, int* launches, float* total_ms);
  * sized for), "big_group" (long-frame plans: segments per column / row round, 1 .. 64), "chirp_single" (chirp-z plans:
  * 0 = the passes of the convolution as separate kernels instead of one launch), "chirp_fuse_big" (chirp-z plans with
  * M > 16384: 0 = the unpack / window / chirp and the power / dB passes as kernels of their own); a library built with
- * -DTDSA_DEV also knows "big_pre_wgs" (empty workgroups ahead of every column pass: tools/c5_xcd_phase.py).
+ * -DTDSA_DEV also knows "big_pre_wgs" (empty workgroups ahead of every column pass: tools/c5_xcd_phase.py) and "cu_mask"
+ * (the plan's stream confined to a set of CUs: tools/c5_two_plans.py).
  * Unknown names are an error. */
 int tdsa_debug_knob(tdsa_plan p, const char* name, int value);
 /* Phase timeline of workgroup 0 of the frame kernel: allocates the plan's stamp buffer on first call;

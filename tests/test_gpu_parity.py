@@ -1431,13 +1431,13 @@ def test_debug_knobs_named_in_the_header_exist_and_unknown_names_are_errors(pkg)
     txt = open(os.path.join(root, "include", "tdsa_hip.h")).read()
     sec = txt[txt.index("developer section"):txt.index("int tdsa_debug_knob")]
     names = re.findall(r'"([a-z0-9_]+)"', sec)
-    shipped = [n for n in names if n != "big_pre_wgs"]
+    shipped = [n for n in names if n not in ("big_pre_wgs", "cu_mask")]
     assert set(shipped) >= {"num_cu", "avg_wg_min", "avg_f64_chunks", "overlap_share", "big_group", "chirp_single", "chirp_fuse_big"}
     values = {"num_cu": 128, "overlap_share": 50, "big_group": 16}
     with pkg.SpectrumEngine(1 << 15, max_frames=4) as e:
         for n in shipped:
             e.debug_knob(n, values.get(n, 1))
-        for bad in ("big_pre_wgs", "no_such_knob", ""):
+        for bad in ("big_pre_wgs", "cu_mask", "no_such_knob", ""):
             with pytest.raises(pkg._native.TdsaError):
                 e.debug_knob(bad, 1)
 

@@ -20,8 +20,8 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--plans", type=int, default=2)
-    ap.add_argument("--masks", default="", help="developer build only (TDSA_HIP_LIB=libtdsa_dev.so): one CU mask per plan, "
-                                                "eight hex words each (a:b:c:d:e:f:g:h), separated by commas")
+    ap.add_argument("--masks", default="", help="developer build only (TDSA_HIP_LIB=libtdsa_dev.so): tdsa_debug_knob cu_mask per "
+                                                "plan, comma separated: 1 / 2 = mask words 0-3 / 4-7, 3 / 4 = every second CU")
     ap.add_argument("--num-cu", type=int, default=0, help="tdsa_debug_knob num_cu on every plan (persistent grids)")
     a = ap.parse_args()
     masks = a.masks.split(",") if a.masks else []
@@ -36,9 +36,9 @@ def main():
         nat.check(nat.lib.tdsa_memcpy_h2d(0, C.c_void_p(di.value + r * iq.nbytes), iq.ctypes.data_as(C.c_void_p), iq.nbytes))
     engs = []
     for k in range(a.plans):
-        if masks:
-            os.environ["TDSA_DEV_CU_MASK"] = masks[k % len(masks)]
         e = SpectrumEngine(n, max_frames=K)
+        if masks:
+            e.debug_knob("cu_mask", int(masks[k % len(masks)]))
         if a.num_cu:
             e.debug_knob("num_cu", a.num_cu)
         e.set_window(np.hanning(n).astype(np.float32))

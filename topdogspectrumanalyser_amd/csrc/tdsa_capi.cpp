@@ -685,14 +685,6 @@ static int plan_init(tdsa_plan p) {
   // one thread per bin walking the frames beats the three launches of the chunked scan up to ~48 frames at N <= 4096
   // (N = 1024, 128 frames: 24.5 against 13.9 us) and up to ~128 at the larger sizes (N = 16384: 33.7 against 35.0 us)
   p->avg_wg_min = nfft <= 4096 ? 48 : 128;
-#ifdef TDSA_DEV
-  // developer experiment (tools/c5_two_plans.py): the plan's stream confined to a set of CUs, TDSA_DEV_CU_MASK = eight hex words
-  if (const char* m = std::getenv("TDSA_DEV_CU_MASK")) {
-    uint32_t mask[8] = {0};
-    std::sscanf(m, "%x:%x:%x:%x:%x:%x:%x:%x", &mask[0], &mask[1], &mask[2], &mask[3], &mask[4], &mask[5], &mask[6], &mask[7]);
-    HIPCHK(hipExtStreamCreateWithCUMask(&p->stream, 8, mask));
-  } else
-#endif
   HIPCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreate(&p->ev0));
   HIPCHK(hipEventCreate(&p->ev1));
@@ -2017,6 +2009,16 @@ int tdsa_debug_knob(tdsa_plan p, const char* name, int value) {
   } else if (k == "chirp_single") {          // chirp-z plans: 1 = one launch per call (default), 0 = the separate passes
     p->chirp_single = value != 0;
 #ifdef TDSA_DEV
+  } else if (k == "cu_mask") {               // the plan's stream confined to a set of CUs (tools/c5_two_plans.py): 1 / 2 = mask words
+    // 0-3 / 4-7 (four whole XCDs each on this chip), 3 / 4 = every second CU (even / odd bits of all eight words)
+    if (value < 1 || value > 4) return fail(TDSA_ERR_ARG, "cu_mask=%d outside [1, 4]", value);
+    uint32_t mask[8];
+    for (int w = 0; w < 8; ++w)
+      mask[w] = value == 1 ? (w < 4 ? 0xffffffffu : 0u) : value == 2 ? (w < 4 ? 0u : 0xffffffffu) : value == 3 ? 0x55555555u : 0xaaaaaaaau;
+    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(hipStreamDestroy(p->stream));
+    p->stream = nullptr;
+    HIPCHK(hipExtStreamCreateWithCUMask(&p->stream, 8, mask));
   } else if (k == "big_pre_wgs") {           // long-frame plans: empty workgroups ahead of every column pass (XCD phase)
     if (value < 0 || value > 64) return fail(TDSA_ERR_ARG, "big_pre_wgs=%d outside [0, 64]", value);
     p->big_pre_wgs = value;
