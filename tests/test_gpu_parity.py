@@ -121,6 +121,43 @@ def test_long_frames_that_are_not_a_power_of_two(pkg, nfft, branch):
         _check(out, gold, f"RTL exp N={nfft}")
 
 
+@pytest.mark.parametrize("nfft", [4, 6, 12, 20, 60, 96, 100, 250, 360, 625, 1000, 1500, 2000, 2187, 3000, 3125, 4050, 6000,
+                                  6561, 7776, 8000, 8100])
+def test_sizes_made_of_the_factors_2_3_5(pkg, nfft):
+    """Frame lengths 2^a 3^b 5^c up to 8192 points - what a user types into set_num_samples / set_fft_size
+    (hackrf_samples.py:392-405, rtl_samples.py:208-214) - run as a mixed-radix Stockham transform of exactly N points
+    (tdsa_smooth.hip; radices 4, 2, 3, 5) instead of the chirp-z convolution: HackRF branch with both hold traces from byte
+    and complex64 samples, RTL branch (uint8) with linear averaging, against the float64 gold; and the chirp-z path of
+    the same plan (tdsa_debug_knob smooth 0) must agree with it within the same bounds."""
+    nf = 5
+    hop = max(1, (2 * nfft) // 3)
+    n = hop * (nf - 1) + nfft
+    iq = so.synth_iq_int8(n, max(64, nfft), seed=nfft % 997)
+    x = so.unpack_iq_int8(iq)
+    gold, gmax, gmin = so.hackrf_batch(iq, nfft, hop, 20e6, precision="gold")
+    for feed in (iq, x):
+        for smooth in (1, 0):
+            with _hackrf_engine(pkg, nfft, nf, hold_max=True, hold_min=True) as e:
+                e.debug_knob("smooth", smooth)
+                out = e.process(feed, hop=hop, n_frames=nf)
+                mx, mn = e.hold()
+            _check(out, gold, f"N={nfft} {feed.dtype} smooth={smooth}")
+            _check(mx, gmax, "max hold")
+            _check(mn, gmin, "min hold")
+            assert np.array_equal(mx, out.max(axis=0)) and np.array_equal(mn, out.min(axis=0))
+    rng = np.random.default_rng(nfft)
+    u8 = rng.integers(0, 256, size=2 * n, dtype=np.uint8)
+    xr = so.unpack_iq_uint8_rtl(u8)
+    br = so.RtlBranchOracle(nfft, 2e6, "hamming", precision="gold")
+    br.averager.set_mode("lin", 4)
+    gavg = np.stack([np.array(br.power_levels(xr[k * hop:k * hop + nfft])) for k in range(nf)])
+    with pkg.SpectrumEngine(nfft, max_frames=nf) as e:
+        e.set_window(so.rtl_window("hamming", nfft).astype(np.float32))
+        e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=-1.0, avg=("lin", 4))
+        out = e.process(u8, hop=hop, n_frames=nf)
+    _check(out, gavg, f"N={nfft} RTL lin 4")
+
+
 @pytest.mark.parametrize("nfft", [1000, 6000, 20000, 100003, 600000])
 @pytest.mark.parametrize("fmt", ["i8", "u8", "c64"])
 def test_chirp_plans_every_input_format_and_both_code_paths(pkg, nfft, fmt):
@@ -148,7 +185,9 @@ def test_chirp_plans_every_input_format_and_both_code_paths(pkg, nfft, fmt):
         feed = x
     br = so.HackrfBranchOracle(nfft, 20e6, precision="gold")
     gold = np.stack([br.power_levels(x[k * hop:k * hop + nfft]) for k in range(nf)])
-    for knobs in ({}, {"chirp_single": 0}, {"chirp_fuse_big": 0}):
+    # (1000 and 6000 are 2^a 5^b 3^c: by default a mixed-radix transform of exactly N points, tdsa_smooth.hip; "smooth" 0
+    # sends them through the chirp-z convolution like the other sizes)
+    for knobs in ({}, {"smooth": 0}, {"smooth": 0, "chirp_single": 0}, {"chirp_fuse_big": 0}):
         with _hackrf_engine(pkg, nfft, nf, hold_max=True, hold_min=True) as e:
             for k, v in knobs.items():
                 e.debug_knob(k, v)

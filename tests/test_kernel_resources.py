@@ -101,6 +101,23 @@ def test_long_chirp_row_pass_instantiation_is_free_of_scratch(reports):
     assert int(k["VGPRs"]) <= 128 and int(k["Occupancy [waves/SIMD]"]) >= 4, k
 
 
+def test_mixed_radix_kernel_is_free_of_scratch(tmp_path):
+    """tdsa_smooth.hip (frame lengths 2^a 3^b 5^c): one kernel, no scratch, registers for at least four waves per SIMD."""
+    if not shutil.which(HIPCC):
+        pytest.skip("hipcc not available")
+    cmd = [HIPCC] + _flags_from_makefile() + ["-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, "tdsa_smooth.hip"),
+                                              "-o", str(tmp_path / "s.o")]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = {}
+    for ln in r.stderr.splitlines():
+        m = re.search(r"remark:\s+([A-Za-z \[\]/]+?):\s+(\S+)\s+\[-Rpass", ln)
+        if m:
+            rep[m.group(1).strip()] = m.group(2)
+    assert "smooth_kernel" in rep["Function Name"], rep
+    assert int(rep["ScratchSize [bytes/lane]"]) == 0 and int(rep["VGPRs Spill"]) == 0 and int(rep["VGPRs"]) <= 128, rep
+
+
 def test_byte_input_hot_instantiations_keep_four_waves(reports):
     """C2 (4096), C4 (8192), C3 (16384): int8 / uint8 frames, no hold / max hold - the BASELINE shapes - at <= 128 VGPRs."""
     for log2n in (12, 13, 14):

@@ -115,6 +115,13 @@ struct tdsa_plan_s {
   BigWindow big_win[3] = {};             // the column pass's window per input format (tdsa_set_window: table or one value)
   int avg_wg_min = 128;                  // batches of more frames than this take the workgroup-chunk scan (tdsa_debug_knob "avg_wg_min")
   bool avg_f64_chunks = false;           // tdsa_debug_knob "avg_f64_chunks": always the scan over fixed 64-frame chunks with float64 aggregates
+  // frame lengths made of 2, 3, 5 only, up to 8192 points: mixed-radix FFT of exactly nfft points (tdsa_smooth.hip) for the
+  // complex path; the plan stays a chirp-z plan for everything else (real input)
+  bool smooth = false;
+  int smooth_on = 1;                     // tdsa_debug_knob "smooth": 0 = such sizes run as chirp-z convolutions like every other
+  int smooth_stages = 0;
+  int smooth_radix[kSmoothMaxStages] = {0};
+  float2* d_smooth_tw = nullptr;         // [nfft] exp(-2 pi i k / nfft)
   int chirp_fuse_big = 1;                // tdsa_debug_knob "chirp_fuse_big": 0 = long chirp-z frames run chirp_pre / chirp_post as their own passes
   int chirp_single = 1;                  // tdsa_debug_knob "chirp_single": 0 = chirp-z plans run chirp_pre / two transforms / chirp_post as separate
                                          // kernels (M <= 16384; developer builds: two launches that carry the passes), separate row passes (M > 16384)
@@ -559,7 +566,8 @@ int process_chirp(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n
   if (averaging && !p->d_lin) HIPCHK(hipMalloc(&p->d_lin, size_t(p->max_frames) * N * sizeof(float)));
   // the power / dB rows leave the second transform directly (linear rows for the averager's scan, else dB rows + hold
   // traces); frames below 1024 points (and the A/B knobs): complex rows in d_u0, chirp_post below
-  const bool fusable = chirp_fusable(p);
+  const bool smooth = p->smooth && p->smooth_on;      // a transform of exactly N points instead of the convolution
+  const bool fusable = chirp_fusable(p) || smooth;
   const bool holding = (m.hold_flags & (TDSA_HOLD_MAX | TDSA_HOLD_MIN)) != 0;
   float* rows = out_db_dev;
   if (fusable && !averaging && rows == nullptr && holding) {   // only the hold traces are wanted: the rows go to scratch
@@ -574,6 +582,31 @@ int process_chirp(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n
                        averaging ? nullptr : rows, averaging ? p->d_lin : nullptr,
                        (!averaging && (m.hold_flags & TDSA_HOLD_MAX)) ? p->d_hold_max : nullptr,
                        (!averaging && (m.hold_flags & TDSA_HOLD_MIN)) ? p->d_hold_min : nullptr};
+  if (smooth) {
+    SmoothParams sp{};
+    sp.in = iq_dev;
+    sp.in_c64 = in_c64;
+    sp.frame_stride = stride;
+    sp.n = N;
+    sp.n_frames = n_frames;
+    sp.n_stages = p->smooth_stages;
+    for (int i = 0; i < p->smooth_stages; ++i) sp.radix[i] = p->smooth_radix[i];
+    sp.tw = p->d_smooth_tw;
+    sp.window = p->d_window[in_format];
+    sp.dc_sub = dc_sub;
+    sp.xor_mask = xor_mask;
+    sp.in_off = in_off;
+    sp.db_mode = post.db_mode;
+    sp.pscale = post.pscale;
+    sp.log_floor = post.log_floor;
+    sp.cal_db = post.cal_db;
+    sp.tare = post.tare;
+    sp.out_db = post.out_db;
+    sp.out_lin = post.out_lin;
+    HIPCHK(launch_smooth(sp, s));
+    if (post.out_lin == nullptr && (post.hold_max || post.hold_min))
+      HIPCHK(launch_chirp_hold(post.out_db, N, n_frames, post.first_frame_index, post.hold_max, post.hold_min, s));
+  } else
   { const int rc = chirp_transform(p, iq_dev, in_format, stride, n_frames, dc_sub, xor_mask, in_off, fusable ? &post : nullptr); if (rc != TDSA_OK) return rc; }
   if (averaging) {
     if (!p->d_carry && p->max_frames > 128) {
@@ -674,6 +707,15 @@ int tdsa_create(int device_id, int nfft, int max_frames, tdsa_plan* out) {
   }
   *out = p;
   return TDSA_OK;
+}
+
+// nfft = 2^a 3^b 5^c: the radices of its stages (4 while it divides, then 2, 3, 5)
+static void smooth_plan(tdsa_plan p) {
+  int r = p->nfft, st = 0;
+  while (r % 4 == 0 && st < kSmoothMaxStages) { p->smooth_radix[st++] = 4; r /= 4; }
+  for (const int f : {2, 3, 5})
+    while (r % f == 0 && st < kSmoothMaxStages) { p->smooth_radix[st++] = f; r /= f; }
+  p->smooth_stages = r == 1 ? st : 0;
 }
 
 static int plan_init(tdsa_plan p) {
@@ -795,6 +837,21 @@ static int plan_init(tdsa_plan p) {
     std::vector<float> ones(M, 1.0f);
     HIPCHK(hipMemcpy(p->d_chirp_a, a32.data(), size_t(nfft) * sizeof(float2), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(p->d_ones, ones.data(), size_t(M) * sizeof(float), hipMemcpyHostToDevice));
+    {   // 2^a 3^b 5^c up to 8192 points: the stages of its mixed-radix transform and W_N^k
+      int r = nfft;
+      for (const int f : {2, 3, 5}) while (r % f == 0) r /= f;
+      if (r == 1 && nfft <= kSmoothMaxN && nfft >= 4) {
+        smooth_plan(p);
+        p->smooth = p->smooth_stages > 0;
+        std::vector<float2> tw(nfft);
+        for (int k = 0; k < nfft; ++k) {
+          const double ang = -2.0 * M_PI * double(k) / double(nfft);
+          tw[k] = float2{float(std::cos(ang)), float(std::sin(ang))};
+        }
+        HIPCHK(hipMalloc(&p->d_smooth_tw, size_t(nfft) * sizeof(float2)));
+        HIPCHK(hipMemcpy(p->d_smooth_tw, tw.data(), size_t(nfft) * sizeof(float2), hipMemcpyHostToDevice));
+      }
+    }
     if (p->chirp_big) {   // the M-point transforms' column-pass seeds (as for a native long frame of M points)
       const int nrow = 1 << kMaxLog2N, n1 = M >> kMaxLog2N, na = n1 < 8 ? n1 : 8;
       const int rows = big_seed_rows(p->log2m);
@@ -875,7 +932,7 @@ int tdsa_destroy(tdsa_plan p) {
                   p->d_window_perm[2], p->d_tw, p->d_hold_max, p->d_hold_min,
                   p->d_avg, p->d_lin, p->d_carry, p->d_agg, p->d_agg_w, p->d_chunk_a, p->d_chunk_v, p->d_cplx, p->d_real, p->d_lin1, p->d_db1, p->d_dc_state, p->d_sums, p->d_dc_sub,
                   p->d_tare_base, p->d_tare_acc, p->d_in_stage, p->d_out_stage, p->d_trace_in,
-                  p->d_trace_live, p->d_scratch, p->d_z, p->d_welch, p->d_clock, p->d_chirp_aw[0], p->d_chirp_aw[1], p->d_chirp_aw[2], p->d_chirp_bm, p->d_chirp_bp, p->d_chirp_a, p->d_chirp_b, p->d_u0, p->d_u1, p->d_acc, p->d_sum, p->d_lin64, p->d_sums64, p->d_tw_seed, p->d_tw_row, p->d_ones,
+                  p->d_trace_live, p->d_scratch, p->d_z, p->d_welch, p->d_clock, p->d_smooth_tw, p->d_chirp_aw[0], p->d_chirp_aw[1], p->d_chirp_aw[2], p->d_chirp_bm, p->d_chirp_bp, p->d_chirp_a, p->d_chirp_b, p->d_u0, p->d_u1, p->d_acc, p->d_sum, p->d_lin64, p->d_sums64, p->d_tw_seed, p->d_tw_row, p->d_ones,
                   p->d_dbg};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -2004,6 +2061,8 @@ int tdsa_debug_knob(tdsa_plan p, const char* name, int value) {
     if (!p->big || value < 1 || value > 64) return fail(TDSA_ERR_ARG, "big_group=%d (long-frame plans, 1 .. 64)", value);
     if (p->d_z && value > p->big_group) return fail(TDSA_ERR_STATE, "big_group can only shrink once the plan has run");
     p->big_group = value;
+  } else if (k == "smooth") {                // sizes 2^a 3^b 5^c <= 8192: 1 = mixed-radix transform of N points (default), 0 = chirp-z
+    p->smooth_on = value != 0;
   } else if (k == "chirp_fuse_big") {        // long chirp-z frames: 1 = element-wise passes inside the column passes (default)
     p->chirp_fuse_big = value != 0;
   } else if (k == "chirp_single") {          // chirp-z plans: 1 = one launch per call (default), 0 = the separate passes

@@ -269,6 +269,30 @@ hipError_t launch_xcd_shift(int wgs, hipStream_t s);
 // n_cu * 4 workgroups of 256 threads, each wave 64 * iters independent v_add_f32 (8 chains): the SIMDs' saturated VALU rate
 hipError_t launch_valu_clock(float* scratch, int n_cu, int iters, hipStream_t s);
 
+// ---- frame lengths made of the factors 2, 3, 5 only, up to 8192 points (tdsa_smooth.hip): mixed-radix Stockham FFT in LDS ----
+constexpr int kSmoothMaxN = 8192;
+constexpr int kSmoothMaxStages = 16;
+struct SmoothParams {
+  const void* in;            // raw frames
+  int in_c64;
+  long long frame_stride;    // bytes
+  int n, n_frames, fpw;      // fpw: frames per workgroup (set by the launcher)
+  int n_stages;
+  int radix[kSmoothMaxStages];   // 4, 2, 3, 5 in any order, product n
+  unsigned magic_per[kSmoothMaxStages], magic_s[kSmoothMaxStages];   // division constants (set by the launcher)
+  const float2* tw;          // [n] exp(-2 pi i k / n)
+  const float* window;       // [n] window * input scale
+  const float2* dc_sub;      // [F] DC estimate minus the zero level, raw units, or null
+  unsigned xor_mask;
+  float in_off;
+  int db_mode;
+  float pscale, log_floor, cal_db;
+  const float* tare;
+  float* out_db;             // [F][n] or null
+  float* out_lin;            // [F][n] linear power * pscale (averaging modes) or null
+};
+hipError_t launch_smooth(SmoothParams p, hipStream_t s);
+
 // ---- frame lengths that are not a power of two, 2 <= N <= 8192 (tdsa_chirp.hip): chirp-z on the frame kernel ----
 constexpr int kChirpMaxN = (1 << 20) - 1; // M = 2^ceil(log2(2N-1)) <= 2^20 up to N = 2^19 (M > 16384: the long-frame kernels); longer
                                          // frames as four half-length sub-convolutions of 2^20 points (tdsa_chirp.hip)

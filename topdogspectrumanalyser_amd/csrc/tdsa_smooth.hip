@@ -1,0 +1,205 @@
+// Frame lengths whose only prime factors are 2, 3 and 5 (1000, 1500, 3000, 6000, ... - what a user types into
+// set_num_samples / set_fft_size: hackrf_samples.py:392-405, rtl_samples.py:208-214), up to 8192 points: a mixed-radix
+// Stockham FFT of exactly N points in LDS instead of the chirp-z convolution's two transforms of M >= 2N - 1 points
+// (tdsa_chirp.hip, which keeps every other size).  np.fft.fft / scipy.fft.fft run the same kind of factorisation on the host
+// (hackrf_samples.py:370, rtl_samples.py:170).
+//
+// One workgroup takes FPW frames; every stage of radix r in {4, 2, 3, 5} reads the frames from one LDS buffer and writes
+// them to the other (autosort: the last stage leaves natural bin order), a barrier between stages:
+//   n = current sub-length, s = N / n, m = n / r;  butterfly (p < m, q < s):
+//     a_t = x[q + s (p + t m)],  b = DFT_r(a),  y[q + s (r p + u)] = b_u W_N^(p u s)
+// Around it the path of the chirp-z plans, operation for operation: unpack, minus the frame mean / tracked DC estimate
+// (chirp_sums_kernel + dc_track_kernel), times window x input scale on load; |X|^2, fftshift by floor(N / 2), dB + cal
+// offset - tare or linear power rows on store; hold traces folded from the rows by chirp_hold_kernel.
+#include <hip/hip_runtime.h>
+
+#include "tdsa_kernels.hpp"
+
+namespace tdsa {
+
+namespace {
+
+using c32 = float2;
+__device__ __forceinline__ c32 cadd(c32 a, c32 b) { return c32{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ c32 csub(c32 a, c32 b) { return c32{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ c32 cmul_(c32 a, c32 b) { return c32{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ c32 mul_mi(c32 a) { return c32{a.y, -a.x}; }      // a * (-i)
+
+constexpr float kTenLog10Of2 = 3.01029995663981195214f;
+
+template <int R>
+__device__ __forceinline__ void dft(c32 (&a)[R]) {
+  if constexpr (R == 2) {
+    const c32 t = a[0];
+    a[0] = cadd(t, a[1]);
+    a[1] = csub(t, a[1]);
+  } else if constexpr (R == 3) {
+    constexpr float s = 0.86602540378443864676f;
+    const c32 t1 = cadd(a[1], a[2]);
+    const c32 t2 = c32{a[0].x - 0.5f * t1.x, a[0].y - 0.5f * t1.y};
+    const c32 d = csub(a[1], a[2]);
+    const c32 t3 = c32{s * d.y, -s * d.x};                                  // -i s (a1 - a2)
+    a[0] = cadd(a[0], t1);
+    a[1] = cadd(t2, t3);
+    a[2] = csub(t2, t3);
+  } else if constexpr (R == 4) {
+    const c32 t0 = cadd(a[0], a[2]), t1 = csub(a[0], a[2]), t2 = cadd(a[1], a[3]), t3 = mul_mi(csub(a[1], a[3]));
+    a[0] = cadd(t0, t2);
+    a[1] = cadd(t1, t3);
+    a[2] = csub(t0, t2);
+    a[3] = csub(t1, t3);
+  } else {
+    static_assert(R == 5, "radix");
+    constexpr float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;   // cos(2 pi / 5), cos(4 pi / 5)
+    constexpr float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;    // sin(2 pi / 5), sin(4 pi / 5)
+    const c32 t1 = cadd(a[1], a[4]), t2 = cadd(a[2], a[3]), t3 = csub(a[1], a[4]), t4 = csub(a[2], a[3]);
+    const c32 m1 = c32{a[0].x + c1 * t1.x + c2 * t2.x, a[0].y + c1 * t1.y + c2 * t2.y};
+    const c32 m2 = c32{a[0].x + c2 * t1.x + c1 * t2.x, a[0].y + c2 * t1.y + c1 * t2.y};
+    const c32 n1 = c32{s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y};
+    const c32 n2 = c32{s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y};
+    a[0] = cadd(a[0], cadd(t1, t2));
+    a[1] = c32{m1.x + n1.y, m1.y - n1.x};                                    // m1 - i n1
+    a[4] = c32{m1.x - n1.y, m1.y + n1.x};
+    a[2] = c32{m2.x + n2.y, m2.y - n2.x};
+    a[3] = c32{m2.x - n2.y, m2.y + n2.x};
+  }
+}
+
+
+// i / d for i < 2^19, d <= 8192 without a division: magic = floor(2^32 / d) + 1
+// (magic 0: d = 1)
+__device__ __forceinline__ int div_magic(int i, unsigned magic) { return magic == 0u ? i : int(__umulhi(unsigned(i), magic)); }
+
+// one stage over the workgroup's FPW frames: butterflies i = (frame, p, q) spread over the threads.  LD(frame, index) /
+// ST(frame, index, value): LDS for the stages in the middle; the first stage takes its inputs straight from the raw frames
+// (unpack, DC, window) and the last one turns its outputs into the dB / power row - two LDS round trips and two barriers less
+template <int R, typename LD, typename ST>
+__device__ __forceinline__ void stage(const c32* __restrict__ tw, int N, int s, int fpw, int threads, unsigned magic_per,
+                                      unsigned magic_s, LD ld, ST st) {
+  const int per = N / R, m = per / s;
+  for (int i = threadIdx.x; i < fpw * per; i += threads) {
+    const int fr = div_magic(i, magic_per), b = i - fr * per;
+    const int pp = s == 1 ? b : div_magic(b, magic_s), q = b - pp * s;
+    c32 a[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) a[t] = ld(fr, q + s * (pp + t * m));
+    dft<R>(a);
+    const int ws = pp * s;                               // W_n^(p u) = W_N^(p u s)
+    st(fr, q + s * (R * pp), a[0]);
+#pragma unroll
+    for (int u = 1; u < R; ++u) st(fr, q + s * (R * pp + u), m == 1 ? a[u] : cmul_(a[u], tw[ws * u]));   // (p u s < N)
+  }
+}
+
+template <typename LD, typename ST>
+__device__ __forceinline__ void stage_r(int r, const c32* tw, int N, int s, int fpw, int threads, unsigned mp, unsigned ms, LD ld, ST st) {
+  switch (r) {
+    case 5: stage<5>(tw, N, s, fpw, threads, mp, ms, ld, st); break;
+    case 4: stage<4>(tw, N, s, fpw, threads, mp, ms, ld, st); break;
+    case 3: stage<3>(tw, N, s, fpw, threads, mp, ms, ld, st); break;
+    default: stage<2>(tw, N, s, fpw, threads, mp, ms, ld, st); break;
+  }
+}
+
+}  // namespace
+
+__global__ void __launch_bounds__(1024) smooth_kernel(const SmoothParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int N = p.n, fpw = p.fpw, T = blockDim.x;
+  c32* buf0 = reinterpret_cast<c32*>(smem);
+  c32* buf1 = buf0 + fpw * N;
+  const int f0 = blockIdx.x * fpw;
+  const int nf = p.n_frames - f0 < fpw ? p.n_frames - f0 : fpw;
+  const int half = N / 2;
+  // sample k of frame slot fr: unpack, DC, window x input scale (slots past the call's last frame: zeros)
+  const auto load_raw = [&](int fr, int k) -> c32 {
+    if (fr >= nf) return c32{0.f, 0.f};
+    const int f = f0 + fr;
+    const unsigned char* fb = static_cast<const unsigned char*>(p.in) + (long long)f * p.frame_stride;
+    float re, im;
+    if (p.in_c64) {
+      const c32 z = reinterpret_cast<const c32*>(fb)[k];
+      re = z.x;
+      im = z.y;
+    } else {
+      const unsigned u = unsigned(reinterpret_cast<const uint16_t*>(fb)[k]) ^ (p.xor_mask & 0xffffu);
+      re = float(u & 0xffu) - p.in_off;                  // exact: small integers / halves
+      im = float(u >> 8) - p.in_off;
+    }
+    if (p.dc_sub != nullptr) { const c32 d = p.dc_sub[f]; re -= d.x; im -= d.y; }
+    const float w = p.window[k];
+    return c32{re * w, im * w};
+  };
+  // bin k of frame slot fr: |X|^2, fftshift, dB + cal - tare / linear power (chirp_post_kernel's arithmetic)
+  const auto store_bin = [&](int fr, int k, c32 X) {
+    if (fr >= nf) return;
+    int j = k + half;                                    // np.fft.fftshift: bin k lands at (k + N / 2) mod N, any N
+    if (j >= N) j -= N;
+    const float pw = X.x * X.x + X.y * X.y;
+    const long long o = (long long)(f0 + fr) * N + j;
+    if (p.out_lin != nullptr) {
+      p.out_lin[o] = pw * p.pscale;
+    } else {
+      float db;
+      if (p.db_mode == 0) db = fmaf(2.0f * kTenLog10Of2, __builtin_amdgcn_logf(__builtin_amdgcn_sqrtf(pw) + p.log_floor), p.cal_db);
+      else db = fmaf(kTenLog10Of2, __builtin_amdgcn_logf(fmaf(pw, p.pscale, p.log_floor)), p.cal_db);
+      if (p.tare != nullptr) db -= p.tare[j];
+      p.out_db[o] = db;
+    }
+  };
+  c32* x = buf0;
+  c32* y = buf1;
+  int sd = 1;                                            // s = N / n of the stage
+  const int last = p.n_stages - 1;
+  for (int st = 0; st <= last; ++st) {
+    const int r = p.radix[st];
+    const unsigned mp = p.magic_per[st], ms = p.magic_s[st];
+    const c32* xs = x;
+    c32* ys = y;
+    const auto ld_lds = [=](int fr, int k) -> c32 { return xs[fr * N + k]; };
+    const auto st_lds = [=](int fr, int k, c32 v) { ys[fr * N + k] = v; };
+    if (st == 0 && st == last) stage_r(r, p.tw, N, sd, fpw, T, mp, ms, load_raw, store_bin);
+    else if (st == 0) stage_r(r, p.tw, N, sd, fpw, T, mp, ms, load_raw, st_lds);
+    else if (st == last) stage_r(r, p.tw, N, sd, fpw, T, mp, ms, ld_lds, store_bin);
+    else stage_r(r, p.tw, N, sd, fpw, T, mp, ms, ld_lds, st_lds);
+    sd *= r;
+    c32* t = x; x = y; y = t;
+    if (st != last) __syncthreads();
+  }
+}
+
+// about 2048 points per workgroup, two frames up to 2048 points each (N = 1500: 63 us per 4096 frames against 77 with one),
+// one above (measured: profiles/r05_chirp.txt)
+int smooth_frames_per_workgroup(int n) {
+  int fpw = 2048 / n;
+  if (fpw < 2 && n <= 2048) fpw = 2;
+  if (fpw < 1) fpw = 1;
+  if (fpw > 16) fpw = 16;
+  return fpw;
+}
+
+hipError_t launch_smooth(SmoothParams p, hipStream_t s) {
+  p.fpw = smooth_frames_per_workgroup(p.n);
+  const auto magic = [](int d) { return d == 1 ? 0u : unsigned((1ull << 32) / unsigned(d)) + 1u; };
+  int sd = 1;
+  for (int st = 0; st < p.n_stages; ++st) {
+    p.magic_per[st] = magic(p.n / p.radix[st]);
+    p.magic_s[st] = magic(sd);
+    sd *= p.radix[st];
+  }
+  // a thread per four points, whole waves, at most 1024
+  int threads = ((p.fpw * p.n / 4 + 63) / 64) * 64;
+  threads = threads < 64 ? 64 : (threads > 1024 ? 1024 : threads);
+  const size_t lds = size_t(2) * p.fpw * p.n * sizeof(float2);
+  static size_t attr_done = 0;
+  if (lds > attr_done) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(smooth_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (e != hipSuccess) return e;
+    attr_done = lds;
+  }
+  const int grid = (p.n_frames + p.fpw - 1) / p.fpw;
+  hipLaunchKernelGGL(smooth_kernel, dim3(grid), dim3(threads), lds, s, p);
+  return hipGetLastError();
+}
+
+}  // namespace tdsa
