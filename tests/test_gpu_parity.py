@@ -145,6 +145,20 @@ def test_sizes_made_of_the_factors_2_3_5(pkg, nfft):
             _check(mx, gmax, "max hold")
             _check(mn, gmin, "min hold")
             assert np.array_equal(mx, out.max(axis=0)) and np.array_equal(mn, out.min(axis=0))
+    # calls of more than eight frames take the frame means from the sums kernel, smaller ones form them in the transform's
+    # kernel (byte samples): the rows of the first frames must be the same bits either way
+    nf2 = 12
+    iq2 = so.synth_iq_int8(hop * (nf2 - 1) + nfft, max(64, nfft), seed=nfft % 997)
+    gold2, _, _ = so.hackrf_batch(iq2, nfft, hop, 20e6, precision="gold")
+    with _hackrf_engine(pkg, nfft, nf2) as e:
+        out2 = e.process(iq2, hop=hop, n_frames=nf2)
+        dc2 = e.dc_estimate
+    _check(out2, gold2, f"N={nfft} 12 frames")
+    with _hackrf_engine(pkg, nfft, nf2) as e:
+        out3 = np.concatenate([e.process(iq2[: 2 * (hop * 5 + nfft)], hop=hop, n_frames=6),
+                               e.process(iq2[2 * hop * 6:], hop=hop, n_frames=6)])
+        assert e.dc_estimate == dc2
+    assert np.array_equal(out2, out3)
     rng = np.random.default_rng(nfft)
     u8 = rng.integers(0, 256, size=2 * n, dtype=np.uint8)
     xr = so.unpack_iq_uint8_rtl(u8)

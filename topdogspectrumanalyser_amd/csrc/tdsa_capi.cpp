@@ -545,14 +545,18 @@ int process_chirp(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n
   const long long stride = (long long)hop * bytes_per_sample(in_format);
   hipStream_t s = p->stream;
   const float2* dc_sub = nullptr;
-  if (m.dc_alpha >= 0.0f) {
+  const bool smooth = p->smooth && p->smooth_on;      // a transform of exactly N points instead of the convolution
+  // ... whose kernel forms the frame means of byte samples itself when the call has few frames (a GUI tick has one: a launch
+  // less, 34 -> 28 us per host call at N = 1000; in batches the frame-by-frame reductions cost more than the sums kernel)
+  const bool dc_own = smooth && !in_c64 && m.dc_alpha >= 1.0f && n_frames <= 8;
+  const int twice_zero = in_format == TDSA_IN_I8 ? 256 : (in_c64 ? 0 : 255);
+  if (m.dc_alpha >= 0.0f && !dc_own) {
     // frame means as residuals (exact sums); 0 <= alpha < 1: the tracker of the native path fed with them
     // directly (n = 1, zero level 0)
     const bool tracked = m.dc_alpha < 1.0f;
     if (chirp_sum_chunks(N) > 1 && !p->d_sums64)      // long frames: several workgroups per frame leave partial sums here
       HIPCHK(hipMalloc(&p->d_sums64, size_t(p->max_frames) * chirp_sum_chunks(N) * 2 * sizeof(double)));
-    HIPCHK(launch_chirp_sums(iq_dev, in_c64, xor_mask, stride, N, n_frames,
-                             in_format == TDSA_IN_I8 ? 256 : (in_c64 ? 0 : 255), p->d_sums,
+    HIPCHK(launch_chirp_sums(iq_dev, in_c64, xor_mask, stride, N, n_frames, twice_zero, p->d_sums,
                              tracked ? nullptr : p->d_dc_state, in_scale, s, p->d_sums64));
     dc_sub = p->d_sums;                   // dc_alpha >= 1: the frame's own mean
     if (tracked) {
@@ -566,7 +570,6 @@ int process_chirp(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n
   if (averaging && !p->d_lin) HIPCHK(hipMalloc(&p->d_lin, size_t(p->max_frames) * N * sizeof(float)));
   // the power / dB rows leave the second transform directly (linear rows for the averager's scan, else dB rows + hold
   // traces); frames below 1024 points (and the A/B knobs): complex rows in d_u0, chirp_post below
-  const bool smooth = p->smooth && p->smooth_on;      // a transform of exactly N points instead of the convolution
   const bool fusable = chirp_fusable(p) || smooth;
   const bool holding = (m.hold_flags & (TDSA_HOLD_MAX | TDSA_HOLD_MIN)) != 0;
   float* rows = out_db_dev;
@@ -575,6 +578,9 @@ int process_chirp(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n
     rows = reinterpret_cast<float*>(p->d_u0);
   }
   if (fusable && !averaging && rows == nullptr) {              // nothing to produce (no rows, no hold, no averaging)
+    if (dc_own)                                                // (but the estimate the plan carries moves on)
+      HIPCHK(launch_chirp_sums(iq_dev, in_c64, xor_mask, stride, N, n_frames, twice_zero, p->d_sums, p->d_dc_state, in_scale, s,
+                               p->d_sums64));
     p->frames_seen += n_frames;
     return TDSA_OK;
   }
@@ -594,6 +600,10 @@ int process_chirp(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n
     sp.tw = p->d_smooth_tw;
     sp.window = p->d_window[in_format];
     sp.dc_sub = dc_sub;
+    sp.dc_own = dc_own;
+    sp.twice_zero = twice_zero;
+    sp.in_scale = in_scale;
+    sp.dc_state = p->d_dc_state;
     sp.xor_mask = xor_mask;
     sp.in_off = in_off;
     sp.db_mode = post.db_mode;

@@ -283,6 +283,10 @@ struct SmoothParams {
   const float2* tw;          // [n] exp(-2 pi i k / n)
   const float* window;       // [n] window * input scale
   const float2* dc_sub;      // [F] DC estimate minus the zero level, raw units, or null
+  int dc_own;                // byte samples, per-frame mean removal: the kernel forms the frame means itself (dc_sub unused)
+  int twice_zero;            // 256 int8 after the xor, 255 uint8
+  float in_scale;
+  float2* dc_state;          // (dc_own) receives the last frame's mean in units of x, or null
   unsigned xor_mask;
   float in_off;
   int db_mode;

@@ -111,6 +111,37 @@ __global__ void __launch_bounds__(1024) smooth_kernel(const SmoothParams p) {
   const int f0 = blockIdx.x * fpw;
   const int nf = p.n_frames - f0 < fpw ? p.n_frames - f0 : fpw;
   const int half = N / 2;
+  // per-frame mean removal of byte samples (dc_alpha = 1, the HackRF branch's default) without the sums kernel's launch:
+  // exact integer I / Q sums of this workgroup's frames, the residual (2 sum - twice_zero n) / (2 n) formed in double exactly
+  // as chirp_sums_kernel forms it - the same bits
+  __shared__ float dc_re[16], dc_im[16];
+  __shared__ unsigned red_i[16], red_q[16];
+  if (p.dc_own) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = T >> 6;
+    for (int fr = 0; fr < nf; ++fr) {
+      const uint16_t* xs = reinterpret_cast<const uint16_t*>(static_cast<const unsigned char*>(p.in) + (long long)(f0 + fr) * p.frame_stride);
+      unsigned ui = 0, uq = 0;
+      for (int k = threadIdx.x; k < N; k += T) {
+        const unsigned u = unsigned(xs[k]) ^ (p.xor_mask & 0xffffu);
+        ui += u & 0xffu;
+        uq += u >> 8;
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) { ui += __shfl_xor(ui, off); uq += __shfl_xor(uq, off); }
+      if (lane == 0) { red_i[wave] = ui; red_q[wave] = uq; }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        unsigned ti = 0, tq = 0;
+        for (int w = 0; w < waves; ++w) { ti += red_i[w]; tq += red_q[w]; }
+        const double dn = double(N), tz = double(p.twice_zero);
+        const float rr = float((2.0 * double(ti) - tz * dn) / (2.0 * dn)), ri = float((2.0 * double(tq) - tz * dn) / (2.0 * dn));
+        dc_re[fr] = rr;
+        dc_im[fr] = ri;
+        if (p.dc_state != nullptr && f0 + fr == p.n_frames - 1) *p.dc_state = float2{rr * p.in_scale, ri * p.in_scale};
+      }
+      __syncthreads();
+    }
+  }
   // sample k of frame slot fr: unpack, DC, window x input scale (slots past the call's last frame: zeros)
   const auto load_raw = [&](int fr, int k) -> c32 {
     if (fr >= nf) return c32{0.f, 0.f};
@@ -126,7 +157,8 @@ __global__ void __launch_bounds__(1024) smooth_kernel(const SmoothParams p) {
       re = float(u & 0xffu) - p.in_off;                  // exact: small integers / halves
       im = float(u >> 8) - p.in_off;
     }
-    if (p.dc_sub != nullptr) { const c32 d = p.dc_sub[f]; re -= d.x; im -= d.y; }
+    if (p.dc_own) { re -= dc_re[fr]; im -= dc_im[fr]; }
+    else if (p.dc_sub != nullptr) { const c32 d = p.dc_sub[f]; re -= d.x; im -= d.y; }
     const float w = p.window[k];
     return c32{re * w, im * w};
   };
