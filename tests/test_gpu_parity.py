@@ -122,9 +122,9 @@ def test_long_frames_that_are_not_a_power_of_two(pkg, nfft, branch):
 
 
 @pytest.mark.parametrize("nfft", [4, 6, 12, 20, 60, 96, 100, 250, 360, 625, 1000, 1500, 2000, 2187, 3000, 3125, 4050, 6000,
-                                  6561, 7776, 8000, 8100])
+                                  6561, 7776, 8000, 8100, 9000, 10000])
 def test_sizes_made_of_the_factors_2_3_5(pkg, nfft):
-    """Frame lengths 2^a 3^b 5^c up to 8192 points - what a user types into set_num_samples / set_fft_size
+    """Frame lengths 2^a 3^b 5^c up to 10 000 points - what a user types into set_num_samples / set_fft_size
     (hackrf_samples.py:392-405, rtl_samples.py:208-214) - run as a mixed-radix Stockham transform of exactly N points
     (tdsa_smooth.hip; radices 4, 2, 3, 5) instead of the chirp-z convolution: HackRF branch with both hold traces from byte
     and complex64 samples, RTL branch (uint8) with linear averaging, against the float64 gold; and the chirp-z path of

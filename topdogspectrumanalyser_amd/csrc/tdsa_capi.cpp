@@ -847,7 +847,7 @@ static int plan_init(tdsa_plan p) {
     std::vector<float> ones(M, 1.0f);
     HIPCHK(hipMemcpy(p->d_chirp_a, a32.data(), size_t(nfft) * sizeof(float2), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(p->d_ones, ones.data(), size_t(M) * sizeof(float), hipMemcpyHostToDevice));
-    {   // 2^a 3^b 5^c up to 8192 points: the stages of its mixed-radix transform and W_N^k
+    {   // 2^a 3^b 5^c up to 10 000 points: the stages of its mixed-radix transform and W_N^k
       int r = nfft;
       for (const int f : {2, 3, 5}) while (r % f == 0) r /= f;
       if (r == 1 && nfft <= kSmoothMaxN && nfft >= 4) {

@@ -269,8 +269,8 @@ hipError_t launch_xcd_shift(int wgs, hipStream_t s);
 // n_cu * 4 workgroups of 256 threads, each wave 64 * iters independent v_add_f32 (8 chains): the SIMDs' saturated VALU rate
 hipError_t launch_valu_clock(float* scratch, int n_cu, int iters, hipStream_t s);
 
-// ---- frame lengths made of the factors 2, 3, 5 only, up to 8192 points (tdsa_smooth.hip): mixed-radix Stockham FFT in LDS ----
-constexpr int kSmoothMaxN = 8192;
+// ---- frame lengths made of the factors 2, 3, 5 only, up to 10 000 points (tdsa_smooth.hip): mixed-radix Stockham FFT in LDS ----
+constexpr int kSmoothMaxN = 10000;     // two LDS buffers of N complex64 values: 160 000 of the 163 840 bytes a workgroup may have
 constexpr int kSmoothMaxStages = 16;
 struct SmoothParams {
   const void* in;            // raw frames

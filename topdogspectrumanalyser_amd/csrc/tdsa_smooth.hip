@@ -1,5 +1,5 @@
 // Frame lengths whose only prime factors are 2, 3 and 5 (1000, 1500, 3000, 6000, ... - what a user types into
-// set_num_samples / set_fft_size: hackrf_samples.py:392-405, rtl_samples.py:208-214), up to 8192 points: a mixed-radix
+// set_num_samples / set_fft_size: hackrf_samples.py:392-405, rtl_samples.py:208-214), up to 10 000 points: a mixed-radix
 // Stockham FFT of exactly N points in LDS instead of the chirp-z convolution's two transforms of M >= 2N - 1 points
 // (tdsa_chirp.hip, which keeps every other size).  np.fft.fft / scipy.fft.fft run the same kind of factorisation on the host
 // (hackrf_samples.py:370, rtl_samples.py:170).
