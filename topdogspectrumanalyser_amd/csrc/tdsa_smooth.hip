@@ -66,7 +66,7 @@ __device__ __forceinline__ void dft(c32 (&a)[R]) {
 }
 
 
-// i / d for i < 2^19, d <= 8192 without a division: magic = floor(2^32 / d) + 1
+// i / d for i d < 2^32 (here: i < 2^17, d <= 10 000) without a division: magic = floor(2^32 / d) + 1
 // (magic 0: d = 1)
 __device__ __forceinline__ int div_magic(int i, unsigned magic) { return magic == 0u ? i : int(__umulhi(unsigned(i), magic)); }
 
