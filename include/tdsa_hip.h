@@ -93,7 +93,8 @@ int tdsa_device_count(int* count);
  * nfft: ANY size from 2 to 2^20 (HackrfSamplesDataSource.set_num_samples
  * is unbounded and np.fft.fft takes any N, hackrf_samples.py:392-405, :370): powers of two 64 .. 16384 run as ONE
  * LDS-resident kernel; 2^15 .. 2^20 as N1 x 16384 in two passes (in-register column DFT kernel + a 16384-point
- * row pass); sizes 2^a 3^b 5^c up to 10 000 as a mixed-radix transform of exactly nfft points in LDS (tdsa_smooth.hip);
+ * row pass); sizes 2^a 3^b 5^c as a mixed-radix transform of exactly nfft points (tdsa_smooth.hip: in LDS up to 10 000 points,
+ * two passes above);
  * every other size as a chirp-z convolution on the power-of-two kernels, M = 2^ceil(log2(2 nfft - 1))
  * (tdsa_chirp.hip: same modes, state and outputs, one row per frame; M <= 16384 - sizes up to 8192 - as ONE kernel per
  * call, about 5x the time of a native size; larger M through the long-frame kernels; sizes above 2^19 as four half-length
@@ -375,8 +376,9 @@ int tdsa_profile_read(tdsa_plan p, int* launches, float* total_ms);
  * "avg_wg_min" (batches of more frames take the workgroup-chunk averager scan), "avg_f64_chunks" (1: always the scan
  * over fixed 64-frame chunks with float64 aggregates), "overlap_share" (percent of the CUs an overlapped launch is
  * sized for), "big_group" (long-frame plans: segments per column / row round, 1 .. 64), "chirp_single" (chirp-z plans:
- * 0 = the passes of the convolution as separate kernels instead of one launch), "smooth" (frame lengths 2^a 3^b 5^c up to 10 000 points: 0 = as a chirp-z convolution like every other size that is not a
- * power of two, instead of the mixed-radix transform), "chirp_fuse_big" (chirp-z plans with
+ * 0 = the passes of the convolution as separate kernels instead of one launch), "smooth" (frame lengths 2^a 3^b 5^c: 0 = as a chirp-z convolution like every other size that is not a
+ * power of two, instead of the mixed-radix transform), "smooth_n1" (such sizes above 10 000 points: the column pass's length of the two-pass transform, a divisor with both factors
+ * <= 10 000), "chirp_fuse_big" (chirp-z plans with
  * M > 16384: 0 = the unpack / window / chirp and the power / dB passes as kernels of their own); a library built with
  * -DTDSA_DEV also knows "big_pre_wgs" (empty workgroups ahead of every column pass: tools/c5_xcd_phase.py) and "cu_mask"
  * (the plan's stream confined to a set of CUs: tools/c5_two_plans.py).

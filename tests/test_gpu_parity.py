@@ -172,6 +172,33 @@ def test_sizes_made_of_the_factors_2_3_5(pkg, nfft):
     _check(out, gavg, f"N={nfft} RTL lin 4")
 
 
+@pytest.mark.parametrize("nfft", [10240 + 2560, 12000, 20000, 30000, 50000, 100000, 250000, 600000, 1000000, 1048576 - 65536])
+def test_long_sizes_made_of_the_factors_2_3_5(pkg, nfft):
+    """2^a 3^b 5^c above the LDS limit (10 000 points) up to 2^20: the mixed-radix transform in two passes (n1-point transforms
+    of adjacent columns, times W_N^(n2 k1), through a complex64 buffer, n2-point transforms of adjacent rows: tdsa_smooth.hip)
+    instead of the chirp-z convolution on the long-frame kernels; both paths against the gold, byte and complex64 samples,
+    hold traces, and the RTL branch with exponential averaging."""
+    nf = 3
+    hop = nfft // 2
+    iq = so.synth_iq_int8(hop * (nf - 1) + nfft, 4096, seed=nfft % 1000)
+    gold, gmax, gmin = so.hackrf_batch(iq, nfft, hop, 20e6, precision="gold")
+    for feed, smooth in ((iq, 1), (iq, 0), (so.unpack_iq_int8(iq), 1)):
+        with _hackrf_engine(pkg, nfft, nf, hold_max=True, hold_min=True) as e:
+            e.debug_knob("smooth", smooth)
+            out = e.process(feed, hop=hop, n_frames=nf)
+            mx, mn = e.hold()
+        _check(out, gold, f"N={nfft} {feed.dtype} smooth={smooth}")
+        _check(mx, gmax, "max hold")
+        assert np.array_equal(mx, out.max(axis=0)) and np.array_equal(mn, out.min(axis=0))
+    if nfft <= 100000:
+        golda, _, _ = so.rtl_batch(iq, nfft, nfft, 2e6, precision="gold", avg=("exp", 3))
+        with pkg.SpectrumEngine(nfft, max_frames=nf) as e:
+            e.set_window(so.rtl_window("hanning", nfft).astype(np.float32))
+            e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=-1.0, avg=("exp", 3))
+            out = e.process(iq, hop=nfft)
+        _check(out, golda, f"RTL exp N={nfft}")
+
+
 @pytest.mark.parametrize("nfft", [1000, 6000, 20000, 100003, 600000])
 @pytest.mark.parametrize("fmt", ["i8", "u8", "c64"])
 def test_chirp_plans_every_input_format_and_both_code_paths(pkg, nfft, fmt):
@@ -1489,7 +1516,17 @@ def test_debug_knobs_named_in_the_header_exist_and_unknown_names_are_errors(pkg)
     values = {"num_cu": 128, "overlap_share": 50, "big_group": 16}
     with pkg.SpectrumEngine(1 << 15, max_frames=4) as e:
         for n in shipped:
+            if n == "smooth_n1":                       # (only a two-pass mixed-radix plan has a split to move)
+                with pytest.raises(pkg._native.TdsaError):
+                    e.debug_knob(n, 100)
+                continue
             e.debug_knob(n, values.get(n, 1))
+    with pkg.SpectrumEngine(20000, max_frames=2) as e:
+        e.debug_knob("smooth_n1", 100)
+        with pytest.raises(pkg._native.TdsaError):
+            e.debug_knob("smooth_n1", 7)                # not a divisor
+        with pytest.raises(pkg._native.TdsaError):
+            e.debug_knob("smooth_n1", 1)                # cofactor 20 000 above the LDS limit
         for bad in ("big_pre_wgs", "cu_mask", "no_such_knob", ""):
             with pytest.raises(pkg._native.TdsaError):
                 e.debug_knob(bad, 1)

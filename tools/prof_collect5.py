@@ -152,9 +152,12 @@ def main():
 def chirp_stats():
     """profiles/<TAG>_chirp_kernel_stats.txt: per-kernel time per call and HBM traffic of three chirp-z plans"""
     import collections
-    cfg = {"n1000": "N = 1000, 4096 frames per call (M = 2048: one launch per call)",
-           "n20000": "N = 20 000, 512 frames per call (M = 65536: columns, rows of both transforms in one kernel, columns out)",
-           "n1000000": "N = 1 000 000, 10 frames per call (split plan: four half-length sub-convolutions of 2^20 points)"}
+    cfg = {"n1000": "N = 1000 = 2^3 5^3, 4096 frames per call (mixed-radix transform of N points, tdsa_smooth.hip)",
+           "n1021": "N = 1021 (a prime), 4096 frames per call (chirp-z, M = 2048: the whole convolution in one launch)",
+           "n20000": "N = 20 000 = 2^5 5^4, 512 frames per call (mixed radix in two passes: 125-point columns, 160-point rows)",
+           "n20011": "N = 20 011 (a prime), 512 frames per call (chirp-z, M = 65536: columns, rows of both transforms in one kernel, columns out)",
+           "n1000000": "N = 1 000 000 = 2^6 5^6, 10 frames per call (mixed radix in two passes: 125-point columns, 8000-point rows)",
+           "n999983": "N = 999 983 (a prime), 10 frames per call (chirp-z split plan: four half-length sub-convolutions of 2^20 points)"}
     out = ["# rocprofv3 --kernel-trace --stats around tools/devbench.py (tools/prof_round5.sh), per-kernel average duration per call;",
            "# one devbench step = one tdsa_process_dev call with --hold 1 (max-hold trace folded)"]
     for n in cfg:
@@ -172,7 +175,7 @@ def chirp_stats():
         out.append(f"  sum of kernels {tot:7.1f} us per call")
     out.append("\n## HBM traffic per call (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; KB units; FETCH_SIZE counts 64 B per 128-B "
                "request for wide reads: the upper bound doubles it)")
-    for n, algo in (("n1000", 4096 * 6 * 1000), ("n20000", 512 * 6 * 20000)):
+    for n, algo in (("n1000", 4096 * 6 * 1000), ("n1021", 4096 * 6 * 1021), ("n20000", 512 * 6 * 20000), ("n20011", 512 * 6 * 20011)):
         tot = {}
         for kind, ctr in (("rd", "FETCH_SIZE"), ("wr", "WRITE_SIZE")):
             f = pc3.newest(f"pmc_chirp_{n}_{kind}/**/*counter_collection.csv")

@@ -39,13 +39,20 @@ pmc c4_wr WRITE_SIZE $DEV --nfft 8192 --hop 8192 --frames 65536 --steps 5
 C5="python bench.py --config c5 --steps 2 --warmup 1 --reps 1 --min-region-s 0.05 --preroll-seconds 0 --no-cpu-baseline --no-parity"
 pmc c5_rd FETCH_SIZE $C5
 pmc c5_wr WRITE_SIZE $C5
-# chirp-z plans: kernel stats and traffic of three sizes (one launch; long-frame kernels; split plan)
+# sizes that are not a power of two: kernel stats and traffic (mixed radix; chirp-z: one launch, long-frame kernels, split plan)
 CH="python tools/devbench.py --hold 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_chirp_n1000 -- $CH --nfft 1000 --hop 1000 --frames 4096 --steps 200 --warmup 20 > $OUT/stats_chirp_n1000.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_chirp_n1021 -- $CH --nfft 1021 --hop 1021 --frames 4096 --steps 200 --warmup 20 > $OUT/stats_chirp_n1021.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_chirp_n20000 -- $CH --nfft 20000 --hop 20000 --frames 512 --steps 100 --warmup 10 > $OUT/stats_chirp_n20000.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_chirp_n1000000 -- $CH --nfft 1000000 --hop 1000000 --frames 10 --steps 50 --warmup 5 > $OUT/stats_chirp_n1000000.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_chirp_n20011 -- $CH --nfft 20011 --hop 20011 --frames 512 --steps 100 --warmup 10 > $OUT/stats_chirp_n20011.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_chirp_n999983 -- $CH --nfft 999983 --hop 999983 --frames 10 --steps 50 --warmup 5 > $OUT/stats_chirp_n999983.log 2>&1
 pmc chirp_n1000_rd FETCH_SIZE $CH --nfft 1000 --hop 1000 --frames 4096 --steps 5 --warmup 2
 pmc chirp_n1000_wr WRITE_SIZE $CH --nfft 1000 --hop 1000 --frames 4096 --steps 5 --warmup 2
+pmc chirp_n1021_rd FETCH_SIZE $CH --nfft 1021 --hop 1021 --frames 4096 --steps 5 --warmup 2
+pmc chirp_n1021_wr WRITE_SIZE $CH --nfft 1021 --hop 1021 --frames 4096 --steps 5 --warmup 2
+pmc chirp_n20011_rd FETCH_SIZE $CH --nfft 20011 --hop 20011 --frames 512 --steps 5 --warmup 2
+pmc chirp_n20011_wr WRITE_SIZE $CH --nfft 20011 --hop 20011 --frames 512 --steps 5 --warmup 2
 pmc chirp_n20000_rd FETCH_SIZE $CH --nfft 20000 --hop 20000 --frames 512 --steps 5 --warmup 2
 pmc chirp_n20000_wr WRITE_SIZE $CH --nfft 20000 --hop 20000 --frames 512 --steps 5 --warmup 2
 find $OUT -name "*kernel_stats.csv" | head -10

@@ -121,6 +121,11 @@ struct tdsa_plan_s {
   int smooth_on = 1;                     // tdsa_debug_knob "smooth": 0 = such sizes run as chirp-z convolutions like every other
   int smooth_stages = 0;
   int smooth_radix[kSmoothMaxStages] = {0};
+  // ... above 10 000 points (up to 2^20): two passes, nfft = smooth_n1 * smooth_n2, both within the LDS limit
+  int smooth_n1 = 0, smooth_n2 = 0;
+  int smooth_stages2 = 0;
+  int smooth_radix2[kSmoothMaxStages] = {0};   // the stages of smooth_n2 (smooth_radix: those of smooth_n1)
+  float2* d_smooth_z = nullptr;          // [max_frames][n1][n2] between the passes
   float2* d_smooth_tw = nullptr;         // [nfft] exp(-2 pi i k / nfft)
   int chirp_fuse_big = 1;                // tdsa_debug_knob "chirp_fuse_big": 0 = long chirp-z frames run chirp_pre / chirp_post as their own passes
   int chirp_single = 1;                  // tdsa_debug_knob "chirp_single": 0 = chirp-z plans run chirp_pre / two transforms / chirp_post as separate
@@ -548,7 +553,7 @@ int process_chirp(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n
   const bool smooth = p->smooth && p->smooth_on;      // a transform of exactly N points instead of the convolution
   // ... whose kernel forms the frame means of byte samples itself when the call has few frames (a GUI tick has one: a launch
   // less, 34 -> 28 us per host call at N = 1000; in batches the frame-by-frame reductions cost more than the sums kernel)
-  const bool dc_own = smooth && !in_c64 && m.dc_alpha >= 1.0f && n_frames <= 8;
+  const bool dc_own = smooth && p->smooth_n1 == 0 && !in_c64 && m.dc_alpha >= 1.0f && n_frames <= 8;
   const int twice_zero = in_format == TDSA_IN_I8 ? 256 : (in_c64 ? 0 : 255);
   if (m.dc_alpha >= 0.0f && !dc_own) {
     // frame means as residuals (exact sums); 0 <= alpha < 1: the tracker of the native path fed with them
@@ -598,6 +603,7 @@ int process_chirp(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n
     sp.n_stages = p->smooth_stages;
     for (int i = 0; i < p->smooth_stages; ++i) sp.radix[i] = p->smooth_radix[i];
     sp.tw = p->d_smooth_tw;
+    sp.tw_step = 1;
     sp.window = p->d_window[in_format];
     sp.dc_sub = dc_sub;
     sp.dc_own = dc_own;
@@ -613,7 +619,25 @@ int process_chirp(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n
     sp.tare = post.tare;
     sp.out_db = post.out_db;
     sp.out_lin = post.out_lin;
-    HIPCHK(launch_smooth(sp, s));
+    if (p->smooth_n1 == 0) {
+      HIPCHK(launch_smooth(sp, s));
+    } else {
+      // above the LDS limit: column pass (n1-point transforms of fpw adjacent columns, times W_N^(n2 k1)) into z, row pass
+      // (n2-point transforms of adjacent rows k1) from z to the dB rows
+      if (!p->d_smooth_z) HIPCHK(hipMalloc(&p->d_smooth_z, size_t(p->max_frames) * N * sizeof(float2)));
+      sp.n_total = N;
+      sp.n1 = p->smooth_n1;
+      sp.n2 = p->smooth_n2;
+      sp.z = p->d_smooth_z;
+      sp.n = p->smooth_n1;
+      sp.tw_step = p->smooth_n2;
+      HIPCHK(launch_smooth(sp, s, 1));
+      sp.n = p->smooth_n2;
+      sp.tw_step = p->smooth_n1;
+      sp.n_stages = p->smooth_stages2;
+      for (int i = 0; i < p->smooth_stages2; ++i) sp.radix[i] = p->smooth_radix2[i];
+      HIPCHK(launch_smooth(sp, s, 2));
+    }
     if (post.out_lin == nullptr && (post.hold_max || post.hold_min))
       HIPCHK(launch_chirp_hold(post.out_db, N, n_frames, post.first_frame_index, post.hold_max, post.hold_min, s));
   } else
@@ -719,13 +743,35 @@ int tdsa_create(int device_id, int nfft, int max_frames, tdsa_plan* out) {
   return TDSA_OK;
 }
 
-// nfft = 2^a 3^b 5^c: the radices of its stages (4 while it divides, then 2, 3, 5)
-static void smooth_plan(tdsa_plan p) {
-  int r = p->nfft, st = 0;
-  while (r % 4 == 0 && st < kSmoothMaxStages) { p->smooth_radix[st++] = 4; r /= 4; }
+// n = 2^a 3^b 5^c: the radices of its stages (4 while it divides, then 2, 3, 5); 0 stages: other factors
+static int smooth_radices(int n, int* radix) {
+  int r = n, st = 0;
+  while (r % 4 == 0 && st < kSmoothMaxStages) { radix[st++] = 4; r /= 4; }
   for (const int f : {2, 3, 5})
-    while (r % f == 0 && st < kSmoothMaxStages) { p->smooth_radix[st++] = f; r /= f; }
-  p->smooth_stages = r == 1 ? st : 0;
+    while (r % f == 0 && st < kSmoothMaxStages) { radix[st++] = f; r /= f; }
+  return r == 1 ? st : 0;
+}
+static void smooth_plan(tdsa_plan p) {
+  if (p->nfft <= kSmoothMaxN) {
+    p->smooth_stages = smooth_radices(p->nfft, p->smooth_radix);
+    return;
+  }
+  // two passes, both factors within the LDS limit; the column pass's length n1 near 128 measured best (N = 10^6: 309 us
+  // per ten frames at 125 x 8000 against 389 at 1000 x 1000; N = 20 000: 185 at 125 x 160 against 254 at 2 x 10 000 -
+  // short columns let a workgroup take sixteen adjacent ones, whose raw samples then sit side by side)
+  int best = 0;
+  double best_d = 1e30;
+  for (int d = 2; d <= kSmoothMaxN && d <= p->nfft / 2; ++d)
+    if (p->nfft % d == 0 && p->nfft / d <= kSmoothMaxN) {
+      const double dist = std::fabs(std::log(double(d) / 128.0));
+      if (dist < best_d) { best_d = dist; best = d; }
+    }
+  if (best == 0) return;
+  p->smooth_n1 = best;
+  p->smooth_n2 = p->nfft / best;
+  p->smooth_stages = smooth_radices(p->smooth_n1, p->smooth_radix);
+  p->smooth_stages2 = smooth_radices(p->smooth_n2, p->smooth_radix2);
+  if (p->smooth_stages == 0 || p->smooth_stages2 == 0) p->smooth_stages = p->smooth_stages2 = p->smooth_n1 = p->smooth_n2 = 0;
 }
 
 static int plan_init(tdsa_plan p) {
@@ -850,9 +896,11 @@ static int plan_init(tdsa_plan p) {
     {   // 2^a 3^b 5^c up to 10 000 points: the stages of its mixed-radix transform and W_N^k
       int r = nfft;
       for (const int f : {2, 3, 5}) while (r % f == 0) r /= f;
-      if (r == 1 && nfft <= kSmoothMaxN && nfft >= 4) {
+      if (r == 1 && nfft >= 4) {
         smooth_plan(p);
         p->smooth = p->smooth_stages > 0;
+      }
+      if (p->smooth) {
         std::vector<float2> tw(nfft);
         for (int k = 0; k < nfft; ++k) {
           const double ang = -2.0 * M_PI * double(k) / double(nfft);
@@ -942,7 +990,7 @@ int tdsa_destroy(tdsa_plan p) {
                   p->d_window_perm[2], p->d_tw, p->d_hold_max, p->d_hold_min,
                   p->d_avg, p->d_lin, p->d_carry, p->d_agg, p->d_agg_w, p->d_chunk_a, p->d_chunk_v, p->d_cplx, p->d_real, p->d_lin1, p->d_db1, p->d_dc_state, p->d_sums, p->d_dc_sub,
                   p->d_tare_base, p->d_tare_acc, p->d_in_stage, p->d_out_stage, p->d_trace_in,
-                  p->d_trace_live, p->d_scratch, p->d_z, p->d_welch, p->d_clock, p->d_smooth_tw, p->d_chirp_aw[0], p->d_chirp_aw[1], p->d_chirp_aw[2], p->d_chirp_bm, p->d_chirp_bp, p->d_chirp_a, p->d_chirp_b, p->d_u0, p->d_u1, p->d_acc, p->d_sum, p->d_lin64, p->d_sums64, p->d_tw_seed, p->d_tw_row, p->d_ones,
+                  p->d_trace_live, p->d_scratch, p->d_z, p->d_welch, p->d_clock, p->d_smooth_tw, p->d_smooth_z, p->d_chirp_aw[0], p->d_chirp_aw[1], p->d_chirp_aw[2], p->d_chirp_bm, p->d_chirp_bp, p->d_chirp_a, p->d_chirp_b, p->d_u0, p->d_u1, p->d_acc, p->d_sum, p->d_lin64, p->d_sums64, p->d_tw_seed, p->d_tw_row, p->d_ones,
                   p->d_dbg};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -2073,6 +2121,14 @@ int tdsa_debug_knob(tdsa_plan p, const char* name, int value) {
     p->big_group = value;
   } else if (k == "smooth") {                // sizes 2^a 3^b 5^c <= 8192: 1 = mixed-radix transform of N points (default), 0 = chirp-z
     p->smooth_on = value != 0;
+  } else if (k == "smooth_n1") {             // two-pass sizes: the column pass's transform length (a divisor; both factors <= 10 000)
+    if (!p->smooth || p->smooth_n1 == 0) return fail(TDSA_ERR_STATE, "not a two-pass mixed-radix plan");
+    if (value < 2 || p->nfft % value != 0 || value > kSmoothMaxN || p->nfft / value > kSmoothMaxN)
+      return fail(TDSA_ERR_ARG, "smooth_n1=%d does not split %d into two factors <= %d", value, p->nfft, kSmoothMaxN);
+    p->smooth_n1 = value;
+    p->smooth_n2 = p->nfft / value;
+    p->smooth_stages = smooth_radices(p->smooth_n1, p->smooth_radix);
+    p->smooth_stages2 = smooth_radices(p->smooth_n2, p->smooth_radix2);
   } else if (k == "chirp_fuse_big") {        // long chirp-z frames: 1 = element-wise passes inside the column passes (default)
     p->chirp_fuse_big = value != 0;
   } else if (k == "chirp_single") {          // chirp-z plans: 1 = one launch per call (default), 0 = the separate passes

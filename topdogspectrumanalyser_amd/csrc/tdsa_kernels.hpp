@@ -280,7 +280,10 @@ struct SmoothParams {
   int n_stages;
   int radix[kSmoothMaxStages];   // 4, 2, 3, 5 in any order, product n
   unsigned magic_per[kSmoothMaxStages], magic_s[kSmoothMaxStages];   // division constants (set by the launcher)
-  const float2* tw;          // [n] exp(-2 pi i k / n)
+  const float2* tw;          // [n] exp(-2 pi i k / n)  (two passes: [n_total], the stages use every tw_step-th entry)
+  int tw_step;               // 1; two passes: n_total / n of the pass
+  int n_total, n1, n2;       // two passes: frame length n1 * n2 (column pass: n = n1, row pass: n = n2)
+  float2* z;                 // two passes: [F][n1][n2] between them
   const float* window;       // [n] window * input scale
   const float2* dc_sub;      // [F] DC estimate minus the zero level, raw units, or null
   int dc_own;                // byte samples, per-frame mean removal: the kernel forms the frame means itself (dc_sub unused)
@@ -295,7 +298,7 @@ struct SmoothParams {
   float* out_db;             // [F][n] or null
   float* out_lin;            // [F][n] linear power * pscale (averaging modes) or null
 };
-hipError_t launch_smooth(SmoothParams p, hipStream_t s);
+hipError_t launch_smooth(SmoothParams p, hipStream_t s, int mode = 0);
 
 // ---- frame lengths that are not a power of two, 2 <= N <= 8192 (tdsa_chirp.hip): chirp-z on the frame kernel ----
 constexpr int kChirpMaxN = (1 << 20) - 1; // M = 2^ceil(log2(2N-1)) <= 2^20 up to N = 2^19 (M > 16384: the long-frame kernels); longer

@@ -1,6 +1,6 @@
 // Frame lengths whose only prime factors are 2, 3 and 5 (1000, 1500, 3000, 6000, ... - what a user types into
-// set_num_samples / set_fft_size: hackrf_samples.py:392-405, rtl_samples.py:208-214), up to 10 000 points: a mixed-radix
-// Stockham FFT of exactly N points in LDS instead of the chirp-z convolution's two transforms of M >= 2N - 1 points
+// set_num_samples / set_fft_size: hackrf_samples.py:392-405, rtl_samples.py:208-214): a mixed-radix
+// Stockham FFT of exactly N points - in LDS up to 10 000 points, in two passes above (up to 2^20) - instead of the chirp-z convolution's two transforms of M >= 2N - 1 points
 // (tdsa_chirp.hip, which keeps every other size).  np.fft.fft / scipy.fft.fft run the same kind of factorisation on the host
 // (hackrf_samples.py:370, rtl_samples.py:170).
 //
@@ -74,8 +74,8 @@ __device__ __forceinline__ int div_magic(int i, unsigned magic) { return magic =
 // ST(frame, index, value): LDS for the stages in the middle; the first stage takes its inputs straight from the raw frames
 // (unpack, DC, window) and the last one turns its outputs into the dB / power row - two LDS round trips and two barriers less
 template <int R, typename LD, typename ST>
-__device__ __forceinline__ void stage(const c32* __restrict__ tw, int N, int s, int fpw, int threads, unsigned magic_per,
-                                      unsigned magic_s, LD ld, ST st) {
+__device__ __forceinline__ void stage(const c32* __restrict__ tw, int tw_step, int N, int s, int fpw, int threads,
+                                      unsigned magic_per, unsigned magic_s, LD ld, ST st) {
   const int per = N / R, m = per / s;
   for (int i = threadIdx.x; i < fpw * per; i += threads) {
     const int fr = div_magic(i, magic_per), b = i - fr * per;
@@ -84,7 +84,7 @@ __device__ __forceinline__ void stage(const c32* __restrict__ tw, int N, int s, 
 #pragma unroll
     for (int t = 0; t < R; ++t) a[t] = ld(fr, q + s * (pp + t * m));
     dft<R>(a);
-    const int ws = pp * s;                               // W_n^(p u) = W_N^(p u s)
+    const int ws = pp * s * tw_step;                     // W_n^(p u) = W_N^(p u s); (two passes: W_N = W_Ntotal^tw_step)
     st(fr, q + s * (R * pp), a[0]);
 #pragma unroll
     for (int u = 1; u < R; ++u) st(fr, q + s * (R * pp + u), m == 1 ? a[u] : cmul_(a[u], tw[ws * u]));   // (p u s < N)
@@ -92,31 +92,41 @@ __device__ __forceinline__ void stage(const c32* __restrict__ tw, int N, int s, 
 }
 
 template <typename LD, typename ST>
-__device__ __forceinline__ void stage_r(int r, const c32* tw, int N, int s, int fpw, int threads, unsigned mp, unsigned ms, LD ld, ST st) {
+__device__ __forceinline__ void stage_r(int r, const c32* tw, int tw_step, int N, int s, int fpw, int threads, unsigned mp, unsigned ms,
+                                        LD ld, ST st) {
   switch (r) {
-    case 5: stage<5>(tw, N, s, fpw, threads, mp, ms, ld, st); break;
-    case 4: stage<4>(tw, N, s, fpw, threads, mp, ms, ld, st); break;
-    case 3: stage<3>(tw, N, s, fpw, threads, mp, ms, ld, st); break;
-    default: stage<2>(tw, N, s, fpw, threads, mp, ms, ld, st); break;
+    case 5: stage<5>(tw, tw_step, N, s, fpw, threads, mp, ms, ld, st); break;
+    case 4: stage<4>(tw, tw_step, N, s, fpw, threads, mp, ms, ld, st); break;
+    case 3: stage<3>(tw, tw_step, N, s, fpw, threads, mp, ms, ld, st); break;
+    default: stage<2>(tw, tw_step, N, s, fpw, threads, mp, ms, ld, st); break;
   }
 }
 
 }  // namespace
 
+// MODE 0: frames of p.n points, a workgroup's slots are fpw consecutive frames.
+// Frames of n_total = n1 n2 points above the LDS limit (10 000 < N <= 2^20, still 2^a 3^b 5^c) take two passes through `z`
+// (n = n1' n2 + n2', k = k1 + n1 k2; blockIdx.y = frame):
+// MODE 1: column pass - slots are fpw adjacent columns n2', transform over n1' (p.n = n1), times W_N^(n2' k1), z[k1][n2'];
+// MODE 2: row pass - slots are fpw adjacent rows k1, transform over n2' (p.n = n2), bins k1 + n1 k2 leave as the dB rows.
+template <int MODE>
 __global__ void __launch_bounds__(1024) smooth_kernel(const SmoothParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int N = p.n, fpw = p.fpw, T = blockDim.x;
   c32* buf0 = reinterpret_cast<c32*>(smem);
   c32* buf1 = buf0 + fpw * N;
-  const int f0 = blockIdx.x * fpw;
-  const int nf = p.n_frames - f0 < fpw ? p.n_frames - f0 : fpw;
-  const int half = N / 2;
+  const int f0 = blockIdx.x * fpw;                       // first frame (MODE 0) / column (1) / row (2) of this workgroup
+  const int count = MODE == 0 ? p.n_frames : (MODE == 1 ? p.n2 : p.n1);
+  const int nf = count - f0 < fpw ? count - f0 : fpw;
+  const int NT = MODE == 0 ? N : p.n_total;              // points of a frame
+  const int half = NT / 2;
+  const int fy = MODE == 0 ? 0 : int(blockIdx.y);        // (two passes) the frame
   // per-frame mean removal of byte samples (dc_alpha = 1, the HackRF branch's default) without the sums kernel's launch:
   // exact integer I / Q sums of this workgroup's frames, the residual (2 sum - twice_zero n) / (2 n) formed in double exactly
   // as chirp_sums_kernel forms it - the same bits
   __shared__ float dc_re[16], dc_im[16];
   __shared__ unsigned red_i[16], red_q[16];
-  if (p.dc_own) {
+  if (MODE == 0 && p.dc_own) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = T >> 6;
     for (int fr = 0; fr < nf; ++fr) {
       const uint16_t* xs = reinterpret_cast<const uint16_t*>(static_cast<const unsigned char*>(p.in) + (long long)(f0 + fr) * p.frame_stride);
@@ -143,9 +153,11 @@ __global__ void __launch_bounds__(1024) smooth_kernel(const SmoothParams p) {
     }
   }
   // sample k of frame slot fr: unpack, DC, window x input scale (slots past the call's last frame: zeros)
-  const auto load_raw = [&](int fr, int k) -> c32 {
+  const auto load_raw = [&](int fr, int kk) -> c32 {
     if (fr >= nf) return c32{0.f, 0.f};
-    const int f = f0 + fr;
+    if constexpr (MODE == 2) return p.z[(long long)fy * NT + (long long)(f0 + fr) * p.n2 + kk];
+    const int f = MODE == 0 ? f0 + fr : fy;
+    const int k = MODE == 0 ? kk : kk * p.n2 + f0 + fr;  // (column pass: sample n1' n2 + n2')
     const unsigned char* fb = static_cast<const unsigned char*>(p.in) + (long long)f * p.frame_stride;
     float re, im;
     if (p.in_c64) {
@@ -157,18 +169,24 @@ __global__ void __launch_bounds__(1024) smooth_kernel(const SmoothParams p) {
       re = float(u & 0xffu) - p.in_off;                  // exact: small integers / halves
       im = float(u >> 8) - p.in_off;
     }
-    if (p.dc_own) { re -= dc_re[fr]; im -= dc_im[fr]; }
+    if (MODE == 0 && p.dc_own) { re -= dc_re[fr]; im -= dc_im[fr]; }
     else if (p.dc_sub != nullptr) { const c32 d = p.dc_sub[f]; re -= d.x; im -= d.y; }
     const float w = p.window[k];
     return c32{re * w, im * w};
   };
   // bin k of frame slot fr: |X|^2, fftshift, dB + cal - tare / linear power (chirp_post_kernel's arithmetic)
-  const auto store_bin = [&](int fr, int k, c32 X) {
+  const auto store_bin = [&](int fr, int kk, c32 X) {
     if (fr >= nf) return;
+    if constexpr (MODE == 1) {                           // column pass: times W_N^(n2' k1), to z[k1][n2']
+      const int n2 = f0 + fr;
+      p.z[(long long)fy * NT + (long long)kk * p.n2 + n2] = cmul_(X, p.tw[n2 * kk]);
+      return;
+    }
+    const int k = MODE == 0 ? kk : f0 + fr + p.n1 * kk;  // (row pass: bin k1 + n1 k2)
     int j = k + half;                                    // np.fft.fftshift: bin k lands at (k + N / 2) mod N, any N
-    if (j >= N) j -= N;
+    if (j >= NT) j -= NT;
     const float pw = X.x * X.x + X.y * X.y;
-    const long long o = (long long)(f0 + fr) * N + j;
+    const long long o = (long long)(MODE == 0 ? f0 + fr : fy) * NT + j;
     if (p.out_lin != nullptr) {
       p.out_lin[o] = pw * p.pscale;
     } else {
@@ -190,10 +208,10 @@ __global__ void __launch_bounds__(1024) smooth_kernel(const SmoothParams p) {
     c32* ys = y;
     const auto ld_lds = [=](int fr, int k) -> c32 { return xs[fr * N + k]; };
     const auto st_lds = [=](int fr, int k, c32 v) { ys[fr * N + k] = v; };
-    if (st == 0 && st == last) stage_r(r, p.tw, N, sd, fpw, T, mp, ms, load_raw, store_bin);
-    else if (st == 0) stage_r(r, p.tw, N, sd, fpw, T, mp, ms, load_raw, st_lds);
-    else if (st == last) stage_r(r, p.tw, N, sd, fpw, T, mp, ms, ld_lds, store_bin);
-    else stage_r(r, p.tw, N, sd, fpw, T, mp, ms, ld_lds, st_lds);
+    if (st == 0 && st == last) stage_r(r, p.tw, p.tw_step, N, sd, fpw, T, mp, ms, load_raw, store_bin);
+    else if (st == 0) stage_r(r, p.tw, p.tw_step, N, sd, fpw, T, mp, ms, load_raw, st_lds);
+    else if (st == last) stage_r(r, p.tw, p.tw_step, N, sd, fpw, T, mp, ms, ld_lds, store_bin);
+    else stage_r(r, p.tw, p.tw_step, N, sd, fpw, T, mp, ms, ld_lds, st_lds);
     sd *= r;
     c32* t = x; x = y; y = t;
     if (st != last) __syncthreads();
@@ -210,7 +228,23 @@ int smooth_frames_per_workgroup(int n) {
   return fpw;
 }
 
-hipError_t launch_smooth(SmoothParams p, hipStream_t s) {
+static hipError_t launch_mode(const SmoothParams& p, int mode, dim3 grid, int threads, size_t lds, hipStream_t s) {
+  static size_t attr_done[3] = {0, 0, 0};
+  const void* fn = mode == 0 ? reinterpret_cast<const void*>(smooth_kernel<0>)
+                             : (mode == 1 ? reinterpret_cast<const void*>(smooth_kernel<1>) : reinterpret_cast<const void*>(smooth_kernel<2>));
+  if (lds > attr_done[mode]) {
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (e != hipSuccess) return e;
+    attr_done[mode] = lds;
+  }
+  if (mode == 0) hipLaunchKernelGGL(smooth_kernel<0>, grid, dim3(threads), lds, s, p);
+  else if (mode == 1) hipLaunchKernelGGL(smooth_kernel<1>, grid, dim3(threads), lds, s, p);
+  else hipLaunchKernelGGL(smooth_kernel<2>, grid, dim3(threads), lds, s, p);
+  return hipGetLastError();
+}
+
+// mode 0: p.n = frame length; modes 1 / 2: p.n = n1 / n2 with radix[] the stages of THAT length
+hipError_t launch_smooth(SmoothParams p, hipStream_t s, int mode) {
   p.fpw = smooth_frames_per_workgroup(p.n);
   const auto magic = [](int d) { return d == 1 ? 0u : unsigned((1ull << 32) / unsigned(d)) + 1u; };
   int sd = 1;
@@ -223,15 +257,9 @@ hipError_t launch_smooth(SmoothParams p, hipStream_t s) {
   int threads = ((p.fpw * p.n / 4 + 63) / 64) * 64;
   threads = threads < 64 ? 64 : (threads > 1024 ? 1024 : threads);
   const size_t lds = size_t(2) * p.fpw * p.n * sizeof(float2);
-  static size_t attr_done = 0;
-  if (lds > attr_done) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(smooth_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-    if (e != hipSuccess) return e;
-    attr_done = lds;
-  }
-  const int grid = (p.n_frames + p.fpw - 1) / p.fpw;
-  hipLaunchKernelGGL(smooth_kernel, dim3(grid), dim3(threads), lds, s, p);
-  return hipGetLastError();
+  const int count = mode == 0 ? p.n_frames : (mode == 1 ? p.n2 : p.n1);
+  const dim3 grid((count + p.fpw - 1) / p.fpw, mode == 0 ? 1 : p.n_frames);
+  return launch_mode(p, mode, grid, threads, lds, s);
 }
 
 }  // namespace tdsa
