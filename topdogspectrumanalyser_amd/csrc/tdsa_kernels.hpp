@@ -279,7 +279,7 @@ struct SmoothParams {
   int n, n_frames, fpw;      // fpw: frames per workgroup (set by the launcher)
   int n_stages;
   int radix[kSmoothMaxStages];   // 4, 2, 3, 5 in any order, product n
-  unsigned magic_per[kSmoothMaxStages], magic_s[kSmoothMaxStages];   // division constants (set by the launcher)
+  unsigned magic_per[kSmoothMaxStages], magic_s[kSmoothMaxStages], magic_fpw;   // division constants (set by the launcher)
   const float2* tw;          // [n] exp(-2 pi i k / n)  (two passes: [n_total], the stages use every tw_step-th entry)
   int tw_step;               // 1; two passes: n_total / n of the pass
   int n_total, n1, n2;       // two passes: frame length n1 * n2 (column pass: n = n1, row pass: n = n2)

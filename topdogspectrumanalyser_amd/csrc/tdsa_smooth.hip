@@ -73,12 +73,16 @@ __device__ __forceinline__ int div_magic(int i, unsigned magic) { return magic =
 // one stage over the workgroup's FPW frames: butterflies i = (frame, p, q) spread over the threads.  LD(frame, index) /
 // ST(frame, index, value): LDS for the stages in the middle; the first stage takes its inputs straight from the raw frames
 // (unpack, DC, window) and the last one turns its outputs into the dB / power row - two LDS round trips and two barriers less
-template <int R, typename LD, typename ST>
+// FRFAST: neighbouring threads take the same butterfly of neighbouring slots (two-pass transforms: the slots are adjacent
+// columns / rows, whose global elements sit side by side) instead of neighbouring butterflies of one slot
+template <int R, bool FRFAST, typename LD, typename ST>
 __device__ __forceinline__ void stage(const c32* __restrict__ tw, int tw_step, int N, int s, int fpw, int threads,
-                                      unsigned magic_per, unsigned magic_s, LD ld, ST st) {
+                                      unsigned magic_per, unsigned magic_s, unsigned magic_fpw, LD ld, ST st) {
   const int per = N / R, m = per / s;
   for (int i = threadIdx.x; i < fpw * per; i += threads) {
-    const int fr = div_magic(i, magic_per), b = i - fr * per;
+    int fr, b;
+    if constexpr (FRFAST) { b = div_magic(i, magic_fpw); fr = i - b * fpw; }
+    else { fr = div_magic(i, magic_per); b = i - fr * per; }
     const int pp = s == 1 ? b : div_magic(b, magic_s), q = b - pp * s;
     c32 a[R];
 #pragma unroll
@@ -91,14 +95,14 @@ __device__ __forceinline__ void stage(const c32* __restrict__ tw, int tw_step, i
   }
 }
 
-template <typename LD, typename ST>
+template <bool FRFAST, typename LD, typename ST>
 __device__ __forceinline__ void stage_r(int r, const c32* tw, int tw_step, int N, int s, int fpw, int threads, unsigned mp, unsigned ms,
-                                        LD ld, ST st) {
+                                        unsigned mf, LD ld, ST st) {
   switch (r) {
-    case 5: stage<5>(tw, tw_step, N, s, fpw, threads, mp, ms, ld, st); break;
-    case 4: stage<4>(tw, tw_step, N, s, fpw, threads, mp, ms, ld, st); break;
-    case 3: stage<3>(tw, tw_step, N, s, fpw, threads, mp, ms, ld, st); break;
-    default: stage<2>(tw, tw_step, N, s, fpw, threads, mp, ms, ld, st); break;
+    case 5: stage<5, FRFAST>(tw, tw_step, N, s, fpw, threads, mp, ms, mf, ld, st); break;
+    case 4: stage<4, FRFAST>(tw, tw_step, N, s, fpw, threads, mp, ms, mf, ld, st); break;
+    case 3: stage<3, FRFAST>(tw, tw_step, N, s, fpw, threads, mp, ms, mf, ld, st); break;
+    default: stage<2, FRFAST>(tw, tw_step, N, s, fpw, threads, mp, ms, mf, ld, st); break;
   }
 }
 
@@ -113,8 +117,9 @@ template <int MODE>
 __global__ void __launch_bounds__(1024) smooth_kernel(const SmoothParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int N = p.n, fpw = p.fpw, T = blockDim.x;
+  const int Ns = MODE == 0 ? N : (N | 1);                // LDS stride of a slot (two passes: odd, neighbouring slots on other banks)
   c32* buf0 = reinterpret_cast<c32*>(smem);
-  c32* buf1 = buf0 + fpw * N;
+  c32* buf1 = buf0 + fpw * Ns;
   const int f0 = blockIdx.x * fpw;                       // first frame (MODE 0) / column (1) / row (2) of this workgroup
   const int count = MODE == 0 ? p.n_frames : (MODE == 1 ? p.n2 : p.n1);
   const int nf = count - f0 < fpw ? count - f0 : fpw;
@@ -206,12 +211,16 @@ __global__ void __launch_bounds__(1024) smooth_kernel(const SmoothParams p) {
     const unsigned mp = p.magic_per[st], ms = p.magic_s[st];
     const c32* xs = x;
     c32* ys = y;
-    const auto ld_lds = [=](int fr, int k) -> c32 { return xs[fr * N + k]; };
-    const auto st_lds = [=](int fr, int k, c32 v) { ys[fr * N + k] = v; };
-    if (st == 0 && st == last) stage_r(r, p.tw, p.tw_step, N, sd, fpw, T, mp, ms, load_raw, store_bin);
-    else if (st == 0) stage_r(r, p.tw, p.tw_step, N, sd, fpw, T, mp, ms, load_raw, st_lds);
-    else if (st == last) stage_r(r, p.tw, p.tw_step, N, sd, fpw, T, mp, ms, ld_lds, store_bin);
-    else stage_r(r, p.tw, p.tw_step, N, sd, fpw, T, mp, ms, ld_lds, st_lds);
+    const auto ld_lds = [=](int fr, int k) -> c32 { return xs[fr * Ns + k]; };
+    const auto st_lds = [=](int fr, int k, c32 v) { ys[fr * Ns + k] = v; };
+    const unsigned mf = p.magic_fpw;
+    // column pass: its first stage reads and its last stage writes elements that are adjacent across the slots; row pass:
+    // the last stage's bins are (the first stage reads along a row: adjacent across the butterflies)
+    constexpr bool F0 = MODE == 1, FL = MODE != 0;
+    if (st == 0 && st == last) stage_r<FL>(r, p.tw, p.tw_step, N, sd, fpw, T, mp, ms, mf, load_raw, store_bin);
+    else if (st == 0) stage_r<F0>(r, p.tw, p.tw_step, N, sd, fpw, T, mp, ms, mf, load_raw, st_lds);
+    else if (st == last) stage_r<FL>(r, p.tw, p.tw_step, N, sd, fpw, T, mp, ms, mf, ld_lds, store_bin);
+    else stage_r<false>(r, p.tw, p.tw_step, N, sd, fpw, T, mp, ms, mf, ld_lds, st_lds);
     sd *= r;
     c32* t = x; x = y; y = t;
     if (st != last) __syncthreads();
@@ -256,7 +265,8 @@ hipError_t launch_smooth(SmoothParams p, hipStream_t s, int mode) {
   // a thread per four points, whole waves, at most 1024
   int threads = ((p.fpw * p.n / 4 + 63) / 64) * 64;
   threads = threads < 64 ? 64 : (threads > 1024 ? 1024 : threads);
-  const size_t lds = size_t(2) * p.fpw * p.n * sizeof(float2);
+  p.magic_fpw = magic(p.fpw);
+  const size_t lds = size_t(2) * p.fpw * (mode == 0 ? p.n : (p.n | 1)) * sizeof(float2);
   const int count = mode == 0 ? p.n_frames : (mode == 1 ? p.n2 : p.n1);
   const dim3 grid((count + p.fpw - 1) / p.fpw, mode == 0 ? 1 : p.n_frames);
   return launch_mode(p, mode, grid, threads, lds, s);
