@@ -270,11 +270,28 @@ int tdsa_set_overlap(tdsa_plan p, int n_streams);
  *                      separated by a valley min_excursion_db below both; bins [n_rows][n_peaks] padded
  *                      with -1 (dB padded with NaN).  n_bins <= 16384 (the row lives in LDS).  Equal-valued
  *                      candidates are visited larger index first (the reference's order for ties is that
- *                      of np.argsort's unstable sort). */
+ *                      of np.argsort's unstable sort).
+ * tdsa_rows_marker_peaks  MarkerManager.snap_to_peak / snap_to_next_peak (core/marker_manager.py:74-127): per row
+ *                      scipy.signal.find_peaks(levels, height=, prominence=, distance=) - local maxima (a flat top
+ *                      counts once, at its middle; never the first / last sample), height >= `height`, from the
+ *                      highest peak down every peak closer than `distance` bins to a kept one is removed, then
+ *                      prominence >= `prominence` (float64, the walk scipy does with wlen = None) - and what the
+ *                      two methods take from it: snap_bin = the highest peak (first of equals), or np.argmax of
+ *                      the row when no peak qualifies (:93-97); next_bin = the first peak right of current_idx
+ *                      (= np.searchsorted(bins, marker position)), wrapping to the first peak, -1 when there is
+ *                      none (:120-126: the marker stays).  The reference calls it with height = peak_threshold
+ *                      (default -200), prominence = peak_excursion (default 6), distance = 3.  Optionally the
+ *                      first max_list peaks in bin order (padded with -1) and their prominences (NaN).  Any
+ *                      output pointer may be NULL.  n_bins <= 16384.  Two EQUAL peaks closer than `distance`:
+ *                      the larger bin is kept (scipy orders them by np.argsort, whose default sort is not stable:
+ *                      the reference's choice between them depends on the CPU's sorting network). */
 int tdsa_rows_stats(tdsa_plan p, const float* rows_dev, int n_rows, int n_bins, int band_lo, int band_hi,
                     double bin_width, float* peak_db_host, int32_t* peak_bin_host, double* band_db_host);
 int tdsa_rows_top_peaks(tdsa_plan p, const float* rows_dev, int n_rows, int n_bins, int n_peaks, int min_sep_bins,
                         float min_excursion_db, int32_t* peak_bins_host, float* peak_db_host);
+int tdsa_rows_marker_peaks(tdsa_plan p, const float* rows_dev, int n_rows, int n_bins, double height, double prominence,
+                           int distance, int current_idx, int max_list, int32_t* n_peaks_host, int32_t* snap_bin_host,
+                           int32_t* next_bin_host, int32_t* peak_bins_host, double* peak_prom_host);
 
 /* -------- display accumulators kept on the device ---------------------------
  * tdsa_density: DensityDisplay._hist (displays/density_display.py:300-320): float32 [n_bins][512]

@@ -177,3 +177,102 @@ class WaterfallOracle:
 
     def view(self) -> np.ndarray:
         return self.buf[self.ptr:self.ptr + self.H]
+
+
+# ---- marker peak search (core/marker_manager.py:74-127) -----------------------------------------------------------
+# The arithmetic lives in scipy.signal.find_peaks (third party: scipy == 1.16.3 pinned in the reference's
+# requirements.txt:99, 1.15.3 in this image; scipy/signal/_peak_finding.py + _peak_finding_utils.pyx, unchanged between
+# the two), called as find_peaks(levels, height=threshold, prominence=excursion, distance=3).  Restated here from its
+# published algorithm, pinned by tests/golden/markers.npz (captured from the imported MarkerManager running the real
+# scipy, generator tests/golden/make_golden_markers.py).
+
+def _local_maxima(x: np.ndarray) -> np.ndarray:
+    """scipy _local_maxima_1d: samples (or the middle `(left + right) // 2` of flat tops) that rise strictly before and
+    fall strictly after; the first and last sample never count, and a plateau that reaches the last sample is no peak."""
+    n = len(x)
+    out = []
+    i, i_max = 1, n - 1
+    while i < i_max:
+        if x[i - 1] < x[i]:
+            ahead = i + 1
+            while ahead < i_max and x[ahead] == x[i]:
+                ahead += 1
+            if x[ahead] < x[i]:
+                out.append((i + ahead - 1) // 2)
+                i = ahead
+        i += 1
+    return np.array(out, dtype=np.intp)
+
+
+def _select_by_distance(peaks: np.ndarray, priority: np.ndarray, distance: float) -> np.ndarray:
+    """scipy _select_by_peak_distance: from the highest peak down, a kept peak removes every peak closer than
+    ceil(distance) samples.  Equal heights: scipy walks np.argsort(priority) backwards, and numpy's default argsort is
+    not a stable sort, so the reference's order between EQUAL peaks closer than `distance` is not defined; here (and on
+    the device) the larger index goes first, which is what a stable sort gives."""
+    d = int(np.ceil(distance))
+    keep = np.ones(len(peaks), dtype=bool)
+    order = np.argsort(priority, kind="stable")
+    for j in order[::-1]:
+        if not keep[j]:
+            continue
+        k = j - 1
+        while k >= 0 and peaks[j] - peaks[k] < d:
+            keep[k] = False
+            k -= 1
+        k = j + 1
+        while k < len(peaks) and peaks[k] - peaks[j] < d:
+            keep[k] = False
+            k += 1
+    return keep
+
+
+def _prominences(x: np.ndarray, peaks: np.ndarray) -> np.ndarray:
+    """scipy _peak_prominences (wlen = None): walk outwards from the peak while the samples are <= the peak, the lowest
+    sample met on each side is that side's base, prominence = peak - the higher base."""
+    n = len(x)
+    out = np.empty(len(peaks), dtype=np.float64)
+    for m, p in enumerate(peaks):
+        i, left_min = p, x[p]
+        while i >= 0 and x[i] <= x[p]:
+            if x[i] < left_min:
+                left_min = x[i]
+            i -= 1
+        i, right_min = p, x[p]
+        while i < n and x[i] <= x[p]:
+            if x[i] < right_min:
+                right_min = x[i]
+            i += 1
+        out[m] = x[p] - max(left_min, right_min)
+    return out
+
+
+def marker_find_peaks(levels: np.ndarray, height: float = -200.0, prominence: float = 6.0, distance: float = 3):
+    """find_peaks(levels, height=, prominence=, distance=) as marker_manager.py:90-91 / 117-118 calls it: conditions in
+    scipy's order - local maxima, height, distance, prominence - on the trace as float64.
+    Returns (peaks, peak_heights, prominences)."""
+    x = np.asarray(levels, dtype=np.float64)
+    peaks = _local_maxima(x)
+    peaks = peaks[x[peaks] >= height]
+    peaks = peaks[_select_by_distance(peaks, x[peaks], distance)]
+    prom = _prominences(x, peaks)
+    ok = prom >= prominence
+    return peaks[ok], x[peaks[ok]], prom[ok]
+
+
+def snap_to_peak_bin(levels: np.ndarray, height: float = -200.0, prominence: float = 6.0, distance: float = 3) -> int:
+    """marker_manager.py:93-97: the highest qualifying peak (first of equals), else np.argmax of the trace."""
+    peaks, heights, _ = marker_find_peaks(levels, height, prominence, distance)
+    if len(peaks) > 0:
+        return int(peaks[int(np.argmax(heights))])
+    return int(np.argmax(levels))
+
+
+def snap_to_next_peak_bin(levels: np.ndarray, current_idx: int, height: float = -200.0, prominence: float = 6.0,
+                          distance: float = 3) -> int:
+    """marker_manager.py:120-126: first qualifying peak right of current_idx (= np.searchsorted(bins, position)),
+    wrapping to the first peak; -1 when there is no peak (the reference then leaves the marker where it is)."""
+    peaks, _, _ = marker_find_peaks(levels, height, prominence, distance)
+    if len(peaks) == 0:
+        return -1
+    right = peaks[peaks > current_idx]
+    return int(right[0]) if len(right) > 0 else int(peaks[0])

@@ -125,3 +125,64 @@ def test_waterfall_oracle_matches_reference_fixture(golden_dir):
         assert w.ptr == int(g["wf_ptr"][step])
         if step in steps:
             assert np.array_equal(w.view(), g["wf_views"][steps[step]])
+
+
+# ---- marker peak search: oracle vs what the imported MarkerManager did (tests/golden/markers.npz) ------------------
+@pytest.fixture(scope="module")
+def markers(golden_dir):
+    return np.load(os.path.join(golden_dir, "markers.npz"))
+
+
+def marker_case(markers, key):
+    _, n, kind, _ = key.split("_")
+    thr, exc, dist, start = markers[key + "_params"]
+    return markers[f"trace_{n}_{kind}"], float(thr), float(exc), int(dist), int(start)
+
+
+def test_marker_find_peaks_matches_reference(markers):
+    assert len(markers["cases"]) >= 32
+    some_peaks = some_fallback = some_plateau = 0
+    for key in map(str, markers["cases"]):
+        tr, thr, exc, dist, start = marker_case(markers, key)
+        pk, heights, prom = ao.marker_find_peaks(tr, thr, exc, dist)
+        assert np.array_equal(pk, markers[key + "_peaks"]), key
+        assert np.array_equal(prom, markers[key + "_prom"]), key
+        assert np.array_equal(heights, tr[pk].astype(np.float64)), key
+        assert ao.snap_to_peak_bin(tr, thr, exc, dist) == int(markers[key + "_snap"]), key
+        pos, walk = start, []
+        for _ in range(len(markers[key + "_walk"])):
+            nxt = ao.snap_to_next_peak_bin(tr, pos, thr, exc, dist)
+            pos = pos if nxt < 0 else nxt                     # no peak: the reference leaves the marker alone
+            walk.append(pos)
+        assert walk == list(markers[key + "_walk"]), key
+        some_peaks += len(pk) > 0
+        some_fallback += len(pk) == 0
+        some_plateau += bool(np.any(tr[pk] == tr[np.minimum(pk + 1, len(tr) - 1)])) if len(pk) else 0
+    assert some_peaks and some_fallback and some_plateau     # the fixture exercises every branch
+
+
+def test_marker_find_peaks_edge_cases():
+    flat = np.zeros(16, dtype=np.float32)
+    assert len(ao.marker_find_peaks(flat)[0]) == 0 and ao.snap_to_peak_bin(flat) == 0
+    assert ao.snap_to_next_peak_bin(flat, 5) == -1
+    x = np.full(32, -100.0, dtype=np.float32)
+    x[10:13] = -20.0                                          # flat top of three: its middle
+    x[28:] = -10.0                                            # a plateau that runs into the last sample is no peak
+    pk, h, pr = ao.marker_find_peaks(x)
+    assert list(pk) == [11] and h[0] == -20.0 and pr[0] == 80.0
+    x[20], x[22] = -30.0, -31.0                               # closer than 3 bins: the higher one stays
+    assert list(ao.marker_find_peaks(x)[0]) == [11, 20]
+    assert list(ao.marker_find_peaks(x, distance=1)[0]) == [11, 20, 22]
+    assert list(ao.marker_find_peaks(x, height=-25.0)[0]) == [11]
+    # prominence: the walk stops at the first higher sample on each side, the higher of the two bases counts
+    y = np.full(32, -100.0, dtype=np.float32)
+    y[16:25] = [-28.0, -35.0, -34.0, -32.0, -30.0, -33.0, -31.0, -34.0, -29.0]
+    y[5] = -10.0
+    pk, _, pr = ao.marker_find_peaks(y, prominence=0.0)
+    assert list(pk) == [5, 16, 20, 24] and list(pr) == [90.0, 72.0, 4.0, 6.0]      # 22 fell to the distance rule
+    assert list(ao.marker_find_peaks(y, prominence=6.0)[0]) == [5, 16, 24]          # `>=`: exactly 6 dB qualifies
+    assert ao.snap_to_next_peak_bin(y, 24, prominence=6.0) == 5          # wraps to the first peak
+    assert ao.snap_to_next_peak_bin(y, 5, prominence=6.0) == 16
+    z = x.copy()
+    z[3] = np.nan                                             # NaN: no comparison holds, walks stop there
+    assert list(ao.marker_find_peaks(z)[0]) == [11, 20]

@@ -377,3 +377,115 @@ def test_top_peaks_random_traces(pkg, an, seed):
             j = next(i for i, (a, b) in enumerate(zip(got + [-1], want + [-1])) if a != b)
             assert j < len(got) and j < len(want) and tr[got[j]] == tr[want[j]], (seed, r, got, want)
         assert np.array_equal(db[r][: len(got)], tr[got])
+
+
+# ---- marker peak search (core/marker_manager.py:74-127) ----------------------------------------------------------
+@pytest.fixture(scope="module")
+def markers(golden_dir):
+    return np.load(os.path.join(golden_dir, "markers.npz"))
+
+
+def test_marker_peaks_match_reference_vectors(pkg, an, markers):
+    """Every case of tests/golden/markers.npz (what the imported MarkerManager did, real scipy find_peaks): the snap
+    target, a walk of snap_to_next_peak calls, the peak list and the prominences, bit for bit."""
+    keys = [str(k) for k in markers["cases"]]
+    assert len(keys) >= 32
+    for key in keys:
+        _, n, kind, _ = key.split("_")
+        n = int(n)
+        tr = markers[f"trace_{n}_{kind}"]
+        thr, exc, dist, start = markers[key + "_params"]
+        want_pk, want_prom = markers[key + "_peaks"], markers[key + "_prom"]
+        cap = max(len(want_pk) + 3, 8)
+        with pkg.SpectrumEngine(max(1 << (n - 1).bit_length(), 64), max_frames=1) as e, DevRows(pkg, tr[None, :]) as d:
+            kw = {} if bool(markers[key + "_defaults"]) else dict(peak_threshold=float(thr), peak_excursion=float(exc))
+            r = an.rows_marker_peaks(e, d, 1, n_bins=n, current_idx=int(start), max_list=cap, **kw)
+            assert r["n_peaks"][0] == len(want_pk), key
+            assert np.array_equal(r["peaks"][0][: len(want_pk)], want_pk), key
+            assert np.all(r["peaks"][0][len(want_pk):] == -1), key
+            assert np.array_equal(r["prominences"][0][: len(want_pk)], want_prom), key
+            assert np.all(np.isnan(r["prominences"][0][len(want_pk):])), key
+            assert r["snap_bin"][0] == int(markers[key + "_snap"]), key
+            pos, walk = int(start), []
+            for _ in range(len(markers[key + "_walk"])):
+                nxt = int(an.rows_marker_peaks(e, d, 1, n_bins=n, current_idx=pos, **kw)["next_bin"][0])
+                pos = pos if nxt < 0 else nxt
+                walk.append(pos)
+            assert walk == list(markers[key + "_walk"]), key
+            # a list shorter than the peaks: the first ones in bin order
+            if len(want_pk) > 2:
+                short = an.rows_marker_peaks(e, d, 1, n_bins=n, max_list=2, **kw)
+                assert list(short["peaks"][0]) == list(want_pk[:2]) and short["n_peaks"][0] == len(want_pk)
+
+
+def _marker_rows(rng, n, count):
+    rows = []
+    for _ in range(count):
+        k = np.arange(n)
+        kind = int(rng.integers(0, 6))
+        p = rng.exponential(1.0, size=n) * 10.0 ** rng.uniform(-12, -6)
+        for _t in range(int(rng.integers(0, 7))):
+            c, a, w = rng.integers(0, n), 10.0 ** rng.uniform(-9, -2), rng.uniform(0.6, 4.0)
+            p += a * np.sinc((k - c) / w) ** 2
+        tr = 10 * np.log10(p + 1e-15)
+        if kind == 1:
+            tr = np.round(tr * 2) / 2                              # equal values, flat tops
+        elif kind == 2:
+            tr = np.minimum(tr, np.percentile(tr, 97))             # clipped: long plateaus
+        elif kind == 3:
+            tr = np.full(n, -120.0)                                # flat row (+ one flat-topped bump)
+            a = int(rng.integers(1, max(2, n - 40)))
+            tr[a:a + int(rng.integers(1, 38))] = -60.0
+        elif kind == 4:
+            tr = np.round(rng.normal(-80, 2, n))                   # dense ties
+        elif kind == 5 and n > 8:
+            tr[rng.integers(0, n, 3)] = np.nan
+        rows.append(tr.astype(np.float32))
+    return np.stack(rows)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TDSA_SWEEP_CASES", "24"))))
+def test_marker_peaks_random_traces(pkg, an, seed):
+    """Seeded random rows (noise, tone combs, quantised and clipped traces, flat rows, NaNs; any length from 3 bins to
+    16384, distances 1 ... 40) against the restatement of scipy's find_peaks, a batch of rows per call."""
+    rng = np.random.default_rng(31000 + seed)
+    n = int(rng.choice([3, 5, 33, 64, 1000, 1024, 4096, 5000, 16384, int(rng.integers(3, 16385))]))
+    rows = _marker_rows(rng, n, 10)
+    thr = float(rng.choice([-200.0, -90.0, -75.0]))
+    exc = float(rng.choice([0.0, 3.0, 6.0, 10.0]))
+    dist = int(rng.choice([1, 2, 3, 3, 3, 7, 40]))
+    cur = int(rng.integers(-1, n + 1))
+    with pkg.SpectrumEngine(64, max_frames=1) as e, DevRows(pkg, rows) as d:
+        r = an.rows_marker_peaks(e, d, len(rows), n_bins=n, peak_threshold=thr, peak_excursion=exc, distance=dist,
+                                 current_idx=cur, max_list=n // 2 + 1)
+    for i, tr in enumerate(rows):
+        pk, _, prom = ao.marker_find_peaks(tr, thr, exc, dist)
+        got = r["peaks"][i][: r["n_peaks"][i]]
+        assert np.array_equal(got, pk), (seed, i, n, dist)
+        assert np.array_equal(r["prominences"][i][: len(pk)], prom), (seed, i)
+        assert r["snap_bin"][i] == ao.snap_to_peak_bin(tr, thr, exc, dist), (seed, i)
+        assert r["next_bin"][i] == ao.snap_to_next_peak_bin(tr, cur, thr, exc, dist), (seed, i)
+
+
+def test_marker_peaks_on_spectra_and_errors(pkg, an):
+    """C3-shaped GPU spectra (64 frames) row by row against the restatement, and the argument checks."""
+    nfft, hop, nf = 16384, 8192, 64
+    iq = so.synth_iq_int8(hop * (nf - 1) + nfft, nfft, seed=78)
+    with pkg.SpectrumEngine(nfft, max_frames=nf) as e:
+        e.set_window(so.hackrf_window(nfft))
+        e.configure(db_mode="mag", log_floor=so.LOG_FLOOR, dc_alpha=1.0)
+        rows = e.process(iq, hop=hop)
+        with DevRows(pkg, rows) as d:
+            r = an.rows_marker_peaks(e, d, nf, current_idx=nfft // 2, max_list=nfft // 2)
+            for i in range(nf):
+                pk, _, prom = ao.marker_find_peaks(rows[i])
+                assert np.array_equal(r["peaks"][i][: r["n_peaks"][i]], pk), i
+                assert np.array_equal(r["prominences"][i][: len(pk)], prom), i
+                assert r["snap_bin"][i] == ao.snap_to_peak_bin(rows[i])
+                assert r["next_bin"][i] == ao.snap_to_next_peak_bin(rows[i], nfft // 2)
+            with pytest.raises(Exception):
+                an.rows_marker_peaks(e, d, 1, n_bins=32768)
+            with pytest.raises(Exception):
+                an.rows_marker_peaks(e, d, 1, distance=0)
+            with pytest.raises(Exception):
+                an.rows_marker_peaks(e, d, 1, peak_excursion=float("nan"))

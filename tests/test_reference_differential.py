@@ -493,6 +493,63 @@ def test_band_power_oracle_random(ref_analytics):
             assert (np.isnan(want) and np.isnan(got)) or want == got, (case, want, got)
 
 
+def test_marker_peak_search_oracle_random(ref_analytics):
+    """oracle.marker_find_peaks / snap_to_peak_bin / snap_to_next_peak_bin against the imported MarkerManager (which
+    runs the real scipy.signal.find_peaks) through random traces, thresholds, excursions and marker positions.
+    Pairs of EQUAL maxima closer than 3 bins are broken up first: between those the reference follows numpy's
+    unstable argsort (see oracle/analytics_oracle.py::_select_by_distance)."""
+    from oracle import analytics_oracle as ao
+    rng = np.random.default_rng(2718)
+    moved = stayed = fallback = 0
+    for case in range(120):
+        n = int(rng.integers(3, 4000))
+        k = np.arange(n)
+        p = rng.exponential(1.0, n) * 10.0 ** rng.uniform(-12, -6)
+        for _ in range(int(rng.integers(0, 6))):
+            p += 10.0 ** rng.uniform(-9, -2) * np.sinc((k - rng.integers(0, n)) / rng.uniform(0.6, 4.0)) ** 2
+        tr = 10 * np.log10(p + 1e-15)
+        mode = int(rng.integers(0, 4))
+        if mode == 1:
+            tr = np.round(tr * 2) / 2
+        elif mode == 2:
+            tr = np.minimum(tr, np.percentile(tr, 95))
+        elif mode == 3:
+            tr = -100 + 10.0 * k / n                                       # nothing qualifies
+        tr = tr.astype(np.float32)
+        for _ in range(1000):                                               # no equal maxima closer than 3 bins
+            lm = ao._local_maxima(tr.astype(np.float64))
+            hit = [b for a, b in zip(lm, lm[1:]) if b - a < 3 and tr[a] == tr[b]]
+            if not hit:
+                break
+            tr[hit] += np.float32(0.5)
+        fb = np.linspace(88e6, 108e6, n)
+        mw = types.SimpleNamespace(frequency_bins=fb, live_power_levels=tr)
+        thr, exc = -200.0, 6.0
+        if rng.integers(0, 3):
+            thr, exc = float(rng.choice([-200.0, -90.0, -70.0])), float(rng.choice([0.5, 3.0, 6.0, 10.0]))
+            mw.peak_threshold, mw.peak_excursion = thr, exc
+        mm = ref_analytics.markers(mw)
+        mm._sync_display = lambda name: None
+        mm._refresh_status = lambda: None
+        mm.active_marker = "F1"
+        f1 = mm.markers["F1"]
+        f1.enabled, f1.position = True, float(fb[0])
+        mm.snap_to_peak()
+        assert f1.position == fb[ao.snap_to_peak_bin(tr, thr, exc, 3)], case
+        fallback += len(ao.marker_find_peaks(tr, thr, exc, 3)[0]) == 0
+        # the marker sits anywhere on the axis (also between bins and outside it)
+        f1.position = float(rng.uniform(fb[0] - 1e5, fb[-1] + 1e5))
+        for _ in range(5):
+            before = f1.position
+            cur = int(np.searchsorted(fb, before))
+            mm.snap_to_next_peak()
+            nxt = ao.snap_to_next_peak_bin(tr, cur, thr, exc, 3)
+            assert f1.position == (before if nxt < 0 else fb[nxt]), case
+            moved += nxt >= 0
+            stayed += nxt < 0
+    assert moved and stayed and fallback
+
+
 def test_duty_cycle_oracle_random(ref_analytics):
     from oracle import analytics_oracle as ao
     rng = np.random.default_rng(42)

@@ -6,6 +6,8 @@ HostPipe) and returns scalars or a small image, so a batch user never reads the 
   rows_stats        np.max / np.argmax per row (DutyCycleAnalyser.update_from_power, core/duty_cycle.py:36;
                     marker snap fallback core/marker_manager.py:97) + MarkerManager._band_power (:308-319)
   rows_top_peaks    DataProcessor._find_top_peaks (core/display_data_processor.py:432-471)
+  rows_marker_peaks MarkerManager.snap_to_peak / snap_to_next_peak (core/marker_manager.py:74-127): scipy's
+                    find_peaks(height, prominence, distance) per row + the bin each method would move the marker to
   DutyCycle         DutyCycleAnalyser (core/duty_cycle.py) fed with device-computed per-frame peaks
   DensityHistogram  DensityDisplay._hist (displays/density_display.py:300-320)
   WaterfallRing     Waterfall._buf / _add_row / _display_view (displays/waterfall.py:163-180, 330-336)
@@ -67,6 +69,32 @@ def rows_top_peaks(engine: SpectrumEngine, rows_dev: int, n_rows: int, n_bins: O
     nat.check(nat.lib.tdsa_rows_top_peaks(engine._h, C.c_void_p(rows_dev), int(n_rows), nb, int(n), sep,
                                           float(min_excursion_db), _p(bins), _p(db)))
     return bins, db
+
+
+def rows_marker_peaks(engine: SpectrumEngine, rows_dev: int, n_rows: int, n_bins: Optional[int] = None,
+                      peak_threshold: float = -200.0, peak_excursion: float = 6.0, distance: int = 3,
+                      current_idx: int = -1, max_list: int = 0):
+    """The marker peak search of core/marker_manager.py:74-127 on device rows.  Defaults are the reference's
+    (getattr(main_window, 'peak_threshold', -200.0), 'peak_excursion' 6.0, distance=3).  Returns a dict:
+      n_peaks[n_rows]   how many peaks find_peaks(levels, height, prominence, distance) reports
+      snap_bin[n_rows]  where snap_to_peak puts the marker: the highest peak, or np.argmax(levels) without one
+      next_bin[n_rows]  where snap_to_next_peak puts it from bin `current_idx` (= np.searchsorted(bins, position)):
+                        next peak to the right, wrapping; -1 = no peak, the marker stays
+      peaks[n_rows, max_list] / prominences   (max_list > 0) the first peaks in bin order, padded with -1 / NaN"""
+    nb = int(n_bins or engine.nfft)
+    cnt = np.empty(n_rows, dtype=np.int32)
+    snap = np.empty(n_rows, dtype=np.int32)
+    nxt = np.empty(n_rows, dtype=np.int32)
+    bins = np.empty((n_rows, max_list), dtype=np.int32) if max_list > 0 else None
+    prom = np.empty((n_rows, max_list), dtype=np.float64) if max_list > 0 else None
+    nat.check(nat.lib.tdsa_rows_marker_peaks(engine._h, C.c_void_p(rows_dev), int(n_rows), nb, float(peak_threshold),
+                                             float(peak_excursion), int(distance), int(current_idx), int(max_list),
+                                             _p(cnt), _p(snap), _p(nxt), _p(bins) if bins is not None else None,
+                                             _p(prom) if prom is not None else None))
+    out = {"n_peaks": cnt, "snap_bin": snap, "next_bin": nxt}
+    if max_list > 0:
+        out["peaks"], out["prominences"] = bins, prom
+    return out
 
 
 def peaks_as_reference(freq_bins: np.ndarray, bins_row: np.ndarray, db_row: np.ndarray) -> List[Tuple[float, float]]:

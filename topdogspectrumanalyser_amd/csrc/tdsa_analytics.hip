@@ -6,6 +6,8 @@
 //   rows_stats_kernel     np.max / np.argmax (core/duty_cycle.py:36, core/marker_manager.py:97) and
 //                         MarkerManager._band_power (core/marker_manager.py:308-319)
 //   top_peaks_kernel      DataProcessor._find_top_peaks (core/display_data_processor.py:432-471)
+//   marker_peaks_kernel   MarkerManager.snap_to_peak / snap_to_next_peak = scipy find_peaks(height, prominence,
+//                         distance) (core/marker_manager.py:74-127)
 //   density_kernel        DensityDisplay._update_hist (displays/density_display.py:306-318)
 //   rows_differ_kernel /  Waterfall new-row test + _add_row (displays/waterfall.py:171-175, 330-336)
 //   waterfall_scatter_kernel
@@ -263,6 +265,241 @@ __global__ void __launch_bounds__(kPeakThreads) top_peaks_kernel(const float* __
   }
 }
 
+// ---- marker peak search ----------------------------------------------------------------------------------
+// MarkerManager.snap_to_peak / snap_to_next_peak (core/marker_manager.py:74-127), i.e.
+// scipy.signal.find_peaks(levels, height=threshold, prominence=excursion, distance=3) and what the two methods pick
+// from its result.  One workgroup per row, the row in LDS.  scipy's conditions in scipy's order:
+//   1. local maxima: strict rise before, strict fall after, a flat top counts once at (left + right) / 2; the first
+//      and last sample never count (scipy _local_maxima_1d)
+//   2. height: x[peak] >= height
+//   3. distance: from the highest peak down, a kept peak removes every peak closer than `distance`
+//      (_select_by_peak_distance).  That greedy order is a fixed point: a peak is removed iff a KEPT peak of higher
+//      priority is within reach, kept iff every higher-priority peak within reach is removed - rounds of local
+//      decisions reach it without sorting (a round settles at least the highest undecided peak; random traces take
+//      3-4 rounds).  Priority = (value, index): between equal peaks the larger index first (a stable sort walked
+//      backwards; numpy's default argsort, which scipy calls, leaves that order to the CPU's sorting network).
+//   4. prominence: walk outwards while the samples are <= the peak, lowest sample met on each side = its base,
+//      prominence = peak - higher base >= prominence (_peak_prominences, wlen = None), in float64 like scipy.
+//      The walk skips whole blocks of 32 / 1024 samples whose maximum does not exceed the peak (block maxima and
+//      minima formed while the row is loaded), so the one strongest peak of a row costs ~150 steps instead of N.
+constexpr int kMarkThreads = 512;
+constexpr int kMarkMaxN = 16384;
+constexpr int kMarkWords = kMarkMaxN / 32;
+
+struct MarkerLds {
+  float bmax1[kMarkWords], bmin1[kMarkWords];         // per 32 samples; a NaN counts as +inf in the maximum
+  float bmax2[kMarkMaxN / 1024], bmin2[kMarkMaxN / 1024];
+  unsigned cand[kMarkWords], kept[kMarkWords], gone[kMarkWords], fin[kMarkWords];
+  int red_i[kMarkThreads / 64][4];
+  float red_f[kMarkThreads / 64], red_a[kMarkThreads / 64];
+  int scan[kMarkThreads / 64];
+};
+
+__device__ __forceinline__ double marker_prominence(const float* row, const MarkerLds& L, int n, int p) {
+  const float xp = row[p];
+  float lmin = xp, rmin = xp;
+  int i = p - 1;
+  while (i >= 0) {
+    if ((i & 31) == 31) {                                   // a whole block of 32 (1024) ends here
+      if ((i & 1023) == 1023 && L.bmax2[i >> 10] <= xp) { lmin = fminf(lmin, L.bmin2[i >> 10]); i -= 1024; continue; }
+      if (L.bmax1[i >> 5] <= xp) { lmin = fminf(lmin, L.bmin1[i >> 5]); i -= 32; continue; }
+    }
+    const float v = row[i];
+    if (!(v <= xp)) break;
+    lmin = fminf(lmin, v);
+    --i;
+  }
+  i = p + 1;
+  while (i < n) {
+    if ((i & 31) == 0) {                                    // a whole block starts here (a ragged last block is padded
+      if ((i & 1023) == 0 && L.bmax2[i >> 10] <= xp) { rmin = fminf(rmin, L.bmin2[i >> 10]); i += 1024; continue; }   // with the identities)
+      if (L.bmax1[i >> 5] <= xp) { rmin = fminf(rmin, L.bmin1[i >> 5]); i += 32; continue; }
+    }
+    const float v = row[i];
+    if (!(v <= xp)) break;
+    rmin = fminf(rmin, v);
+    ++i;
+  }
+  return (double)xp - (double)fmaxf(lmin, rmin);
+}
+
+__global__ void __launch_bounds__(kMarkThreads) marker_peaks_kernel(const float* __restrict__ rows, int n, double height,
+                                                                    double prominence, int distance, int current_idx,
+                                                                    int max_list, int* out_count, int* out_snap,
+                                                                    int* out_next, int* out_bins, double* out_prom) {
+  extern __shared__ float smem[];
+  float* row = smem;                                        // [n]
+  __shared__ MarkerLds L;
+  const float* src = rows + (size_t)blockIdx.x * n;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nw = (n + 31) >> 5, nw2 = (n + 1023) >> 10;
+
+  // load + block extrema of 32: a half-wave holds one block
+  PeakPair amax{-INFINITY, 0x7fffffff};                     // np.argmax of the row (the fallback of snap_to_peak)
+  for (int i0 = 0; i0 < n; i0 += kMarkThreads) {
+    const int i = i0 + tid;
+    const bool in = i < n;
+    const float v = in ? src[i] : 0.0f;
+    if (in) {
+      row[i] = v;
+      const PeakPair c{v, i};
+      if (better(c, amax)) amax = c;
+    }
+    float mx = in ? (v != v ? INFINITY : v) : -INFINITY, mn = in ? v : INFINITY;
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) {
+      mx = fmaxf(mx, __shfl_xor(mx, o));
+      mn = fminf(mn, __shfl_xor(mn, o));                   // fminf skips NaN: such a block is never skipped anyway
+    }
+    if ((lane & 31) == 0 && (i >> 5) < nw) {
+      L.bmax1[i >> 5] = mx;
+      L.bmin1[i >> 5] = mn;
+    }
+  }
+  for (int w = tid; w < kMarkWords; w += kMarkThreads) L.cand[w] = L.kept[w] = L.gone[w] = L.fin[w] = 0u;
+  __syncthreads();
+  for (int b = tid; b < nw2; b += kMarkThreads) {
+    float mx = -INFINITY, mn = INFINITY;
+    for (int k = 32 * b; k < 32 * b + 32 && k < nw; ++k) {
+      mx = fmaxf(mx, L.bmax1[k]);
+      mn = fminf(mn, L.bmin1[k]);
+    }
+    L.bmax2[b] = mx;
+    L.bmin2[b] = mn;
+  }
+  // 1 + 2: the thread of a rising left edge walks its flat top (whole equal blocks at a time) and marks the middle
+  for (int i = tid; i < n; i += kMarkThreads) {
+    if (i < 1 || i > n - 2) continue;
+    const float v = row[i];
+    if (!(row[i - 1] < v)) continue;
+    int a = i + 1;
+    while (a < n - 1) {
+      if ((a & 31) == 0 && a + 32 < n - 1 && L.bmax1[a >> 5] == v && L.bmin1[a >> 5] == v) { a += 32; continue; }
+      if (row[a] != v) break;
+      ++a;
+    }
+    if (row[a] < v && (double)v >= height) {
+      const int mid = (i + a - 1) >> 1;
+      atomicOr(&L.cand[mid >> 5], 1u << (mid & 31));
+    }
+  }
+  __syncthreads();
+  // 3: distance rule (peaks are never adjacent: distance <= 2 removes nothing)
+  if (distance > 2) {
+    const int reach = distance - 1;
+    for (;;) {
+      int open = 0;
+      for (int w = tid; w < nw; w += kMarkThreads) {
+        unsigned k = L.kept[w], g = L.gone[w];
+        for (unsigned m = L.cand[w] & ~k & ~g; m != 0u; m &= m - 1u) {
+          const int b = __builtin_ctz(m), p = 32 * w + b;
+          const float xp = row[p];
+          bool removed = false, wait = false;
+          const int q0 = p - reach < 0 ? 0 : p - reach, q1 = p + reach > n - 1 ? n - 1 : p + reach;
+          for (int q = q0; q <= q1; ++q) {
+            if (q == p || !((L.cand[q >> 5] >> (q & 31)) & 1u)) continue;
+            const float xq = row[q];
+            if (!(xq > xp || (xq == xp && q > p))) continue;            // lower priority: it waits for us
+            if ((L.kept[q >> 5] >> (q & 31)) & 1u) removed = true;
+            else if (!((L.gone[q >> 5] >> (q & 31)) & 1u)) wait = true;
+          }
+          if (removed) g |= 1u << b;
+          else if (!wait) k |= 1u << b;
+          else open = 1;
+        }
+        // a thread writes only its own words; a neighbour that still reads the old ones decides a round later
+        L.kept[w] = k;
+        L.gone[w] = g;
+      }
+      if (!__syncthreads_or(open)) break;
+    }
+  } else {
+    for (int w = tid; w < nw; w += kMarkThreads) L.kept[w] = L.cand[w];
+    __syncthreads();
+  }
+  // 4: prominence
+  int mine = 0;                                              // peaks of this thread's words
+  int first = 0x7fffffff, next = 0x7fffffff;
+  PeakPair top{-INFINITY, 0x7fffffff};
+  for (int w = tid; w < nw; w += kMarkThreads) {
+    unsigned f = 0u;
+    for (unsigned m = L.kept[w]; m != 0u; m &= m - 1u) {
+      const int b = __builtin_ctz(m), p = 32 * w + b;
+      if (marker_prominence(row, L, n, p) >= prominence) {
+        f |= 1u << b;
+        const PeakPair c{row[p], p};
+        if (c.v > top.v || (c.v == top.v && c.i < top.i)) top = c;        // np.argmax of the heights: first of equals
+        first = p < first ? p : first;
+        if (p > current_idx && p < next) next = p;
+      }
+    }
+    L.fin[w] = f;
+    mine += __builtin_popcount(f);
+  }
+  // block results: count (and the exclusive scan the list needs), highest peak, first peak, first peak right of the marker
+  int incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const PeakPair q{__shfl_xor(top.v, o), __shfl_xor(top.i, o)};
+    if (q.v > top.v || (q.v == top.v && q.i < top.i)) top = q;
+    const int f2 = __shfl_xor(first, o), n2 = __shfl_xor(next, o);
+    first = f2 < first ? f2 : first;
+    next = n2 < next ? n2 : next;
+  }
+  amax = wave_best(amax);
+  if (lane == 63) L.scan[wv] = incl;
+  if (lane == 0) {
+    L.red_i[wv][0] = top.i;
+    L.red_i[wv][1] = first;
+    L.red_i[wv][2] = next;
+    L.red_i[wv][3] = amax.i;
+    L.red_f[wv] = top.v;
+    L.red_a[wv] = amax.v;
+  }
+  __syncthreads();
+  int base = 0, total = 0;
+#pragma unroll
+  for (int k = 0; k < kMarkThreads / 64; ++k) {
+    const int c = L.scan[k];
+    base += k < wv ? c : 0;
+    total += c;
+  }
+  if (tid == 0) {
+    PeakPair am{L.red_a[0], L.red_i[0][3]};
+    for (int k = 1; k < kMarkThreads / 64; ++k) {
+      const PeakPair t{L.red_f[k], L.red_i[k][0]};
+      if (t.v > top.v || (t.v == top.v && t.i < top.i)) top = t;
+      first = L.red_i[k][1] < first ? L.red_i[k][1] : first;
+      next = L.red_i[k][2] < next ? L.red_i[k][2] : next;
+      const PeakPair a{L.red_a[k], L.red_i[k][3]};
+      if (better(a, am)) am = a;
+    }
+    if (out_count) out_count[blockIdx.x] = total;
+    if (out_snap) out_snap[blockIdx.x] = total > 0 ? top.i : am.i;                       // marker_manager.py:93-97
+    if (out_next) out_next[blockIdx.x] = total == 0 ? -1 : (next != 0x7fffffff ? next : first);   // :120-126, wraps
+  }
+  if (out_bins && max_list > 0) {
+    int rank = base + incl - mine;                          // peaks before this thread's first one, in index order
+    // (with more than one word per thread the order inside a thread is not the global one: n <= 16384 has one)
+    for (int w = tid; w < nw && rank < max_list; w += kMarkThreads) {
+      for (unsigned m = L.fin[w]; m != 0u && rank < max_list; m &= m - 1u, ++rank) {
+        const int p = 32 * w + __builtin_ctz(m);
+        out_bins[(size_t)blockIdx.x * max_list + rank] = p;
+        if (out_prom) out_prom[(size_t)blockIdx.x * max_list + rank] = marker_prominence(row, L, n, p);
+      }
+    }
+    for (int r = total + tid; r < max_list; r += kMarkThreads) {
+      out_bins[(size_t)blockIdx.x * max_list + r] = -1;
+      if (out_prom) out_prom[(size_t)blockIdx.x * max_list + r] = NAN;
+    }
+  }
+}
+
 // ---- density histogram ----------------------------------------------------------------------------------
 // hist[f][a] for kDensFreq neighbouring frequency bins per workgroup; thread a owns amplitude bin a of each.
 // Rows are applied in order with the reference's float32 arithmetic: hist *= decay (when decay < 1), then
@@ -396,6 +633,19 @@ hipError_t launch_top_peaks(const float* rows, int n_rows, int n, int n_peaks, i
   const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(top_peaks_kernel), 72 * 1024, attr_done);
   if (e != hipSuccess) return e;
   top_peaks_kernel<<<n_rows, kPeakThreads, lds, s>>>(rows, n, n_peaks, min_sep, excursion, out_bins, out_db);
+  return hipGetLastError();
+}
+
+hipError_t launch_marker_peaks(const float* rows, int n_rows, int n, double height, double prominence, int distance,
+                               int current_idx, int max_list, int* out_count, int* out_snap, int* out_next,
+                               int* out_bins, double* out_prom, hipStream_t s) {
+  if (n_rows <= 0) return hipSuccess;
+  const size_t lds = size_t(n) * sizeof(float);
+  static std::atomic<unsigned long long> attr_done{0};
+  const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(marker_peaks_kernel), 64 * 1024, attr_done);
+  if (e != hipSuccess) return e;
+  marker_peaks_kernel<<<n_rows, kMarkThreads, lds, s>>>(rows, n, height, prominence, distance, current_idx, max_list,
+                                                        out_count, out_snap, out_next, out_bins, out_prom);
   return hipGetLastError();
 }
 

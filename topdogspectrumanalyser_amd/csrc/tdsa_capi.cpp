@@ -2440,6 +2440,41 @@ int tdsa_rows_top_peaks(tdsa_plan p, const float* rows_dev, int n_rows, int n_bi
   return TDSA_OK;
 }
 
+int tdsa_rows_marker_peaks(tdsa_plan p, const float* rows_dev, int n_rows, int n_bins, double height, double prominence,
+                           int distance, int current_idx, int max_list, int32_t* n_peaks_host, int32_t* snap_bin_host,
+                           int32_t* next_bin_host, int32_t* peak_bins_host, double* peak_prom_host) {
+  if (!p) return fail(TDSA_ERR_ARG, "null plan");
+  if (n_rows == 0) return TDSA_OK;
+  if (!rows_dev || n_rows < 0) return fail(TDSA_ERR_ARG, "null / negative argument");
+  if (n_bins < 1 || n_bins > 16384) return fail(TDSA_ERR_ARG, "n_bins=%d outside [1, 16384] (row must fit the LDS)", n_bins);
+  if (distance < 1) return fail(TDSA_ERR_ARG, "distance=%d (scipy: `distance` must be greater or equal to 1)", distance);
+  if (max_list < 0 || (max_list > 0 && !peak_bins_host)) return fail(TDSA_ERR_ARG, "max_list=%d without a list buffer", max_list);
+  if (height != height || prominence != prominence) return fail(TDSA_ERR_ARG, "NaN height / prominence");
+  HIPCHK(hipSetDevice(p->device));
+  JOIN(p);
+  const size_t cnt = size_t(n_rows) * max_list;
+  int rc = plan_scratch(p, cnt * (sizeof(double) + sizeof(int)) + size_t(n_rows) * 3 * sizeof(int));
+  if (rc != TDSA_OK) return rc;
+  double* d_prom = static_cast<double*>(p->d_scratch);
+  int* d_bins = reinterpret_cast<int*>(d_prom + cnt);
+  int* d_count = d_bins + cnt;
+  int* d_snap = d_count + n_rows;
+  int* d_next = d_snap + n_rows;
+  HIPCHK(launch_marker_peaks(rows_dev, n_rows, n_bins, height, prominence, distance, current_idx, max_list, d_count, d_snap,
+                             d_next, max_list > 0 ? d_bins : nullptr, max_list > 0 && peak_prom_host ? d_prom : nullptr,
+                             p->stream));
+  const size_t rb = size_t(n_rows) * sizeof(int);
+  if (n_peaks_host) HIPCHK(hipMemcpyAsync(n_peaks_host, d_count, rb, hipMemcpyDeviceToHost, p->stream));
+  if (snap_bin_host) HIPCHK(hipMemcpyAsync(snap_bin_host, d_snap, rb, hipMemcpyDeviceToHost, p->stream));
+  if (next_bin_host) HIPCHK(hipMemcpyAsync(next_bin_host, d_next, rb, hipMemcpyDeviceToHost, p->stream));
+  if (max_list > 0) {
+    HIPCHK(hipMemcpyAsync(peak_bins_host, d_bins, cnt * sizeof(int), hipMemcpyDeviceToHost, p->stream));
+    if (peak_prom_host) HIPCHK(hipMemcpyAsync(peak_prom_host, d_prom, cnt * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  }
+  HIPCHK(hipStreamSynchronize(p->stream));
+  return TDSA_OK;
+}
+
 // ---- density histogram --------------------------------------------------------------------------
 struct tdsa_density_s {
   int device = 0, n = 0;

@@ -331,6 +331,9 @@ hipError_t launch_rows_stats(const float* rows, int n_rows, int n, int band_lo, 
                              float* peak_db, int* peak_bin, double* band_db, hipStream_t s);
 hipError_t launch_top_peaks(const float* rows, int n_rows, int n, int n_peaks, int min_sep, float excursion,
                             int* out_bins, float* out_db, hipStream_t s);
+hipError_t launch_marker_peaks(const float* rows, int n_rows, int n, double height, double prominence, int distance,
+                               int current_idx, int max_list, int* out_count, int* out_snap, int* out_next,
+                               int* out_bins, double* out_prom, hipStream_t s);
 hipError_t launch_density(const float* rows, int n_rows, int n, float decay, float* hist, hipStream_t s);
 hipError_t launch_log1p(const float* in, float* out, size_t count, hipStream_t s);
 hipError_t launch_rows_differ(const float* rows, const float* last, int have_last, int n_rows, int n, int* differs,
