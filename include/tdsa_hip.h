@@ -289,6 +289,24 @@ int tdsa_rows_stats(tdsa_plan p, const float* rows_dev, int n_rows, int n_bins, 
                     double bin_width, float* peak_db_host, int32_t* peak_bin_host, double* band_db_host);
 int tdsa_rows_top_peaks(tdsa_plan p, const float* rows_dev, int n_rows, int n_bins, int n_peaks, int min_sep_bins,
                         float min_excursion_db, int32_t* peak_bins_host, float* peak_db_host);
+/* Per-frame scalars as a by-product of the spectra ("fused as optional epilogues so only scalars
+ * return to the host").  With enable != 0 every tdsa_process_* call also leaves, per frame, what tdsa_rows_stats would
+ * report for its dB row: peak_db = np.max (DutyCycleAnalyser.update_from_power, core/duty_cycle.py:36), peak_bin =
+ * np.argmax (marker snap fallback, core/marker_manager.py:97; first of equals, a NaN first) and band_lin = the sum of
+ * 10^(dB / 10) over the inclusive display-bin range [band_lo, band_hi] (MarkerManager._band_power,
+ * core/marker_manager.py:308-319, before `* bin_width` and the log; band_lo > band_hi: no band, zeros).
+ * Frames of 1024 ... 16384 points in the plain dB modes (no averaging, no tare, hold none / max): the frame kernel's
+ * waves form them from the bins in their registers - no second pass over the rows, which need not even be written
+ * (out_db_dev = NULL); band_lin is then summed from the linear power the kernel holds (float32 per wave, float64 across
+ * waves; within 1e-6 relative of the sum over the rounded dB values).  Every other plan / mode: rows_stats_kernel runs on
+ * the rows the call wrote (a call without rows then has no statistics).  Not for plans above 16384 x 2^k points that
+ * return one row per call.  The results of the last four calls are kept: calls_back = 0 is the latest call, 1 the one
+ * before ... - tdsa_get_frame_stats waits for that call only, so overlapped calls (tdsa_set_overlap) stay in flight.
+ * Any output pointer may be NULL; *n_frames = frames of that call (batched captures: all of them, capture after
+ * capture). */
+int tdsa_set_frame_stats(tdsa_plan p, int enable, int band_lo, int band_hi);
+int tdsa_get_frame_stats(tdsa_plan p, int calls_back, int capacity, int* n_frames, float* peak_db_host,
+                         int32_t* peak_bin_host, double* band_lin_host);
 int tdsa_rows_marker_peaks(tdsa_plan p, const float* rows_dev, int n_rows, int n_bins, double height, double prominence,
                            int distance, int current_idx, int max_list, int32_t* n_peaks_host, int32_t* snap_bin_host,
                            int32_t* next_bin_host, int32_t* peak_bins_host, double* peak_prom_host);

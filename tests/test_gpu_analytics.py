@@ -489,3 +489,191 @@ def test_marker_peaks_on_spectra_and_errors(pkg, an):
                 an.rows_marker_peaks(e, d, 1, distance=0)
             with pytest.raises(Exception):
                 an.rows_marker_peaks(e, d, 1, peak_excursion=float("nan"))
+
+
+# ---- per-frame scalars from the frame kernel's epilogue (tdsa_set_frame_stats) -------------------------------------
+def _stats_of_rows(rows, lo, hi):
+    """what tdsa_rows_stats / the reference's np.max, np.argmax and sum(10 ** (levels / 10)) give per row"""
+    peak = rows.max(axis=1)
+    pbin = rows.argmax(axis=1).astype(np.int32)
+    if lo > hi:
+        band = np.zeros(len(rows))
+    else:
+        band = (10.0 ** (rows[:, lo:hi + 1] / np.float32(10.0))).astype(np.float64).sum(axis=1)
+    return peak, pbin, band
+
+
+def _check_frame_stats(e, rows, lo, hi, tag, exact_band=False):
+    peak, pbin, band = e.frame_stats()
+    wp, wb, wband = _stats_of_rows(rows, lo, hi)
+    assert np.array_equal(peak, wp, equal_nan=True), tag
+    assert np.array_equal(pbin, wb), tag
+    if exact_band:
+        assert np.allclose(band, wband, rtol=1e-6, atol=0), tag        # exp10f on the device, float32 10 ** x in numpy
+    else:
+        # the fused sum is formed from the linear power the kernel holds, the rows carry its rounded dB
+        # (one float32 unit of a dB value near -110 is 1.8e-6 of the power; v_log_f32 and numpy's float32 10 ** x add theirs)
+        assert np.allclose(band, wband, rtol=1e-5, atol=1e-300), (tag, np.max(np.abs(band / np.maximum(wband, 1e-300) - 1)))
+
+
+@pytest.mark.parametrize("nfft", [1024, 2048, 4096, 8192, 16384])
+@pytest.mark.parametrize("fmt", ["i8", "u8", "c64"])
+def test_frame_stats_fused_match_rows(pkg, an, nfft, fmt):
+    """peak / argmax bit for bit and the band power within 3e-6 of what the rows give, every fused size x input format x
+    hold none / max x dB mode, bands of every kind (none, one bin, ends inside a wave's bins, the whole row)."""
+    rng = np.random.default_rng(nfft + len(fmt))
+    nf, hop = 13, nfft // 2
+    iq = so.synth_iq_int8(hop * (nf - 1) + nfft, nfft, seed=nfft % 97)
+    if fmt == "u8":
+        iq = (iq.astype(np.int16) + 128).astype(np.uint8)
+    elif fmt == "c64":
+        iq = ((iq[0::2].astype(np.float32) + 1j * iq[1::2].astype(np.float32)) / 128).astype(np.complex64)
+    bands = [(1, 0), (0, nfft - 1), (nfft // 2, nfft // 2), (5, 5), (nfft - 1, nfft - 1)]
+    bands += [tuple(sorted(int(x) for x in rng.integers(0, nfft, 2))) for _ in range(5)]
+    with pkg.SpectrumEngine(nfft, max_frames=nf) as e:
+        e.set_window(so.hackrf_window(nfft))
+        for k, (lo, hi) in enumerate(bands):
+            mode = [dict(db_mode="mag", log_floor=so.LOG_FLOOR, dc_alpha=1.0, cal_offset_db=0.0),
+                    dict(db_mode="pow", power_scale=1.0 / (20e6 * nfft), log_floor=1e-12, dc_alpha=-1.0, cal_offset_db=-0.8087),
+                    dict(db_mode="pow", power_scale=1.0, log_floor=1e-10, dc_alpha=1.0, cal_offset_db=2.5)][k % 3]
+            e.configure(hold_max=bool(k & 1), hold_min=False, **mode)
+            e.set_frame_stats(True, (lo, hi))
+            rows = e.process(iq, hop=hop)
+            _check_frame_stats(e, rows, lo, hi, (nfft, fmt, k, lo, hi))
+            # the same scalars as tdsa_rows_stats of those rows
+            with DevRows(pkg, rows) as d:
+                fb = np.arange(nfft, dtype=np.float64)
+                peak, pbin, bdb = an.rows_stats(e, d, nf, freq_bins=fb, band=(lo, hi) if lo <= hi else None)
+            p2, b2, band2 = e.frame_stats(bin_width=1.0)
+            assert np.array_equal(peak, p2) and np.array_equal(pbin, b2)
+            if lo <= hi:
+                assert np.max(np.abs(band2 - bdb)) <= 5e-5, (nfft, fmt, k)             # dB
+
+
+def test_frame_stats_special_rows(pkg):
+    """silence (every bin at the floor: argmax 0), a NaN sample in complex64 input (np.max -> NaN, np.argmax -> the first
+    NaN bin), equal maxima, and the statistics of a call that wrote no rows."""
+    nfft, nf = 4096, 6
+    with pkg.SpectrumEngine(nfft, max_frames=nf) as e:
+        e.set_window(np.ones(nfft, dtype=np.float32))
+        e.configure(db_mode="mag", log_floor=so.LOG_FLOOR, dc_alpha=-1.0)
+        e.set_frame_stats(True, (100, 3000))
+        silent = np.zeros(2 * nfft * nf, dtype=np.int8)
+        rows = e.process(silent)
+        assert np.all(rows == rows[0, 0])
+        _check_frame_stats(e, rows, 100, 3000, "silence")
+        assert np.all(e.frame_stats()[1] == 0)
+        # an impulse: |X| the same in every bin up to rounding - many equal maxima
+        imp = np.zeros(2 * nfft * nf, dtype=np.int8)
+        imp[0::2 * nfft] = 64
+        rows = e.process(imp)
+        _check_frame_stats(e, rows, 100, 3000, "impulse")
+        x = (np.random.default_rng(3).normal(size=nfft * nf) + 0j).astype(np.complex64)
+        x[nfft + 7] = np.nan                                  # frame 1: every bin NaN
+        rows = e.process(x)
+        peak, pbin, band = e.frame_stats()
+        assert np.isnan(peak[1]) and pbin[1] == 0 and np.isnan(band[1]) and not np.isnan(peak[[0, 2, 3]]).any()
+        good = [0, 2, 3, 4, 5]
+        wp, wb, wband = _stats_of_rows(rows[good], 100, 3000)
+        assert np.array_equal(peak[good], wp) and np.array_equal(pbin[good], wb) and np.allclose(band[good], wband, rtol=1e-5)
+        # no rows wanted: the fused path still reports
+        iq = so.synth_iq_int8(nfft * nf, nfft, seed=5)
+        rows = e.process(iq)
+        want = e.frame_stats()
+        assert e.process(iq, want_db=False) is None
+        got = e.frame_stats()
+        assert all(np.array_equal(a, b) for a, b in zip(want, got))
+        assert all(np.array_equal(a, b) for a, b in zip(want, e.frame_stats(calls_back=1)))
+        with pytest.raises(Exception):
+            e.frame_stats(calls_back=4)
+        e.set_frame_stats(False)
+        with pytest.raises(Exception):
+            e.frame_stats()
+
+
+@pytest.mark.parametrize("case", ["n512", "n1000", "n1021", "avg", "tare", "holdmin"])
+def test_frame_stats_unfused_plans_take_them_from_the_rows(pkg, case):
+    """Plans / modes without the fused epilogue (frames below 1024 points, sizes that are not a power of two, averaging,
+    tare, min hold) run rows_stats_kernel on the rows they wrote: identical to numpy on those rows."""
+    nfft = {"n512": 512, "n1000": 1000, "n1021": 1021}.get(case, 2048)
+    nf = 9
+    iq = so.synth_iq_int8(nfft * nf, max(nfft, 64), seed=11)
+    with pkg.SpectrumEngine(nfft, max_frames=nf) as e:
+        e.set_window(np.hanning(nfft).astype(np.float32))
+        e.configure(db_mode="pow", power_scale=1.0, log_floor=1e-10, dc_alpha=-1.0,
+                    avg=("exp", 4) if case == "avg" else ("off", 1), hold_min=case == "holdmin")
+        if case == "tare":
+            e.set_tare_baseline(np.linspace(-3, 3, nfft).astype(np.float32))
+        lo, hi = nfft // 5, nfft // 2
+        e.set_frame_stats(True, (lo, hi))
+        rows = e.process(iq)
+        _check_frame_stats(e, rows, lo, hi, case, exact_band=True)
+        if case in ("n512", "tare"):
+            e.process(iq, want_db=False)
+            with pytest.raises(Exception):
+                e.frame_stats()                               # nothing to take them from
+
+
+def test_frame_stats_full_c3_second_and_overlapped_calls(pkg, an):
+    """One second of C3 (2440 frames of 16384 points, hop 8192, max hold) on the device path: the fused scalars against
+    tdsa_rows_stats of the rows the same call wrote; then three overlapped calls, each read back by calls_back."""
+    nat = pkg._native
+    nfft, hop, nf = 16384, 8192, 2440
+    n_samples = hop * (nf - 1) + nfft
+    iq = so.synth_iq_int8(n_samples, nfft, seed=3)
+    d_in, d_out = C.c_void_p(), C.c_void_p()
+    nat.check(nat.lib.tdsa_dev_alloc(0, iq.nbytes, C.byref(d_in)))
+    nat.check(nat.lib.tdsa_dev_alloc(0, nf * nfft * 4, C.byref(d_out)))
+    try:
+        nat.check(nat.lib.tdsa_memcpy_h2d(0, d_in, iq.ctypes.data_as(C.c_void_p), iq.nbytes))
+        with pkg.SpectrumEngine(nfft, max_frames=nf) as e:
+            e.set_window(so.hackrf_window(nfft))
+            e.configure(db_mode="mag", log_floor=so.LOG_FLOOR, dc_alpha=1.0, hold_max=True)
+            lo, hi = 3000, 11000
+            e.set_frame_stats(True, (lo, hi))
+            e.process_device(nat.IN_I8, d_in.value, n_samples, hop, nf, d_out.value)
+            peak, pbin, band = e.frame_stats(bin_width=1.0)
+            rp, rb, rband = an.rows_stats(e, d_out.value, nf, freq_bins=np.arange(nfft, dtype=np.float64), band=(lo, hi))
+            assert np.array_equal(peak, rp) and np.array_equal(pbin, rb)
+            assert np.max(np.abs(band - rband)) <= 5e-5
+            mx, _ = e.hold()
+            rows = np.empty((nf, nfft), dtype=np.float32)
+            nat.check(nat.lib.tdsa_memcpy_d2h(0, rows.ctypes.data_as(C.c_void_p), d_out, rows.nbytes))
+            assert np.array_equal(mx, rows.max(axis=0))           # the hold trace is untouched by the extra epilogue
+            assert peak.max() == mx.max()
+            # overlapped calls of different lengths: each slot keeps its own call
+            e.set_overlap(3)
+            lens = [2440, 1000, 37]
+            for n in lens:
+                e.process_device(nat.IN_I8, d_in.value, hop * (n - 1) + nfft, hop, n, None)
+            for back, n in enumerate(reversed(lens)):
+                p2, b2, _ = e.frame_stats(calls_back=back)
+                assert len(p2) == n and np.array_equal(p2, peak[:n]) and np.array_equal(b2, pbin[:n])
+    finally:
+        nat.lib.tdsa_dev_free(0, d_in)
+        nat.lib.tdsa_dev_free(0, d_out)
+
+
+def test_frame_stats_batched_captures(pkg):
+    """tdsa_process_dev_batch: the frames of all captures of the one launch, capture after capture."""
+    nat = pkg._native
+    nfft, hop, nf, nseg = 8192, 8192, 32, 5
+    per = hop * (nf - 1) + nfft
+    iq = so.synth_iq_int8(per * nseg, nfft, seed=9)
+    d_in, d_out = C.c_void_p(), C.c_void_p()
+    nat.check(nat.lib.tdsa_dev_alloc(0, iq.nbytes, C.byref(d_in)))
+    nat.check(nat.lib.tdsa_dev_alloc(0, nseg * nf * nfft * 4, C.byref(d_out)))
+    try:
+        nat.check(nat.lib.tdsa_memcpy_h2d(0, d_in, iq.ctypes.data_as(C.c_void_p), iq.nbytes))
+        with pkg.SpectrumEngine(nfft, max_frames=nf) as e:
+            e.set_window(np.hanning(nfft).astype(np.float32))
+            e.configure(db_mode="pow", power_scale=1.0, log_floor=1e-10, dc_alpha=-1.0)
+            e.set_frame_stats(True, (10, 8000))
+            e.process_device_batch(nat.IN_I8, d_in.value, per * 2, nseg, per, hop, nf, d_out.value)
+            rows = np.empty((nseg * nf, nfft), dtype=np.float32)
+            e.synchronize()
+            nat.check(nat.lib.tdsa_memcpy_d2h(0, rows.ctypes.data_as(C.c_void_p), d_out, rows.nbytes))
+            _check_frame_stats(e, rows, 10, 8000, "batch")
+    finally:
+        nat.lib.tdsa_dev_free(0, d_in)
+        nat.lib.tdsa_dev_free(0, d_out)

@@ -73,6 +73,8 @@ _SIGNATURES = {
     "tdsa_set_overlap": (C.c_int, [_P, C.c_int]),
     "tdsa_rows_stats": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _P, _P, _P]),
     "tdsa_rows_top_peaks": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P]),
+    "tdsa_set_frame_stats": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
+    "tdsa_get_frame_stats": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P]),
     "tdsa_rows_marker_peaks": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int,
                                          _P, _P, _P, _P, _P]),
     "tdsa_density_create": (C.c_int, [C.c_int, C.c_int, C.c_float, C.POINTER(_P)]),

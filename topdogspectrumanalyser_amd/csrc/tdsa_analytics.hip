@@ -115,12 +115,37 @@ __global__ void __launch_bounds__(256) rows_stats_kernel(const float* __restrict
     }
     if (peak_db) peak_db[blockIdx.x] = best.v;
     if (peak_bin) peak_bin[blockIdx.x] = best.i;
-    if (band_db) {
+    if (band_db && bin_width < 0.0) {
+      band_db[blockIdx.x] = bsum;           // the band's linear sum itself (per-frame scalars of plans without the fused epilogue)
+    } else if (band_db) {
       const double total = bsum * bin_width;
       // Python's max(total, 1e-30) keeps a NaN total (1e-30 > nan is False): so does `total < 1e-30 ? ... : total`
       band_db[blockIdx.x] = band_lo > band_hi ? NAN : 10.0 * log10(total < 1e-30 ? 1e-30 : total);
     }
   }
+}
+
+// ---- per-frame scalars left by the frame kernel's STATS epilogue ------------------------------------------
+// parts[f][w] = {max dB of wave w's bins, first display bin holding it, linear band power of its bins, 0}: thread f folds
+// its frame's waves in wave order - np.max / np.argmax rules (`better`), the band in float64 times 10^(cal / 10) (the
+// records carry the power BEFORE the calibration offset; the rows carry it after).
+__global__ void __launch_bounds__(256) frame_stats_finish_kernel(const uint4* __restrict__ parts, int n_frames, int wpf,
+                                                                 double cal_lin, float* peak_db, int* peak_bin,
+                                                                 double* band_lin) {
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= n_frames) return;
+  const uint4* r = parts + (size_t)f * wpf;
+  PeakPair best{-INFINITY, 0x7fffffff};
+  double bsum = 0.0;
+  for (int w = 0; w < wpf; ++w) {
+    const uint4 q = r[w];
+    const PeakPair c{__uint_as_float(q.x), int(q.y)};
+    if (better(c, best)) best = c;
+    bsum += (double)__uint_as_float(q.z);
+  }
+  peak_db[f] = best.v;
+  peak_bin[f] = best.i;
+  band_lin[f] = bsum * cal_lin;
 }
 
 // ---- top-N peak list ----------------------------------------------------------------------------------
@@ -622,6 +647,14 @@ hipError_t launch_rows_stats(const float* rows, int n_rows, int n, int band_lo, 
                              float* peak_db, int* peak_bin, double* band_db, hipStream_t s) {
   if (n_rows <= 0) return hipSuccess;
   rows_stats_kernel<<<n_rows, 256, 0, s>>>(rows, n, band_lo, band_hi, bin_width, peak_db, peak_bin, band_db);
+  return hipGetLastError();
+}
+
+hipError_t launch_frame_stats_finish(const void* parts, int n_frames, int wpf, double cal_lin, float* peak_db,
+                                     int* peak_bin, double* band_lin, hipStream_t s) {
+  if (n_frames <= 0) return hipSuccess;
+  frame_stats_finish_kernel<<<(n_frames + 255) / 256, 256, 0, s>>>(static_cast<const uint4*>(parts), n_frames, wpf, cal_lin,
+                                                                   peak_db, peak_bin, band_lin);
   return hipGetLastError();
 }
 

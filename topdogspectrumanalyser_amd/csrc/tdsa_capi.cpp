@@ -148,6 +148,22 @@ struct tdsa_plan_s {
   float2* d_u1 = nullptr;
   void* d_scratch = nullptr;             // grows on demand: results of tdsa_rows_stats / tdsa_rows_top_peaks
   size_t scratch_bytes = 0;
+  // per-frame scalars (tdsa_set_frame_stats): the results of the last kFsSlots calls
+  static constexpr int kFsSlots = 4;
+  struct FsSlot {
+    void* d_part = nullptr;              // [frames][waves per frame] records of the frame kernel's STATS epilogue
+    float* d_peak = nullptr;             // [frames]
+    int* d_bin = nullptr;
+    double* d_band = nullptr;
+    size_t cap = 0, cap_part = 0;
+    int n_frames = 0;
+    int state = 0;                       // 0: nothing, 1: results (in flight until ev), 2: the call produced no rows to take them from
+    hipEvent_t ev = nullptr;
+  } fs[kFsSlots];
+  bool fs_on = false;
+  int fs_lo = 1, fs_hi = 0;              // band: inclusive display-bin range, lo > hi = none
+  unsigned long long fs_seq = 0;         // calls that left (or tried to leave) statistics
+  hipStream_t fs_stream = nullptr;       // read-back of a slot (waits for that slot's event only)
   bool profiling = false;
   bool sync_call = false;                // set by the synchronous host entry points around their device call
   std::vector<hipEvent_t> prof_events;   // pairs (begin, end) around frame-kernel launches
@@ -996,6 +1012,13 @@ int tdsa_destroy(tdsa_plan p) {
     if (b) (void)hipFree(b);
   if (p->h_in_pin) (void)hipHostFree(p->h_in_pin);
   if (p->h_out_pin) (void)hipHostFree(p->h_out_pin);
+  for (auto& sl : p->fs) {
+    void* fb[] = {sl.d_part, sl.d_peak, sl.d_bin, sl.d_band};
+    for (void* b : fb)
+      if (b) (void)hipFree(b);
+    if (sl.ev) (void)hipEventDestroy(sl.ev);
+  }
+  if (p->fs_stream) { (void)hipStreamSynchronize(p->fs_stream); (void)hipStreamDestroy(p->fs_stream); }
   for (hipEvent_t e : p->prof_events) (void)hipEventDestroy(e);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
   if (p->ev1) (void)hipEventDestroy(p->ev1);
@@ -1144,6 +1167,59 @@ int tdsa_set_tare_baseline(tdsa_plan p, const float* baseline_db_host, int n) {
   return TDSA_OK;
 }
 
+// ---- per-frame scalars of a call (tdsa_set_frame_stats) -------------------------------------------------------------
+// The frame kernel's STATS instantiations exist for frames of whole waves (N >= 1024), dB rows without tare, hold none / max.
+static bool frame_stats_fusable(tdsa_plan p, bool averaging) {
+  return p->fs_on && !averaging && !p->chirp && !p->big && p->log2n >= 10 && !p->tare_active &&
+         (p->mode.hold_flags & TDSA_HOLD_MIN) == 0;
+}
+// the slot the call at hand writes: grown to n_frames, ordered after whatever last used it
+static int frame_stats_begin(tdsa_plan p, int n_frames, int wpf, hipStream_t s, tdsa_plan_s::FsSlot** out) {
+  tdsa_plan_s::FsSlot& sl = p->fs[p->fs_seq % tdsa_plan_s::kFsSlots];
+  if (!sl.ev) HIPCHK(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+  else if (sl.state == 1) HIPCHK(hipStreamWaitEvent(s, sl.ev, 0));
+  if (size_t(n_frames) > sl.cap || size_t(n_frames) * wpf > sl.cap_part) {
+    if (sl.state == 1) HIPCHK(hipEventSynchronize(sl.ev));
+    if (p->fs_stream) HIPCHK(hipStreamSynchronize(p->fs_stream));
+    void* fb[] = {sl.d_part, sl.d_peak, sl.d_bin, sl.d_band};
+    for (void* b : fb)
+      if (b) HIPCHK(hipFree(b));
+    sl.d_part = nullptr; sl.d_peak = nullptr; sl.d_bin = nullptr; sl.d_band = nullptr;
+    sl.cap = sl.cap_part = 0;
+    const size_t cap = size_t(n_frames) > size_t(p->max_frames) ? size_t(n_frames) : size_t(p->max_frames);
+    HIPCHK(hipMalloc(&sl.d_part, cap * 16 * 16));            // up to 16 waves per frame
+    HIPCHK(hipMalloc(&sl.d_peak, cap * sizeof(float)));
+    HIPCHK(hipMalloc(&sl.d_bin, cap * sizeof(int)));
+    HIPCHK(hipMalloc(&sl.d_band, cap * sizeof(double)));
+    sl.cap = cap;
+    sl.cap_part = cap * 16;
+  }
+  sl.n_frames = n_frames;
+  sl.state = 0;
+  *out = &sl;
+  return TDSA_OK;
+}
+static int frame_stats_end(tdsa_plan p, tdsa_plan_s::FsSlot* sl, int state, hipStream_t s) {
+  sl->state = state;
+  if (state == 1) HIPCHK(hipEventRecord(sl->ev, s));
+  ++p->fs_seq;
+  return TDSA_OK;
+}
+// plans / modes without the fused epilogue: the same scalars from the rows the call wrote (rows_stats_kernel)
+static int frame_stats_from_rows(tdsa_plan p, const float* rows, int n_frames, int n_seg, int frames_per_seg,
+                                 long long seg_stride_elems, hipStream_t s) {
+  if (!p->fs_on) return TDSA_OK;
+  tdsa_plan_s::FsSlot* sl = nullptr;
+  int rc = frame_stats_begin(p, n_frames, 1, s, &sl);
+  if (rc != TDSA_OK) return rc;
+  if (rows == nullptr) return frame_stats_end(p, sl, 2, s);
+  for (int g = 0; g < n_seg; ++g)
+    HIPCHK(launch_rows_stats(rows + (long long)g * seg_stride_elems, frames_per_seg, p->nfft, p->fs_lo, p->fs_hi, -1.0,
+                             sl->d_peak + (size_t)g * frames_per_seg, sl->d_bin + (size_t)g * frames_per_seg,
+                             sl->d_band + (size_t)g * frames_per_seg, s));
+  return frame_stats_end(p, sl, 1, s);
+}
+
 // several captures in one launch (tdsa_process_dev_batch): n_frames = n_seg * frames_per_seg frames in all
 struct SegInfo {
   int n_seg = 1;
@@ -1175,7 +1251,8 @@ static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size
   if (p->chirp) {
     JOIN(p);
     if (before) HIPCHK(hipStreamWaitEvent(p->stream, before, 0));
-    const int rc_chirp = process_chirp(p, in_format, iq_dev, hop, n_frames, out_db_dev);
+    int rc_chirp = process_chirp(p, in_format, iq_dev, hop, n_frames, out_db_dev);
+    if (rc_chirp == TDSA_OK) rc_chirp = frame_stats_from_rows(p, out_db_dev, n_frames, 1, n_frames, 0, p->stream);
     if (rc_chirp == TDSA_OK && after) HIPCHK(hipEventRecord(after, p->stream));
     return rc_chirp;
   }
@@ -1322,6 +1399,10 @@ static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size
     int rc_p = launch_spectrum_profiled(p, in_c64, sp, g);
     if (rc_p != TDSA_OK) return rc_p;
     HIPCHK(launch_avg_scan(ap, p->stream, p->d_carry));
+    {
+      const int rc_fs = frame_stats_from_rows(p, out_db_dev, n_frames, 1, n_frames, 0, p->stream);
+      if (rc_fs != TDSA_OK) return rc_fs;
+    }
     if (m.avg_mode == TDSA_AVG_LIN) {
       long long c = (long long)p->avg_count + n_frames;
       p->avg_count = int(c < m.avg_n ? c : m.avg_n);
@@ -1335,8 +1416,29 @@ static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size
       sp.part_max = p->d_hold_max;
       sp.part_min = p->d_hold_min;
     }
+    tdsa_plan_s::FsSlot* fsl = nullptr;
+    const bool fs_fused = frame_stats_fusable(p, false);
+    if (fs_fused) {
+      const int wpf = spectrum_waves_per_frame(p->log2n);
+      const int rc_b = frame_stats_begin(p, n_frames, wpf, s, &fsl);
+      if (rc_b != TDSA_OK) return rc_b;
+      sp.stats_part = fsl->d_part;
+      sp.band_lohi = p->fs_lo <= p->fs_hi ? (unsigned(p->fs_lo) | (unsigned(p->fs_hi) << 16)) : 1u;
+    }
     int rc_p = launch_spectrum_profiled(p, in_c64, sp, g, s);
     if (rc_p != TDSA_OK) return rc_p;
+    if (fs_fused) {
+      // the records hold the power before the calibration offset: 10^(dB / 10) = power x 10^(cal / 10)
+      HIPCHK(launch_frame_stats_finish(fsl->d_part, n_frames, spectrum_waves_per_frame(p->log2n),
+                                       std::pow(10.0, double(m.cal_offset_db) / 10.0), fsl->d_peak, fsl->d_bin, fsl->d_band, s));
+      const int rc_e = frame_stats_end(p, fsl, 1, s);
+      if (rc_e != TDSA_OK) return rc_e;
+    } else if (p->fs_on) {
+      const bool one = !seg || seg->single_frames;
+      const int rc_r = frame_stats_from_rows(p, out_db_dev, n_frames, one ? 1 : seg->n_seg, one ? n_frames : seg->frames_per_seg,
+                                             one ? 0 : seg->out_stride_elems, s);
+      if (rc_r != TDSA_OK) return rc_r;
+    }
   }
   if (after) HIPCHK(hipEventRecord(after, s));
   if (m.hold_flags & TDSA_HOLD_MAX) p->held_max += n_frames;
@@ -2394,6 +2496,48 @@ int plan_scratch(tdsa_plan p, size_t need) {
 }
 
 }  // namespace
+
+int tdsa_set_frame_stats(tdsa_plan p, int enable, int band_lo, int band_hi) {
+  if (!p) return fail(TDSA_ERR_ARG, "null plan");
+  if (enable && p->big) return fail(TDSA_ERR_STATE, "long-frame plans return one row per call: take tdsa_rows_stats of it");
+  if (enable && band_lo <= band_hi && (band_lo < 0 || band_hi >= p->nfft))
+    return fail(TDSA_ERR_ARG, "band [%d, %d] outside [0, %d)", band_lo, band_hi, p->nfft);
+  HIPCHK(hipSetDevice(p->device));
+  JOIN(p);
+  p->fs_on = enable != 0;
+  p->fs_lo = band_lo;
+  p->fs_hi = band_hi;
+  for (auto& sl : p->fs) {
+    if (sl.state == 1) HIPCHK(hipEventSynchronize(sl.ev));
+    sl.state = 0;
+  }
+  p->fs_seq = 0;
+  return TDSA_OK;
+}
+
+int tdsa_get_frame_stats(tdsa_plan p, int calls_back, int capacity, int* n_frames, float* peak_db_host,
+                         int32_t* peak_bin_host, double* band_lin_host) {
+  if (!p) return fail(TDSA_ERR_ARG, "null plan");
+  if (!p->fs_on) return fail(TDSA_ERR_STATE, "tdsa_set_frame_stats has not enabled the per-frame scalars");
+  if (calls_back < 0 || calls_back >= tdsa_plan_s::kFsSlots || (unsigned long long)calls_back >= p->fs_seq)
+    return fail(TDSA_ERR_ARG, "calls_back=%d: the results of the last %d calls are kept, %llu made", calls_back,
+                tdsa_plan_s::kFsSlots, p->fs_seq);
+  tdsa_plan_s::FsSlot& sl = p->fs[(p->fs_seq - 1 - calls_back) % tdsa_plan_s::kFsSlots];
+  if (sl.state == 2) return fail(TDSA_ERR_STATE, "that call wrote no dB rows and its plan / mode has no fused statistics");
+  if (sl.state != 1) return fail(TDSA_ERR_STATE, "no statistics in that slot");
+  if (n_frames) *n_frames = sl.n_frames;
+  if (capacity < sl.n_frames && (peak_db_host || peak_bin_host || band_lin_host))
+    return fail(TDSA_ERR_ARG, "capacity %d < %d frames", capacity, sl.n_frames);
+  HIPCHK(hipSetDevice(p->device));
+  HIPCHK(hipEventSynchronize(sl.ev));
+  if (!p->fs_stream) HIPCHK(hipStreamCreateWithFlags(&p->fs_stream, hipStreamNonBlocking));
+  const size_t nf = size_t(sl.n_frames);
+  if (peak_db_host) HIPCHK(hipMemcpyAsync(peak_db_host, sl.d_peak, nf * sizeof(float), hipMemcpyDeviceToHost, p->fs_stream));
+  if (peak_bin_host) HIPCHK(hipMemcpyAsync(peak_bin_host, sl.d_bin, nf * sizeof(int), hipMemcpyDeviceToHost, p->fs_stream));
+  if (band_lin_host) HIPCHK(hipMemcpyAsync(band_lin_host, sl.d_band, nf * sizeof(double), hipMemcpyDeviceToHost, p->fs_stream));
+  HIPCHK(hipStreamSynchronize(p->fs_stream));
+  return TDSA_OK;
+}
 
 int tdsa_rows_stats(tdsa_plan p, const float* rows_dev, int n_rows, int n_bins, int band_lo, int band_hi,
                     double bin_width, float* peak_db_host, int32_t* peak_bin_host, double* band_db_host) {

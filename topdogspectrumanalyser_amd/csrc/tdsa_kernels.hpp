@@ -85,7 +85,13 @@ struct SpecParams {
   float post_inv_m;          // 1 / M
   int rows_twice;            // long chirp-z frames (size 14 only): the row passes of the first and of the (transposed) second
                              // transform run back to back on each row: X -> conj(X out_mul) -> through LDS -> transform -> out_cplx
+  // ---- per-frame scalars from the epilogue (STATS instantiations: N >= 1024, dB rows, no tare, hold none / max; appended in
+  //      round 6) ----
+  void* stats_part;          // [F][waves per frame] 16-byte records {max dB, its first display bin, band power (linear), 0}, or null
+  unsigned band_lohi;        // band power: inclusive display-bin range lo | hi << 16; lo > hi: none
 };
+// waves of one frame in the frame kernel (frames of whole waves: N >= 1024)
+inline int spectrum_waves_per_frame(int log2n) { return log2n <= 10 ? 1 : (1 << log2n) / 1024; }
 
 struct LaunchGeom {
   int grid, block, fpw;
@@ -329,6 +335,9 @@ hipError_t launch_chirp_post_real(const float2* y, int n, int m, int n_frames, i
 // ---- trace analytics / accumulators (tdsa_analytics.hip) ---------------------------------------------
 hipError_t launch_rows_stats(const float* rows, int n_rows, int n, int band_lo, int band_hi, double bin_width,
                              float* peak_db, int* peak_bin, double* band_db, hipStream_t s);
+// bin_width < 0: band_db receives the band's linear sum (no width, no log)
+hipError_t launch_frame_stats_finish(const void* parts, int n_frames, int wpf, double cal_lin, float* peak_db,
+                                     int* peak_bin, double* band_lin, hipStream_t s);
 hipError_t launch_top_peaks(const float* rows, int n_rows, int n, int n_peaks, int min_sep, float excursion,
                             int* out_bins, float* out_db, hipStream_t s);
 hipError_t launch_marker_peaks(const float* rows, int n_rows, int n, double height, double prominence, int distance,

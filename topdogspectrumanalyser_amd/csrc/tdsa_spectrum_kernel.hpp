@@ -112,6 +112,29 @@ __device__ __forceinline__ float in_vgpr(float x) { asm volatile("" : "+v"(x)); 
 // the compiler's fmaxf first canonicalises both inputs with two extra v_max (half-rate ops on gfx950)
 __device__ __forceinline__ float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// wave64 float maximum (NaN operands ignored) / sum with DPP moves; the result is valid in lane 63
+__device__ __forceinline__ float dpp_wave_max63(float x) {
+  auto mv = [&](auto ctrl, auto rm) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(x), __float_as_uint(x), decltype(ctrl)::value, decltype(rm)::value, 0xf, false));
+  };
+  x = hw_max(x, mv(std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xf>{}));
+  x = hw_max(x, mv(std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xf>{}));
+  x = hw_max(x, mv(std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xf>{}));
+  x = hw_max(x, mv(std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xf>{}));
+  x = hw_max(x, mv(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{}));
+  x = hw_max(x, mv(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{}));
+  return x;
+}
+__device__ __forceinline__ float dpp_wave_sum63(float x) {
+  x += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0xB1, 0xf, 0xf, true));
+  x += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0x4E, 0xf, 0xf, true));
+  x += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0x141, 0xf, 0xf, true));
+  x += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0x140, 0xf, 0xf, true));
+  x += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0x142, 0xa, 0xf, false));
+  x += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0x143, 0xc, 0xf, false));
+  return x;
+}
 
 // wave64 integer sum with DPP adds (no LDS round trips); the total is valid in lanes 48..63
 __device__ __forceinline__ int dpp_wave_sum(int x) {
@@ -269,8 +292,17 @@ __device__ __forceinline__ void combine_const(c32& e, c32& o) {
 // rows stored); 4 = the two row passes of a LONG chirp-z frame's transforms in one (16384-point rows: transform, x the
 // filter spectrum's row, conjugate, through LDS, transform; complex64 rows in and out): tdsa_chirp.hip's two element-wise passes folded into the transforms, in instantiations of their own -
 // as run-time branches of the plain complex64 kernel they cost it 68 - 83 spilled registers
-template <int LOG2N, bool IN_C64, int HOLD, int CHIRP = 0>   // HOLD: bit0 = max trace, bit1 = min trace; 4 = AGG (see below)
+// STATS (frames of whole waves, dB rows, HOLD 0 / 1): every wave also leaves what the per-frame scalars of the trace analytics
+// need from ITS bins while they sit in its registers - maximum dB, its first bin, the band's linear power - as one 16-byte
+// record per wave and frame (SpecParams::stats_part); frame_stats_finish_kernel (tdsa_analytics.hip) folds a frame's records.
+// What np.max / np.argmax (core/duty_cycle.py:36, core/marker_manager.py:97) and MarkerManager._band_power (:308-319) would
+// otherwise take a second pass over the rows for (rows_stats_kernel).
+// (HOLDX = HOLD | 8 x STATS: one template argument, so that the names of the instantiations without STATS - what the
+// profiles, tests/test_isa_frozen.py and tools/ key on - stay what they were)
+template <int LOG2N, bool IN_C64, int HOLDX, int CHIRP = 0>   // HOLD: bit0 = max trace, bit1 = min trace; 4 = AGG (see below); bit 3: STATS
 __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const SpecParams p) {
+  constexpr int HOLD = HOLDX & 7;
+  constexpr bool STATS = (HOLDX & 8) != 0;
   using C = Cfg<LOG2N>;
   constexpr int N = C::N, SG = C::SG, A = C::A, M = C::M, H = C::H, FPW = C::FPW, NPAD = C::NPAD;
   constexpr int LH = ilog2(H);
@@ -371,6 +403,25 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     if constexpr ((HOLD & 1) != 0) hmax[i] = -INFINITY;
     if constexpr ((HOLD & 2) != 0) hmin[i] = INFINITY;
   });
+  // STATS: which of the thread's 16 bins (display position (kcs + 8h) SG + t) lie in the band [band_lo, band_hi] is a
+  // property of the wave for all but the bins at the band's two ends: bit q of st_mask = every lane's bin q is in the
+  // band, bit 16 + q = some are (the lanes then test their own position).
+  unsigned st_mask = 0u;
+  if constexpr (STATS) {
+    static_assert(UNI && CHIRP == 0 && HOLD < 2, "frame statistics: whole waves per frame, plain dB rows, no min hold");
+    const int st_t0 = __builtin_amdgcn_readfirstlane((wave & (C::WPF - 1)) * 32);     // first butterfly row of the wave
+    const int lo = int(p.band_lohi & 0xffffu), hi = int(p.band_lohi >> 16);
+    static_for<0, 16>([&](auto ic) {
+      constexpr int q = decltype(ic)::value;
+      constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
+      const int a0 = kcs * SG + st_t0, a1 = a0 + 8 * SG;           // first position of the lower / upper half-wave
+      const bool in0 = lo <= a0 && a0 + 31 <= hi, in1 = lo <= a1 && a1 + 31 <= hi;
+      const bool out0 = hi < a0 || lo > a0 + 31, out1 = hi < a1 || lo > a1 + 31;
+      const bool full = in0 && in1, part = lo <= hi && !full && !(out0 && out1);     // (lo > hi: no band)
+      st_mask |= (unsigned(full) << q) | (unsigned(part) << (16 + q));
+    });
+    st_mask = __builtin_amdgcn_readfirstlane(st_mask);
+  }
   // (with max AND min hold in registers the loop has no VGPR to spare: the wave-uniform constants stay in SGPRs there
   //  and their few uses issue at half rate)
   constexpr bool PIN = HOLD < 3;
@@ -395,6 +446,21 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
   const unsigned lane_in_off = INL ? (unsigned(t) * M + unsigned(h) * CPT) * SB
                                    : unsigned(t) * (M * SB) + unsigned(h) * ((N / A) * SB);
   const unsigned out_voff = unsigned(t) * 4u + unsigned(h) * (8u * SG * 4u);
+  float st_band = 0.f;                          // this thread's share of the frame's band power (linear)
+  unsigned st_maskc = 0u;                       // st_mask as the frame at hand sees it (an opaque copy: tested bit by bit with
+                                                // s_bitcmp inside the loop, not hoisted out of it as 32 lane masks)
+  auto st_band_add = [&](auto qc, float a) {
+    constexpr int q = decltype(qc)::value;
+    constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
+    if (st_maskc & (1u << q)) {
+      st_band += a;
+    } else if (st_maskc & (0x10000u << q)) {
+      unsigned ov = out_voff;                   // (opaque: the test must not leave the loop as sixteen lane masks either)
+      asm volatile("" : "+v"(ov));
+      const unsigned lo = p.band_lohi & 0xffffu, hi = p.band_lohi >> 16;
+      st_band += ((ov >> 2) + unsigned(kcs * SG) - lo <= hi - lo) ? a : 0.f;
+    }
+  };
   // frame -> byte offset of its samples / element offset of its output row (several captures per launch:
   // SpecParams::seg_*; with one capture seg_magic = 0 and these are frame * frame_stride, frame * N)
   auto in_byte_off = [&](int frame) -> long long {
@@ -735,21 +801,34 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
           db[q] = X.x * X.x + X.y * X.y;
           tiny |= db[q] < kMagExactBelow;
         });
+        if constexpr (STATS) {
+          st_band = 0.f;
+          st_maskc = st_mask;
+          asm volatile("" : "+s"(st_maskc));
+        }
         if (mag_mode && __builtin_amdgcn_ballot_w64(tiny) != 0) {   // near-silent frame: exact DB_MAG
           static_for<0, 16>([&](auto ic) {
             constexpr int q = decltype(ic)::value;
             const float mag = __builtin_amdgcn_sqrtf(db[q]);
+            if constexpr (STATS) st_band_add(ic, (mag + p.log_floor) * (mag + p.log_floor));
             db[q] = fmaf(2.0f * k10Log10_2, __builtin_amdgcn_logf(mag + p.log_floor), cal_v);
           });
         } else if (mag_mode) {          // 10*log10(|X|^2): no power scale, no floor (wave-uniform branch)
           static_for<0, 16>([&](auto ic) {
             constexpr int q = decltype(ic)::value;
+            if constexpr (STATS) st_band_add(ic, db[q]);
             db[q] = fmaf(k10Log10_2, __builtin_amdgcn_logf(db[q]), cal_v);
           });
         } else {
           static_for<0, 16>([&](auto ic) {
             constexpr int q = decltype(ic)::value;
-            db[q] = fmaf(k10Log10_2, __builtin_amdgcn_logf(fmaf(db[q], ps_v, fl_v)), cal_v);
+            if constexpr (STATS) {
+              const float a = fmaf(db[q], ps_v, fl_v);
+              st_band_add(ic, a);
+              db[q] = fmaf(k10Log10_2, __builtin_amdgcn_logf(a), cal_v);
+            } else {
+              db[q] = fmaf(k10Log10_2, __builtin_amdgcn_logf(fmaf(db[q], ps_v, fl_v)), cal_v);
+            }
           });
         }
         if (p.tare != nullptr) {
@@ -761,6 +840,50 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
             constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
             db[q] -= __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(tr, out_voff, kcs * SG * 4u, 0));
           });
+        }
+        if constexpr (STATS) {
+          // the wave's record: maximum of its 16 x 64 dB values, the first display position that holds it (np.argmax:
+          // first of equals, a NaN before everything - only complex64 input can carry one), the band's linear sum
+          const float m = hw_max3(hw_max3(hw_max3(db[0], db[1], db[2]), hw_max3(db[3], db[4], db[5]), hw_max3(db[6], db[7], db[8])),
+                                  hw_max3(hw_max3(db[9], db[10], db[11]), hw_max3(db[12], db[13], db[14]), db[15]), db[15]);
+          const float mw = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dpp_wave_max63(m)), 63));
+          int wq = __builtin_amdgcn_readfirstlane(wave);         // (the scalar wave index rebuilt per frame: no SGPR held for it)
+          asm volatile("" : "+s"(wq));
+          wq &= C::WPF - 1;
+          int best = 0x7fffffff, nbest = 0x7fffffff;
+          static_for<0, 16>([&](auto ic) {
+            constexpr int q = decltype(ic)::value;
+            constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
+            // (one ballot at a time: left to itself the scheduler forms all sixteen masks first - 32 SGPRs the kernel
+            //  does not have)
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long mk = __builtin_amdgcn_ballot_w64(db[q] == mw);
+            if (mk != 0ull) {
+              const int l = __builtin_ctzll(mk);                  // lanes ascend with the position inside a half, halves with 8 SG
+              const int cand = (kcs + 8 * (l >> 5)) * SG + (l & 31);
+              best = cand < best ? cand : best;
+            }
+            if constexpr (IN_C64) {
+              const unsigned long long nk = __builtin_amdgcn_ballot_w64(db[q] != db[q]);
+              if (nk != 0ull) {
+                const int l = __builtin_ctzll(nk);
+                const int cand = (kcs + 8 * (l >> 5)) * SG + (l & 31);
+                nbest = cand < nbest ? cand : nbest;
+              }
+            }
+          });
+          __builtin_amdgcn_sched_barrier(0);
+          const float bw = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dpp_wave_sum63(st_band)), 63));
+          const bool has_nan = IN_C64 && nbest != 0x7fffffff;
+          const unsigned soff = (unsigned(frame) * C::WPF + unsigned(wq)) * 16u;
+          const rsrc_t sr = make_rsrc(p.stats_part, unsigned(p.n_frames) * (C::WPF * 16u));
+          const u32x4 rec = {has_nan ? 0x7fc00000u : __float_as_uint(mw), unsigned(has_nan ? nbest : best) + unsigned(wq) * 32u,
+                             __float_as_uint(bw), 0u};
+          // one lane stores the record: exec narrowed to lane 0 around the store (a lane test on the thread index is
+          // hoisted out of the frame loop as a mask the kernel has no SGPR pair for)
+          unsigned long long ex_save;
+          asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tbuffer_store_dwordx4 %1, off, %2, %3\n\ts_mov_b64 exec, %0"
+                       : "=&s"(ex_save) : "v"(rec), "s"(sr), "s"(soff) : "memory");
         }
         if constexpr (!C::WIN_LDS) load_window();     // next frame's window, ahead of this frame's stores
         TDSA_PRIO(0);
@@ -985,6 +1108,15 @@ hipError_t launch_n(int in_c64, const SpecParams& p, const LaunchGeom& g, hipStr
 #endif
   }
   if (p.pre_raw != nullptr || p.post_n != 0 || p.rows_twice != 0) return hipErrorInvalidValue;   // no such instantiation
+  if (p.stats_part != nullptr) {          // per-frame scalars from the epilogue (the host asks only where these exist)
+    if constexpr (Cfg<LOG2N>::TPF >= 64) {
+      if (hold > 1 || p.tare != nullptr || p.out_cplx != nullptr || p.out_lin != nullptr) return hipErrorInvalidValue;
+      if (in_c64) return hold ? launch_one<LOG2N, true, 9>(p, g, s) : launch_one<LOG2N, true, 8>(p, g, s);
+      return hold ? launch_one<LOG2N, false, 9>(p, g, s) : launch_one<LOG2N, false, 8>(p, g, s);
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
   if (in_c64) {
     switch (hold) {
       case 0: return launch_one<LOG2N, true, 0>(p, g, s);

@@ -90,6 +90,29 @@ class SpectrumEngine:
             b = np.ascontiguousarray(baseline_db, dtype=np.float32)
             nat.check(nat.lib.tdsa_set_tare_baseline(self._h, _ptr(b), int(b.size)))
 
+    def set_frame_stats(self, enable: bool = True, band_bins: Optional[Tuple[int, int]] = None) -> None:
+        """Per-frame scalars as a by-product of every process call (tdsa_set_frame_stats): np.max / np.argmax of each
+        dB row (core/duty_cycle.py:36, core/marker_manager.py:97) and the linear power of the inclusive display-bin
+        range `band_bins` (MarkerManager._band_power, core/marker_manager.py:308-319; analytics.band_bin_range maps a
+        frequency band onto bins).  Read them with frame_stats()."""
+        lo, hi = (1, 0) if band_bins is None else (int(band_bins[0]), int(band_bins[1]))
+        nat.check(nat.lib.tdsa_set_frame_stats(self._h, int(bool(enable)), lo, hi))
+
+    def frame_stats(self, calls_back: int = 0, bin_width: Optional[float] = None):
+        """(peak_db[frames] f32, peak_bin[frames] i32, band) of the latest call (calls_back = 1: the one before, ... the
+        last four are kept).  band = the band's linear sums (float64), or with bin_width (Hz per bin: `(bins[-1] -
+        bins[0]) / max(len(bins) - 1, 1)`) the reference's 10 log10(max(sum * bin_width, 1e-30))."""
+        n = C.c_int()
+        nat.check(nat.lib.tdsa_get_frame_stats(self._h, int(calls_back), 0, C.byref(n), None, None, None))
+        peak = np.empty(n.value, dtype=np.float32)
+        pbin = np.empty(n.value, dtype=np.int32)
+        band = np.empty(n.value, dtype=np.float64)
+        nat.check(nat.lib.tdsa_get_frame_stats(self._h, int(calls_back), n.value, None, _ptr(peak), _ptr(pbin), _ptr(band)))
+        if bin_width is not None:
+            total = band * float(bin_width)
+            band = 10.0 * np.log10(np.where(total < 1e-30, 1e-30, total))      # max(total, 1e-30) keeps a NaN
+        return peak, pbin, band
+
     # ------------------------------------------------------------------ hot path
     def process(self, iq: np.ndarray, hop: Optional[int] = None, n_frames: Optional[int] = None,
                 want_db: bool = True) -> Optional[np.ndarray]:
