@@ -296,9 +296,12 @@ int tdsa_rows_top_peaks(tdsa_plan p, const float* rows_dev, int n_rows, int n_bi
  * 10^(dB / 10) over the inclusive display-bin range [band_lo, band_hi] (MarkerManager._band_power,
  * core/marker_manager.py:308-319, before `* bin_width` and the log; band_lo > band_hi: no band, zeros).
  * Frames of 1024 ... 16384 points in the plain dB modes (no averaging, no tare, hold none / max): the frame kernel's
- * waves form them from the bins in their registers - no second pass over the rows, which need not even be written
- * (out_db_dev = NULL); band_lin is then summed from the linear power the kernel holds (float32 per wave, float64 across
- * waves; within 1e-6 relative of the sum over the rounded dB values).  Every other plan / mode: rows_stats_kernel runs on
+ * waves form them from the bins in their registers: a wave leaves its maximum, its band sum and the sixteen dB values of
+ * the one lane that holds the maximum (80 bytes per wave and frame; ties between lanes and NaNs are resolved in the
+ * kernel); tdsa_get_frame_stats folds a frame's waves when it is called.  No second pass over the rows, which need not
+ * even be written (out_db_dev = NULL).  band_lin is summed from the linear power the kernel holds (float32 per wave,
+ * float64 across waves; within 1e-5 relative of the sum over the rounded dB values, one
+ * float32 unit of a dB value near -110 being 2e-6 of the power).  Every other plan / mode: rows_stats_kernel runs on
  * the rows the call wrote (a call without rows then has no statistics).  Not for plans above 16384 x 2^k points that
  * return one row per call.  The results of the last four calls are kept: calls_back = 0 is the latest call, 1 the one
  * before ... - tdsa_get_frame_stats waits for that call only, so overlapped calls (tdsa_set_overlap) stay in flight.

@@ -387,13 +387,16 @@ def rtl_batch(iq_i8: np.ndarray, nfft: int, hop: int, sample_rate: float, *,
 
 
 def max_hold_at_positions(iq_i8: np.ndarray, nfft: int, hop: int, positions, branch: str = "hackrf",
-                          n_frames: Optional[int] = None, chunk: int = 128) -> np.ndarray:
+                          n_frames: Optional[int] = None, chunk: int = 128, allowance_units: float = 0.0):
     """float64 gold of the max-hold trace of a whole capture at a FEW fftshift-ed positions, evaluated from the DFT
     definition X[k] = sum_n x[n] exp(-2 pi i k n / N) as one matrix product per chunk of frames - what bench.py checks
     the (combined) hold trace against where a full FFT of every frame of every rank would take minutes.  Per frame the
     arithmetic is the branch's own, in float64: HackRF (hackrf_samples.py:360-383: mean removal, power-normalised
     Hann, 20 log10(|X| + 1e-12)) or RTL (rtl_samples.py:169-184: raw Hann, 10 log10(|X|^2 + 1e-10)); the hold is
-    np.fmax over the frames (core/display_data_processor.py:371-382)."""
+    np.fmax over the frames (core/display_data_processor.py:371-382).
+    allowance_units > 0: returns (hold, allowance) - the |dB| allowance of the trace at those positions by HoldAllowance's
+    rule (the largest allowance any held frame had there, with `allowance_units` float32 rounding units as the amplitude
+    floor); a frame's maximum is taken over the positions given, so they must include its strongest bin."""
     x = unpack_iq_int8(iq_i8)
     nf = num_frames(len(x), nfft, hop) if n_frames is None else n_frames
     pos = np.asarray(positions, dtype=np.int64)
@@ -408,6 +411,7 @@ def max_hold_at_positions(iq_i8: np.ndarray, nfft: int, hop: int, positions, bra
     frames = np.lib.stride_tricks.as_strided(x, shape=(nf, nfft), strides=(hop * x.strides[0], x.strides[0]),
                                              writeable=False)
     hold = np.full(len(pos), -np.inf)
+    allow = np.zeros(len(pos))
     for f0 in range(0, nf, chunk):
         blk = frames[f0: f0 + chunk].astype(np.complex128)
         if branch == "hackrf":
@@ -416,7 +420,9 @@ def max_hold_at_positions(iq_i8: np.ndarray, nfft: int, hop: int, positions, bra
         else:
             db = 10.0 * np.log10(np.abs(blk @ ew) ** 2 + POWER_LOG_FLOOR)
         hold = np.fmax(hold, db.max(axis=0))
-    return hold
+        if allowance_units > 0:
+            allow = np.maximum(allow, row_allowance_db(db, 100.0, allowance_units * AMP_FLOOR).max(axis=0))
+    return (hold, allow) if allowance_units > 0 else hold
 
 
 # ----------------------------------------------------------------------------------------------
@@ -472,6 +478,50 @@ def parity_metrics(db_gpu: np.ndarray, db_gold: np.ndarray, floor_rel_db: float 
     with np.errstate(invalid="ignore"):
         ddb = np.where(mask, np.abs(db_gpu - db_gold) / allowance, 0.0) * 1e-3
     return float(rel.max()), float(np.nanmax(ddb))
+
+
+def row_allowance_db(db_gold: np.ndarray, floor_rel_db: float = 100.0, amp_floor: float = AMP_FLOOR) -> np.ndarray:
+    """The |dB| allowance parity_metrics grants every bin of every row (same shape as db_gold); +inf where the bin lies
+    more than floor_rel_db below its frame's maximum (not checked)."""
+    db_gold = np.asarray(db_gold, dtype=np.float64)
+    depth = db_gold.max(axis=-1, keepdims=True) - db_gold
+    allowance = np.maximum(1e-3, (20.0 / np.log(10.0)) * amp_floor * 10.0 ** (depth / 20.0))
+    return np.where(depth <= floor_rel_db, allowance, np.inf)
+
+
+class HoldAllowance:
+    """What a max / min hold trace may differ from the gold trace by - NOT a statistical figure of its own but what
+    follows from the rows' allowance: for any two sequences |max_f a_f - max_f b_f| <= max_f |a_f - b_f| (the same for
+    min), bin by bin, so a trace held over rows that each keep their allowance differs from the gold trace by at most
+    the LARGEST allowance any held row had at that bin (and its linear power by at most 1e-4 of the largest frame
+    maximum).  Judging a hold trace by parity_metrics instead - i.e. against the allowance of a single row whose
+    maximum is the trace's own - is wrong on two counts: a min-hold trace keeps per bin the lowest of up to hundreds
+    of values, an extreme of as many draws of the rounding error (round 5's soak: 2.49 units on a trace whose rows
+    stood at 0.1), and the trace's own maximum is not the amplitude any frame's transform carried.
+    (core/display_data_processor.py:371-395: np.fmax / np.fmin over the displayed rows.)
+
+    update(gold_rows) with every batch of rows the trace has seen since its reset, then metrics(trace_gpu, trace_gold)
+    -> (rel, ddb) with the meaning and bounds of parity_metrics (rel <= 1e-4, ddb <= 1e-3)."""
+
+    def __init__(self, floor_rel_db: float = 100.0, amp_floor: float = AMP_FLOOR):
+        self.floor_rel_db, self.amp_floor = floor_rel_db, amp_floor
+        self.allow = None
+        self.pmax = 0.0
+
+    def update(self, gold_rows: np.ndarray) -> "HoldAllowance":
+        rows = np.atleast_2d(np.asarray(gold_rows, dtype=np.float64))
+        a = row_allowance_db(rows, self.floor_rel_db, self.amp_floor).max(axis=0)
+        self.allow = a if self.allow is None else np.maximum(self.allow, a)
+        self.pmax = max(self.pmax, float(10.0 ** (rows.max() / 10.0)))
+        return self
+
+    def metrics(self, trace_gpu: np.ndarray, trace_gold: np.ndarray):
+        g = np.asarray(trace_gpu, dtype=np.float64)
+        d = np.asarray(trace_gold, dtype=np.float64)
+        rel = np.abs(10.0 ** (g / 10.0) - 10.0 ** (d / 10.0)) / self.pmax
+        with np.errstate(invalid="ignore"):
+            ddb = np.where(np.isfinite(self.allow), np.abs(g - d) / self.allow, 0.0) * 1e-3
+        return float(rel.max()), float(np.nanmax(ddb))
 
 
 def parity_raw_db(db_gpu: np.ndarray, db_gold: np.ndarray, floor_rel_db: float) -> float:

@@ -30,14 +30,29 @@ def pkg():
     return p
 
 
-def _check(db_gpu, db_gold, what="", floor_units=None):
+def _check(db_gpu, db_gold, what="", floor_units=None, rows_gold=None):
     """Allowance 1e-3 dB, or two float32 rounding units of the frame's largest amplitude (2^-23 A_max) where that
     is worth more: the bound that held over the 3000-configuration soak of tools/parity_soak.py (median 0.14 units,
-    worst 1.38: the bin N/2 away from an on-bin full-scale tone; long frames worst 1.03)."""
+    worst 1.38: the bin N/2 away from an on-bin full-scale tone; long frames worst 1.03).
+    rows_gold: db_gpu / db_gold are a max / min HOLD trace over these gold rows - its allowance is what follows from
+    theirs, bin by bin (so.HoldAllowance: |max a - max b| <= max |a - b|), not that of a single row."""
     units = floor_units if floor_units is not None else 2
-    rel, ddb = so.parity_metrics(db_gpu, db_gold, amp_floor=units * so.AMP_FLOOR)
+    if rows_gold is not None:
+        rel, ddb = so.HoldAllowance(amp_floor=units * so.AMP_FLOOR).update(rows_gold).metrics(db_gpu, db_gold)
+    else:
+        rel, ddb = so.parity_metrics(db_gpu, db_gold, amp_floor=units * so.AMP_FLOOR)
     assert rel <= REL_TOL and ddb <= DB_TOL, f"{what}: rel={rel:.3e} ddb={ddb:.3e}"
     return rel, ddb
+
+
+def _two_transforms(nfft):
+    """sizes that run as a chirp-z convolution (two transforms of M >= 2 N points: about 1.6 x the error variance of one
+    transform - profiles/r05_parity_soak.txt): neither a power of two nor made of the factors 2, 3, 5"""
+    n = int(nfft)
+    for f in (2, 3, 5):
+        while n % f == 0:
+            n //= f
+    return n != 1
 
 
 def _hackrf_engine(pkg, nfft, nf, **cfg):
@@ -63,8 +78,8 @@ def test_hackrf_plain_int8_all_sizes(pkg, nfft):
         mx, mn = e.hold()
     assert out.shape == gold.shape and out.dtype == np.float32
     _check(out, gold, f"N={nfft}")
-    _check(mx, gmax, "max hold")
-    _check(mn, gmin, "min hold")
+    _check(mx, gmax, "max hold", rows_gold=gold)
+    _check(mn, gmin, "min hold", rows_gold=gold)
     assert np.array_equal(mx, out.max(axis=0)) and np.array_equal(mn, out.min(axis=0))
 
 
@@ -82,8 +97,8 @@ def test_hackrf_plain_int8_sizes_that_are_not_a_power_of_two(pkg, nfft):
         assert e.info().nfft == nfft
     assert out.shape == gold.shape and out.dtype == np.float32
     _check(out, gold, f"N={nfft}")
-    _check(mx, gmax, "max hold")
-    _check(mn, gmin, "min hold")
+    _check(mx, gmax, "max hold", rows_gold=gold)
+    _check(mn, gmin, "min hold", rows_gold=gold)
     assert np.array_equal(mx, out.max(axis=0)) and np.array_equal(mn, out.min(axis=0))
 
 
@@ -110,7 +125,7 @@ def test_long_frames_that_are_not_a_power_of_two(pkg, nfft, branch):
             mx, mn = e.hold()
         assert out.shape == gold.shape and out.dtype == np.float32
         _check(out, gold, f"N={nfft}")
-        _check(mx, gmax, "max hold")
+        _check(mx, gmax, "max hold", rows_gold=gold)
         assert np.array_equal(mx, out.max(axis=0)) and np.array_equal(mn, out.min(axis=0))
     else:
         gold, _, _ = so.rtl_batch(iq, nfft, hop, 2e6, precision="gold", avg=("exp", 3))
@@ -142,8 +157,8 @@ def test_sizes_made_of_the_factors_2_3_5(pkg, nfft):
                 out = e.process(feed, hop=hop, n_frames=nf)
                 mx, mn = e.hold()
             _check(out, gold, f"N={nfft} {feed.dtype} smooth={smooth}")
-            _check(mx, gmax, "max hold")
-            _check(mn, gmin, "min hold")
+            _check(mx, gmax, "max hold", rows_gold=gold)
+            _check(mn, gmin, "min hold", rows_gold=gold)
             assert np.array_equal(mx, out.max(axis=0)) and np.array_equal(mn, out.min(axis=0))
     # calls of more than eight frames take the frame means from the sums kernel, smaller ones form them in the transform's
     # kernel (byte samples): the rows of the first frames must be the same bits either way
@@ -188,7 +203,7 @@ def test_long_sizes_made_of_the_factors_2_3_5(pkg, nfft):
             out = e.process(feed, hop=hop, n_frames=nf)
             mx, mn = e.hold()
         _check(out, gold, f"N={nfft} {feed.dtype} smooth={smooth}")
-        _check(mx, gmax, "max hold")
+        _check(mx, gmax, "max hold", rows_gold=gold)
         assert np.array_equal(mx, out.max(axis=0)) and np.array_equal(mn, out.min(axis=0))
     if nfft <= 100000:
         golda, _, _ = so.rtl_batch(iq, nfft, nfft, 2e6, precision="gold", avg=("exp", 3))
@@ -1212,7 +1227,7 @@ def test_hold_and_averager_state_across_calls(pkg):
         out = np.concatenate([a, b])
         _check(out, gold, "split batch, lin avg")
         mx, _ = e.hold()
-        _check(mx, gmax, "hold across calls")
+        _check(mx, gmax, "hold across calls", rows_gold=gold)
         buf, cnt = e.averaged()
         assert cnt == 5
         _check(10 * np.log10(buf + so.POWER_LOG_FLOOR), gold[-1], "averager state read-back")
@@ -2399,8 +2414,8 @@ def _run_sweep_case(pkg, case_id, c):
         mx, mn = e.hold()
     what = f"case {case_id}: {c}"
     _check(out, gold, what)
-    _check(mx, gmax, what + " max hold")
-    _check(mn, gmin, what + " min hold")
+    _check(mx, gmax, what + " max hold", rows_gold=gold)
+    _check(mn, gmin, what + " min hold", rows_gold=gold)
 
 
 @pytest.mark.parametrize("case_id", range(int(os.environ.get("TDSA_ANYSIZE_CASES", "24"))))
@@ -2459,7 +2474,7 @@ def call_sequence_trial(pkg, trial, report=None, any_size=False):
         raw = so.unpack_iq_int8(iq)
         x, per = raw, 1
     br = so.HackrfBranchOracle(nfft, fs, dc_alpha, psd, "gold")
-    hold = so.HoldOracle(True, True)
+    hold, hold_allow = so.HoldOracle(True, True), so.HoldAllowance()
     cal, tare = 0.0, None
     worst_units, worst_rel, calls = 0.0, 0.0, 0
     with pkg.SpectrumEngine(nfft, max_frames=max_call) as e:
@@ -2479,7 +2494,7 @@ def call_sequence_trial(pkg, trial, report=None, any_size=False):
                 br.averager.reset()
                 e.reset(nat.RESET_AVG)
             elif op == 2:
-                hold = so.HoldOracle(True, True)
+                hold, hold_allow = so.HoldOracle(True, True), so.HoldAllowance()
                 e.reset(nat.RESET_HOLD_MAX | nat.RESET_HOLD_MIN)
             elif op == 3:
                 cal = float(rng.choice([0.0, -0.8087, 3.5]))
@@ -2498,7 +2513,8 @@ def call_sequence_trial(pkg, trial, report=None, any_size=False):
                     gold[j] = g
                     hold.update(g)
                 mx, mn = e.hold()
-                pairs = (so.parity_metrics(out, gold), so.parity_metrics(mx, hold.max), so.parity_metrics(mn, hold.min))
+                hold_allow.update(gold)          # the traces' allowance follows from that of every row they have seen
+                pairs = (so.parity_metrics(out, gold), hold_allow.metrics(mx, hold.max), hold_allow.metrics(mn, hold.min))
                 units = max(p[1] for p in pairs) / 1e-3
                 rel = max(p[0] for p in pairs)
                 if report is not None and (units > 2.0 or rel > REL_TOL):
@@ -2510,6 +2526,26 @@ def call_sequence_trial(pkg, trial, report=None, any_size=False):
     return worst_units, worst_rel, calls
 
 
+# trials of round 5's 1200-trial soak that stood above two units under the old rule (hold traces judged like single rows):
+# 871 (N = 8192, lin 16, tare: MIN hold 2.49, rows 0.08), any-size 1031 (N = 5921: min hold 2.17, rows 1.17) and any-size 83
+# (N = 4095 chirp-z, exp 8, tracked DC: a ROW at 2.03) - kept as fixed regression cases
+SEQUENCE_REGRESSIONS = [(871, False), (1031, True), (83, True)]
+
+
+def _sequence_bound(pkg, trial, any_size):
+    """(bound in rounding units, nfft): two for one transform, three where a frame takes two (chirp-z sizes)"""
+    rng = np.random.default_rng((9000 if not any_size else 19000) + trial)
+    nfft = _any_size(rng) if any_size else int(2 ** rng.integers(6, 14))
+    return (3.0 if _two_transforms(nfft) else 2.0), nfft
+
+
+@pytest.mark.parametrize("trial,any_size", SEQUENCE_REGRESSIONS)
+def test_call_sequences_that_crossed_the_old_allowance(pkg, trial, any_size):
+    bound, nfft = _sequence_bound(pkg, trial, any_size)
+    units, rel, calls = call_sequence_trial(pkg, trial, any_size=any_size)
+    assert calls > 0 and rel <= REL_TOL and units <= bound, f"trial {trial} (N = {nfft}): {units:.2f} units, rel {rel:.2e}"
+
+
 @pytest.mark.parametrize("trial", range(int(os.environ.get("TDSA_SEQUENCE_TRIALS", "24"))))
 def test_random_call_sequences(pkg, trial):
     units, rel, calls = call_sequence_trial(pkg, trial)
@@ -2518,8 +2554,9 @@ def test_random_call_sequences(pkg, trial):
 
 @pytest.mark.parametrize("trial", range(int(os.environ.get("TDSA_ANYSIZE_TRIALS", "12"))))
 def test_random_call_sequences_any_size(pkg, trial):
+    bound, nfft = _sequence_bound(pkg, trial, True)
     units, rel, calls = call_sequence_trial(pkg, trial, any_size=True)
-    assert calls > 0 and rel <= REL_TOL and units <= 2.0, f"trial {trial}: {units:.2f} units, rel {rel:.2e}"
+    assert calls > 0 and rel <= REL_TOL and units <= bound, f"trial {trial} (N = {nfft}): {units:.2f} units, rel {rel:.2e}"
 
 
 def test_engine_closes_its_pipes_first(pkg):

@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--streams", type=int, default=1)
     ap.add_argument("--fmt", default="i8", choices=["i8", "c64"])
     ap.add_argument("--knob", action="append", default=[], help="name=value for tdsa_debug_knob (repeatable)")
+    ap.add_argument("--stats", default="", help="per-frame scalars from the epilogue: 'none' (peak / argmax only) or lo:hi (band bins)")
+    ap.add_argument("--rows-stats", type=int, default=0, help="1: tdsa_rows_stats on the rows after every call instead (the second pass)")
     a = ap.parse_args()
     n, hop, F = a.nfft, (a.hop or a.nfft // 2), a.frames
     ns = hop * (F - 1) + n
@@ -52,6 +54,12 @@ def main():
         k, v = kv.split("=")
         e.debug_knob(k, int(v))
     out_ptr = None if a.nodb else dev_out.value
+    band = None
+    if a.stats:
+        band = None if a.stats == "none" else tuple(int(x) for x in a.stats.split(":"))
+        if not a.rows_stats:
+            e.set_frame_stats(True, band)
+    pk, pb, bd = np.empty(F * B, np.float32), np.empty(F * B, np.int32), np.empty(F * B, np.float64)
     e.set_overlap(a.streams)
 
     def call():
@@ -59,6 +67,11 @@ def main():
             e.process_device(fmt, dev_in.value, ns, hop, F, out_ptr)
         else:
             e.process_device_batch(fmt, dev_in.value, iq.nbytes, B, ns, hop, F, out_ptr, F * n)
+        if a.rows_stats:      # the second pass over the rows (synchronous: launch + read-back)
+            lo, hi = band if band else (0, -1)
+            nat.check(nat.lib.tdsa_rows_stats(e._h, C.c_void_p(dev_out.value), F * B, n, lo, hi, 1.0,
+                                              pk.ctypes.data_as(C.c_void_p), pb.ctypes.data_as(C.c_void_p),
+                                              bd.ctypes.data_as(C.c_void_p) if band else None))
     for _ in range(max(1, a.warmup // B)):
         call()
     e.synchronize()
@@ -78,7 +91,7 @@ def main():
     fps = F / (per * 1e-3)
     bytes_per_frame = sb * hop + 4 * n
     inf = e.info()
-    print(f"lib={os.path.basename(nat.LIB_PATH)} {' '.join(a.knob)} fmt={a.fmt} N={n} hop={hop} F={F} batch={B} streams={a.streams} hold={a.hold} grid={inf.grid}x{inf.block} lds={inf.lds_bytes} "
+    print(f"lib={os.path.basename(nat.LIB_PATH)} {' '.join(a.knob)} stats={a.stats or '-'}{' (rows pass)' if a.rows_stats else ''} fmt={a.fmt} N={n} hop={hop} F={F} batch={B} streams={a.streams} hold={a.hold} grid={inf.grid}x{inf.block} lds={inf.lds_bytes} "
           f"step={per*1e3:.1f} us  {fps/1e6:.3f} Mframes/s  {fps*bytes_per_frame/1e12:.3f} TB/s algorithmic "
           f"({fps*bytes_per_frame/8e12*100:.1f}% of 8 TB/s)  host wall {((t1-t0)/(calls*B))*1e6:.1f} us/step")
 

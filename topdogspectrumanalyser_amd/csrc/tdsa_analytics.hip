@@ -126,22 +126,23 @@ __global__ void __launch_bounds__(256) rows_stats_kernel(const float* __restrict
 }
 
 // ---- per-frame scalars left by the frame kernel's STATS epilogue ------------------------------------------
-// parts[f][w] = {max dB of wave w's bins, first display bin holding it, linear band power of its bins, 0}: thread f folds
-// its frame's waves in wave order - np.max / np.argmax rules (`better`), the band in float64 times 10^(cal / 10) (the
-// records carry the power BEFORE the calibration offset; the rows carry it after).
-__global__ void __launch_bounds__(256) frame_stats_finish_kernel(const uint4* __restrict__ parts, int n_frames, int wpf,
-                                                                 double cal_lin, float* peak_db, int* peak_bin,
-                                                                 double* band_lin) {
+// One 16-byte record per wave and frame: {max dB of the wave's bins, the first display position among them that holds it
+// (bit 30 set: the position of the first NaN instead - np.max is then NaN, np.argmax that bin), linear band power of its
+// bins, 0}.  Thread f folds its frame's waves in wave order: np.max / np.argmax rules (`better`), the band in float64
+// times 10^(cal / 10) (the records carry the power BEFORE the calibration offset, the rows after).  Reads nothing but
+// the records: it runs when the scalars are asked for (tdsa_get_frame_stats), not behind every frame-kernel launch.
+__global__ void __launch_bounds__(256) frame_stats_finish_kernel(const uint4* __restrict__ parts, int n_frames,
+                                                                 int wpf, double cal_lin, float* peak_db,
+                                                                 int* peak_bin, double* band_lin) {
   const int f = blockIdx.x * 256 + threadIdx.x;
   if (f >= n_frames) return;
-  const uint4* r = parts + (size_t)f * wpf;
   PeakPair best{-INFINITY, 0x7fffffff};
   double bsum = 0.0;
   for (int w = 0; w < wpf; ++w) {
-    const uint4 q = r[w];
-    const PeakPair c{__uint_as_float(q.x), int(q.y)};
+    const uint4 h = parts[(size_t)f * wpf + w];
+    bsum += (double)__uint_as_float(h.z);
+    const PeakPair c{(h.y & 0x40000000u) ? NAN : __uint_as_float(h.x), int(h.y & 0x3fffffffu)};
     if (better(c, best)) best = c;
-    bsum += (double)__uint_as_float(q.z);
   }
   peak_db[f] = best.v;
   peak_bin[f] = best.i;

@@ -148,22 +148,29 @@ struct tdsa_plan_s {
   float2* d_u1 = nullptr;
   void* d_scratch = nullptr;             // grows on demand: results of tdsa_rows_stats / tdsa_rows_top_peaks
   size_t scratch_bytes = 0;
-  // per-frame scalars (tdsa_set_frame_stats): the results of the last kFsSlots calls
-  static constexpr int kFsSlots = 4;
+  // per-frame scalars (tdsa_set_frame_stats): the results of the last kFsKeep calls.  A call takes the next of ITS stream's
+  // kFsKeep slots, so a slot is only ever rewritten by later work of the stream that wrote it (in order, no events between
+  // the frame-kernel launches), and the last kFsKeep calls overall are always still there.
+  static constexpr int kFsKeep = 4;
   struct FsSlot {
     void* d_part = nullptr;              // [frames][waves per frame] records of the frame kernel's STATS epilogue
     float* d_peak = nullptr;             // [frames]
     int* d_bin = nullptr;
     double* d_band = nullptr;
-    size_t cap = 0, cap_part = 0;
+    size_t cap = 0;
     int n_frames = 0;
-    int state = 0;                       // 0: nothing, 1: results (in flight until ev), 2: the call produced no rows to take them from
-    hipEvent_t ev = nullptr;
-  } fs[kFsSlots];
+    int state = 0;                       // 0: nothing, 1: results (in flight on `stream`), 2: the call produced no rows to take them from
+    bool pending = false;                // the frame kernel's records are there, frame_stats_finish_kernel has not run yet
+    int wpf = 1;
+    double cal_lin = 1.0;
+    hipStream_t stream = nullptr;
+  } fs[kMaxOverlap][kFsKeep];
+  unsigned fs_count[kMaxOverlap] = {};   // calls that took a slot, per stream
+  FsSlot* fs_hist[kFsKeep] = {};         // the slots of the last calls, newest at fs_seq - 1
   bool fs_on = false;
   int fs_lo = 1, fs_hi = 0;              // band: inclusive display-bin range, lo > hi = none
   unsigned long long fs_seq = 0;         // calls that left (or tried to leave) statistics
-  hipStream_t fs_stream = nullptr;       // read-back of a slot (waits for that slot's event only)
+  hipStream_t fs_stream = nullptr;       // folds and reads back a slot
   bool profiling = false;
   bool sync_call = false;                // set by the synchronous host entry points around their device call
   std::vector<hipEvent_t> prof_events;   // pairs (begin, end) around frame-kernel launches
@@ -1012,12 +1019,12 @@ int tdsa_destroy(tdsa_plan p) {
     if (b) (void)hipFree(b);
   if (p->h_in_pin) (void)hipHostFree(p->h_in_pin);
   if (p->h_out_pin) (void)hipHostFree(p->h_out_pin);
-  for (auto& sl : p->fs) {
-    void* fb[] = {sl.d_part, sl.d_peak, sl.d_bin, sl.d_band};
-    for (void* b : fb)
-      if (b) (void)hipFree(b);
-    if (sl.ev) (void)hipEventDestroy(sl.ev);
-  }
+  for (auto& per_stream : p->fs)
+    for (auto& sl : per_stream) {
+      void* fb[] = {sl.d_part, sl.d_peak, sl.d_bin, sl.d_band};
+      for (void* b : fb)
+        if (b) (void)hipFree(b);
+    }
   if (p->fs_stream) { (void)hipStreamSynchronize(p->fs_stream); (void)hipStreamDestroy(p->fs_stream); }
   for (hipEvent_t e : p->prof_events) (void)hipEventDestroy(e);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -1173,36 +1180,37 @@ static bool frame_stats_fusable(tdsa_plan p, bool averaging) {
   return p->fs_on && !averaging && !p->chirp && !p->big && p->log2n >= 10 && !p->tare_active &&
          (p->mode.hold_flags & TDSA_HOLD_MIN) == 0;
 }
-// the slot the call at hand writes: grown to n_frames, ordered after whatever last used it
-static int frame_stats_begin(tdsa_plan p, int n_frames, int wpf, hipStream_t s, tdsa_plan_s::FsSlot** out) {
-  tdsa_plan_s::FsSlot& sl = p->fs[p->fs_seq % tdsa_plan_s::kFsSlots];
-  if (!sl.ev) HIPCHK(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
-  else if (sl.state == 1) HIPCHK(hipStreamWaitEvent(s, sl.ev, 0));
-  if (size_t(n_frames) > sl.cap || size_t(n_frames) * wpf > sl.cap_part) {
-    if (sl.state == 1) HIPCHK(hipEventSynchronize(sl.ev));
+// the slot the call at hand writes (the next one of its stream's), grown to n_frames
+static int frame_stats_begin(tdsa_plan p, int n_frames, hipStream_t s, tdsa_plan_s::FsSlot** out) {
+  int si = 0;
+  for (int i = 0; i < tdsa_plan_s::kMaxOverlap - 1; ++i)
+    if (s == p->aux[i] && s != p->stream) si = i + 1;
+  tdsa_plan_s::FsSlot& sl = p->fs[si][p->fs_count[si]++ % tdsa_plan_s::kFsKeep];
+  if (size_t(n_frames) > sl.cap) {
+    HIPCHK(hipStreamSynchronize(s));                         // whatever last wrote the slot ran on this stream
     if (p->fs_stream) HIPCHK(hipStreamSynchronize(p->fs_stream));
     void* fb[] = {sl.d_part, sl.d_peak, sl.d_bin, sl.d_band};
     for (void* b : fb)
       if (b) HIPCHK(hipFree(b));
     sl.d_part = nullptr; sl.d_peak = nullptr; sl.d_bin = nullptr; sl.d_band = nullptr;
-    sl.cap = sl.cap_part = 0;
+    sl.cap = 0;
     const size_t cap = size_t(n_frames) > size_t(p->max_frames) ? size_t(n_frames) : size_t(p->max_frames);
-    HIPCHK(hipMalloc(&sl.d_part, cap * 16 * 16));            // up to 16 waves per frame
+    HIPCHK(hipMalloc(&sl.d_part, cap * 16 * kStatsRecBytes));   // up to 16 waves per frame
     HIPCHK(hipMalloc(&sl.d_peak, cap * sizeof(float)));
     HIPCHK(hipMalloc(&sl.d_bin, cap * sizeof(int)));
     HIPCHK(hipMalloc(&sl.d_band, cap * sizeof(double)));
     sl.cap = cap;
-    sl.cap_part = cap * 16;
   }
   sl.n_frames = n_frames;
   sl.state = 0;
+  sl.pending = false;
+  sl.stream = s;
   *out = &sl;
   return TDSA_OK;
 }
-static int frame_stats_end(tdsa_plan p, tdsa_plan_s::FsSlot* sl, int state, hipStream_t s) {
+static int frame_stats_end(tdsa_plan p, tdsa_plan_s::FsSlot* sl, int state) {
   sl->state = state;
-  if (state == 1) HIPCHK(hipEventRecord(sl->ev, s));
-  ++p->fs_seq;
+  p->fs_hist[p->fs_seq++ % tdsa_plan_s::kFsKeep] = sl;
   return TDSA_OK;
 }
 // plans / modes without the fused epilogue: the same scalars from the rows the call wrote (rows_stats_kernel)
@@ -1210,14 +1218,14 @@ static int frame_stats_from_rows(tdsa_plan p, const float* rows, int n_frames, i
                                  long long seg_stride_elems, hipStream_t s) {
   if (!p->fs_on) return TDSA_OK;
   tdsa_plan_s::FsSlot* sl = nullptr;
-  int rc = frame_stats_begin(p, n_frames, 1, s, &sl);
+  int rc = frame_stats_begin(p, n_frames, s, &sl);
   if (rc != TDSA_OK) return rc;
-  if (rows == nullptr) return frame_stats_end(p, sl, 2, s);
+  if (rows == nullptr) return frame_stats_end(p, sl, 2);
   for (int g = 0; g < n_seg; ++g)
     HIPCHK(launch_rows_stats(rows + (long long)g * seg_stride_elems, frames_per_seg, p->nfft, p->fs_lo, p->fs_hi, -1.0,
                              sl->d_peak + (size_t)g * frames_per_seg, sl->d_bin + (size_t)g * frames_per_seg,
                              sl->d_band + (size_t)g * frames_per_seg, s));
-  return frame_stats_end(p, sl, 1, s);
+  return frame_stats_end(p, sl, 1);
 }
 
 // several captures in one launch (tdsa_process_dev_batch): n_frames = n_seg * frames_per_seg frames in all
@@ -1419,8 +1427,7 @@ static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size
     tdsa_plan_s::FsSlot* fsl = nullptr;
     const bool fs_fused = frame_stats_fusable(p, false);
     if (fs_fused) {
-      const int wpf = spectrum_waves_per_frame(p->log2n);
-      const int rc_b = frame_stats_begin(p, n_frames, wpf, s, &fsl);
+      const int rc_b = frame_stats_begin(p, n_frames, s, &fsl);
       if (rc_b != TDSA_OK) return rc_b;
       sp.stats_part = fsl->d_part;
       sp.band_lohi = p->fs_lo <= p->fs_hi ? (unsigned(p->fs_lo) | (unsigned(p->fs_hi) << 16)) : 1u;
@@ -1428,10 +1435,12 @@ static int process_dev_impl(tdsa_plan p, int in_format, const void* iq_dev, size
     int rc_p = launch_spectrum_profiled(p, in_c64, sp, g, s);
     if (rc_p != TDSA_OK) return rc_p;
     if (fs_fused) {
-      // the records hold the power before the calibration offset: 10^(dB / 10) = power x 10^(cal / 10)
-      HIPCHK(launch_frame_stats_finish(fsl->d_part, n_frames, spectrum_waves_per_frame(p->log2n),
-                                       std::pow(10.0, double(m.cal_offset_db) / 10.0), fsl->d_peak, fsl->d_bin, fsl->d_band, s));
-      const int rc_e = frame_stats_end(p, fsl, 1, s);
+      // the records hold the power before the calibration offset: 10^(dB / 10) = power x 10^(cal / 10).  They are folded
+      // when someone asks (tdsa_get_frame_stats): nothing runs behind the frame kernel on its stream
+      fsl->pending = true;
+      fsl->wpf = spectrum_waves_per_frame(p->log2n);
+      fsl->cal_lin = std::pow(10.0, double(m.cal_offset_db) / 10.0);
+      const int rc_e = frame_stats_end(p, fsl, 1);
       if (rc_e != TDSA_OK) return rc_e;
     } else if (p->fs_on) {
       const bool one = !seg || seg->single_frames;
@@ -2507,10 +2516,10 @@ int tdsa_set_frame_stats(tdsa_plan p, int enable, int band_lo, int band_hi) {
   p->fs_on = enable != 0;
   p->fs_lo = band_lo;
   p->fs_hi = band_hi;
-  for (auto& sl : p->fs) {
-    if (sl.state == 1) HIPCHK(hipEventSynchronize(sl.ev));
-    sl.state = 0;
-  }
+  HIPCHK(hipStreamSynchronize(p->stream));                   // (joined: everything in flight is behind the main stream)
+  for (auto& per_stream : p->fs)
+    for (auto& sl : per_stream) sl.state = 0;
+  for (auto& h : p->fs_hist) h = nullptr;
   p->fs_seq = 0;
   return TDSA_OK;
 }
@@ -2519,18 +2528,23 @@ int tdsa_get_frame_stats(tdsa_plan p, int calls_back, int capacity, int* n_frame
                          int32_t* peak_bin_host, double* band_lin_host) {
   if (!p) return fail(TDSA_ERR_ARG, "null plan");
   if (!p->fs_on) return fail(TDSA_ERR_STATE, "tdsa_set_frame_stats has not enabled the per-frame scalars");
-  if (calls_back < 0 || calls_back >= tdsa_plan_s::kFsSlots || (unsigned long long)calls_back >= p->fs_seq)
+  if (calls_back < 0 || calls_back >= tdsa_plan_s::kFsKeep || (unsigned long long)calls_back >= p->fs_seq)
     return fail(TDSA_ERR_ARG, "calls_back=%d: the results of the last %d calls are kept, %llu made", calls_back,
-                tdsa_plan_s::kFsSlots, p->fs_seq);
-  tdsa_plan_s::FsSlot& sl = p->fs[(p->fs_seq - 1 - calls_back) % tdsa_plan_s::kFsSlots];
+                tdsa_plan_s::kFsKeep, p->fs_seq);
+  tdsa_plan_s::FsSlot& sl = *p->fs_hist[(p->fs_seq - 1 - calls_back) % tdsa_plan_s::kFsKeep];
   if (sl.state == 2) return fail(TDSA_ERR_STATE, "that call wrote no dB rows and its plan / mode has no fused statistics");
   if (sl.state != 1) return fail(TDSA_ERR_STATE, "no statistics in that slot");
   if (n_frames) *n_frames = sl.n_frames;
   if (capacity < sl.n_frames && (peak_db_host || peak_bin_host || band_lin_host))
     return fail(TDSA_ERR_ARG, "capacity %d < %d frames", capacity, sl.n_frames);
   HIPCHK(hipSetDevice(p->device));
-  HIPCHK(hipEventSynchronize(sl.ev));
+  HIPCHK(hipStreamSynchronize(sl.stream));                   // the call's own stream (later calls on other streams stay in flight)
   if (!p->fs_stream) HIPCHK(hipStreamCreateWithFlags(&p->fs_stream, hipStreamNonBlocking));
+  if (sl.pending) {
+    HIPCHK(launch_frame_stats_finish(sl.d_part, sl.n_frames, sl.wpf, sl.cal_lin, sl.d_peak, sl.d_bin, sl.d_band,
+                                     p->fs_stream));
+    sl.pending = false;
+  }
   const size_t nf = size_t(sl.n_frames);
   if (peak_db_host) HIPCHK(hipMemcpyAsync(peak_db_host, sl.d_peak, nf * sizeof(float), hipMemcpyDeviceToHost, p->fs_stream));
   if (peak_bin_host) HIPCHK(hipMemcpyAsync(peak_bin_host, sl.d_bin, nf * sizeof(int), hipMemcpyDeviceToHost, p->fs_stream));

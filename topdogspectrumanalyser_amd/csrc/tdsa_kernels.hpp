@@ -87,9 +87,10 @@ struct SpecParams {
                              // transform run back to back on each row: X -> conj(X out_mul) -> through LDS -> transform -> out_cplx
   // ---- per-frame scalars from the epilogue (STATS instantiations: N >= 1024, dB rows, no tare, hold none / max; appended in
   //      round 6) ----
-  void* stats_part;          // [F][waves per frame] 16-byte records {max dB, its first display bin, band power (linear), 0}, or null
+  void* stats_part;          // [F][waves per frame] records of kStatsRecBytes (see the STATS epilogue of the frame kernel), or null
   unsigned band_lohi;        // band power: inclusive display-bin range lo | hi << 16; lo > hi: none
 };
+constexpr int kStatsRecBytes = 16;   // {max dB, its first display position among the wave's bins (bit 30: a NaN), band power, 0}
 // waves of one frame in the frame kernel (frames of whole waves: N >= 1024)
 inline int spectrum_waves_per_frame(int log2n) { return log2n <= 10 ? 1 : (1 << log2n) / 1024; }
 

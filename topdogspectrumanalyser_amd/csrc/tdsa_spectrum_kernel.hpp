@@ -113,17 +113,17 @@ __device__ __forceinline__ float in_vgpr(float x) { asm volatile("" : "+v"(x)); 
 __device__ __forceinline__ float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-// wave64 float maximum (NaN operands ignored) / sum with DPP moves; the result is valid in lane 63
+// wave64 float maximum (NaN operands ignored) / sum across the lanes; the result is valid in lane 63
 __device__ __forceinline__ float dpp_wave_max63(float x) {
-  auto mv = [&](auto ctrl, auto rm) {
-    return __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(x), __float_as_uint(x), decltype(ctrl)::value, decltype(rm)::value, 0xf, false));
-  };
-  x = hw_max(x, mv(std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xf>{}));
-  x = hw_max(x, mv(std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xf>{}));
-  x = hw_max(x, mv(std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xf>{}));
-  x = hw_max(x, mv(std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xf>{}));
-  x = hw_max(x, mv(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{}));
-  x = hw_max(x, mv(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{}));
+  // v_max_f32 with the DPP operand in ONE instruction each (through the builtins it is v_mov, v_mov_dpp, v_max and three
+  // s_nop per step); the two wait states a DPP read of a freshly written VGPR needs sit inside every statement, whatever
+  // the compiler puts in front of it (its hazard recognizer does not look into inline assembly)
+  asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(x));
+  asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(x));
+  asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(x));
+  asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(x));
+  asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(x));
+  asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 0" : "+v"(x));
   return x;
 }
 __device__ __forceinline__ float dpp_wave_sum63(float x) {
@@ -842,45 +842,61 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
           });
         }
         if constexpr (STATS) {
-          // the wave's record: maximum of its 16 x 64 dB values, the first display position that holds it (np.argmax:
-          // first of equals, a NaN before everything - only complex64 input can carry one), the band's linear sum
+          // the wave's record: {maximum of its 16 x 64 dB values, the first display position of the wave's bins that holds it
+          // (np.argmax: first of equals; 0x40000000 | position of the first NaN - only complex64 input can carry one - and the
+          // maximum is then NaN), the band's linear sum, 0}.  ONE lane holds the maximum in all but degenerate frames: its
+          // sixteen bins are tested against it with one compare each, the holder's bit of every mask picked with
+          // s_bitcmp.  Several holders (silence, flat spectra) or a NaN: one ballot per bin over the whole wave.
+          // (That search for every wave and frame cost 17 us per C3 step; the holder's sixteen values stored for a later
+          //  look-up - sixteen one-lane stores - 13; this: see profiles/r06_frame_stats.txt.)
           const float m = hw_max3(hw_max3(hw_max3(db[0], db[1], db[2]), hw_max3(db[3], db[4], db[5]), hw_max3(db[6], db[7], db[8])),
                                   hw_max3(hw_max3(db[9], db[10], db[11]), hw_max3(db[12], db[13], db[14]), db[15]), db[15]);
           const float mw = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dpp_wave_max63(m)), 63));
+          const unsigned long long holders = __builtin_amdgcn_ballot_w64(m == mw);
+          const unsigned who = unsigned(__builtin_ctzll(holders));
+          bool nan = false;
+          if constexpr (IN_C64) {
+            static_for<0, 16>([&](auto ic) { nan |= db[decltype(ic)::value] != db[decltype(ic)::value]; });
+            nan = __builtin_amdgcn_ballot_w64(nan) != 0ull;
+          }
+          int best = 0x3fffffff;
+          if (__builtin_popcountll(holders) == 1 && !nan) {      // wave-uniform
+            int bk = 0;
+            static_for<0, 16>([&](auto ic) {                      // from the highest position down: the lowest match stays
+              constexpr int q = decltype(ic)::value < 8 ? 7 - decltype(ic)::value : 23 - decltype(ic)::value;
+              constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
+              __builtin_amdgcn_sched_barrier(0);                   // (one mask at a time: the kernel has no SGPRs for sixteen)
+              const unsigned long long mk = __builtin_amdgcn_ballot_w64(db[q] == mw);
+              if ((mk >> who) & 1ull) bk = kcs;
+            });
+            best = (bk + 8 * int(who >> 5)) * SG + int(who & 31u);
+          } else {
+            asm volatile("; several holders / NaN" ::: "memory");    // (a side effect: this path must stay a branch, folded into
+                                                                      //  selects it runs - sixteen more ballots - for every frame)
+            static_for<0, 16>([&](auto ic) {
+              constexpr int q = decltype(ic)::value;
+              constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
+              __builtin_amdgcn_sched_barrier(0);
+              // (`>=`, not `==`: the same lanes - mw is the maximum - but not the same expression as the other path's, or all
+              //  sixteen compares are hoisted above the branch as common subexpressions, into 32 SGPRs the kernel has not got)
+              const unsigned long long mk = __builtin_amdgcn_ballot_w64(nan ? db[q] != db[q] : db[q] >= mw);
+              if (mk != 0ull) {
+                const int l = __builtin_ctzll(mk);                // lanes ascend with the position inside a half, halves with 8 SG
+                const int cand = (kcs + 8 * (l >> 5)) * SG + (l & 31);
+                best = cand < best ? cand : best;
+              }
+            });
+          }
+          __builtin_amdgcn_sched_barrier(0);
           int wq = __builtin_amdgcn_readfirstlane(wave);         // (the scalar wave index rebuilt per frame: no SGPR held for it)
           asm volatile("" : "+s"(wq));
           wq &= C::WPF - 1;
-          int best = 0x7fffffff, nbest = 0x7fffffff;
-          static_for<0, 16>([&](auto ic) {
-            constexpr int q = decltype(ic)::value;
-            constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
-            // (one ballot at a time: left to itself the scheduler forms all sixteen masks first - 32 SGPRs the kernel
-            //  does not have)
-            __builtin_amdgcn_sched_barrier(0);
-            const unsigned long long mk = __builtin_amdgcn_ballot_w64(db[q] == mw);
-            if (mk != 0ull) {
-              const int l = __builtin_ctzll(mk);                  // lanes ascend with the position inside a half, halves with 8 SG
-              const int cand = (kcs + 8 * (l >> 5)) * SG + (l & 31);
-              best = cand < best ? cand : best;
-            }
-            if constexpr (IN_C64) {
-              const unsigned long long nk = __builtin_amdgcn_ballot_w64(db[q] != db[q]);
-              if (nk != 0ull) {
-                const int l = __builtin_ctzll(nk);
-                const int cand = (kcs + 8 * (l >> 5)) * SG + (l & 31);
-                nbest = cand < nbest ? cand : nbest;
-              }
-            }
-          });
-          __builtin_amdgcn_sched_barrier(0);
           const float bw = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dpp_wave_sum63(st_band)), 63));
-          const bool has_nan = IN_C64 && nbest != 0x7fffffff;
-          const unsigned soff = (unsigned(frame) * C::WPF + unsigned(wq)) * 16u;
-          const rsrc_t sr = make_rsrc(p.stats_part, unsigned(p.n_frames) * (C::WPF * 16u));
-          const u32x4 rec = {has_nan ? 0x7fc00000u : __float_as_uint(mw), unsigned(has_nan ? nbest : best) + unsigned(wq) * 32u,
-                             __float_as_uint(bw), 0u};
-          // one lane stores the record: exec narrowed to lane 0 around the store (a lane test on the thread index is
-          // hoisted out of the frame loop as a mask the kernel has no SGPR pair for)
+          const unsigned soff = (unsigned(frame) * C::WPF + unsigned(wq)) * unsigned(kStatsRecBytes);
+          const rsrc_t sr = make_rsrc(p.stats_part, unsigned(p.n_frames) * (C::WPF * unsigned(kStatsRecBytes)));
+          const u32x4 rec = {__float_as_uint(mw), (unsigned(best) + unsigned(wq) * 32u) | (nan ? 0x40000000u : 0u), __float_as_uint(bw), 0u};
+          // lane 0 stores the record: exec narrowed around the store (a lane test on the thread index is hoisted out of
+          // the frame loop as a mask the kernel has no SGPR pair for)
           unsigned long long ex_save;
           asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tbuffer_store_dwordx4 %1, off, %2, %3\n\ts_mov_b64 exec, %0"
                        : "=&s"(ex_save) : "v"(rec), "s"(sr), "s"(soff) : "memory");
