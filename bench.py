@@ -670,7 +670,7 @@ def run_config(args, comm: Comm, torch) -> dict:
                                                "mtime_utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime(os.path.getmtime(path)))}
         return json.loads(blob)
 
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         pmc_path = os.path.join(ROOT, "profiles", f"{rnd}_{args.config}_pmc.json")
         if os.path.exists(pmc_path):
             pmc = _quote(pmc_path)
@@ -680,11 +680,32 @@ def run_config(args, comm: Comm, torch) -> dict:
                            + (f"; collected by {pmc['collected_by']}" if "collected_by" in pmc else "") + ")")
             break
     valu_issue = None
-    for rnd in ("r05", "r04", "r03"):
+    for rnd in ("r06", "r05", "r04", "r03"):
         vi_path = os.path.join(ROOT, "profiles", f"{rnd}_{args.config}_valu_issue.json")
         if os.path.exists(vi_path):
             valu_issue = _quote(vi_path)
             break
+
+    # N > 1: what the node says about GPU-to-GPU reads (hipDeviceCanAccessPeer for every ordered pair of the devices the
+    # ranks run on), so that the line explains which Welch exchange it took and why
+    peer_matrix = None
+    if rank == 0 and world > 1 and not args.dry_run:
+        import ctypes as _C
+        devs = sorted({r % max(1, visible) for r in range(world)})
+        can = {}
+        for a_ in devs:
+            for b_ in devs:
+                if a_ != b_:
+                    v = _C.c_int(0)
+                    rc = nat.lib.tdsa_peer_can_access(a_, b_, _C.byref(v))
+                    can[f"{a_}->{b_}"] = bool(v.value) if rc == 0 else None
+        peer_matrix = {"devices_used": devs, "hipDeviceCanAccessPeer": can,
+                       "all_pairs": bool(can) and all(bool(x) for x in can.values()),
+                       "ranks_share_devices": world > len(devs),
+                       "welch_exchange": ("peer (device buffers mapped through HIP IPC, read in place)" if (welch and peer) else
+                                          "host (pinned shared memory)" if (welch and combine) else
+                                          "none needed by this configuration (rows and hold traces stay per rank; hold traces "
+                                          "meet on the host with np.fmax)")}
 
     result = None
     if rank == 0:
@@ -745,6 +766,7 @@ def run_config(args, comm: Comm, torch) -> dict:
                        "input": "int8 IQ resident in HBM", "input_ring": ring, "streams_per_gpu": head["streams"],
                        "steps_per_call": head["per_call"], "inner_repeats": head["inner"],
                        "gpus_visible_per_process": visible,
+                       **({"peer_access": peer_matrix} if peer_matrix is not None else {}),
                        "launcher": "torch.distributed.run" if not os.environ.get("TDSA_BENCH_WORKER") and world > 1
                                    else ("self-spawned workers" if world > 1 else "single process"),
                        "parallelism": par},
@@ -776,6 +798,37 @@ def run_config(args, comm: Comm, torch) -> dict:
                                                 "algorithmic_bytes_per_launch": algo_step,
                                                 "frames_per_launch": my_frames}},
         }
+        if welch and kern_b and not args.dry_run:
+            # The spec roof (8 TB/s, algorithmic bytes) next to the design's own ceiling: a two-pass transform moves 18 N bytes
+            # per segment (2 N samples in, Z = 8 N out and in again, + 4 N / K of sums) through the links between the XCDs and
+            # the fabric, which carry reads and writes TOGETHER at the rate measured for them on this chip
+            # (profiles/r04_c5_experiments.txt: the column pass's stores alone saturate at 6.7 TB/s, 537 MB in 79.6 us, with Z in
+            # HBM or in the Infinity Cache alike; tools/ubench/stream_mix.hip)
+            link_gbs = 6700.0
+            impl_seg = 18 * nfft + 4 * nfft // frames
+            impl_launch = impl_seg * my_frames * head["per_call"]
+            result["roofline"]["fabric_roof"] = {
+                "implementation_bytes_per_segment": impl_seg, "implementation_bytes_per_launch": impl_launch,
+                "link_rate_gbs": link_gbs, "link_rate_from": "profiles/r04_c5_experiments.txt (column pass with stores only: 537 MB "
+                                                              "of Z in 79.6 us), tools/ubench/stream_mix.hip",
+                "roof_us_per_launch": impl_launch / (link_gbs * 1e9) * 1e6,
+                "achieved_implementation_gbs": impl_launch / kern_b / 1e9,
+                "frac_of_fabric_roof": impl_launch / kern_b / 1e9 / link_gbs,
+                "is": "implementation bytes of the two-pass transform / the XCD <-> fabric link rate: what this design could reach "
+                      "at best; `frac` above prices the same time against the algorithmic bytes and the 8 TB/s spec peak"}
+        if not welch and launches_b and not args.dry_run:
+            # a cheap in-run check of the traffic figure quoted from the committed counter passes: what the plan itself knows
+            # it read and wrote per launch (every sample byte of the capture once - overlapping frames share theirs -, every
+            # dB row once) against the counters' bytes for the same shape
+            known = (((my_frames - 1) * hop + nfft) * 2 + my_frames * nfft * 4)
+            chk = {"plan_known_bytes_per_one_step_launch": known,
+                   "is": "samples of the capture x 2 bytes (each read once: neighbouring frames share theirs through L2) + rows x 4 N"}
+            if traffic:
+                chk["counters_over_known"] = traffic / known
+                chk["consistent"] = bool(0.9 <= traffic / known <= 1.35)
+                chk["note"] = ("FETCH_SIZE is an upper figure (x2 of the 32-byte unit, gfx950 correction of the guide): the shared "
+                               "halves of overlapping frames that miss L2 and the window / twiddle tables are in it")
+            result["roofline"]["traffic_check"] = chk
         if welch and compute_only is None:             # one rank, or whole captures per rank: nothing to combine
             result["value_compute_only"] = value
             result["ms_per_step_compute_only"] = result["ms_per_step"]
@@ -1109,6 +1162,8 @@ def main() -> None:
                                "algorithmic_bytes_per_launch": rf.get("algorithmic_bytes_per_launch"),
                                "shader_clock_mhz": rf.get("shader_clock_mhz"),
                                "traffic": rf.get("traffic"), "traffic_source": rf.get("traffic_source"),
+                               **({"fabric_roof": rf["fabric_roof"]} if "fabric_roof" in rf else {}),
+                               **({"traffic_check": rf["traffic_check"]} if "traffic_check" in rf else {}),
                                "parity": {k: pb.get(k) for k in ("pass", "north_star_pass", "survey_8d_strict_pass",
                                                                   "max_rel_power_err", "max_db_err_top100dB", "hold_trace_pass",
                                                                   "checked")},

@@ -220,6 +220,9 @@ int tdsa_welch_combine(tdsa_plan p, const void* parts_host, size_t part_stride_b
 #define TDSA_PEER_HANDLE_BYTES 64
 int tdsa_peer_alloc(int device_id, size_t bytes, void** dev_ptr, unsigned char* handle64);
 int tdsa_peer_free(int device_id, void* dev_ptr);
+/* hipDeviceCanAccessPeer(device_id -> peer_device_id): what tdsa_peer_open checks, for a launcher that wants to report the
+ * node's peer matrix before it picks the exchange */
+int tdsa_peer_can_access(int device_id, int peer_device_id, int* can_access);
 int tdsa_peer_open(int device_id, const unsigned char* handle64, int owner_device_id, void** dev_ptr);
 int tdsa_peer_close(int device_id, void* dev_ptr);
 int tdsa_welch_export_dev(tdsa_plan p, void* mean_dev, int as_f32, int* count);
@@ -333,6 +336,11 @@ int tdsa_density_reset(tdsa_density d);
 int tdsa_density_update_dev(tdsa_density d, tdsa_plan p, const float* rows_dev, int n_rows);
 int tdsa_density_update(tdsa_density d, const float* row_host, int n);
 int tdsa_density_read(tdsa_density d, float* hist_host, int as_log1p);
+/* The image as the display takes it - what ImageItem.setImage(np.log1p(hist), autoLevels=True) feeds its colour table
+ * (displays/density_display.py:318): uint8 [n_bins][512], float32 (v - lo) / (hi - lo) * 255 clipped and truncated with
+ * lo / hi = the image's minimum / maximum (returned in levels2, may be NULL; pyqtgraph samples a large image for its auto
+ * levels, here they are those of the whole image).  One byte per pixel over PCIe instead of four. */
+int tdsa_density_read_u8(tdsa_density d, uint8_t* img_host, float* levels2);
 
 typedef struct tdsa_waterfall_s* tdsa_waterfall;
 int tdsa_waterfall_create(int device_id, int history_lines, int n_bins, float min_db, tdsa_waterfall* out);
@@ -340,6 +348,10 @@ int tdsa_waterfall_destroy(tdsa_waterfall w);
 int tdsa_waterfall_push_dev(tdsa_waterfall w, tdsa_plan p, const float* rows_dev, int n_rows, int* n_new);
 int tdsa_waterfall_push(tdsa_waterfall w, const float* row_host, int n, int* is_new);
 int tdsa_waterfall_view(tdsa_waterfall w, float* view_host, int* ptr);
+/* _display_view() as ImageItem.setImage(img, autoLevels=False, levels=(wf_min_db, wf_max_db)) quantises it
+ * (displays/waterfall.py:353-356): uint8 [history][n_bins], np.clip((view - min_db) / (max_db - min_db) * 255, 0, 255)
+ * truncated, float32 arithmetic; a NaN pixel -> 0. */
+int tdsa_waterfall_view_u8(tdsa_waterfall w, float min_db, float max_db, uint8_t* view_host);
 
 /* -------- host pipeline: pinned ring + asynchronous copy / compute / read-back legs -------------
  * Batch counterpart of the reader-thread -> queue.Queue(4) -> get_power_levels() front end

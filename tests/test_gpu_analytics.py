@@ -677,3 +677,50 @@ def test_frame_stats_batched_captures(pkg):
     finally:
         nat.lib.tdsa_dev_free(0, d_in)
         nat.lib.tdsa_dev_free(0, d_out)
+
+
+# ---- levels -> uint8 views (what ImageItem.setImage makes of the images before the colour table) -------------------
+def _levels_u8(img, lo, hi):
+    """np.clip((view - lo) / (hi - lo) * 255, 0, 255).astype(uint8) in float32 (numpy >= 2 keeps float32 against Python
+    floats); NaN pixels -> 0"""
+    with np.errstate(invalid="ignore"):
+        t = np.clip((img - lo) / (hi - lo) * 255, 0, 255)
+    return np.where(np.isnan(t), 0, t).astype(np.uint8)
+
+
+def test_waterfall_view_u8_matches_setimage_levels(pkg, an, golden_dir):
+    """displays/waterfall.py:353-356: the view of the reference fixture's sequence under three level pairs, byte for byte;
+    NaN / -inf / +inf pixels included."""
+    g = np.load(os.path.join(golden_dir, "displays.npz"))
+    H, W = int(g["wf_history_lines"]), g["wf_rows"].shape[1]
+    with an.WaterfallRing(H, W, float(g["wf_min_db"])) as wf:
+        for idx in g["wf_order"]:
+            wf.push(g["wf_rows"][idx])
+        view = wf.view()
+        assert np.array_equal(view, g["wf_views"][-1])
+        for lo, hi in ((float(g["wf_min_db"]), float(g["wf_min_db"]) + 80.0), (-100.0, -20.0), (-63.7, -61.2)):
+            assert np.array_equal(wf.view_u8(lo, hi), _levels_u8(view, lo, hi)), (lo, hi)
+        with pytest.raises(Exception):
+            wf.view_u8(-20.0, -20.0)
+    rng = np.random.default_rng(12)
+    with an.WaterfallRing(33, 1001, -120.0) as wf:               # ragged sizes, special values
+        rows = rng.normal(-70, 15, size=(50, 1001)).astype(np.float32)
+        rows[3, 5], rows[7, 9], rows[9, 11] = np.nan, -np.inf, np.inf
+        for r in rows:
+            wf.push(r)
+        assert np.array_equal(wf.view_u8(-110.0, -30.0), _levels_u8(wf.view(), -110.0, -30.0))
+
+
+def test_density_image_u8_matches_setimage_autolevels(pkg, an, golden_dir):
+    """displays/density_display.py:318: np.log1p(hist) under its own minimum / maximum as levels."""
+    g = np.load(os.path.join(golden_dir, "displays.npz"))
+    rows = np.ascontiguousarray(g["density_rows"])
+    with an.DensityHistogram(rows.shape[1], float(g["density_medium_decay"])) as dh:
+        u8, (lo, hi) = dh.image_u8()
+        assert not u8.any() and lo == hi == 0.0                    # empty histogram
+        for row in rows[:20]:
+            dh.update(row)
+        img = dh.image()
+        u8, (lo, hi) = dh.image_u8()
+        assert lo == img.min() and hi == img.max()
+        assert np.array_equal(u8, _levels_u8(img, lo, hi)) and u8.max() == 255

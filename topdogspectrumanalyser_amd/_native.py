@@ -63,6 +63,7 @@ _SIGNATURES = {
     "tdsa_peer_alloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(_P), _P]),
     "tdsa_peer_free": (C.c_int, [C.c_int, _P]),
     "tdsa_peer_open": (C.c_int, [C.c_int, _P, C.c_int, C.POINTER(_P)]),
+    "tdsa_peer_can_access": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "tdsa_peer_close": (C.c_int, [C.c_int, _P]),
     "tdsa_welch_export_dev": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
     "tdsa_welch_combine_dev": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int32), C.c_int, C.c_int, _P, _P]),
@@ -84,11 +85,13 @@ _SIGNATURES = {
     "tdsa_density_update_dev": (C.c_int, [_P, _P, _P, C.c_int]),
     "tdsa_density_update": (C.c_int, [_P, _P, C.c_int]),
     "tdsa_density_read": (C.c_int, [_P, _P, C.c_int]),
+    "tdsa_density_read_u8": (C.c_int, [_P, _P, _P]),
     "tdsa_waterfall_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(_P)]),
     "tdsa_waterfall_destroy": (C.c_int, [_P]),
     "tdsa_waterfall_push_dev": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_int)]),
     "tdsa_waterfall_push": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
     "tdsa_waterfall_view": (C.c_int, [_P, _P, C.POINTER(C.c_int)]),
+    "tdsa_waterfall_view_u8": (C.c_int, [_P, C.c_float, C.c_float, _P]),
     "tdsa_pipe_create": (C.c_int, [_P, C.c_int, C.c_size_t, C.c_int, C.c_int, C.POINTER(_P)]),
     "tdsa_pipe_destroy": (C.c_int, [_P]),
     "tdsa_pipe_acquire": (C.c_int, [_P, C.POINTER(_P)]),

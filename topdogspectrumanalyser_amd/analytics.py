@@ -165,6 +165,15 @@ class DensityHistogram(_Handle):
         return out
 
 
+    def image_u8(self):
+        """(uint8 [n_bins, 512], (lo, hi)): np.log1p(hist) as setImage(..., autoLevels=True) quantises it for its colour
+        table (density_display.py:318), levels = the image's minimum / maximum; a quarter of the bytes of image()."""
+        out = np.empty((self.n_bins, AMP_BINS), dtype=np.uint8)
+        lv = np.empty(2, dtype=np.float32)
+        nat.check(nat.lib.tdsa_density_read_u8(self._h, _p(out), _p(lv)))
+        return out, (float(lv[0]), float(lv[1]))
+
+
 class WaterfallRing(_Handle):
     """Waterfall._buf on the device: [2H, n_bins] float32 with the reference's pointer walk and dedup."""
     _destroy = staticmethod(lambda h: nat.lib.tdsa_waterfall_destroy(h))
@@ -197,4 +206,11 @@ class WaterfallRing(_Handle):
     def view(self) -> np.ndarray:
         out = np.empty((self.history_lines, self.n_bins), dtype=np.float32)
         nat.check(nat.lib.tdsa_waterfall_view(self._h, _p(out), None))
+        return out
+
+    def view_u8(self, min_db: float, max_db: float) -> np.ndarray:
+        """uint8 [history_lines, n_bins]: the view as setImage(img, autoLevels=False, levels=(wf_min_db, wf_max_db))
+        quantises it (displays/waterfall.py:353-356)."""
+        out = np.empty((self.history_lines, self.n_bins), dtype=np.uint8)
+        nat.check(nat.lib.tdsa_waterfall_view_u8(self._h, float(min_db), float(max_db), _p(out)))
         return out

@@ -613,6 +613,47 @@ __global__ void log1p_kernel(const float* __restrict__ in, float* out, size_t co
   if (i < count) out[i] = log1pf(in[i]);
 }
 
+// ---- images as the display takes them: levels -> uint8 ----------------------------------------------------------
+// What ImageItem.setImage(img, levels=(lo, hi)) makes of a float image before the colour table
+// (displays/waterfall.py:353-356; displays/density_display.py:318 with autoLevels): float32 (v - lo) / (hi - lo) * 255,
+// clipped to [0, 255], truncated - one byte per pixel over PCIe instead of four.  A NaN pixel -> 0.
+__global__ void __launch_bounds__(256) quantize_u8_kernel(const float* __restrict__ in, unsigned char* out, size_t count,
+                                                          float lo, float span) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= count) return;
+  unsigned pk = 0u;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (i + k < count) {
+      float t = __fmul_rn(__fdiv_rn(__fsub_rn(in[i + k], lo), span), 255.0f);
+      t = t < 0.f ? 0.f : (t > 255.f ? 255.f : t);              // NaN: both tests fail
+      const unsigned b = t == t ? unsigned(t) : 0u;
+      pk |= b << (8 * k);
+    }
+  }
+  if (i + 4 <= count && (reinterpret_cast<uintptr_t>(out) & 3) == 0) *reinterpret_cast<unsigned*>(out + i) = pk;
+  else for (int k = 0; k < 4 && i + k < count; ++k) out[i + k] = (unsigned char)(pk >> (8 * k));
+}
+// min / max of a NaN-free image of non-negative values (log1p of a histogram): positive floats order like their bits
+__global__ void __launch_bounds__(256) minmax_pos_kernel(const float* __restrict__ in, size_t count, unsigned* mm) {
+  unsigned lo = 0x7f800000u, hi = 0u;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+    const unsigned b = __float_as_uint(in[i]);
+    lo = b < lo ? b : lo;
+    hi = b > hi ? b : hi;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const unsigned l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&mm[0], lo);
+    atomicMax(&mm[1], hi);
+  }
+}
+
 // ---- waterfall ring -------------------------------------------------------------------------------------
 // differs[r] = !np.array_equal(rows[r], previous row)  (previous of row 0 = `last`, or "no previous")
 __global__ void __launch_bounds__(256) rows_differ_kernel(const float* __restrict__ rows, const float* __restrict__ last,
@@ -692,6 +733,22 @@ hipError_t launch_density(const float* rows, int n_rows, int n, float decay, flo
 hipError_t launch_log1p(const float* in, float* out, size_t count, hipStream_t s) {
   if (count == 0) return hipSuccess;
   log1p_kernel<<<unsigned((count + 255) / 256), 256, 0, s>>>(in, out, count);
+  return hipGetLastError();
+}
+
+hipError_t launch_quantize_u8(const float* in, unsigned char* out, size_t count, float lo, float hi, hipStream_t s) {
+  if (count == 0) return hipSuccess;
+  const float span = float(double(hi) - double(lo));            // Python forms (hi - lo) in double; the division is float32
+  quantize_u8_kernel<<<unsigned((count + 1023) / 1024), 256, 0, s>>>(in, out, count, lo, span);
+  return hipGetLastError();
+}
+hipError_t launch_minmax_pos(const float* in, size_t count, unsigned* mm_dev, hipStream_t s) {
+  if (count == 0) return hipSuccess;
+  const unsigned init[2] = {0x7f800000u, 0u};
+  hipError_t e = hipMemcpyAsync(mm_dev, init, sizeof(init), hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) return e;
+  const size_t blocks = (count + 255) / 256;
+  minmax_pos_kernel<<<unsigned(blocks < 2048 ? blocks : 2048), 256, 0, s>>>(in, count, mm_dev);
   return hipGetLastError();
 }
 

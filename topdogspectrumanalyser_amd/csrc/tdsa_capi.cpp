@@ -1843,6 +1843,14 @@ int tdsa_peer_free(int device_id, void* dev_ptr) {
   return TDSA_OK;
 }
 
+int tdsa_peer_can_access(int device_id, int peer_device_id, int* can_access) {
+  if (!can_access) return fail(TDSA_ERR_ARG, "null argument");
+  *can_access = 0;
+  if (device_id == peer_device_id) { *can_access = 1; return TDSA_OK; }
+  HIPCHK(hipDeviceCanAccessPeer(can_access, device_id, peer_device_id));
+  return TDSA_OK;
+}
+
 int tdsa_peer_open(int device_id, const unsigned char* handle64, int owner_device_id, void** dev_ptr) {
   if (!dev_ptr || !handle64) return fail(TDSA_ERR_ARG, "null argument");
   *dev_ptr = nullptr;
@@ -2639,6 +2647,7 @@ struct tdsa_density_s {
   float decay = 0.96f;
   float* d_hist = nullptr;     // [n][512]
   float* d_img = nullptr;      // log1p image scratch
+  unsigned char* d_u8 = nullptr;   // the image as bytes (+ 8 bytes: its min / max)
   float* d_row = nullptr;      // staging for host rows
   hipStream_t stream = nullptr;
 };
@@ -2672,6 +2681,7 @@ int tdsa_density_destroy(tdsa_density d) {
   if (d->stream) (void)hipStreamSynchronize(d->stream);
   if (d->d_hist) (void)hipFree(d->d_hist);
   if (d->d_img) (void)hipFree(d->d_img);
+  if (d->d_u8) (void)hipFree(d->d_u8);
   if (d->d_row) (void)hipFree(d->d_row);
   if (d->stream) (void)hipStreamDestroy(d->stream);
   delete d;
@@ -2734,6 +2744,29 @@ int tdsa_density_read(tdsa_density d, float* hist_host, int as_log1p) {
   return TDSA_OK;
 }
 
+int tdsa_density_read_u8(tdsa_density d, uint8_t* img_host, float* levels2) {
+  if (!d || !img_host) return fail(TDSA_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(d->device));
+  const size_t cnt = size_t(d->n) * 512;
+  if (!d->d_img) HIPCHK(hipMalloc(&d->d_img, cnt * sizeof(float)));
+  if (!d->d_u8) HIPCHK(hipMalloc(&d->d_u8, cnt + 16));
+  unsigned* d_mm = reinterpret_cast<unsigned*>(d->d_u8 + ((cnt + 7) & ~size_t(7)));
+  HIPCHK(launch_log1p(d->d_hist, d->d_img, cnt, d->stream));
+  HIPCHK(launch_minmax_pos(d->d_img, cnt, d_mm, d->stream));
+  float mm[2];
+  HIPCHK(hipMemcpyAsync(mm, d_mm, sizeof(mm), hipMemcpyDeviceToHost, d->stream));
+  HIPCHK(hipStreamSynchronize(d->stream));
+  if (levels2) { levels2[0] = mm[0]; levels2[1] = mm[1]; }
+  if (mm[1] > mm[0]) {
+    HIPCHK(launch_quantize_u8(d->d_img, d->d_u8, cnt, mm[0], mm[1], d->stream));
+  } else {
+    HIPCHK(hipMemsetAsync(d->d_u8, 0, cnt, d->stream));      // a flat image (an empty histogram): every pixel at the lower level
+  }
+  HIPCHK(hipMemcpyAsync(img_host, d->d_u8, cnt, hipMemcpyDeviceToHost, d->stream));
+  HIPCHK(hipStreamSynchronize(d->stream));
+  return TDSA_OK;
+}
+
 // ---- waterfall ring -----------------------------------------------------------------------------
 struct tdsa_waterfall_s {
   int device = 0, n = 0, history = 0;
@@ -2741,6 +2774,7 @@ struct tdsa_waterfall_s {
   bool have_last = false;
   float* d_ring = nullptr;     // [2*history][n]
   float* d_last = nullptr;     // [n] Waterfall._last_row
+  unsigned char* d_u8 = nullptr;   // [history][n] the view as bytes (tdsa_waterfall_view_u8)
   float* d_row = nullptr;      // staging for host rows
   int* d_flags = nullptr;      // [cap] differs / destination per pushed row
   int cap = 0;
@@ -2778,6 +2812,7 @@ int tdsa_waterfall_destroy(tdsa_waterfall w) {
   if (w->stream) (void)hipStreamSynchronize(w->stream);
   if (w->d_ring) (void)hipFree(w->d_ring);
   if (w->d_last) (void)hipFree(w->d_last);
+  if (w->d_u8) (void)hipFree(w->d_u8);
   if (w->d_row) (void)hipFree(w->d_row);
   if (w->d_flags) (void)hipFree(w->d_flags);
   if (w->stream) (void)hipStreamDestroy(w->stream);
@@ -2864,5 +2899,17 @@ int tdsa_waterfall_view(tdsa_waterfall w, float* view_host, int* ptr) {
     HIPCHK(hipStreamSynchronize(w->stream));
   }
   if (ptr) *ptr = w->ptr;
+  return TDSA_OK;
+}
+
+int tdsa_waterfall_view_u8(tdsa_waterfall w, float min_db, float max_db, uint8_t* view_host) {
+  if (!w || !view_host) return fail(TDSA_ERR_ARG, "null argument");
+  if (!(max_db > min_db)) return fail(TDSA_ERR_ARG, "levels (%g, %g): need max > min", double(min_db), double(max_db));
+  HIPCHK(hipSetDevice(w->device));
+  const size_t cnt = size_t(w->history) * w->n;
+  if (!w->d_u8) HIPCHK(hipMalloc(&w->d_u8, cnt));
+  HIPCHK(launch_quantize_u8(w->d_ring + size_t(w->ptr) * w->n, w->d_u8, cnt, min_db, max_db, w->stream));
+  HIPCHK(hipMemcpyAsync(view_host, w->d_u8, cnt, hipMemcpyDeviceToHost, w->stream));
+  HIPCHK(hipStreamSynchronize(w->stream));
   return TDSA_OK;
 }

@@ -346,6 +346,8 @@ hipError_t launch_marker_peaks(const float* rows, int n_rows, int n, double heig
                                int* out_bins, double* out_prom, hipStream_t s);
 hipError_t launch_density(const float* rows, int n_rows, int n, float decay, float* hist, hipStream_t s);
 hipError_t launch_log1p(const float* in, float* out, size_t count, hipStream_t s);
+hipError_t launch_quantize_u8(const float* in, unsigned char* out, size_t count, float lo, float hi, hipStream_t s);
+hipError_t launch_minmax_pos(const float* in, size_t count, unsigned* mm_dev, hipStream_t s);
 hipError_t launch_rows_differ(const float* rows, const float* last, int have_last, int n_rows, int n, int* differs,
                               hipStream_t s);
 hipError_t launch_waterfall_scatter(const float* rows, const int* dst, int n_rows, int n, int history, float* ring,
