@@ -175,11 +175,15 @@ int tdsa_process_dev_batch(tdsa_plan p, int in_format, const void* iq_dev, size_
  * non-DC / non-Nyquist bins doubled (:131), PSD scale, TraceAverager, 10*log10(. + floor).
  * channel: TDSA_CH_MONO ((L+R)/2), _LEFT, _RIGHT -> out [n_frames][N/2+1];
  *          TDSA_CH_STEREO -> out [n_frames][2][N/2+1] (left averaged, right not, as :158-171).
- * Uses the plan's window, power_scale, log_floor and averager settings (db_mode must be TDSA_DB_POW). */
+ * Uses the plan's window, power_scale, log_floor and averager settings (db_mode must be TDSA_DB_POW).
+ * Frame lengths: any size up to 16384, and sizes that are not a power of two up to 2^19 = 524288 points; the
+ * native long-frame plans (2^15 ... 2^20) and the split chirp-z plans above 2^19 return TDSA_ERR_ARG before any work
+ * is queued (tdsa_real_input_supported tells beforehand). */
 #define TDSA_CH_MONO 0
 #define TDSA_CH_LEFT 1
 #define TDSA_CH_RIGHT 2
 #define TDSA_CH_STEREO 3
+int tdsa_real_input_supported(int nfft);     /* 1 / 0: has tdsa_process_real2 a path for frames of nfft points */
 int tdsa_process_real2(tdsa_plan p, const float* lr_host, size_t n_samples, int hop, int n_frames,
                        int channel, float* out_db_host);
 

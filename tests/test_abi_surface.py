@@ -86,3 +86,30 @@ def test_peer_buffer_entry_points_refuse_bad_arguments_without_touching_a_device
     assert nat.lib.tdsa_welch_export_dev(None, None, 1, None) == -1
     assert nat.lib.tdsa_welch_combine_dev(None, None, None, 1, 1, None, None) == -1
     assert b"null" in nat.lib.tdsa_last_error_string()
+
+
+def test_real_input_predicate_matches_the_library():
+    """utils.constants.gpu_real_input_size_supported (what the audio source checks at plan time) and the library's own
+    tdsa_real_input_supported agree - no device needed for either."""
+    from topdogspectrumanalyser_amd import _native as nat
+    from topdogspectrumanalyser_amd.utils.constants import gpu_real_input_size_supported
+    for n in (0, 1, 2, 3, 64, 1000, 16384, 16385, 32768, 65536, 300000, 1 << 19, (1 << 19) + 1, 600000, 10 ** 6, 1 << 20):
+        assert bool(nat.lib.tdsa_real_input_supported(n)) == gpu_real_input_size_supported(n), n
+
+
+def test_audio_source_refuses_sizes_without_a_real_input_plan_at_plan_time():
+    from topdogspectrumanalyser_amd.datasources.audio_samples import MicrophoneSamplesDataSource
+    src = MicrophoneSamplesDataSource(sample_rate=48000, centre_freq=0)
+    src.fft_size = 600000
+    import pytest
+    with pytest.raises(ValueError):
+        src._main_plan()
+
+
+def test_welch_slab_waits_give_up():
+    """a rank waiting for rank 0 to release a slot must not spin for ever"""
+    import pytest
+    from topdogspectrumanalyser_amd import sharding
+    with pytest.raises(TimeoutError):
+        sharding._wait_for(lambda: False, 0.05, "never")
+    sharding._wait_for(lambda: True, 0.05, "at once")

@@ -39,7 +39,13 @@ def test_baseline_instantiations_keep_their_instruction_stream(tmp_path):
     if not shutil.which(HIPCC):
         pytest.skip("hipcc not available")
     import isa_hash
-    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "isa_frozen.json")))["kernels"]
+    record = json.load(open(os.path.join(ROOT, "tests", "golden", "isa_frozen.json")))
+    ver = subprocess.run([HIPCC, "--version"], capture_output=True, text=True).stdout
+    hip = re.search(r"HIP version:\s*(\S+)", ver)
+    if not hip or hip.group(1) != record["compiler"]["hip_version"]:
+        pytest.skip(f"fingerprints are those of hipcc {record['compiler']['hip_version']}; this is "
+                    f"{hip.group(1) if hip else 'unknown'}: another compiler's instruction selection is not a changed kernel")
+    gold = record["kernels"]
     assert len(gold) == 6
     with concurrent.futures.ThreadPoolExecutor(3) as ex:
         listings = list(ex.map(lambda k: _listing(k, str(tmp_path)), (12, 13, 14)))

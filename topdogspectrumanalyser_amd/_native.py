@@ -54,6 +54,7 @@ _SIGNATURES = {
     "tdsa_process_dev_batch": (C.c_int, [_P, C.c_int, _P, C.c_size_t, C.c_int, C.c_size_t, C.c_int, C.c_int, _P,
                                          C.c_size_t]),
     "tdsa_process_real2": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, C.c_int, _P]),
+    "tdsa_real_input_supported": (C.c_int, [C.c_int]),
     "tdsa_get_hold": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int64)]),
     "tdsa_get_avg": (C.c_int, [_P, _P, C.POINTER(C.c_int)]),
     "tdsa_host_register": (C.c_int, [_P, C.c_size_t]),

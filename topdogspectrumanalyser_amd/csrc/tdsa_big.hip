@@ -57,7 +57,7 @@ typedef unsigned bu32x4 __attribute__((ext_vector_type(4)));
 // offset in the VGPR offset so that the recognizer padded it; since round 5 the store and its wait states are ONE
 // inline-asm block, whatever the compiler's recognizer thinks (tests/test_kernel_resources.py checks the ISA).
 __device__ __forceinline__ void store16_pinned(bu32x4 data, brsrc_t r, unsigned voff) {
-  asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(data), "v"(voff), "s"(r));
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(data), "v"(voff), "s"(r) : "memory");
 }
 
 // One thread per column n2.  X[k1] of the column sits in v[bitrev(k1)] after the in-register DIF.

@@ -115,7 +115,7 @@ struct tdsa_plan_s {
   BigWindow big_win[3] = {};             // the column pass's window per input format (tdsa_set_window: table or one value)
   int avg_wg_min = 128;                  // batches of more frames than this take the workgroup-chunk scan (tdsa_debug_knob "avg_wg_min")
   bool avg_f64_chunks = false;           // tdsa_debug_knob "avg_f64_chunks": always the scan over fixed 64-frame chunks with float64 aggregates
-  // frame lengths made of 2, 3, 5 only, up to 8192 points: mixed-radix FFT of exactly nfft points (tdsa_smooth.hip) for the
+  // frame lengths made of 2, 3, 5 only (up to 10 000 points in one LDS pass, two passes above): mixed-radix FFT of exactly nfft points (tdsa_smooth.hip) for the
   // complex path; the plan stays a chirp-z plan for everything else (real input)
   bool smooth = false;
   int smooth_on = 1;                     // tdsa_debug_knob "smooth": 0 = such sizes run as chirp-z convolutions like every other
@@ -1607,10 +1607,19 @@ int tdsa_process_c64(tdsa_plan p, const float* iq_host, size_t n_samples, int ho
   return process_host(p, TDSA_IN_C64, iq_host, n_samples, hop, n_frames, out_db_host);
 }
 
+int tdsa_real_input_supported(int nfft) {
+  if (nfft < 2) return 0;
+  const bool pow2 = (nfft & (nfft - 1)) == 0;
+  if (pow2) return nfft <= (1 << kMaxLog2N) ? 1 : 0;        // the native long-frame plans have no real-input path
+  return nfft <= (1 << 19) ? 1 : 0;                          // chirp-z plans; above 2^19 they split the frame in two
+}
+
 int tdsa_process_real2(tdsa_plan p, const float* lr_host, size_t n_samples, int hop, int n_frames, int channel,
                        float* out_db_host) {
   if (!p) return fail(TDSA_ERR_ARG, "null plan");
   if (p->big) return fail(TDSA_ERR_ARG, "real-input path needs an FFT size of at most 16384");
+  if (p->chirp_split)      // (before any allocation or launch: the call leaves the plan as it found it)
+    return fail(TDSA_ERR_ARG, "real-input path: frames above 2^19 points that are not a power of two have no plan (nfft=%d)", p->nfft);
   if (channel < TDSA_CH_MONO || channel > TDSA_CH_STEREO) return fail(TDSA_ERR_ARG, "channel %d", channel);
   if (n_frames == 0) return TDSA_OK;
   if (!lr_host || !out_db_host) return fail(TDSA_ERR_ARG, "null buffer");
@@ -1667,7 +1676,6 @@ int tdsa_process_real2(tdsa_plan p, const float* lr_host, size_t n_samples, int 
   float2* const za = p->d_real;
   float2* const zb = p->d_real + need;
   HIPCHK(launch_real_select(lr_dev, need, channel, za, zb, p->stream));
-  if (p->chirp_split) return fail(TDSA_ERR_STATE, "the real-input path has no plan for frames above 2^19 points that are not a power of two");
   for (int sig = 0; sig < n_sig; ++sig) {
     if (p->chirp) {
       // a size that is not a power of two: signal + 0i through the chirp-z core, mean removed (exact sums), and
@@ -2238,7 +2246,7 @@ int tdsa_debug_knob(tdsa_plan p, const char* name, int value) {
     if (!p->big || value < 1 || value > 64) return fail(TDSA_ERR_ARG, "big_group=%d (long-frame plans, 1 .. 64)", value);
     if (p->d_z && value > p->big_group) return fail(TDSA_ERR_STATE, "big_group can only shrink once the plan has run");
     p->big_group = value;
-  } else if (k == "smooth") {                // sizes 2^a 3^b 5^c <= 8192: 1 = mixed-radix transform of N points (default), 0 = chirp-z
+  } else if (k == "smooth") {                // sizes 2^a 3^b 5^c (<= 10 000 in one pass, two passes above): 1 = mixed-radix transform of N points (default), 0 = chirp-z
     p->smooth_on = value != 0;
   } else if (k == "smooth_n1") {             // two-pass sizes: the column pass's transform length (a divisor; both factors <= 10 000)
     if (!p->smooth || p->smooth_n1 == 0) return fail(TDSA_ERR_STATE, "not a two-pass mixed-radix plan");

@@ -78,7 +78,7 @@ struct SpecParams {
   long long pre_stride;      // bytes between raw frames
   const float2* pre_aw;      // [in_valid] window * input scale * chirp a[n] (made in double, rounded once)
   int pre_c64;
-  unsigned pre_xor;          // 0x8080 for int8 (-> offset binary), 0 for uint8
+  unsigned pre_xor;          // 0x80808080 for int8 (-> offset binary; the kernel uses the low 16 bits: one sample per load), 0 for uint8
   float pre_off;             // 128 / 127.5 / 0: the raw format's zero level (in_off / xor_mask above stay those of complex64 rows)
   int post_n;                // SECOND transform: > 0: bins k < post_n leave as |X / M|^2 -> power (out_lin) or dB (out_db, tare,
                              // part_max / part_min) rows of post_n values, bin k at (k + post_n / 2) mod post_n; out_cplx is not written

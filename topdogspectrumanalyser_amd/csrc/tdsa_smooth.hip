@@ -238,14 +238,15 @@ int smooth_frames_per_workgroup(int n) {
 }
 
 static hipError_t launch_mode(const SmoothParams& p, int mode, dim3 grid, int threads, size_t lds, hipStream_t s) {
-  static size_t attr_done[3] = {0, 0, 0};
+  // the largest request any plan makes (160 000 bytes: a 10 000-point frame), raised once per kernel and DEVICE
+  // (ensure_dynamic_lds: function attributes belong to the device the module is loaded on; a process may hold plans on
+  // several GPUs and launch from several threads)
+  static std::atomic<unsigned long long> attr_done[3];
   const void* fn = mode == 0 ? reinterpret_cast<const void*>(smooth_kernel<0>)
                              : (mode == 1 ? reinterpret_cast<const void*>(smooth_kernel<1>) : reinterpret_cast<const void*>(smooth_kernel<2>));
-  if (lds > attr_done[mode]) {
-    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-    if (e != hipSuccess) return e;
-    attr_done[mode] = lds;
-  }
+  const hipError_t e = ensure_dynamic_lds(fn, 160 * 1000, attr_done[mode]);
+  if (e != hipSuccess) return e;
+  if (lds > size_t(160 * 1000)) return hipErrorInvalidValue;
   if (mode == 0) hipLaunchKernelGGL(smooth_kernel<0>, grid, dim3(threads), lds, s, p);
   else if (mode == 1) hipLaunchKernelGGL(smooth_kernel<1>, grid, dim3(threads), lds, s, p);
   else hipLaunchKernelGGL(smooth_kernel<2>, grid, dim3(threads), lds, s, p);

@@ -20,7 +20,7 @@ from typing import Callable, Optional, Tuple
 import numpy as np
 
 from ..engine import SpectrumEngine
-from ..utils.constants import DSPConstants
+from ..utils.constants import DSPConstants, gpu_real_input_size_supported
 from ._gpu import GpuSpectrumMixin
 from .base import SampleDataSource
 
@@ -161,6 +161,9 @@ class MicrophoneSamplesDataSource(GpuSpectrumMixin, SampleDataSource):
         return dict(db_mode="pow", power_scale=1.0, log_floor=DSPConstants.POWER_LOG_FLOOR, dc_alpha=1.0)
 
     def _main_plan(self) -> SpectrumEngine:
+        if not gpu_real_input_size_supported(self.fft_size):      # at plan time, not as a device error on every frame
+            raise ValueError(f"FFT size {self.fft_size}: the real-input path plans powers of two up to 16384 and any other "
+                             "size up to 2^19")
         eng = self._gpu_engine(self.fft_size)
         key = (self.use_psd, self.sample_rate)
         if self._engine_dirty or getattr(self, "_engine_cfg", None) != key:

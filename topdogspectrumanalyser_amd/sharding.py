@@ -48,6 +48,19 @@ def combine_welch(means: Sequence[np.ndarray], counts: Sequence[int]) -> Tuple[n
     return acc / total, total
 
 
+
+def _wait_for(cond, timeout_s: float, what: str) -> None:
+    """spin on a shared-memory condition: a few thousand polls flat out (the wait is normally microseconds), then yielding
+    the GIL and the core; TimeoutError after timeout_s"""
+    t0 = time.perf_counter()
+    polls = 0
+    while not cond():
+        polls += 1
+        if polls > 2000:
+            time.sleep(0)
+            if time.perf_counter() - t0 > timeout_s:
+                raise TimeoutError(what)
+
 class WelchSlab:
     """Host side of the cross-GPU Welch combine when every GPU has its own PROCESS (bench.py --config c5 --gpus N): a
     POSIX shared-memory slab every rank maps - `slots` x world partial means of n float32 / float64 values plus the
@@ -87,10 +100,11 @@ class WelchSlab:
             except Exception:
                 self.pinned = False
 
-    def part(self, step: int) -> np.ndarray:
-        """this rank's partial of `step` (1-based); waits until the slot's previous use has been combined"""
-        while int(self._ctr[8 * self.world]) < step - self.slots:
-            pass
+    def part(self, step: int, timeout_s: float = 60.0) -> np.ndarray:
+        """this rank's partial of `step` (1-based); waits until the slot's previous use has been combined - not for ever:
+        a rank 0 that died or gave up (its wait_all timed out) must not leave the others spinning at 100 % CPU"""
+        _wait_for(lambda: int(self._ctr[8 * self.world]) >= step - self.slots, timeout_s,
+                  f"rank 0 did not combine step {step - self.slots}: slot of step {step} still in use")
         return self.parts[step % self.slots, self.rank]
 
     def publish(self, step: int) -> None:
@@ -215,8 +229,8 @@ class WelchPeerSlab:
     # -- per step ---------------------------------------------------------------------------------------------------
     def part_ptr(self, step: int) -> int:
         """device pointer of this rank's partial of `step` (1-based); waits until the slot's previous use is combined"""
-        while int(self._ctr[8 * self.world]) < step - self.slots:
-            pass
+        _wait_for(lambda: int(self._ctr[8 * self.world]) >= step - self.slots, self._timeout,
+                  f"rank 0 did not combine step {step - self.slots}: slot of step {step} still in use")
         return self._mine + (step % self.slots) * self.n * self.dtype.itemsize
 
     def publish(self, step: int) -> None:

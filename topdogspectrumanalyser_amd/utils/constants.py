@@ -56,6 +56,17 @@ def gpu_fft_size_supported(nfft: int) -> bool:
     return GPU_MIN_FFT <= nfft <= GPU_MAX_FFT and nfft & (nfft - 1) == 0
 
 
+def gpu_real_input_size_supported(nfft: int) -> bool:
+    """Sizes tdsa_process_real2 (the audio source's path) has a plan for: powers of two up to 16384 and any other size
+    up to 2^19 (include/tdsa_hip.h: tdsa_real_input_supported)."""
+    nfft = int(nfft)
+    if nfft < 2:
+        return False
+    if nfft & (nfft - 1) == 0:
+        return nfft <= 16384
+    return nfft <= 1 << 19
+
+
 class WindowType(str, Enum):
     HAMMING = "hamming"
     HANNING = "hanning"
