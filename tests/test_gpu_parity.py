@@ -2669,6 +2669,8 @@ def test_process_sharded_random(pkg, seed):
 def test_no_device_memory_left_behind(pkg):
     """Plans, pipes, trace objects and display accumulators created, used through their lazily allocating paths
     (averaging, real input, long frames, analytics scratch) and closed, many times: the free device memory comes back."""
+    if os.environ.get("PYTEST_XDIST_WORKER"):
+        pytest.skip("free device memory is a property of the whole GPU: other xdist workers allocate beside this one")
     import torch
     from topdogspectrumanalyser_amd import analytics as an
 

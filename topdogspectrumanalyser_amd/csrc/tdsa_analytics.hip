@@ -11,6 +11,7 @@
 //   density_kernel        DensityDisplay._update_hist (displays/density_display.py:306-318)
 //   rows_differ_kernel /  Waterfall new-row test + _add_row (displays/waterfall.py:171-175, 330-336)
 //   waterfall_scatter_kernel
+#include "tdsa_fft.hpp"        // static_for
 #include "tdsa_kernels.hpp"
 
 #include <math.h>
@@ -155,6 +156,7 @@ __global__ void __launch_bounds__(256) frame_stats_finish_kernel(const uint4* __
 // block argmax over the live candidates plus one pass that forms the valley minimum against each peak
 // accepted so far.  Ends as soon as n_peaks are accepted or the candidates run out.
 constexpr int kPeakThreads = 1024;
+constexpr int kMarkMaxNTop = 16384;                 // rows_top_peaks: n_bins <= 16384 (the row lives in LDS)
 constexpr int kMaxPeaks = 8;
 
 __global__ void __launch_bounds__(kPeakThreads) top_peaks_kernel(const float* __restrict__ rows, int n, int n_peaks,
@@ -168,9 +170,18 @@ __global__ void __launch_bounds__(kPeakThreads) top_peaks_kernel(const float* __
   __shared__ float s_selv[kMaxPeaks];
   __shared__ int s_nsel;
 
+  __shared__ float s_bmin[kMarkMaxNTop / 32];       // minimum of every 32 bins (a half-wave's run while the row is loaded)
   const float* src = rows + (size_t)blockIdx.x * n;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  for (int i = tid; i < n; i += kPeakThreads) row[i] = src[i];
+  for (int i0 = 0; i0 < n; i0 += kPeakThreads) {
+    const int i = i0 + tid;
+    const float v = i < n ? src[i] : INFINITY;
+    if (i < n) row[i] = v;
+    float mn = v;
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o));
+    if ((lane & 31) == 0 && i < n) s_bmin[i >> 5] = mn;
+  }
   if (tid == 0) s_nsel = 0;
   __syncthreads();
   // live candidates (strict interior local maxima) of this thread's elements i = tid + 1024 k: bit k of a register
@@ -236,13 +247,22 @@ __global__ void __launch_bounds__(kPeakThreads) top_peaks_kernel(const float* __
       hi[k] = cur < sk ? sk : cur;
       vmin[k] = INFINITY;
     }
-    for (int i = tid; i < n; i += kPeakThreads) {
-      const float v = row[i];
+    // (until round 6 every thread walked its 16 bins of the row against every range: 200 of a round's ~400 instructions
+    //  per wave; now one thread per block of 32 bins takes the block's minimum where the block lies inside a range and
+    //  walks it only at a range's two ends)
+    for (int b = tid; b < (n + 31) / 32; b += kPeakThreads) {
+      const float bm = s_bmin[b];
+      const int b0 = 32 * b, b1 = b0 + 31 < n - 1 ? b0 + 31 : n - 1;
 #pragma unroll
       for (int k = 0; k < kMaxPeaks; ++k) {
         if (k < nsel) {
-          if (i >= lo[k] && i <= hi[k]) vmin[k] = fminf(vmin[k], v);   // (a NaN in the range would make np.min NaN
-        }                                                               //  and never reject; rows here carry none)
+          if (b0 >= lo[k] && b1 <= hi[k]) {
+            vmin[k] = fminf(vmin[k], bm);                               // (a NaN in the range would make np.min NaN
+          } else if (b1 >= lo[k] && b0 <= hi[k]) {                      //  and never reject; rows here carry none)
+            const int i0 = b0 > lo[k] ? b0 : lo[k], i1 = b1 < hi[k] ? b1 : hi[k];
+            for (int i = i0; i <= i1; ++i) vmin[k] = fminf(vmin[k], row[i]);
+          }
+        }
       }
     }
 #pragma unroll
@@ -536,6 +556,13 @@ constexpr float kAmpMin = -200.0f, kAmpRng = 300.0f;
 
 constexpr int kDensRows = kAmpBins / kDensFreq;   // rows whose bin indices one pass of the workgroup forms
 
+// Round 6 tried two other decompositions, both bit-identical and both slower on the C3 second (rocprofv3, same box):
+// (i) a wave multiplies only once one of its 64 amplitude bins x 16 frequency bins has been hit, and looks at the bit table
+// only in rows that marked it: 1.15 ms - the wave that owns the trace's amplitude bins sets the pace of its workgroup
+// either way (its 48 instructions per row to place sixteen +1), idling the other seven waves buys nothing;
+// (ii) one wave per frequency bin, lanes = amplitude cells, the hit cell a scalar (exec-masked +1), only the groups of 64
+// cells that hold anything multiplied: 1.02 - 1.35 ms - ~30 issue slots per row and wave at an IPC of one half.
+// profiles/r06_analytics.txt.
 // Cost is VALU: every cell takes one multiply per row whatever happens, the question is what finding the ONE cell per
 // (row, frequency bin) that also gets +1 costs.  The first version had every thread compare its amplitude bin with
 // all 16 indices of every row (16 LDS reads + 16 compares + 16 selects per row: 2.1 ms per second of C3 spectra).
