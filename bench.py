@@ -539,6 +539,32 @@ def run_config(args, comm: Comm, torch) -> dict:
         if legs["value"] is None:
             legs["value"] = legs["streams"]
     head = legs["value"]
+    # ---- per-frame scalars from the frame kernel's epilogue (tdsa_set_frame_stats): the same submission
+    #      mode as `value` with peak / argmax / band power of every frame left beside the rows, and the scalars of one
+    #      launch checked against tdsa_rows_stats of the rows that launch wrote
+    frame_stats_block = None
+    if (args.config == "c3" and only == "all" and world == 1 and not args.dry_run and not getattr(args, "short_leg", False)
+            and not args.no_frame_stats):
+        from topdogspectrumanalyser_amd import analytics as _an
+        band = (nfft // 4, 3 * nfft // 4)
+        eng.set_frame_stats(True, band)
+        leg_fs = measure(head["streams"], head["per_call"])
+        eng.set_overlap(1)
+        step(0)
+        pk, pb, bd = eng.frame_stats(bin_width=1.0)
+        rp, rb, rband = _an.rows_stats(eng, out_ring[0].data_ptr(), my_frames, freq_bins=np.arange(nfft, dtype=np.float64),
+                                       band=(float(band[0]), float(band[1])))
+        eng.set_frame_stats(False)
+        frame_stats_block = {
+            "ms_per_step": leg_fs["med"] / leg_fs["steps"] * 1e3, "ms_per_step_without": head["med"] / head["steps"] * 1e3,
+            "overhead": leg_fs["med"] / leg_fs["steps"] / (head["med"] / head["steps"]) - 1.0,
+            "band_bins": list(band), "steps_per_call": leg_fs["per_call"], "streams": leg_fs["streams"],
+            "peak_and_bin_equal_rows_stats": bool(np.array_equal(pk, rp) and np.array_equal(pb, rb)),
+            "band_db_max_abs_diff_vs_rows_stats": float(np.max(np.abs(bd - rband))),
+            "is": "the `value` leg again with tdsa_set_frame_stats on: every wave of the frame kernel also leaves the maximum of "
+                  "its bins, its first position and the band's linear power (16 bytes per wave and frame), folded per frame when "
+                  "read; the alternative - tdsa_rows_stats, a second pass over the 160 MB of rows per step - costs more than the "
+                  "spectra themselves (profiles/r06_frame_stats.txt)"}
     steps_timed = head["steps"]
     total_frames = frames if strong else world * frames          # frames (segments) one step covers, all ranks together
     per_rank_fps = [my_f * steps_timed / t for my_f, t in zip(counts, head["per_rank"])]
@@ -798,6 +824,8 @@ def run_config(args, comm: Comm, torch) -> dict:
                                                 "algorithmic_bytes_per_launch": algo_step,
                                                 "frames_per_launch": my_frames}},
         }
+        if frame_stats_block is not None:
+            result["frame_stats"] = frame_stats_block
         if welch and kern_b and not args.dry_run:
             # The spec roof (8 TB/s, algorithmic bytes) next to the design's own ceiling: a two-pass transform moves 18 N bytes
             # per segment (2 N samples in, Z = 8 N out and in again, + 4 N / K of sums) through the links between the XCDs and
@@ -1077,6 +1105,8 @@ def main() -> None:
     ap.add_argument("--c5-shard", default="segments", choices=["segments", "captures"],
                     help="--config c5 on several GPUs: shard the 64 segments of ONE capture (strong scaling; every step pays "
                          "the cross-GPU combine) or give every GPU whole captures (weak scaling, no combine)")
+    ap.add_argument("--no-frame-stats", action="store_true",
+                    help="C3, one GPU: skip the extra leg with the per-frame scalars of the frame kernel's epilogue switched on")
     ap.add_argument("--c5-combine", default="auto", choices=["auto", "peer", "host"],
                     help="C5 at N > 1, segments sharded: where the ranks' partial means meet - peer = they stay in device "
                          "buffers rank 0 reads in place (HIP IPC, over xGMI), host = pinned shared memory; auto = peer when "

@@ -3,7 +3,7 @@
 
 The worst bin every soak has found is the one N/2 away from a full-scale tone that falls exactly on a bin: in the last
 radix-2 stage X[k0 + N/2] = E - W O with E = W O = X[k0] / 2, so what is left is the difference of the rounding errors
-the two half-amplitude partial sums carry (DESIGN.md section 2 has the budget).  This tool draws ONLY such cases -
+the two half-amplitude partial sums carry (profiles/HISTORY.md, appendix "(old) 2. Oracle", has the budget).  This tool draws ONLY such cases -
 a complex exponential of 100 ... 127 LSB exactly on a random bin, random phase, optionally a little noise, every native
 size 64 ... 16384 (and long frames 2^15 ... 2^17 with --long), both branches, per-frame / tracked / no DC removal, the
 three windows - and reports, as |dB error| over the parity allowance with ONE float32 rounding unit of the frame's largest

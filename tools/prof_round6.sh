@@ -8,7 +8,7 @@ rm -rf $OUT && mkdir -p $OUT && export TMPDIR=/tmp
 python bench.py --gpus 8 --reps 2 --min-region-s 0.1 --no-cpu-baseline --no-other-configs > $OUT/bench_c3_8ranks.json 2>> $OUT/bench.err
 python bench.py --gpus 8 --config c4 --reps 2 --min-region-s 0.1 --no-cpu-baseline > $OUT/bench_c4_8ranks.json 2>> $OUT/bench.err
 python bench.py --gpus 8 --config c5 --reps 2 --min-region-s 0.1 --no-cpu-baseline > $OUT/bench_c5_8ranks.json 2>> $OUT/bench.err
-FAST="--reps 3 --min-region-s 0.15 --no-cpu-baseline --no-parity --no-other-configs"
+FAST="--reps 3 --min-region-s 0.15 --no-cpu-baseline --no-parity --no-other-configs --no-frame-stats"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3_batch -- python bench.py --legs value --streams 1 --batch 8 --steps 800 --warmup 100 $FAST > $OUT/stats_c3_batch.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c5 -- python bench.py --config c5 --steps 30 --warmup 5 --reps 3 --min-region-s 0.05 --no-cpu-baseline --no-parity > $OUT/stats_c5.log 2>&1
 find $OUT -name "*.db" -delete; find $OUT -name "*kernel_trace.csv" -size +20M -delete
