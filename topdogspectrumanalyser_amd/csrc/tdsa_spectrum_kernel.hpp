@@ -806,30 +806,69 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
           st_maskc = st_mask;
           asm volatile("" : "+s"(st_maskc));
         }
+        if constexpr (STATS) {
+          // the band sum rides the dB loops only in waves that have bins in the band (st_maskc is wave-uniform: tested per bin
+          // inside ONE loop, a wave outside the band took 32 branches per frame for nothing).  (The loops stay spelled out:
+          // wrapped in a lambda they moved the instruction streams of the frozen instantiations.)
+          if (st_maskc != 0u) {
+          if (mag_mode && __builtin_amdgcn_ballot_w64(tiny) != 0) {
+            static_for<0, 16>([&](auto ic) {
+              constexpr int q = decltype(ic)::value;
+              const float mag = __builtin_amdgcn_sqrtf(db[q]);
+              st_band_add(ic, (mag + p.log_floor) * (mag + p.log_floor));
+              db[q] = fmaf(2.0f * k10Log10_2, __builtin_amdgcn_logf(mag + p.log_floor), cal_v);
+            });
+          } else if (mag_mode) {
+            static_for<0, 16>([&](auto ic) {
+              constexpr int q = decltype(ic)::value;
+              st_band_add(ic, db[q]);
+              db[q] = fmaf(k10Log10_2, __builtin_amdgcn_logf(db[q]), cal_v);
+            });
+          } else {
+            static_for<0, 16>([&](auto ic) {
+              constexpr int q = decltype(ic)::value;
+              const float a = fmaf(db[q], ps_v, fl_v);
+              st_band_add(ic, a);
+              db[q] = fmaf(k10Log10_2, __builtin_amdgcn_logf(a), cal_v);
+            });
+          }
+          } else {
+          if (mag_mode && __builtin_amdgcn_ballot_w64(tiny) != 0) {   // near-silent frame: exact DB_MAG
+            static_for<0, 16>([&](auto ic) {
+              constexpr int q = decltype(ic)::value;
+              const float mag = __builtin_amdgcn_sqrtf(db[q]);
+              db[q] = fmaf(2.0f * k10Log10_2, __builtin_amdgcn_logf(mag + p.log_floor), cal_v);
+            });
+          } else if (mag_mode) {          // 10*log10(|X|^2): no power scale, no floor (wave-uniform branch)
+            static_for<0, 16>([&](auto ic) {
+              constexpr int q = decltype(ic)::value;
+              db[q] = fmaf(k10Log10_2, __builtin_amdgcn_logf(db[q]), cal_v);
+            });
+          } else {
+            static_for<0, 16>([&](auto ic) {
+              constexpr int q = decltype(ic)::value;
+              db[q] = fmaf(k10Log10_2, __builtin_amdgcn_logf(fmaf(db[q], ps_v, fl_v)), cal_v);
+            });
+          }
+          }
+        } else {
         if (mag_mode && __builtin_amdgcn_ballot_w64(tiny) != 0) {   // near-silent frame: exact DB_MAG
           static_for<0, 16>([&](auto ic) {
             constexpr int q = decltype(ic)::value;
             const float mag = __builtin_amdgcn_sqrtf(db[q]);
-            if constexpr (STATS) st_band_add(ic, (mag + p.log_floor) * (mag + p.log_floor));
             db[q] = fmaf(2.0f * k10Log10_2, __builtin_amdgcn_logf(mag + p.log_floor), cal_v);
           });
         } else if (mag_mode) {          // 10*log10(|X|^2): no power scale, no floor (wave-uniform branch)
           static_for<0, 16>([&](auto ic) {
             constexpr int q = decltype(ic)::value;
-            if constexpr (STATS) st_band_add(ic, db[q]);
             db[q] = fmaf(k10Log10_2, __builtin_amdgcn_logf(db[q]), cal_v);
           });
         } else {
           static_for<0, 16>([&](auto ic) {
             constexpr int q = decltype(ic)::value;
-            if constexpr (STATS) {
-              const float a = fmaf(db[q], ps_v, fl_v);
-              st_band_add(ic, a);
-              db[q] = fmaf(k10Log10_2, __builtin_amdgcn_logf(a), cal_v);
-            } else {
-              db[q] = fmaf(k10Log10_2, __builtin_amdgcn_logf(fmaf(db[q], ps_v, fl_v)), cal_v);
-            }
+            db[q] = fmaf(k10Log10_2, __builtin_amdgcn_logf(fmaf(db[q], ps_v, fl_v)), cal_v);
           });
+        }
         }
         if (p.tare != nullptr) {
           // SGPR descriptor + the store offsets: no per-thread 64-bit pointers (hoisted out of the frame loop
@@ -841,6 +880,37 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
             db[q] -= __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(tr, out_voff, kcs * SG * 4u, 0));
           });
         }
+        if constexpr (!C::WIN_LDS) load_window();     // next frame's window, ahead of this frame's stores
+        TDSA_PRIO(0);
+        if (p.out_db != nullptr) {
+          float* orow = p.out_db + out_elem_off(frame);
+          if constexpr (UNI) {
+            const rsrc_t r = make_rsrc(orow, N * 4u);
+            static_for<0, 16>([&](auto ic) {
+              constexpr int q = decltype(ic)::value;
+              constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(db[q]), r, out_voff, kcs * SG * 4u, kRowStorePolicy);
+            });
+          } else {
+            float* orow_t = orow + t + 8 * h * SG;
+            static_for<0, 16>([&](auto ic) {
+              constexpr int q = decltype(ic)::value;
+              constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
+              __builtin_nontemporal_store(db[q], &orow_t[kcs * SG]);
+            });
+          }
+        }
+        if constexpr ((HOLD & 3) != 0) {
+          const bool nanfix = IN_C64 && (p.first_frame_index + frame == 0);
+          static_for<0, 16>([&](auto ic) {
+            constexpr int q = decltype(ic)::value;
+            float dmx = db[q], dmn = db[q];
+            if (nanfix && dmx != dmx) { dmx = -500.f; dmn = 500.f; }            // _nan_safe, first frame
+            if constexpr ((HOLD & 1) != 0) hmax[q] = hw_max(hmax[q], dmx);      // np.fmax: NaN ignored
+            if constexpr ((HOLD & 2) != 0) hmin[q] = hw_min(hmin[q], dmn);
+          });
+        }
+        // (last in the epilogue: the dB values have no other reader left, the registers around them are at their fewest)
         if constexpr (STATS) {
           // the wave's record: {maximum of its 16 x 64 dB values, the first display position of the wave's bins that holds it
           // (np.argmax: first of equals; 0x40000000 | position of the first NaN - only complex64 input can carry one - and the
@@ -861,14 +931,41 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
           }
           int best = 0x3fffffff;
           if (__builtin_popcountll(holders) == 1 && !nan) {      // wave-uniform
-            int bk = 0;
-            static_for<0, 16>([&](auto ic) {                      // from the highest position down: the lowest match stays
-              constexpr int q = decltype(ic)::value < 8 ? 7 - decltype(ic)::value : 23 - decltype(ic)::value;
-              constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
-              __builtin_amdgcn_sched_barrier(0);                   // (one mask at a time: the kernel has no SGPRs for sixteen)
-              const unsigned long long mk = __builtin_amdgcn_ballot_w64(db[q] == mw);
-              if ((mk >> who) & 1ull) bk = kcs;
-            });
+            // the holder parks its sixteen values in the wave's 64 bytes of LDS, in display order (rank r = kcs for
+            // kcs < 8, kcs - 8 above), lanes 0 .. 15 read one each and compare: the first match is np.argmax's bin.
+            // (Sixteen compares of all lanes with the holder's bit picked from each mask: 64 instructions; this: ~30.
+            //  A wave's DS operations execute in order: the read needs no wait for the writes.)
+            typedef __attribute__((address_space(3))) float* lds_fp;
+            int wv = __builtin_amdgcn_readfirstlane(wave);
+            asm volatile("" : "+s"(wv));
+            // frames of several waves: 64 bytes per wave behind everything else; a frame inside one wave (N = 1024, where
+            // four workgroups fill a CU's LDS to within 768 bytes): the head of the wave's own frame buffer, dead by now
+            const unsigned st_addr = C::TPF <= 64 ? unsigned(uintptr_t((lds_fp)(buf)))
+                                                  : unsigned(uintptr_t((lds_fp)(smem + C::LDS_ALLOC))) + 64u * unsigned(wv);
+            unsigned long long ex_save;
+            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %18\n\t"
+                         "ds_write_b32 %17, %9 offset:0\n\tds_write_b32 %17, %10 offset:4\n\tds_write_b32 %17, %11 offset:8\n\t"
+                         "ds_write_b32 %17, %12 offset:12\n\tds_write_b32 %17, %13 offset:16\n\tds_write_b32 %17, %14 offset:20\n\t"
+                         "ds_write_b32 %17, %15 offset:24\n\tds_write_b32 %17, %16 offset:28\n\t"
+                         "ds_write_b32 %17, %1 offset:32\n\tds_write_b32 %17, %2 offset:36\n\tds_write_b32 %17, %3 offset:40\n\t"
+                         "ds_write_b32 %17, %4 offset:44\n\tds_write_b32 %17, %5 offset:48\n\tds_write_b32 %17, %6 offset:52\n\t"
+                         "ds_write_b32 %17, %7 offset:56\n\tds_write_b32 %17, %8 offset:60\n\t"
+                         "s_mov_b64 exec, %0"
+                         : "=&s"(ex_save)
+                         : "v"(db[0]), "v"(db[1]), "v"(db[2]), "v"(db[3]), "v"(db[4]), "v"(db[5]), "v"(db[6]), "v"(db[7]),
+                           "v"(db[8]), "v"(db[9]), "v"(db[10]), "v"(db[11]), "v"(db[12]), "v"(db[13]), "v"(db[14]), "v"(db[15]),
+                           "v"(st_addr), "s"(holders)
+                         : "memory");
+            float mine;                                   // (a ds_read of the wave's own slot: through a generic pointer it
+            {                                             //  became a flat load behind vmcnt(0), its address a spilled pair)
+              int tl = tid;
+              asm volatile("" : "+v"(tl));
+              const unsigned rd_addr = st_addr + unsigned(tl & 15) * 4u;
+              asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(mine) : "v"(rd_addr) : "memory");
+            }
+            const unsigned hit = unsigned(__builtin_amdgcn_ballot_w64(mine == mw)) & 0xffffu;   // (never empty: the maximum is among them)
+            const int r = __builtin_ctz(hit | 0x10000u);
+            const int bk = r < 8 ? r : r + 8;
             best = (bk + 8 * int(who >> 5)) * SG + int(who & 31u);
           } else {
             asm volatile("; several holders / NaN" ::: "memory");    // (a side effect: this path must stay a branch, folded into
@@ -900,36 +997,6 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
           unsigned long long ex_save;
           asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tbuffer_store_dwordx4 %1, off, %2, %3\n\ts_mov_b64 exec, %0"
                        : "=&s"(ex_save) : "v"(rec), "s"(sr), "s"(soff) : "memory");
-        }
-        if constexpr (!C::WIN_LDS) load_window();     // next frame's window, ahead of this frame's stores
-        TDSA_PRIO(0);
-        if (p.out_db != nullptr) {
-          float* orow = p.out_db + out_elem_off(frame);
-          if constexpr (UNI) {
-            const rsrc_t r = make_rsrc(orow, N * 4u);
-            static_for<0, 16>([&](auto ic) {
-              constexpr int q = decltype(ic)::value;
-              constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
-              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(db[q]), r, out_voff, kcs * SG * 4u, kRowStorePolicy);
-            });
-          } else {
-            float* orow_t = orow + t + 8 * h * SG;
-            static_for<0, 16>([&](auto ic) {
-              constexpr int q = decltype(ic)::value;
-              constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
-              __builtin_nontemporal_store(db[q], &orow_t[kcs * SG]);
-            });
-          }
-        }
-        if constexpr ((HOLD & 3) != 0) {
-          const bool nanfix = IN_C64 && (p.first_frame_index + frame == 0);
-          static_for<0, 16>([&](auto ic) {
-            constexpr int q = decltype(ic)::value;
-            float dmx = db[q], dmn = db[q];
-            if (nanfix && dmx != dmx) { dmx = -500.f; dmn = 500.f; }            // _nan_safe, first frame
-            if constexpr ((HOLD & 1) != 0) hmax[q] = hw_max(hmax[q], dmx);      // np.fmax: NaN ignored
-            if constexpr ((HOLD & 2) != 0) hmin[q] = hw_min(hmin[q], dmn);
-          });
         }
       }
     }
@@ -1102,9 +1169,11 @@ template <int LOG2N, bool IN_C64, int HOLD, int CHIRP = 0>
 inline hipError_t launch_one(const SpecParams& p, const LaunchGeom& g, hipStream_t s) {
   auto k = spectrum_kernel<LOG2N, IN_C64, HOLD, CHIRP>;
   static std::atomic<unsigned long long> attr_done{0};
-  const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), int(g.lds_bytes), attr_done);
+  // (STATS instantiations: 64 bytes per wave behind everything else - the sixteen dB values of the lane that holds the wave's maximum)
+  const size_t lds = g.lds_bytes + ((HOLD & 8) != 0 && Cfg<LOG2N>::TPF > 64 ? size_t(Cfg<LOG2N>::NWAVE) * 64 : 0);
+  const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k), int(lds), attr_done);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k, dim3(g.grid), dim3(g.block), g.lds_bytes, s, p);
+  hipLaunchKernelGGL(k, dim3(g.grid), dim3(g.block), lds, s, p);
   return hipGetLastError();
 }
 
