@@ -78,6 +78,22 @@ def test_every_instantiation_is_free_of_scratch(reports, log2n, in_c64, hold):
 
 
 @pytest.mark.parametrize("log2n", [10, 11, 12, 13, 14])
+@pytest.mark.parametrize("in_c64", [False, True])
+@pytest.mark.parametrize("hold", [8, 9])
+def test_frame_statistics_instantiations_are_free_of_scratch(reports, log2n, in_c64, hold):
+    """HOLD | 8 = the STATS epilogue (per-frame peak / argmax / band power from the bins in registers; hold none / max, frames
+    of whole waves): no scratch and no spilled VGPR in any of them - in the C3-shaped one (16384 points, bytes, max hold) a
+    single spilled trace register is reloaded behind vmcnt(0) every frame (three variants of the epilogue did that) - and no
+    spilled SGPR in the byte-format ones of the BASELINE sizes."""
+    k = _kernel(reports, log2n, in_c64, hold)
+    assert int(k["ScratchSize [bytes/lane]"]) == 0, k
+    assert int(k["VGPRs Spill"]) == 0, k
+    assert int(k["VGPRs"]) <= 128 and int(k["Occupancy [waves/SIMD]"]) >= 4, k
+    if not in_c64 and log2n >= 12:                         # the BASELINE shapes (C2 / C4 / C3)
+        assert int(k["SGPRs Spill"]) == 0, k
+
+
+@pytest.mark.parametrize("log2n", [10, 11, 12, 13, 14])
 @pytest.mark.parametrize("chirp", [3])
 def test_chirp_transform_instantiations_are_free_of_scratch(reports, log2n, chirp):
     """The instantiation that carries a chirp-z plan's element-wise passes (tdsa_chirp.hip; complex64 in, no hold,
