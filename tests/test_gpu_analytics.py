@@ -724,3 +724,36 @@ def test_density_image_u8_matches_setimage_autolevels(pkg, an, golden_dir):
         u8, (lo, hi) = dh.image_u8()
         assert lo == img.min() and hi == img.max()
         assert np.array_equal(u8, _levels_u8(img, lo, hi)) and u8.max() == 255
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TDSA_SWEEP_CASES", "24"))))
+def test_frame_stats_random(pkg, seed):
+    """Seeded random plans - any size from 64 to 16384 incl. sizes that are not a power of two, the three input formats,
+    dB modes, calibration offsets, hold combinations, hops, frame counts, bands - every one against numpy on the rows the
+    same call wrote: peak and argmax bit for bit (fused or not), the band within 1e-5 (fused) / 1e-6 (from the rows)."""
+    rng = np.random.default_rng(52000 + seed)
+    nfft = int(rng.choice([64, 256, 512, 1000, 1024, 1024, 2048, 2048, 3000, 4096, 4096, 8192, 8192, 16384, 16384]))
+    nf = int(rng.integers(1, 40))
+    hop = int(rng.choice([nfft, nfft // 2, int(rng.integers(1, 2 * nfft))]))
+    iq = so.synth_iq_int8(hop * (nf - 1) + nfft, max(nfft, 64), seed=int(rng.integers(1, 1 << 30)))
+    fmt = str(rng.choice(["i8", "u8", "c64"]))
+    if fmt == "u8":
+        iq = (iq.astype(np.int16) + 128).astype(np.uint8)
+    elif fmt == "c64":
+        iq = ((iq[0::2].astype(np.float32) + 1j * iq[1::2].astype(np.float32)) / 128).astype(np.complex64)
+    mode = [dict(db_mode="mag", log_floor=so.LOG_FLOOR), dict(db_mode="pow", power_scale=1.0 / (20e6 * nfft), log_floor=1e-12),
+            dict(db_mode="pow", power_scale=1.0, log_floor=1e-10)][int(rng.integers(0, 3))]
+    lo, hi = sorted(int(x) for x in rng.integers(0, nfft, 2))
+    if rng.integers(0, 5) == 0:
+        lo, hi = 1, 0
+    with pkg.SpectrumEngine(nfft, max_frames=nf) as e:
+        e.set_window(np.hanning(nfft).astype(np.float32) if rng.integers(0, 2) else so.hackrf_window(nfft))
+        e.configure(dc_alpha=float(rng.choice([1.0, -1.0, 0.3])), cal_offset_db=float(rng.choice([0.0, -0.8087, 3.5])),
+                    hold_max=bool(rng.integers(0, 2)), hold_min=bool(rng.integers(0, 4) == 0), **mode)
+        e.set_frame_stats(True, (lo, hi))
+        rows = e.process(iq, hop=hop, n_frames=nf)
+        peak, pbin, band = e.frame_stats()
+    wp, wb, wband = _stats_of_rows(rows, lo, hi)
+    tag = (seed, nfft, fmt, nf, hop, lo, hi)
+    assert np.array_equal(peak, wp) and np.array_equal(pbin, wb), tag
+    assert np.allclose(band, wband, rtol=1e-5, atol=1e-300), tag
