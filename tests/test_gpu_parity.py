@@ -1380,6 +1380,68 @@ def test_c5_welch_is_reproducible_bit_for_bit(pkg):
     _check(rows[0], gold, "Welch of 16 segments of 2^20 points")
 
 
+@pytest.mark.parametrize("log2n,k", [(15, 5), (17, 12), (20, 8), (20, 64)])
+def test_c5_row_pass_and_gather_as_one_launch(pkg, log2n, k):
+    """tdsa_debug_knob big_fuse_gather 1: the row pass of a Welch capture and gather + finish run as ONE launch whose
+    workgroups draw tickets from a dependency-counted queue (tdsa_big.hip) - the same partial rows summed in the same order:
+    the dB row, the float64 state and the hold trace must be the bits of the three-launch chain, call after call (the
+    queue's counters only grow), also with the state carried across calls; no workgroup ever gave up waiting."""
+    n = 1 << log2n
+    iq = so.synth_iq_int8(n * k, min(n, 1 << 16), seed=log2n + k)
+    outs = []
+    for knob in (0, 1):
+        with pkg.SpectrumEngine(n, max_frames=k) as e:
+            e.set_window(so.rtl_window("hanning", n).astype(np.float32))
+            e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=-1.0, avg=("lin", 3 * k),
+                        cal_offset_db=-0.8087, hold_max=True)
+            e.debug_knob("big_fuse_gather", knob)
+            got = []
+            for rep in range(3):                               # the averager's state is carried: 3 k segments in all
+                got.append(e.process(iq, hop=n)[0].copy())
+            got.append(e.averaged()[0].copy())
+            got.append(e.hold()[0].copy())
+            e.reset()
+            got.append(e.process(iq, hop=n)[0].copy())         # and from a fresh state again
+            e.debug_knob("big_queue_gave_up", 0)               # raises if a workgroup of a fused launch ever gave up
+            outs.append(got)
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
+def test_c5_fused_launches_of_two_plans_share_the_gpu(pkg):
+    """Two plans on their own streams, both with the fused row + gather launch, captures queued alternately without a
+    synchronize in between: a device-wide barrier would deadlock here (each launch's waiting workgroups holding the CUs
+    the other's unstarted ones need); with the ticket queue a waiting workgroup only waits for workgroups that are running."""
+    import ctypes as C
+    nat = pkg._native
+    n, k = 1 << 20, 16
+    iq = so.synth_iq_int8(n * k, 1 << 16, seed=77)
+    d_in = C.c_void_p()
+    nat.check(nat.lib.tdsa_dev_alloc(0, iq.nbytes, C.byref(d_in)))
+    try:
+        nat.check(nat.lib.tdsa_memcpy_h2d(0, d_in, iq.ctypes.data_as(C.c_void_p), iq.nbytes))
+        plans = []
+        for knob in (1, 1, 0):
+            e = pkg.SpectrumEngine(n, max_frames=k)
+            e.set_window(so.rtl_window("hanning", n).astype(np.float32))
+            e.configure(db_mode="pow", power_scale=1.0, log_floor=so.POWER_LOG_FLOOR, dc_alpha=-1.0, avg=("lin", k))
+            e.debug_knob("big_fuse_gather", knob)
+            plans.append(e)
+        for rep in range(40):
+            for e in plans:
+                e.reset(nat.RESET_AVG)
+                e.process_device(nat.IN_I8, d_in.value, n * k, n, k, None)
+        means = []
+        for e in plans:
+            e.synchronize()
+            e.debug_knob("big_queue_gave_up", 0)
+            means.append(e.averaged()[0].copy())
+            e.close()
+        assert np.array_equal(means[0], means[2]) and np.array_equal(means[1], means[2])
+    finally:
+        nat.lib.tdsa_dev_free(0, d_in)
+
+
 def test_c5_single_frame_with_dc_removal(pkg):
     nfft = 1 << 20
     iq = so.synth_iq_int8(nfft, nfft, seed=6)

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--ks", default="8,16,32,64,128")
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--capture", type=int, default=64, help="segments of the capture whose strong-scaling curve is predicted")
+    ap.add_argument("--knob", action="append", default=[], help="name=value for tdsa_debug_knob on every plan (repeatable)")
     a = ap.parse_args()
     ks = [int(k) for k in a.ks.split(",")]
     n, kmax = 1 << 20, max(ks)
@@ -36,6 +37,8 @@ def main():
     for rep in range(a.reps):
         for K in ks:
             e = SpectrumEngine(n, max_frames=K)
+            for kv in a.knob:
+                e.debug_knob(kv.split('=')[0], int(kv.split('=')[1]))
             e.set_window(np.hanning(n).astype(np.float32))
             e.configure(db_mode="pow", power_scale=1.0, log_floor=1e-12, dc_alpha=-1.0, avg=("lin", K), cal_offset_db=-0.8087)
 

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--masks", default="", help="developer build only (TDSA_HIP_LIB=libtdsa_dev.so): tdsa_debug_knob cu_mask per "
                                                 "plan, comma separated: 1 / 2 = mask words 0-3 / 4-7, 3 / 4 = every second CU")
     ap.add_argument("--num-cu", type=int, default=0, help="tdsa_debug_knob num_cu on every plan (persistent grids)")
+    ap.add_argument("--knob", action="append", default=[], help="name=value for tdsa_debug_knob on every plan (repeatable)")
     a = ap.parse_args()
     masks = a.masks.split(",") if a.masks else []
     n, K = 1 << 20, 64
@@ -37,6 +38,8 @@ def main():
     engs = []
     for k in range(a.plans):
         e = SpectrumEngine(n, max_frames=K)
+        for kv in a.knob:
+            e.debug_knob(kv.split('=')[0], int(kv.split('=')[1]))
         if masks:
             e.debug_knob("cu_mask", int(masks[k % len(masks)]))
         if a.num_cu:

@@ -227,7 +227,12 @@ struct BigRowsParams {
   const float2* tw;          // exp(-2 pi i m / 16384)
 };
 
-__global__ void __launch_bounds__(1024, 4) big_rows_kernel(const BigRowsParams p) {
+// the row pass of ONE work item: row k1, the j-th share of the round's segments (the whole kernel when workgroup b = k1 act + j
+// takes item b; an item of the ticket queue of big_rows_gather_kernel below)
+// COHERENT: the item's row of P leaves with agent-scope stores (through to memory: readable from another XCD inside the same
+// launch without a write-back of the whole L2 - the fused launch below)
+template <bool COHERENT = false>
+__device__ __forceinline__ void big_rows_item(const BigRowsParams& p, const int k1, const int j) {
   using C = Cfg<kRowLog2>;
   constexpr int N = C::N, SG = C::SG, A = C::A, H = C::H;
   static_assert(A == 16 && C::M == 2 && !C::INL && C::NPASS == 3 && C::FPW == 1, "row pass is written for N = 16 x 32 x 32");
@@ -241,7 +246,6 @@ __global__ void __launch_bounds__(1024, 4) big_rows_kernel(const BigRowsParams p
   const int h = (tid >> 5) & 1;
   const int t = wave * 32 + (tid & 31);
   const bool odd_half = h != 0;
-  const int k1 = int(blockIdx.x) / p.act, j = int(blockIdx.x) - k1 * p.act;
   const int chunk = (p.group + p.act - 1) / p.act;
   const int s0 = min(p.group, j * chunk), s1 = min(p.group, s0 + chunk);
 
@@ -398,9 +402,15 @@ __global__ void __launch_bounds__(1024, 4) big_rows_kernel(const BigRowsParams p
       constexpr int kc = (q < 8 ? q : q + 8);
       float x = pacc[q];
       if (p.acc_add != 0) x += arow[kc * SG];
-      arow[kc * SG] = x;
+      if constexpr (COHERENT) __hip_atomic_store(&arow[kc * SG], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else arow[kc * SG] = x;
     });
   }
+}
+
+__global__ void __launch_bounds__(1024, 4) big_rows_kernel(const BigRowsParams p) {
+  const int k1 = int(blockIdx.x) / p.act;
+  big_rows_item<false>(p, k1, int(blockIdx.x) - k1 * p.act);
 }
 
 hipError_t launch_big_rows(const float2* z, long long seg_stride, int group, int n1, int act, float* acc, int acc_split,
@@ -586,6 +596,150 @@ __global__ void __launch_bounds__(256) big_gather_kernel(const float* s, int spl
     const double sum = add ? dst[ks] + x : x;
     dst[ks] = sum;
     if (fuse) big_finish_bin(fin, ks, sum);
+  }
+}
+
+// ---- row pass + gather + finish as ONE launch with a dependency-counted work queue (round 6; the round-5 verdict's
+//      "tile queue, no device-wide barrier", for the part of the chain whose two kernels share a launch shape) -------------
+// Tickets are drawn from one counter: 0 .. R-1 are the row items (k1, j), R .. R+G-1 gather tiles (four 16 x 64 tiles of the
+// gather kernel per ticket, one per 256 threads), anything above ends the workgroup.  A workgroup that draws a gather ticket
+// waits until rows_done has reached this launch's target: every row ticket has by then been DRAWN by a workgroup that is
+// running and waits for nobody, so the wait ends whatever else shares the GPU (two plans on two streams, two ranks on one
+// GPU: a grid barrier - every workgroup waiting for every other, started or not - deadlocks there).  The counters only
+// grow; the host passes each launch its base values, so nothing is reset between launches.  The spin is bounded: a
+// workgroup that gives up sets q->gave_up and leaves (tests read it), it never hangs the device.
+struct BigQueue {
+  unsigned long long ticket, rows_done, gave_up, pad;
+};
+struct BigGatherParams {
+  const float* s;          // P rows
+  int split;
+  double* dst;
+  int add;
+  BigFinishParams fin;
+  int fuse;
+};
+
+template <int LOG2N1>
+__device__ __forceinline__ void big_gather_tile256(const BigGatherParams& g, double (*tile)[65], int tile_id, int t256) {
+  constexpr int N1 = 1 << LOG2N1, T = 64, R = N1 < 16 ? N1 : 16;
+  const int k2b = (tile_id % (kRowN / T)) * T, k1b = (tile_id / (kRowN / T)) * R;
+  for (int i = t256; i < R * T; i += 256) {
+    const int k1 = i / T, c = i % T;
+    const float* q = g.s + (long long)(k1b + k1) * g.split * kRowN + k2b + c;
+    double acc = 0.0;                                     // the row items' partials of this k1, in a fixed order
+    // (plain loads, four in flight: the workgroup invalidated its caches when the rows were complete; agent-scope atomic
+    //  loads instead are issued one at a time - sixteen memory round trips per thread, +25 us per capture)
+    int j = 0;
+    for (; j + 4 <= g.split; j += 4) {
+      const float a0 = q[(long long)j * kRowN], a1 = q[(long long)(j + 1) * kRowN], a2 = q[(long long)(j + 2) * kRowN],
+                  a3 = q[(long long)(j + 3) * kRowN];
+      acc += double(a0); acc += double(a1); acc += double(a2); acc += double(a3);
+    }
+    for (; j < g.split; ++j) acc += double(q[(long long)j * kRowN]);
+    tile[k1][c] = acc;
+  }
+  __syncthreads();                                        // (all four tile groups of the workgroup pass here together)
+  constexpr long long half = (long long)N1 * kRowN / 2;
+  for (int i = t256; i < R * T; i += 256) {
+    const int c = i / R, k1 = i % R;
+    const long long k = (long long)(k2b + c) * N1 + k1b + k1;
+    const long long ks = k ^ half;
+    const double x = tile[k1][c];
+    const double sum = g.add ? g.dst[ks] + x : x;
+    g.dst[ks] = sum;
+    if (g.fuse) big_finish_bin(g.fin, ks, sum);
+  }
+  __syncthreads();
+}
+
+template <int LOG2N1>
+__global__ void __launch_bounds__(1024, 4) big_rows_gather_kernel(const BigRowsParams p, const BigGatherParams g, BigQueue* q,
+                                                                  unsigned long long ticket_base, unsigned long long rows_target,
+                                                                  int n_row_items, int n_gather_tickets, int variant) {
+  constexpr int N1 = 1 << LOG2N1, R = N1 < 16 ? N1 : 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ long long s_ticket;
+  // `variant`: timing-only experiments behind tdsa_debug_knob big_fuse_gather = 1 + 2 x variant (results undefined): bit 0 no
+  // acquire fence
+  auto draw = [&]() -> long long {
+    __syncthreads();
+    if (threadIdx.x == 0)
+      s_ticket = (long long)(__hip_atomic_fetch_add(&q->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ticket_base);
+    __syncthreads();
+    return s_ticket;
+  };
+  // phase 1: row items while there are any (two loops, not one with a branch: as one loop the gather's addresses were
+  // hoisted above the row pass and spilled - 30 dwords reloaded behind vmcnt(0) in every row)
+  long long t = draw();
+  while (t < n_row_items) {
+    const int k1 = int(t) / p.act;
+    big_rows_item<true>(p, k1, int(t) - k1 * p.act);
+    __syncthreads();                                    // every thread's agent-scope stores of the item's row of P have been acknowledged ...
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(&q->rows_done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before it counts
+    // (a release fence here - __threadfence - is a write-back of the XCD's whole L2 per wave: it made the launch 200 us longer)
+    t = draw();
+  }
+  // phase 2: gather tickets; all row tickets have been drawn by running workgroups, so this wait ends
+  if (t < n_row_items + n_gather_tickets) {
+    if (threadIdx.x == 0) {
+      unsigned spins = 0;
+      while (__hip_atomic_load(&q->rows_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < rows_target) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1u << 22)) {                     // seconds: something is wrong, leave instead of hanging the device
+          __hip_atomic_fetch_add(&q->gave_up, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      // acquire at agent scope = invalidate this CU's L1 and the XCD's L2 of what they hold of P (the last capture's rows):
+      // no write-back, unlike the release side
+      if (!(variant & 1)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+  }
+  while (t < n_row_items + n_gather_tickets) {
+    double (*tile)[65] = reinterpret_cast<double (*)[65]>(smem) + (threadIdx.x >> 8) * R;
+    big_gather_tile256<LOG2N1>(g, tile, int(t - n_row_items) * 4 + int(threadIdx.x >> 8), int(threadIdx.x & 255));
+    t = draw();
+  }
+}
+
+template <int L>
+static hipError_t rows_gather_launch(const BigRowsParams& p, const BigGatherParams& g, void* q, unsigned long long ticket_base,
+                                     unsigned long long rows_target, int grid, int variant, hipStream_t s) {
+  using C = Cfg<kRowLog2>;
+  constexpr int N1 = 1 << L, R = N1 < 16 ? N1 : 16;
+  static std::atomic<unsigned long long> attr_done{0};
+  const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(big_rows_gather_kernel<L>), int(C::LDS_BYTES), attr_done);
+  if (e != hipSuccess) return e;
+  const int tiles = (kRowN / 64) * (N1 / R);
+  hipLaunchKernelGGL(big_rows_gather_kernel<L>, dim3(grid), dim3(C::WGT), C::LDS_BYTES, s, p, g, static_cast<BigQueue*>(q),
+                     ticket_base, rows_target, grid, (tiles + 3) / 4, variant);
+  return hipGetLastError();
+}
+
+// one launch: the row pass of a round of `group` segments and gather + finish behind it; consumes n1 * act + tiles / 4 + grid
+// tickets (*tickets_used) and n1 * act row counts of the queue
+hipError_t launch_big_rows_gather(int log2n, const float2* z, long long seg_stride, int group, int n1, int act, float* acc,
+                                  const float2* tw, double* dst, int add, double* mean_out, int count, int db_mode, float pscale,
+                                  float log_floor, float cal_db, const float* tare, float* out_db, float* hold_max,
+                                  float* hold_min, int max_first, int min_first, void* queue, unsigned long long ticket_base,
+                                  unsigned long long rows_target, unsigned long long* tickets_used, int variant, hipStream_t s) {
+  const BigRowsParams p{z, seg_stride, group, act, acc, act, 0, tw};
+  const BigFinishParams fin{dst, mean_out, count, db_mode, pscale, log_floor, cal_db, tare, out_db, hold_max, hold_min,
+                            max_first, min_first};
+  const BigGatherParams g{acc, act, dst, add, fin, 1};
+  const int grid = n1 * act;
+  const int R = n1 < 16 ? n1 : 16;
+  *tickets_used = (unsigned long long)grid + (unsigned long long)(((kRowN / 64) * (n1 / R) + 3) / 4) + (unsigned long long)grid;
+  switch (log2n - kRowLog2) {
+    case 1: return rows_gather_launch<1>(p, g, queue, ticket_base, rows_target, grid, variant, s);
+    case 2: return rows_gather_launch<2>(p, g, queue, ticket_base, rows_target, grid, variant, s);
+    case 3: return rows_gather_launch<3>(p, g, queue, ticket_base, rows_target, grid, variant, s);
+    case 4: return rows_gather_launch<4>(p, g, queue, ticket_base, rows_target, grid, variant, s);
+    case 5: return rows_gather_launch<5>(p, g, queue, ticket_base, rows_target, grid, variant, s);
+    case 6: return rows_gather_launch<6>(p, g, queue, ticket_base, rows_target, grid, variant, s);
+    default: return hipErrorInvalidValue;
   }
 }
 

@@ -132,6 +132,10 @@ struct tdsa_plan_s {
                                          // kernels (M <= 16384; developer builds: two launches that carry the passes), separate row passes (M > 16384)
   int big_pre_wgs = 0;                   // developer builds, tdsa_debug_knob "big_pre_wgs": empty workgroups launched ahead of every column pass
   int big_group = 64;                    // segments per column-pass / row-pass round (one round for the K = 64 Welch capture)
+  int big_fuse_gather = 0;               // tdsa_debug_knob "big_fuse_gather": 1 = Welch captures of one round run row pass + gather + finish as ONE
+                                         // launch with a ticket queue (measured: profiles/r06_c5_fused_gather.txt)
+  void* d_bigq = nullptr;                // the queue's counters (32 bytes, zeroed once; they only grow)
+  unsigned long long bigq_tickets = 0, bigq_rows = 0;   // what the next launch starts from
   // frame lengths that are not a power of two (tdsa_chirp.hip): chirp-z on the m_fft-point frame kernel
   bool chirp = false;
   int m_fft = 0, log2m = 0;              // M = 2^log2m >= 2 nfft - 1
@@ -334,6 +338,7 @@ int process_big(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n_f
   // the gather sums over j - nothing is carried from call to call, so a failed call leaves no residue
   const int split_max = p->num_cu / n1 > 1 ? p->num_cu / n1 : 1;
   int split_layout = 1;
+  bool fused_tail = false;
   for (int s0 = 0; s0 < n_frames; s0 += group) {
     const int ns = n_frames - s0 < group ? n_frames - s0 : group;
     const int act = ns < split_max ? ns : split_max;
@@ -354,6 +359,25 @@ int process_big(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n_f
       }
       HIPCHK(hipEventRecord(p->prof_events[p->prof_used], p->stream));
     }
+    fused_tail = welch && p->big_fuse_gather && !p->profiling && n_frames <= group;
+    if (fused_tail) {
+      if (!p->d_bigq) {
+        HIPCHK(hipMalloc(&p->d_bigq, 32));
+        HIPCHK(hipMemsetAsync(p->d_bigq, 0, 32, p->stream));
+        p->bigq_tickets = p->bigq_rows = 0;
+      }
+      unsigned long long used = 0;
+      p->bigq_rows += (unsigned long long)n1 * act;
+      HIPCHK(launch_big_rows_gather(p->log2n, p->d_z, (long long)N * sizeof(float2), ns, n1, act, p->d_acc, p->d_tw_row, p->d_sum,
+                                    p->avg_count > 0, nullptr, p->avg_count + n_frames, m.db_mode,
+                                    m.db_mode == TDSA_DB_POW ? m.power_scale : 1.0f, m.log_floor, m.cal_offset_db,
+                                    p->tare_active ? p->d_tare_base : nullptr, out_db_dev,
+                                    (m.hold_flags & TDSA_HOLD_MAX) ? p->d_hold_max : nullptr,
+                                    (m.hold_flags & TDSA_HOLD_MIN) ? p->d_hold_min : nullptr, p->held_max == 0, p->held_min == 0,
+                                    p->d_bigq, p->bigq_tickets, p->bigq_rows, &used, p->big_fuse_gather >> 1, p->stream));
+      p->bigq_tickets += used;
+      break;
+    }
     HIPCHK(launch_big_rows(p->d_z, (long long)N * sizeof(float2), ns, n1, act, p->d_acc, split_layout, s0 > 0, p->d_tw_row,
                                 p->stream));
     if (p->profiling) {
@@ -366,7 +390,10 @@ int process_big(tdsa_plan p, int in_format, const void* iq_dev, int hop, int n_f
   float* const tare = p->tare_active ? p->d_tare_base : nullptr;
   float* const hold_max = hmax ? p->d_hold_max : nullptr;
   float* const hold_min = hmin ? p->d_hold_min : nullptr;
-  if (welch) {
+  if (welch && fused_tail) {
+    p->avg_count += n_frames;
+    p->big_mean_in_sum = true;
+  } else if (welch) {
     HIPCHK(launch_big_gather_finish(p->log2n, p->d_acc, split_layout, p->d_sum, p->avg_count > 0, nullptr, p->avg_count + n_frames,
                                     m.db_mode, pscale, m.log_floor, m.cal_offset_db, tare, out_db_dev, hold_max, hold_min,
                                     p->held_max == 0, p->held_min == 0, p->stream));
@@ -1014,7 +1041,7 @@ int tdsa_destroy(tdsa_plan p) {
                   p->d_avg, p->d_lin, p->d_carry, p->d_agg, p->d_agg_w, p->d_chunk_a, p->d_chunk_v, p->d_cplx, p->d_real, p->d_lin1, p->d_db1, p->d_dc_state, p->d_sums, p->d_dc_sub,
                   p->d_tare_base, p->d_tare_acc, p->d_in_stage, p->d_out_stage, p->d_trace_in,
                   p->d_trace_live, p->d_scratch, p->d_z, p->d_welch, p->d_clock, p->d_smooth_tw, p->d_smooth_z, p->d_chirp_aw[0], p->d_chirp_aw[1], p->d_chirp_aw[2], p->d_chirp_bm, p->d_chirp_bp, p->d_chirp_a, p->d_chirp_b, p->d_u0, p->d_u1, p->d_acc, p->d_sum, p->d_lin64, p->d_sums64, p->d_tw_seed, p->d_tw_row, p->d_ones,
-                  p->d_dbg};
+                  p->d_dbg, p->d_bigq};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (p->h_in_pin) (void)hipHostFree(p->h_in_pin);
@@ -2246,6 +2273,12 @@ int tdsa_debug_knob(tdsa_plan p, const char* name, int value) {
     if (!p->big || value < 1 || value > 64) return fail(TDSA_ERR_ARG, "big_group=%d (long-frame plans, 1 .. 64)", value);
     if (p->d_z && value > p->big_group) return fail(TDSA_ERR_STATE, "big_group can only shrink once the plan has run");
     p->big_group = value;
+  } else if (k == "big_fuse_gather") {
+    p->big_fuse_gather = value;
+  } else if (k == "big_queue_gave_up") {       // reads (value ignored): how many workgroups of the fused launch ever gave up waiting - as the error text
+    unsigned long long q[4] = {0, 0, 0, 0};
+    if (p->d_bigq) { HIPCHK(hipStreamSynchronize(p->stream)); HIPCHK(hipMemcpy(q, p->d_bigq, sizeof(q), hipMemcpyDeviceToHost)); }
+    return q[2] == 0 ? TDSA_OK : fail(TDSA_ERR_STATE, "%llu workgroups of a fused row + gather launch gave up waiting", q[2]);
   } else if (k == "smooth") {                // sizes 2^a 3^b 5^c (<= 10 000 in one pass, two passes above): 1 = mixed-radix transform of N points (default), 0 = chirp-z
     p->smooth_on = value != 0;
   } else if (k == "smooth_n1") {             // two-pass sizes: the column pass's transform length (a divisor; both factors <= 10 000)

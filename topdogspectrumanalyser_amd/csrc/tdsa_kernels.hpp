@@ -249,6 +249,13 @@ hipError_t launch_big_dc(const void* in, int in_c64, unsigned xor_mask, long lon
 // row pass: 16384-point transforms of the rows, power summed per workgroup (tdsa_big.hip)
 hipError_t launch_big_rows(const float2* z, long long seg_stride, int group, int n1, int act, float* acc, int acc_split,
                            int acc_add, const float2* tw, hipStream_t s);
+// the row pass of one round and gather + finish as ONE launch with a dependency-counted ticket queue (tdsa_big.hip);
+// queue: 32 zeroed bytes of device memory owned by the plan, ticket_base / rows_target: the counters' values this launch starts from / waits for
+hipError_t launch_big_rows_gather(int log2n, const float2* z, long long seg_stride, int group, int n1, int act, float* acc,
+                                  const float2* tw, double* dst, int add, double* mean_out, int count, int db_mode, float pscale,
+                                  float log_floor, float cal_db, const float* tare, float* out_db, float* hold_max,
+                                  float* hold_min, int max_first, int min_first, void* queue, unsigned long long ticket_base,
+                                  unsigned long long rows_target, unsigned long long* tickets_used, int variant, hipStream_t s);
 // P[k1 * split + j][k2] float partial sums -> dst[(k1 + N1*k2) ^ N/2] double (overwrite or accumulate)
 hipError_t launch_big_gather(int log2n, const float* s_rows, int split, double* dst, int add, hipStream_t s);
 // the same + mean = dst / count -> dB (+cal, -tare) row and hold traces, one launch
