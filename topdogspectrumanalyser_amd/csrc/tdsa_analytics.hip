@@ -547,92 +547,132 @@ __global__ void __launch_bounds__(kMarkThreads) marker_peaks_kernel(const float*
 }
 
 // ---- density histogram ----------------------------------------------------------------------------------
-// hist[f][a] for kDensFreq neighbouring frequency bins per workgroup; thread a owns amplitude bin a of each.
-// Rows are applied in order with the reference's float32 arithmetic: hist *= decay (when decay < 1), then
+// hist[f][a]: rows are applied in order with the reference's float32 arithmetic: hist *= decay (when decay < 1), then
 // += 1 at int32(((v - AMP_MIN) / AMP_RNG) * AMP_BINS) (truncation toward zero, NaN / out of range dropped).
+//
+// The arithmetic floor of touching every cell is one multiply per cell and row: 16384 x 512 x 2440 on 1024 SIMDs of 16
+// lanes = 0.52 ms per second of C3 spectra (a wave64 instruction holds its SIMD for four clocks) - and rounds 2 - 5 sat at
+// 0.93 ms with amplitude bins across the lanes: every wave multiplies every row, and the wave that owns the trace's amplitude
+// bins places sixteen +1 on top (48 instructions).  But most cells are ZERO and 0 x decay = 0 exactly: a trace lives in a few
+// dozen of the 512 amplitude bins.  Round 6, third attempt (the first two lost: profiles/r06_analytics.txt): FREQUENCY bins
+// across the lanes, 16 amplitude cells per lane in registers, a workgroup = 64 frequency bins x 256 amplitude cells (16
+// waves).  Neighbouring frequency bins sit at similar levels, so a wave's 64 x 16 cells are all zero or not together: only
+// the 3 - 4 waves per 64 frequency bins that hold the traces multiply (16 per row) and place hits (3 instructions per cell
+// of the lane's sixteen), the others pass a row in three scalar instructions - 2.8 x fewer issue slots per frequency bin, and
+// the longest serial stream (a hit wave: ~70 instructions per row) a quarter of the old one.  The 1024 threads of a
+// workgroup form the cell indices of a chunk of 32 rows once (LDS, int16) and mark, per row, which waves they hit.
 constexpr int kAmpBins = 512;
-constexpr int kDensFreq = 16;
 constexpr float kAmpMin = -200.0f, kAmpRng = 300.0f;
+constexpr int kDensLanes = 64;                      // frequency bins per workgroup (one per lane)
+constexpr int kDensCells = 16;                      // amplitude cells per lane
+constexpr int kDensWaves = 16;                      // waves per workgroup: 256 amplitude cells
+constexpr int kDensRows = 32;                       // rows per chunk
 
-constexpr int kDensRows = kAmpBins / kDensFreq;   // rows whose bin indices one pass of the workgroup forms
-
-// Round 6 tried two other decompositions, both bit-identical and both slower on the C3 second (rocprofv3, same box):
-// (i) a wave multiplies only once one of its 64 amplitude bins x 16 frequency bins has been hit, and looks at the bit table
-// only in rows that marked it: 1.15 ms - the wave that owns the trace's amplitude bins sets the pace of its workgroup
-// either way (its 48 instructions per row to place sixteen +1), idling the other seven waves buys nothing;
-// (ii) one wave per frequency bin, lanes = amplitude cells, the hit cell a scalar (exec-masked +1), only the groups of 64
-// cells that hold anything multiplied: 1.02 - 1.35 ms - ~30 issue slots per row and wave at an IPC of one half.
-// profiles/r06_analytics.txt.
-// Cost is VALU: every cell takes one multiply per row whatever happens, the question is what finding the ONE cell per
-// (row, frequency bin) that also gets +1 costs.  The first version had every thread compare its amplitude bin with
-// all 16 indices of every row (16 LDS reads + 16 compares + 16 selects per row: 2.1 ms per second of C3 spectra).
-// Now the 512 threads of the workgroup scatter the 512 indices of a 32-row chunk into a bit table in LDS -
-// word [row][a / 2] holds, for amplitude bins a and a + 1, one bit per frequency bin that hit them - and a thread
-// reads ONE word per row; only waves in which some lane was hit (the few whose 64 amplitude bins cover the trace)
-// run the 16 adds, the others do their 16 multiplies and move on.
-__global__ void __launch_bounds__(kAmpBins) density_kernel(const float* __restrict__ rows, int n_rows, int n,
-                                                           float decay, float* hist) {
-  __shared__ unsigned s_hit[kDensRows][kAmpBins / 2];
-  const int f0 = blockIdx.x * kDensFreq;
-  const int a = threadIdx.x;
-  const int rr = a / kDensFreq, jj = a % kDensFreq;     // this thread forms the index of (row r0 + rr, bin f0 + jj)
-  const int sh = 16 * (a & 1);
-  float h[kDensFreq];
+__global__ void __launch_bounds__(kDensWaves * 64) density_kernel(const float* __restrict__ rows, int n_rows, int n,
+                                                                  float decay, float* hist) {
+  __shared__ __attribute__((aligned(8))) short s_idx[2][kDensLanes][kDensRows + 4];   // cell index of (frequency bin, row), -1: none; 72-byte rows:
+                                                                                        // a lane fetches its chunk as eight 8-byte reads
+  __shared__ unsigned s_wh[2][kDensRows];               // per row: which waves of this workgroup are hit
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int f = blockIdx.x * kDensLanes + lane;
+  const int a_wg = blockIdx.y * (kDensWaves * kDensCells);       // first amplitude cell of the workgroup
+  const int a0 = a_wg + w * kDensCells;                          // ... of this wave
+  const bool f_ok = f < n;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  float h[kDensCells];
+  bool nz = false;
+  if (f_ok) {
+    const f4* src = reinterpret_cast<const f4*>(hist + (size_t)f * kAmpBins + a0);
 #pragma unroll
-  for (int j = 0; j < kDensFreq; ++j) h[j] = (f0 + j < n) ? hist[(size_t)(f0 + j) * kAmpBins + a] : 0.0f;
-  for (int i = a; i < kDensRows * (kAmpBins / 2); i += kAmpBins) (&s_hit[0][0])[i] = 0u;
+    for (int k = 0; k < kDensCells / 4; ++k) {
+      const f4 q = src[k];
+      h[4 * k] = q.x; h[4 * k + 1] = q.y; h[4 * k + 2] = q.z; h[4 * k + 3] = q.w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < kDensCells; ++k) h[k] = 0.0f;
+  }
+#pragma unroll
+  for (int k = 0; k < kDensCells; ++k) nz |= h[k] != 0.0f;        // (a NaN cell counts: it has to keep being multiplied)
+  bool wave_nz = __builtin_amdgcn_ballot_w64(nz) != 0ull;
+  if (tid < 2 * kDensRows) (&s_wh[0][0])[tid] = 0u;
   const bool do_decay = decay < 1.0f;
   float decay_v = decay;
   asm volatile("" : "+v"(decay_v));      // a VALU op with an SGPR source issues at half rate on gfx950
-  const bool col_ok = f0 + jj < n;
-  float v_next = (rr < n_rows && col_ok) ? rows[(size_t)rr * n + f0 + jj] : NAN;
-  for (int r0 = 0; r0 < n_rows; r0 += kDensRows) {
-    int idx = -1;
-    const float v = v_next;                       // fetched while the previous chunk was applied
-    v_next = (r0 + kDensRows + rr < n_rows && col_ok) ? rows[(size_t)(r0 + kDensRows + rr) * n + f0 + jj] : NAN;
-    if (r0 + rr < n_rows && col_ok) {
-      const float x = (v - kAmpMin) / kAmpRng * float(kAmpBins);
-      // astype(int32) truncates toward zero; NaN and anything outside [0, AMP_BINS) is dropped
-      if (v == v && x > -1.0f && x < float(kAmpBins)) idx = int(x);
-    }
-    __syncthreads();                 // previous chunk fully consumed (every word read and cleared by its owners)
-    if (idx >= 0) atomicOr(&s_hit[rr][idx >> 1], 1u << (jj + 16 * (idx & 1)));
+  // the workgroup's fetch of a chunk: thread t takes rows t / 64 and t / 64 + 16 at frequency bin lane (256-byte runs)
+  const int lr = tid >> 6;
+  auto fetch = [&](int r) -> float { return (r < n_rows && f_ok) ? rows[(size_t)r * n + f] : NAN; };
+  float v0 = fetch(lr), v1 = fetch(lr + 16);
+  __syncthreads();                       // s_wh is zero
+  int par = 0;
+  for (int r0 = 0; r0 < n_rows; r0 += kDensRows, par ^= 1) {
+    auto cell = [&](float v, int r) {
+      int idx = -1;
+      if (r0 + r < n_rows && f_ok) {
+        const float x = (v - kAmpMin) / kAmpRng * float(kAmpBins);
+        // astype(int32) truncates toward zero; NaN and anything outside [0, AMP_BINS) is dropped
+        if (v == v && x > -1.0f && x < float(kAmpBins)) idx = int(x);
+      }
+      s_idx[par][lane][r] = short(idx);
+      const int rel = idx - a_wg;
+      if (idx >= 0 && rel >= 0 && rel < kDensWaves * kDensCells) atomicOr(&s_wh[par][r], 1u << (rel / kDensCells));
+    };
+    cell(v0, lr);
+    cell(v1, lr + 16);
+    v0 = fetch(r0 + kDensRows + lr);      // the next chunk's values travel while this one is applied
+    v1 = fetch(r0 + kDensRows + lr + 16);
     __syncthreads();
     const int lim = n_rows - r0 < kDensRows ? n_rows - r0 : kDensRows;
-    constexpr int RB = 4;                                   // rows whose words are fetched together
-    for (int rb = 0; rb < kDensRows; rb += RB) {
-      if (rb >= lim) break;
-      unsigned w[RB];
+    const unsigned whv = lane < kDensRows ? s_wh[par][lane] : 0u;
+    const unsigned hit_rows = unsigned(__builtin_amdgcn_ballot_w64(((whv >> w) & 1u) != 0u));
+    __syncthreads();                                    // every wave has its rows' masks: this parity can be cleared for the chunk after next
+    if (tid < kDensRows) s_wh[par][tid] = 0u;           // (wave 0 clears it before it reaches the next chunk's barrier; the marks of the
+                                                        //  chunk after next come behind that barrier)
+    if (hit_rows != 0u || wave_nz) {
+      // the lane's 32 cell indices of the chunk in sixteen registers (fetched only by waves that are hit); the rows unrolled,
+      // so that picking row r's index is a register and a half-word known at compile time and nothing waits on LDS per row
+      unsigned iw[kDensRows / 2];
+      if (hit_rows != 0u) {
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        const u2* ip = reinterpret_cast<const u2*>(&s_idx[par][lane][0]);
 #pragma unroll
-      for (int u = 0; u < RB; ++u) {
-        // lanes a and a ^ 1 share a word and a wave: both have read it before either clears it
-        w[u] = s_hit[rb + u][a >> 1];
-        s_hit[rb + u][a >> 1] = 0u;
+        for (int k = 0; k < kDensRows / 4; ++k) { const u2 q = ip[k]; iw[2 * k] = q.x; iw[2 * k + 1] = q.y; }
+      } else {
+#pragma unroll
+        for (int k = 0; k < kDensRows / 2; ++k) iw[k] = 0xffffffffu;
       }
+      static_for<0, kDensRows>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        const bool hit = (hit_rows >> r) & 1u;
+        if (r < lim && (hit || wave_nz)) {
+          if (do_decay && wave_nz) {
 #pragma unroll
-      for (int u = 0; u < RB; ++u) {
-        if (rb + u < lim) {
-          const unsigned m = (w[u] >> sh) & 0xffffu;
-          if (do_decay) {
-#pragma unroll
-            for (int j = 0; j < kDensFreq; ++j) h[j] = __fmul_rn(h[j], decay_v);   // `hist *= d`
+            for (int k = 0; k < kDensCells; ++k) h[k] = __fmul_rn(h[k], decay_v);   // `hist *= d`
           }
-          if (__builtin_amdgcn_ballot_w64(m != 0u) != 0) {                        // `hist[f, idx] += 1`, its own rounding
-            // bit j of m -> 0.0f or 1.0f without a select (v_cndmask with an implicit vcc mask is the slowest
-            // VALU instruction of the chip); h + 0.0f leaves h as it is (h >= 0)
+          if (hit) {
+            // `hist[f, idx] += 1`, its own rounding: the lane's cell as a one-hot word, bit k -> 0.0f or 1.0f without a select
+            // (h + 0.0f leaves h as it is: h >= 0)
+            const int idx = int(short((r & 1) ? (iw[r / 2] >> 16) : (iw[r / 2] & 0xffffu)));
+            const int rel = idx - a0;
+            const unsigned onehot = (unsigned(rel) < unsigned(kDensCells)) ? (1u << rel) : 0u;   // (a cell of another wave's sixteen: none)
 #pragma unroll
-            for (int j = 0; j < kDensFreq; ++j) {
-              const unsigned all = unsigned(__builtin_amdgcn_sbfe(int(m), j, 1));   // 0 or 0xffffffff
-              h[j] = __fadd_rn(h[j], __uint_as_float(all & 0x3f800000u));
+            for (int k = 0; k < kDensCells; ++k) {
+              const unsigned all = unsigned(__builtin_amdgcn_sbfe(int(onehot), k, 1));   // 0 or 0xffffffff
+              h[k] = __fadd_rn(h[k], __uint_as_float(all & 0x3f800000u));
             }
+            // (exec narrowed per cell by v_cmpx + a plain add - two vector instructions per cell instead of three - measured
+            //  0.81 ms against 0.63: every write of exec drains the vector pipe)
+            wave_nz = true;
           }
         }
-      }
+      });
     }
   }
+  if (f_ok) {
+    f4* dst = reinterpret_cast<f4*>(hist + (size_t)f * kAmpBins + a0);
 #pragma unroll
-  for (int j = 0; j < kDensFreq; ++j)
-    if (f0 + j < n) hist[(size_t)(f0 + j) * kAmpBins + a] = h[j];
+    for (int k = 0; k < kDensCells / 4; ++k) dst[k] = f4{h[4 * k], h[4 * k + 1], h[4 * k + 2], h[4 * k + 3]};
+  }
 }
 
 __global__ void log1p_kernel(const float* __restrict__ in, float* out, size_t count) {
@@ -753,7 +793,7 @@ hipError_t launch_marker_peaks(const float* rows, int n_rows, int n, double heig
 
 hipError_t launch_density(const float* rows, int n_rows, int n, float decay, float* hist, hipStream_t s) {
   if (n_rows <= 0) return hipSuccess;
-  density_kernel<<<(n + kDensFreq - 1) / kDensFreq, kAmpBins, 0, s>>>(rows, n_rows, n, decay, hist);
+  density_kernel<<<dim3((n + kDensLanes - 1) / kDensLanes, kAmpBins / (kDensWaves * kDensCells)), kDensWaves * 64, 0, s>>>(rows, n_rows, n, decay, hist);
   return hipGetLastError();
 }
 
