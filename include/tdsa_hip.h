@@ -433,7 +433,10 @@ int tdsa_profile_read(tdsa_plan p, int* launches, float* total_ms);
  * 0 = the passes of the convolution as separate kernels instead of one launch), "smooth" (frame lengths 2^a 3^b 5^c: 0 = as a chirp-z convolution like every other size that is not a
  * power of two, instead of the mixed-radix transform), "smooth_n1" (such sizes above 10 000 points: the column pass's length of the two-pass transform, a divisor with both factors
  * <= 10 000), "chirp_fuse_big" (chirp-z plans with
- * M > 16384: 0 = the unpack / window / chirp and the power / dB passes as kernels of their own); a library built with
+ * M > 16384: 0 = the unpack / window / chirp and the power / dB passes as kernels of their own), "big_fuse_gather"
+ * (long-frame Welch captures of one round: 1 = row pass + gather + finish as ONE launch with a dependency-counted ticket
+ * queue instead of two launches - same bits, measured slower, profiles/r06_c5_fused_gather.txt; default 0) and
+ * "big_queue_gave_up" (reads: an error if a workgroup of such a launch ever gave up waiting); a library built with
  * -DTDSA_DEV also knows "big_pre_wgs" (empty workgroups ahead of every column pass: tools/c5_xcd_phase.py) and "cu_mask"
  * (the plan's stream confined to a set of CUs: tools/c5_two_plans.py).
  * Unknown names are an error. */

@@ -207,3 +207,29 @@ def test_c5_million_point_fixture(golden_dir):
             assert p.sum() == float(g[f"{tag}_sum_db"])
     fb = so.shifted_freq_bins(n, float(g["sample_rate"]), float(g["centre_freq"]))
     assert fb[0] == float(g["freq_first"]) and fb[-1] == float(g["freq_last"])
+
+
+def test_hold_allowance_follows_from_the_rows():
+    """oracle.HoldAllowance: |max_f a_f - max_f b_f| <= max_f |a_f - b_f| (the same for min) bin by bin - rows perturbed by
+    anything up to their own allowance give hold traces within the inherited allowance, whatever the perturbation's sign
+    pattern (the extreme of many draws included); a trace pushed beyond it is caught; bins no row had checked stay unchecked."""
+    rng = np.random.default_rng(7)
+    for trial in range(40):
+        nf, n = int(rng.integers(1, 60)), int(rng.choice([64, 257, 1024]))
+        gold = -60.0 + 10 * np.log10(rng.exponential(1.0, size=(nf, n)) + 1e-9)
+        gold[:, n // 3] = 40.0 + rng.normal(0, 3, nf)                       # a tone: the other bins sit ~100 dB down
+        units = float(rng.choice([1.0, 2.0, 3.0]))
+        allow = so.row_allowance_db(gold, 100.0, units * so.AMP_FLOOR)
+        sign = rng.choice([-1.0, 1.0], size=gold.shape) if trial % 3 else -np.ones_like(gold)
+        rows = gold + sign * np.where(np.isfinite(allow), allow, 0.0) * rng.uniform(0.0, 1.0, gold.shape)
+        rel_r, ddb_r = so.parity_metrics(rows, gold, amp_floor=units * so.AMP_FLOOR)
+        assert ddb_r <= 1e-3 * (1 + 1e-9)
+        ha = so.HoldAllowance(amp_floor=units * so.AMP_FLOOR).update(gold[: nf // 2 + 1]).update(gold[nf // 2 + 1:] if nf // 2 + 1 < nf else gold[:1])
+        for fn in (np.max, np.min):
+            rel, ddb = ha.metrics(fn(rows, axis=0), fn(gold, axis=0))
+            assert ddb <= 1e-3 * (1 + 1e-9), (trial, fn.__name__, ddb)
+        # the old rule - the trace judged like a single row of its own maximum - rejects some of these min traces
+        worse = fn(rows, axis=0).copy()
+        k = int(np.argmax(np.isfinite(ha.allow)))
+        worse[k] += 3.0 * ha.allow[k]
+        assert ha.metrics(worse, fn(gold, axis=0))[1] > 1e-3
