@@ -22,3 +22,7 @@ with SpectrumEngine(n, max_frames=F) as e:
         print("rows", rows, "%.3f ms" % t(lambda: an.rows_top_peaks(e, d_out.value, rows, n=5)))
     print("marker", "%.3f ms" % t(lambda: an.rows_marker_peaks(e, d_out.value, F)))
     print("stats", "%.3f ms" % t(lambda: an.rows_stats(e, d_out.value, F)))
+    for d in (1, 3):
+        for thr in (-200.0, -20.0):
+            print("marker distance", d, "threshold", thr, "%.3f ms" % t(lambda: an.rows_marker_peaks(e, d_out.value, F, distance=d, peak_threshold=thr)))
+    print("marker 256 rows", "%.3f ms" % t(lambda: an.rows_marker_peaks(e, d_out.value, 256)))

@@ -369,12 +369,60 @@ __device__ __forceinline__ double marker_prominence(const float* row, const Mark
   return (double)xp - (double)fmaxf(lmin, rmin);
 }
 
+// The FILTER needs only `prominence >= threshold`, and that is decided long before the walk ends: the difference
+// (double)xp - (double)v falls as v rises, so `xp - min(side) >= threshold` holds iff SOME sample of the side's walk has
+// `xp - v >= threshold` - the walk of a side stops at the first such sample (side passed), or at the first sample above
+// the peak / NaN / the end of the row (side failed: the peak is out).  A noise peak is settled in a handful of steps,
+// a carrier in two or three (the window's skirt); only ripple of less than the threshold walks far, in blocks.
+__device__ __forceinline__ bool marker_prominent(const float* row, const MarkerLds& L, int n, int p, double prominence) {
+  if (0.0 >= prominence) return true;                        // the bases start at the peak itself: prominence >= 0
+  const float xp = row[p];
+  const double dxp = (double)xp;
+  bool ok = false;
+  int i = p - 1;
+  while (i >= 0) {
+    if ((i & 31) == 31) {
+      if ((i & 1023) == 1023 && L.bmax2[i >> 10] <= xp) {
+        if (dxp - (double)L.bmin2[i >> 10] >= prominence) { ok = true; break; }
+        i -= 1024; continue;
+      }
+      if (L.bmax1[i >> 5] <= xp) {
+        if (dxp - (double)L.bmin1[i >> 5] >= prominence) { ok = true; break; }
+        i -= 32; continue;
+      }
+    }
+    const float v = row[i];
+    if (!(v <= xp)) break;
+    if (dxp - (double)v >= prominence) { ok = true; break; }
+    --i;
+  }
+  if (!ok) return false;
+  i = p + 1;
+  while (i < n) {
+    if ((i & 31) == 0) {
+      if ((i & 1023) == 0 && L.bmax2[i >> 10] <= xp) {
+        if (dxp - (double)L.bmin2[i >> 10] >= prominence) return true;
+        i += 1024; continue;
+      }
+      if (L.bmax1[i >> 5] <= xp) {
+        if (dxp - (double)L.bmin1[i >> 5] >= prominence) return true;
+        i += 32; continue;
+      }
+    }
+    const float v = row[i];
+    if (!(v <= xp)) return false;
+    if (dxp - (double)v >= prominence) return true;
+    ++i;
+  }
+  return false;
+}
+
 __global__ void __launch_bounds__(kMarkThreads) marker_peaks_kernel(const float* __restrict__ rows, int n, double height,
                                                                     double prominence, int distance, int current_idx,
                                                                     int max_list, int* out_count, int* out_snap,
                                                                     int* out_next, int* out_bins, double* out_prom) {
-  extern __shared__ float smem[];
-  float* row = smem;                                        // [n]
+  extern __shared__ __attribute__((aligned(16))) float mark_smem[];
+  float* row = mark_smem;                                        // [n]
   __shared__ MarkerLds L;
   const float* src = rows + (size_t)blockIdx.x * n;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -382,6 +430,46 @@ __global__ void __launch_bounds__(kMarkThreads) marker_peaks_kernel(const float*
 
   // load + block extrema of 32: a half-wave holds one block
   PeakPair amax{-INFINITY, 0x7fffffff};                     // np.argmax of the row (the fallback of snap_to_peak)
+  if ((n & 3) == 0) {
+    // four samples per lane, every load of the row in flight before the first is used; eight lanes hold a block of 32
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4* src4 = reinterpret_cast<const f4*>(src);
+    f4* row4 = reinterpret_cast<f4*>(row);
+    const int nc = n >> 2;
+    constexpr int kChunks = kMarkMaxN / 4 / kMarkThreads;
+    f4 q[kChunks];
+#pragma unroll
+    for (int k = 0; k < kChunks; ++k) {
+      const int c = tid + kMarkThreads * k;
+      q[k] = c < nc ? __builtin_nontemporal_load(src4 + c) : f4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+#pragma unroll
+    for (int k = 0; k < kChunks; ++k) {
+      const int c = tid + kMarkThreads * k;
+      const bool in = c < nc;
+      float mx = -INFINITY, mn = INFINITY;
+      if (in) {
+        row4[c] = q[k];
+        const float e[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const PeakPair cnd{e[j], 4 * c + j};
+          if (better(cnd, amax)) amax = cnd;
+          mx = fmaxf(mx, e[j] != e[j] ? INFINITY : e[j]);
+          mn = fminf(mn, e[j]);
+        }
+      }
+#pragma unroll
+      for (int o = 4; o >= 1; o >>= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, o));
+        mn = fminf(mn, __shfl_xor(mn, o));
+      }
+      if ((lane & 7) == 0 && (c >> 3) < nw) {
+        L.bmax1[c >> 3] = mx;
+        L.bmin1[c >> 3] = mn;
+      }
+    }
+  } else
   for (int i0 = 0; i0 < n; i0 += kMarkThreads) {
     const int i = i0 + tid;
     const bool in = i < n;
@@ -471,7 +559,7 @@ __global__ void __launch_bounds__(kMarkThreads) marker_peaks_kernel(const float*
     unsigned f = 0u;
     for (unsigned m = L.kept[w]; m != 0u; m &= m - 1u) {
       const int b = __builtin_ctz(m), p = 32 * w + b;
-      if (marker_prominence(row, L, n, p) >= prominence) {
+      if (marker_prominent(row, L, n, p, prominence)) {
         f |= 1u << b;
         const PeakPair c{row[p], p};
         if (c.v > top.v || (c.v == top.v && c.i < top.i)) top = c;        // np.argmax of the heights: first of equals
