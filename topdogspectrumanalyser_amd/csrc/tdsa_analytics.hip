@@ -645,22 +645,26 @@ __global__ void __launch_bounds__(kMarkThreads) marker_peaks_kernel(const float*
 // dozen of the 512 amplitude bins.  Round 6, third attempt (the first two lost: profiles/r06_analytics.txt): FREQUENCY bins
 // across the lanes, 16 amplitude cells per lane in registers, a workgroup = 64 frequency bins x 256 amplitude cells (16
 // waves).  Neighbouring frequency bins sit at similar levels, so a wave's 64 x 16 cells are all zero or not together: only
-// the 3 - 4 waves per 64 frequency bins that hold the traces multiply (16 per row) and place hits (3 instructions per cell
-// of the lane's sixteen), the others pass a row in three scalar instructions - 2.8 x fewer issue slots per frequency bin, and
-// the longest serial stream (a hit wave: ~70 instructions per row) a quarter of the old one.  The 1024 threads of a
-// workgroup form the cell indices of a chunk of 32 rows once (LDS, int16) and mark, per row, which waves they hit.
+// the 3 - 4 waves per 64 frequency bins that hold the traces multiply (16 per row) and place hits (four 128-bit LDS reads of
+// the lane's row of a one-hot table + 16 adds), the others pass a row in three scalar instructions.  The 1024 threads of a
+// workgroup form the cell indices of a chunk of 32 rows once (LDS, int16: the byte offset of the cell's one-hot row) and mark,
+// per row, which waves they hit.
 constexpr int kAmpBins = 512;
 constexpr float kAmpMin = -200.0f, kAmpRng = 300.0f;
 constexpr int kDensLanes = 64;                      // frequency bins per workgroup (one per lane)
 constexpr int kDensCells = 16;                      // amplitude cells per lane
 constexpr int kDensWaves = 16;                      // waves per workgroup: 256 amplitude cells
 constexpr int kDensRows = 32;                       // rows per chunk
+constexpr int kDensOneStride = 20;                  // floats per row of the one-hot table: 80-byte rows put the sixteen rows' 128-bit
+                                                    // reads on sixteen different quads of banks
+constexpr int kDensNone = 0x7fff;                   // s_idx of a sample that hits no cell of the workgroup
 
-__global__ void __launch_bounds__(kDensWaves * 64) density_kernel(const float* __restrict__ rows, int n_rows, int n,
+__global__ void __launch_bounds__(kDensWaves * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) density_kernel(const float* __restrict__ rows, int n_rows, int n,
                                                                   float decay, float* hist) {
   __shared__ __attribute__((aligned(8))) short s_idx[2][kDensLanes][kDensRows + 4];   // cell index of (frequency bin, row), -1: none; 72-byte rows:
                                                                                         // a lane fetches its chunk as eight 8-byte reads
   __shared__ unsigned s_wh[2][kDensRows];               // per row: which waves of this workgroup are hit
+  __shared__ __attribute__((aligned(16))) float s_one[kDensCells + 1][kDensOneStride];   // row k: 1.0f at cell k, row 16: zeros
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int f = blockIdx.x * kDensLanes + lane;
   const int a_wg = blockIdx.y * (kDensWaves * kDensCells);       // first amplitude cell of the workgroup
@@ -684,9 +688,12 @@ __global__ void __launch_bounds__(kDensWaves * 64) density_kernel(const float* _
   for (int k = 0; k < kDensCells; ++k) nz |= h[k] != 0.0f;        // (a NaN cell counts: it has to keep being multiplied)
   bool wave_nz = __builtin_amdgcn_ballot_w64(nz) != 0ull;
   if (tid < 2 * kDensRows) (&s_wh[0][0])[tid] = 0u;
+  if (tid < (kDensCells + 1) * kDensOneStride) (&s_one[0][0])[tid] = (tid % kDensOneStride == tid / kDensOneStride) ? 1.0f : 0.0f;
   const bool do_decay = decay < 1.0f;
   float decay_v = decay;
   asm volatile("" : "+v"(decay_v));      // a VALU op with an SGPR source issues at half rate on gfx950
+  float decay_one = do_decay ? decay : 1.0f;   // h x 1.0f is h: the branch-free path multiplies always
+  asm volatile("" : "+v"(decay_one));
   // the workgroup's fetch of a chunk: thread t takes rows t / 64 and t / 64 + 16 at frequency bin lane (256-byte runs)
   const int lr = tid >> 6;
   auto fetch = [&](int r) -> float { return (r < n_rows && f_ok) ? rows[(size_t)r * n + f] : NAN; };
@@ -701,9 +708,12 @@ __global__ void __launch_bounds__(kDensWaves * 64) density_kernel(const float* _
         // astype(int32) truncates toward zero; NaN and anything outside [0, AMP_BINS) is dropped
         if (v == v && x > -1.0f && x < float(kAmpBins)) idx = int(x);
       }
-      s_idx[par][lane][r] = short(idx);
+      // what the waves read: the byte offset of the cell's one-hot row counted from the workgroup's first cell (wave w subtracts
+      // its 16 x 80 x w and clamps: anything outside its sixteen cells lands on the row of zeros)
       const int rel = idx - a_wg;
-      if (idx >= 0 && rel >= 0 && rel < kDensWaves * kDensCells) atomicOr(&s_wh[par][r], 1u << (rel / kDensCells));
+      const bool mine = idx >= 0 && rel >= 0 && rel < kDensWaves * kDensCells;
+      s_idx[par][lane][r] = short(mine ? rel * (kDensOneStride * 4) : kDensNone);
+      if (mine) atomicOr(&s_wh[par][r], 1u << (rel / kDensCells));
     };
     cell(v0, lr);
     cell(v1, lr + 16);
@@ -716,20 +726,38 @@ __global__ void __launch_bounds__(kDensWaves * 64) density_kernel(const float* _
     __syncthreads();                                    // every wave has its rows' masks: this parity can be cleared for the chunk after next
     if (tid < kDensRows) s_wh[par][tid] = 0u;           // (wave 0 clears it before it reaches the next chunk's barrier; the marks of the
                                                         //  chunk after next come behind that barrier)
-    if (hit_rows != 0u || wave_nz) {
-      // the lane's 32 cell indices of the chunk in sixteen registers (fetched only by waves that are hit); the rows unrolled,
-      // so that picking row r's index is a register and a half-word known at compile time and nothing waits on LDS per row
-      unsigned iw[kDensRows / 2];
-      if (hit_rows != 0u) {
-        typedef unsigned u2 __attribute__((ext_vector_type(2)));
-        const u2* ip = reinterpret_cast<const u2*>(&s_idx[par][lane][0]);
-#pragma unroll
-        for (int k = 0; k < kDensRows / 4; ++k) { const u2 q = ip[k]; iw[2 * k] = q.x; iw[2 * k + 1] = q.y; }
-      } else {
-#pragma unroll
-        for (int k = 0; k < kDensRows / 2; ++k) iw[k] = 0xffffffffu;
-      }
+    if (hit_rows != 0u && lim == kDensRows) {
+      // a wave that is hit in a full chunk takes every row the same way - multiply, fetch the one-hot row (the row of zeros where
+      // the sample belongs to other cells), add - as one block without branches: the reads of later rows are issued under the
+      // arithmetic of earlier ones
+      typedef unsigned u2 __attribute__((ext_vector_type(2)));
+      const u2* ip = reinterpret_cast<const u2*>(&s_idx[par][lane][0]);
+      u2 iwq = {0u, 0u};                  // four rows' offsets at a time
       static_for<0, kDensRows>([&](auto rc) {
+#pragma clang fp contract(off)            // two roundings per row and cell, like the reference's `*=` and `+=`: never an fma
+        constexpr int r = decltype(rc)::value;
+        if constexpr (r % 4 == 0) iwq = ip[r / 4];
+        const unsigned iwr = (r & 2) ? iwq.y : iwq.x;
+        const unsigned off = (r & 1) ? (iwr >> 16) : (iwr & 0xffffu);
+        const unsigned mine = off - unsigned(w * kDensCells * kDensOneStride * 4);
+        const unsigned row_off = mine < unsigned(kDensCells * kDensOneStride * 4) ? mine : unsigned(kDensCells * kDensOneStride * 4);
+        const f4* one = reinterpret_cast<const f4*>(reinterpret_cast<const char*>(&s_one[0][0]) + row_off);
+#pragma unroll
+        for (int k = 0; k < kDensCells / 4; ++k) {
+          const f4 q = one[k];
+          // (plain operators: __fmul_rn / __fadd_rn are inline functions of a header compiled with contraction on, and carry it here)
+          const float m0 = h[4 * k] * decay_one, m1 = h[4 * k + 1] * decay_one, m2 = h[4 * k + 2] * decay_one, m3 = h[4 * k + 3] * decay_one;
+          h[4 * k] = m0 + q.x;
+          h[4 * k + 1] = m1 + q.y;
+          h[4 * k + 2] = m2 + q.z;
+          h[4 * k + 3] = m3 + q.w;
+        }
+      });
+      wave_nz = true;
+    } else if (hit_rows != 0u || wave_nz) {
+      // a wave whose cells only fade (no hit in this chunk), or the ragged last chunk: row by row
+      static_for<0, kDensRows>([&](auto rc) {
+#pragma clang fp contract(off)
         constexpr int r = decltype(rc)::value;
         const bool hit = (hit_rows >> r) & 1u;
         if (r < lim && (hit || wave_nz)) {
@@ -740,13 +768,17 @@ __global__ void __launch_bounds__(kDensWaves * 64) density_kernel(const float* _
           if (hit) {
             // `hist[f, idx] += 1`, its own rounding: the lane's cell as a one-hot word, bit k -> 0.0f or 1.0f without a select
             // (h + 0.0f leaves h as it is: h >= 0)
-            const int idx = int(short((r & 1) ? (iw[r / 2] >> 16) : (iw[r / 2] & 0xffffu)));
-            const int rel = idx - a0;
-            const unsigned onehot = (unsigned(rel) < unsigned(kDensCells)) ? (1u << rel) : 0u;   // (a cell of another wave's sixteen: none)
+            const unsigned off = (unsigned short)s_idx[par][lane][r];
+            const unsigned mine = off - unsigned(w * kDensCells * kDensOneStride * 4);
+            const unsigned row_off = mine < unsigned(kDensCells * kDensOneStride * 4) ? mine : unsigned(kDensCells * kDensOneStride * 4);
+            const f4* one = reinterpret_cast<const f4*>(reinterpret_cast<const char*>(&s_one[0][0]) + row_off);
 #pragma unroll
-            for (int k = 0; k < kDensCells; ++k) {
-              const unsigned all = unsigned(__builtin_amdgcn_sbfe(int(onehot), k, 1));   // 0 or 0xffffffff
-              h[k] = __fadd_rn(h[k], __uint_as_float(all & 0x3f800000u));
+            for (int k = 0; k < kDensCells / 4; ++k) {
+              const f4 q = one[k];
+              h[4 * k] = __fadd_rn(h[4 * k], q.x);
+              h[4 * k + 1] = __fadd_rn(h[4 * k + 1], q.y);
+              h[4 * k + 2] = __fadd_rn(h[4 * k + 2], q.z);
+              h[4 * k + 3] = __fadd_rn(h[4 * k + 3], q.w);
             }
             // (exec narrowed per cell by v_cmpx + a plain add - two vector instructions per cell instead of three - measured
             //  0.81 ms against 0.63: every write of exec drains the vector pipe)
