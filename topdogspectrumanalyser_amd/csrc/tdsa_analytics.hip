@@ -63,7 +63,7 @@ __device__ __forceinline__ float wave_min_to_lane63(float x) {
   return x;
 }
 // strongest candidate of the wave, equal values: larger index (the order of the reference's reversed ascending sort)
-__device__ __forceinline__ PeakPair wave_strongest_to_lane63(PeakPair p) {
+__device__ __forceinline__ PeakPair row_strongest(PeakPair p) {      // every lane: the strongest of its row of 16 lanes
   auto step = [&](float qv, int qi) {
     if (qv > p.v || (qv == p.v && qi > p.i)) p = PeakPair{qv, qi};
   };
@@ -71,6 +71,20 @@ __device__ __forceinline__ PeakPair wave_strongest_to_lane63(PeakPair p) {
   step(dpp_f<0x4E, 0xf>(p.v), dpp_i<0x4E, 0xf>(p.i));
   step(dpp_f<0x141, 0xf>(p.v), dpp_i<0x141, 0xf>(p.i));
   step(dpp_f<0x140, 0xf>(p.v), dpp_i<0x140, 0xf>(p.i));
+  return p;
+}
+__device__ __forceinline__ float row_min(float x) {                   // every lane: the minimum of its row of 16 lanes
+  x = fminf(x, dpp_f<0xB1, 0xf>(x));
+  x = fminf(x, dpp_f<0x4E, 0xf>(x));
+  x = fminf(x, dpp_f<0x141, 0xf>(x));
+  x = fminf(x, dpp_f<0x140, 0xf>(x));
+  return x;
+}
+__device__ __forceinline__ PeakPair wave_strongest_to_lane63(PeakPair p) {
+  auto step = [&](float qv, int qi) {
+    if (qv > p.v || (qv == p.v && qi > p.i)) p = PeakPair{qv, qi};
+  };
+  p = row_strongest(p);
   step(dpp_f<0x142, 0xa>(p.v), dpp_i<0x142, 0xa>(p.i));
   step(dpp_f<0x143, 0xc>(p.v), dpp_i<0x143, 0xc>(p.i));
   return p;
@@ -158,8 +172,10 @@ __global__ void __launch_bounds__(256) frame_stats_finish_kernel(const uint4* __
 constexpr int kPeakThreads = 1024;
 constexpr int kMarkMaxNTop = 16384;                 // rows_top_peaks: n_bins <= 16384 (the row lives in LDS)
 constexpr int kMaxPeaks = 8;
+constexpr int kPeakVals = kMarkMaxNTop / kPeakThreads;   // bins per thread
+static_assert(kPeakThreads == 1024, "the pruning step shifts by 10");
 
-__global__ void __launch_bounds__(kPeakThreads) top_peaks_kernel(const float* __restrict__ rows, int n, int n_peaks,
+__global__ void __launch_bounds__(kPeakThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) top_peaks_kernel(const float* __restrict__ rows, int n, int n_peaks,
                                                                  int min_sep, float excursion, int* out_bins,
                                                                  float* out_db) {
   extern __shared__ float smem[];
@@ -168,37 +184,46 @@ __global__ void __launch_bounds__(kPeakThreads) top_peaks_kernel(const float* __
   __shared__ float s_min[kMaxPeaks][kPeakThreads / 64];
   __shared__ int s_sel[kMaxPeaks];
   __shared__ float s_selv[kMaxPeaks];
+  __shared__ float s_sel_upto[kMaxPeaks], s_sel_from[kMaxPeaks];   // minimum of an accepted peak's block up to / from the peak
   __shared__ int s_nsel;
 
   __shared__ float s_bmin[kMarkMaxNTop / 32];       // minimum of every 32 bins (a half-wave's run while the row is loaded)
   const float* src = rows + (size_t)blockIdx.x * n;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  for (int i0 = 0; i0 < n; i0 += kPeakThreads) {
-    const int i = i0 + tid;
-    const float v = i < n ? src[i] : INFINITY;
-    if (i < n) row[i] = v;
-    float mn = v;
+  float vals[kPeakVals];                              // the thread's own bins i = tid + 1024 k stay in registers
 #pragma unroll
-    for (int o = 16; o >= 1; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o));
-    if ((lane & 31) == 0 && i < n) s_bmin[i >> 5] = mn;
+  for (int k = 0; k < kPeakVals; ++k) {
+    const int i = tid + kPeakThreads * k;
+    vals[k] = i < n ? src[i] : INFINITY;
+  }
+#pragma unroll
+  for (int k = 0; k < kPeakVals; ++k) {
+    const int i = tid + kPeakThreads * k;
+    if (kPeakThreads * k < n) {                       // (uniform)
+      if (i < n) row[i] = vals[k];
+      float mn = row_min(vals[k]);
+      mn = fminf(mn, dpp_f<0x142, 0xa>(mn));          // row_bcast:15: lanes 31 and 63 hold the minimum of their 32 bins
+      if ((lane & 31) == 31 && (i & ~31) < n) s_bmin[i >> 5] = mn;
+    }
   }
   if (tid == 0) s_nsel = 0;
   __syncthreads();
   // live candidates (strict interior local maxima) of this thread's elements i = tid + 1024 k: bit k of a register
   unsigned live = 0u;
-  for (int i = tid, k = 0; i < n; i += kPeakThreads, ++k) {
-    const bool is_max = i > 0 && i < n - 1 && row[i] > row[i - 1] && row[i] > row[i + 1];
+#pragma unroll
+  for (int k = 0; k < kPeakVals; ++k) {
+    const int i = tid + kPeakThreads * k;
+    const bool is_max = i > 0 && i < n - 1 && vals[k] > row[i - 1] && vals[k] > row[i + 1];
     live |= is_max ? (1u << k) : 0u;
   }
   // strongest live candidate of this thread; equal values: larger index first (reversed ascending sort).  Only a
   // thread whose mask changed looks at the row again.
   PeakPair mine{-INFINITY, -1};
-  auto rescan = [&] {
+  auto rescan = [&] {                                 // from the registers, highest bin first: a strict compare keeps the larger index
     mine = PeakPair{-INFINITY, -1};
-    for (unsigned m = live; m != 0u; m &= m - 1u) {
-      const int i = tid + kPeakThreads * __builtin_ctz(m);
-      const float v = row[i];
-      if (v > mine.v || (v == mine.v && i > mine.i)) mine = PeakPair{v, i};
+#pragma unroll
+    for (int k = kPeakVals - 1; k >= 0; --k) {
+      if (((live >> k) & 1u) && vals[k] > mine.v) mine = PeakPair{vals[k], tid + kPeakThreads * k};
     }
   };
   rescan();
@@ -207,21 +232,16 @@ __global__ void __launch_bounds__(kPeakThreads) top_peaks_kernel(const float* __
     PeakPair best = wave_strongest_to_lane63(mine);
     if (lane == 63) s_best[w] = best;
     __syncthreads();
-    // every thread folds the 16 wave results itself (LDS broadcasts): no serial section, one barrier less
-    PeakPair gb = s_best[0];
-#pragma unroll
-    for (int k = 1; k < kPeakThreads / 64; ++k) {
-      const PeakPair q = s_best[k];
-      if (q.v > gb.v || (q.v == gb.v && q.i > gb.i)) gb = q;
-    }
-    const int cur = gb.v == -INFINITY ? -1 : gb.i;
+    // every row of 16 lanes folds the 16 wave results itself (one LDS read per lane, four DPP steps): no serial section
+    const PeakPair gb = row_strongest(s_best[lane & (kPeakThreads / 64 - 1)]);
+    const int cur = __builtin_amdgcn_readfirstlane(gb.v == -INFINITY ? -1 : gb.i);   // (the same in every lane: scalar registers)
     if (cur < 0) break;
     if (tid == (cur & (kPeakThreads - 1))) {      // the candidate leaves the list whatever happens to it
       live &= ~(1u << (cur / kPeakThreads));
       rescan();
     }
     const float curv = gb.v;
-    const int nsel = s_nsel;
+    const int nsel = __builtin_amdgcn_readfirstlane(s_nsel);
     // the separation test needs no valley: a candidate too close to an accepted peak is dropped right away
     bool too_close = false;
 #pragma unroll
@@ -238,32 +258,25 @@ __global__ void __launch_bounds__(kPeakThreads) top_peaks_kernel(const float* __
     }
     // valley minimum between the candidate and every accepted peak, one pass over the row; the ranges are formed
     // once per round (registers), peaks beyond nsel are skipped by uniform branches
-    int lo[kMaxPeaks], hi[kMaxPeaks];
+    int lo[kMaxPeaks], hi[kMaxPeaks];                 // in blocks of 32 bins: the blocks that hold the two peaks
     float vmin[kMaxPeaks];
 #pragma unroll
     for (int k = 0; k < kMaxPeaks; ++k) {
-      const int sk = k < nsel ? s_sel[k] : cur;
-      lo[k] = cur < sk ? cur : sk;
-      hi[k] = cur < sk ? sk : cur;
+      const int sk = k < nsel ? __builtin_amdgcn_readfirstlane(s_sel[k]) : cur;
+      lo[k] = (cur < sk ? cur : sk) >> 5;
+      hi[k] = (cur < sk ? sk : cur) >> 5;
       vmin[k] = INFINITY;
     }
     // (until round 6 every thread walked its 16 bins of the row against every range: 200 of a round's ~400 instructions
-    //  per wave; now one thread per block of 32 bins takes the block's minimum where the block lies inside a range and
-    //  walks it only at a range's two ends)
+    //  per wave; then one thread per block of 32 bins took the block's minimum where the block lay inside a range and walked
+    //  it at a range's two ends - up to 62 dependent LDS reads by one thread, the longest chain of a round.  Now the threads
+    //  take whole blocks strictly between the two peaks' blocks only; the two end blocks are wave 0's, below)
     for (int b = tid; b < (n + 31) / 32; b += kPeakThreads) {
       const float bm = s_bmin[b];
-      const int b0 = 32 * b, b1 = b0 + 31 < n - 1 ? b0 + 31 : n - 1;
 #pragma unroll
       for (int k = 0; k < kMaxPeaks; ++k) {
-        if (k < nsel) {
-          if (b0 >= lo[k] && b1 <= hi[k]) {
-            vmin[k] = fminf(vmin[k], bm);                               // (a NaN in the range would make np.min NaN
-          } else if (b1 >= lo[k] && b0 <= hi[k]) {                      //  and never reject; rows here carry none)
-            const int i0 = b0 > lo[k] ? b0 : lo[k], i1 = b1 < hi[k] ? b1 : hi[k];
-            for (int i = i0; i <= i1; ++i) vmin[k] = fminf(vmin[k], row[i]);
-          }
-        }
-      }
+        if (k < nsel && b > lo[k] && b < hi[k]) vmin[k] = fminf(vmin[k], bm);   // (a NaN in the range would make np.min
+      }                                                                          //  NaN and never reject; rows here carry none)
     }
 #pragma unroll
     for (int k = 0; k < kMaxPeaks; ++k) {
@@ -275,17 +288,49 @@ __global__ void __launch_bounds__(kPeakThreads) top_peaks_kernel(const float* __
     __syncthreads();
     if (w == 0) {
       // wave 0: lane l folds the 16 wave minima of every accepted peak (one LDS read + shuffles per peak)
-      bool reject = false;
-      for (int k = 0; k < nsel; ++k) {
-        const float valley = __shfl(wave_min_to_lane63(lane < kPeakThreads / 64 ? s_min[k][lane] : INFINITY), 63);
+      // the candidate's own block, a half-wave per side: lanes 0 - 31 the bins up to the candidate, lanes 32 - 63 the bins
+      // from it on (the part of a valley that lies in this block, whichever side the accepted peak is on); an accepted peak
+      // keeps the two minima it had as a candidate
+      const int cidx = (cur & ~31) + (lane & 31);
+      const float cv = cidx < n ? row[cidx] : INFINITY;
+      float part = (lane < 32 ? cidx <= cur : cidx >= cur) ? cv : INFINITY;
+      part = fminf(part, dpp_f<0xB1, 0xf>(part));
+      part = fminf(part, dpp_f<0x4E, 0xf>(part));
+      part = fminf(part, dpp_f<0x141, 0xf>(part));
+      part = fminf(part, dpp_f<0x140, 0xf>(part));
+      part = fminf(part, dpp_f<0x142, 0xa>(part));          // row_bcast:15: lanes 31 and 63 hold their half's minimum
+      const float cur_upto = __shfl(part, 31), cur_from = __shfl(part, 63);
+      // four accepted peaks at a time, one per row of 16 lanes: the row folds the peak's 16 wave minima, adds the end blocks
+      bool rej = false;
+      for (int base = 0; base < nsel; base += 4) {
+        const int kq = base + (lane >> 4);
+        const bool valid = kq < nsel;
+        const int k = valid ? kq : 0;
+        float valley = row_min(valid ? s_min[k][lane & 15] : INFINITY);
+        const int sk = s_sel[k];
+        valley = fminf(valley, cur < sk ? fminf(cur_from, s_sel_upto[k]) : fminf(cur_upto, s_sel_from[k]));
+        const bool same = valid && (sk >> 5) == (cur >> 5);
+        if (__builtin_amdgcn_ballot_w64(same) != 0ull) {      // both peaks in one block of 32: the bins between them
+          for (int q = 0; q < 4; ++q) {
+            const int k2 = base + q;
+            if (k2 < nsel && (s_sel[k2] >> 5) == (cur >> 5)) {
+              const int s2 = s_sel[k2], a = cur < s2 ? cur : s2, z = cur < s2 ? s2 : cur;
+              const float m = __shfl(wave_min_to_lane63(cidx >= a && cidx <= z ? cv : INFINITY), 63);
+              if ((lane >> 4) == q) valley = m;
+            }
+          }
+        }
         // reference arithmetic: power[idx] - valley is float32 - Python float (float32 under numpy >= 2),
         // sel_pwr - valley is Python float - Python float (double)
-        if (curv - valley < excursion || (double)s_selv[k] - (double)valley < (double)excursion) reject = true;
+        if (valid && (curv - valley < excursion || (double)s_selv[k] - (double)valley < (double)excursion)) rej = true;
       }
+      const bool reject = __builtin_amdgcn_ballot_w64(rej) != 0ull;
       if (lane == 0) {
         if (!reject) {
           s_sel[nsel] = cur;
           s_selv[nsel] = curv;
+          s_sel_upto[nsel] = cur_upto;
+          s_sel_from[nsel] = cur_from;
           s_nsel = nsel + 1;
         }
       }
@@ -297,9 +342,15 @@ __global__ void __launch_bounds__(kPeakThreads) top_peaks_kernel(const float* __
       // accepted: every candidate closer than min_sep would be turned down when its turn came (the accepted set
       // only grows and a rejected candidate leaves no trace), so they go now instead of costing a round each
       const unsigned before = live;
-      for (unsigned m = live; m != 0u; m &= m - 1u) {
-        const int k = __builtin_ctz(m), i = tid + kPeakThreads * k;
-        if (i > cur - min_sep && i < cur + min_sep) live &= ~(1u << k);
+      if (2 * min_sep - 1 <= kPeakThreads) {
+        // the window (cur - min_sep, cur + min_sep) is no wider than the stride of a thread's bins: it holds at most one of them
+        const int last = cur + min_sep - 1, k = (last - tid) >> 10, i = tid + kPeakThreads * k;
+        if (last >= tid && k < kPeakVals && i > cur - min_sep) live &= ~(1u << k);
+      } else {
+        for (unsigned m = live; m != 0u; m &= m - 1u) {
+          const int k = __builtin_ctz(m), i = tid + kPeakThreads * k;
+          if (i > cur - min_sep && i < cur + min_sep) live &= ~(1u << k);
+        }
       }
       if (live != before) rescan();
     }
