@@ -350,6 +350,8 @@ def test_top_peaks_random_traces(pkg, an, seed):
     near-threshold valleys occur) against the restated reference, all rows of a batch at once."""
     rng = np.random.default_rng(9000 + seed)
     n = int(2 ** rng.integers(6, 15))
+    if seed % 4 == 3:
+        n = int(rng.choice([70, 100, 1000, 5000, 12345, 16383]))     # ragged last block of 32 bins
     rows = []
     for _ in range(12):
         k = np.arange(n)
@@ -363,9 +365,9 @@ def test_top_peaks_random_traces(pkg, an, seed):
         rows.append(tr.astype(np.float32))
     rows = np.stack(rows)
     exc = float(rng.choice([3.0, 6.0, 10.0]))
-    sep = int(rng.choice([max(10, n // 50), 2, 5]))
+    sep = int(rng.choice([max(10, n // 50), 2, 5, 600, 31, 33]))  # (600: wider than the stride of a thread's bins)
     npk = int(rng.integers(1, 9))
-    with pkg.SpectrumEngine(max(n, 64), max_frames=1) as e, DevRows(pkg, rows) as d:
+    with pkg.SpectrumEngine(64 if n < 64 else 1 << (n - 1).bit_length(), max_frames=1) as e, DevRows(pkg, rows) as d:
         bins, db = an.rows_top_peaks(e, d, len(rows), n_bins=n, n=npk, min_sep_bins=sep, min_excursion_db=exc)
     for r, tr in enumerate(rows):
         want = ao.find_top_peak_bins(tr, npk, sep, exc)
