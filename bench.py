@@ -547,6 +547,8 @@ def run_config(args, comm: Comm, torch) -> dict:
             and not args.no_frame_stats):
         from topdogspectrumanalyser_amd import analytics as _an
         band = (nfft // 4, 3 * nfft // 4)
+        eng.set_frame_stats(True, None)                      # peak + argmax only
+        leg_pk = measure(head["streams"], head["per_call"])
         eng.set_frame_stats(True, band)
         leg_fs = measure(head["streams"], head["per_call"])
         eng.set_overlap(1)
@@ -558,6 +560,8 @@ def run_config(args, comm: Comm, torch) -> dict:
         frame_stats_block = {
             "ms_per_step": leg_fs["med"] / leg_fs["steps"] * 1e3, "ms_per_step_without": head["med"] / head["steps"] * 1e3,
             "overhead": leg_fs["med"] / leg_fs["steps"] / (head["med"] / head["steps"]) - 1.0,
+            "ms_per_step_peak_and_bin_only": leg_pk["med"] / leg_pk["steps"] * 1e3,
+            "overhead_peak_and_bin_only": leg_pk["med"] / leg_pk["steps"] / (head["med"] / head["steps"]) - 1.0,
             "band_bins": list(band), "steps_per_call": leg_fs["per_call"], "streams": leg_fs["streams"],
             "peak_and_bin_equal_rows_stats": bool(np.array_equal(pk, rp) and np.array_equal(pb, rb)),
             "band_db_max_abs_diff_vs_rows_stats": float(np.max(np.abs(bd - rband))),

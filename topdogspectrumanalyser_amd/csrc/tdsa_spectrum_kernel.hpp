@@ -404,9 +404,10 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
     if constexpr ((HOLD & 2) != 0) hmin[i] = INFINITY;
   });
   // STATS: which of the thread's 16 bins (display position (kcs + 8h) SG + t) lie in the band [band_lo, band_hi] is a
-  // property of the wave for all but the bins at the band's two ends: bit q of st_mask = every lane's bin q is in the
-  // band, bit 16 + q = some are (the lanes then test their own position).
-  unsigned st_mask = 0u;
+  // property of the HALF-WAVE (32 consecutive positions) for all but the two runs that hold the band's ends: bit q of
+  // st_mask = the run of bin q in lanes 0 - 31 lies inside the band, bit 16 + q = the run in lanes 32 - 63 does; st_part,
+  // same layout = the run is cut by an end of the band (at most two runs of a frame: their waves test every lane).
+  unsigned st_mask = 0u, st_part = 0u;
   if constexpr (STATS) {
     static_assert(UNI && CHIRP == 0 && HOLD < 2, "frame statistics: whole waves per frame, plain dB rows, no min hold");
     const int st_t0 = __builtin_amdgcn_readfirstlane((wave & (C::WPF - 1)) * 32);     // first butterfly row of the wave
@@ -417,10 +418,12 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
       const int a0 = kcs * SG + st_t0, a1 = a0 + 8 * SG;           // first position of the lower / upper half-wave
       const bool in0 = lo <= a0 && a0 + 31 <= hi, in1 = lo <= a1 && a1 + 31 <= hi;
       const bool out0 = hi < a0 || lo > a0 + 31, out1 = hi < a1 || lo > a1 + 31;
-      const bool full = in0 && in1, part = lo <= hi && !full && !(out0 && out1);     // (lo > hi: no band)
-      st_mask |= (unsigned(full) << q) | (unsigned(part) << (16 + q));
+      const bool cut0 = lo <= hi && !in0 && !out0, cut1 = lo <= hi && !in1 && !out1;   // (lo > hi: no band)
+      st_mask |= (unsigned(in0) << q) | (unsigned(in1) << (16 + q));
+      st_part |= (unsigned(cut0) << q) | (unsigned(cut1) << (16 + q));
     });
     st_mask = __builtin_amdgcn_readfirstlane(st_mask);
+    st_part = __builtin_amdgcn_readfirstlane(st_part);
   }
   // (with max AND min hold in registers the loop has no VGPR to spare: the wave-uniform constants stay in SGPRs there
   //  and their few uses issue at half rate)
@@ -447,19 +450,25 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
                                    : unsigned(t) * (M * SB) + unsigned(h) * ((N / A) * SB);
   const unsigned out_voff = unsigned(t) * 4u + unsigned(h) * (8u * SG * 4u);
   float st_band = 0.f;                          // this thread's share of the frame's band power (linear)
-  unsigned st_maskc = 0u;                       // st_mask as the frame at hand sees it (an opaque copy: tested bit by bit with
-                                                // s_bitcmp inside the loop, not hoisted out of it as 32 lane masks)
+  unsigned st_maskc = 0u;                       // st_mask as the frame at hand sees it (an opaque copy: turned into lane masks bin
+                                                // by bin inside the loop, not hoisted out of it as 32 scalar registers)
+  // a bin whose two runs are whole: the lane mask is two sign-extended bits (scalar unit), the add one select + one add
   auto st_band_add = [&](auto qc, float a) {
     constexpr int q = decltype(qc)::value;
+    const unsigned mlo = unsigned(__builtin_amdgcn_sbfe(int(st_maskc), q, 1)), mhi = unsigned(__builtin_amdgcn_sbfe(int(st_maskc), 16 + q, 1));
+    const unsigned long long m = mlo | ((unsigned long long)mhi << 32);
+    float t;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(t) : "v"(a), "s"(m));
+    st_band += t;
+  };
+  // a wave that holds an end of the band: every lane tests its own position
+  auto st_band_add_exact = [&](auto qc, float a) {
+    constexpr int q = decltype(qc)::value;
     constexpr int kcs = (q < 8 ? q : q + 8) ^ 16;
-    if (st_maskc & (1u << q)) {
-      st_band += a;
-    } else if (st_maskc & (0x10000u << q)) {
-      unsigned ov = out_voff;                   // (opaque: the test must not leave the loop as sixteen lane masks either)
-      asm volatile("" : "+v"(ov));
-      const unsigned lo = p.band_lohi & 0xffffu, hi = p.band_lohi >> 16;
-      st_band += ((ov >> 2) + unsigned(kcs * SG) - lo <= hi - lo) ? a : 0.f;
-    }
+    unsigned ov = out_voff;                     // (opaque: the test must not leave the loop as sixteen lane masks)
+    asm volatile("" : "+v"(ov));
+    const unsigned lo = p.band_lohi & 0xffffu, hi = p.band_lohi >> 16;
+    st_band += ((ov >> 2) + unsigned(kcs * SG) - lo <= hi - lo) ? a : 0.f;
   };
   // frame -> byte offset of its samples / element offset of its output row (several captures per launch:
   // SpecParams::seg_*; with one capture seg_magic = 0 and these are frame * frame_stride, frame * N)
@@ -807,31 +816,37 @@ __global__ void __launch_bounds__(Cfg<LOG2N>::WGT, 4) spectrum_kernel(const Spec
           asm volatile("" : "+s"(st_maskc));
         }
         if constexpr (STATS) {
-          // the band sum rides the dB loops only in waves that have bins in the band (st_maskc is wave-uniform: tested per bin
-          // inside ONE loop, a wave outside the band took 32 branches per frame for nothing).  (The loops stay spelled out:
-          // wrapped in a lambda they moved the instruction streams of the frozen instantiations.)
-          if (st_maskc != 0u) {
-          if (mag_mode && __builtin_amdgcn_ballot_w64(tiny) != 0) {
-            static_for<0, 16>([&](auto ic) {
-              constexpr int q = decltype(ic)::value;
-              const float mag = __builtin_amdgcn_sqrtf(db[q]);
-              st_band_add(ic, (mag + p.log_floor) * (mag + p.log_floor));
-              db[q] = fmaf(2.0f * k10Log10_2, __builtin_amdgcn_logf(mag + p.log_floor), cal_v);
-            });
-          } else if (mag_mode) {
-            static_for<0, 16>([&](auto ic) {
-              constexpr int q = decltype(ic)::value;
-              st_band_add(ic, db[q]);
-              db[q] = fmaf(k10Log10_2, __builtin_amdgcn_logf(db[q]), cal_v);
-            });
-          } else {
-            static_for<0, 16>([&](auto ic) {
-              constexpr int q = decltype(ic)::value;
-              const float a = fmaf(db[q], ps_v, fl_v);
-              st_band_add(ic, a);
-              db[q] = fmaf(k10Log10_2, __builtin_amdgcn_logf(a), cal_v);
-            });
-          }
+          // the band sum rides the dB loops only in waves that have bins in the band (a wave outside it took 32 branches per frame
+          // for nothing).  (The loops of the other instantiations stay spelled out: wrapped in a lambda they moved the instruction
+          // streams of the frozen ones.)
+          unsigned st_partc = st_part;
+          asm volatile("" : "+s"(st_partc));
+          auto band_loops = [&](auto add) {
+            if (mag_mode && __builtin_amdgcn_ballot_w64(tiny) != 0) {
+              static_for<0, 16>([&](auto ic) {
+                constexpr int q = decltype(ic)::value;
+                const float mag = __builtin_amdgcn_sqrtf(db[q]);
+                add(ic, (mag + p.log_floor) * (mag + p.log_floor));
+                db[q] = fmaf(2.0f * k10Log10_2, __builtin_amdgcn_logf(mag + p.log_floor), cal_v);
+              });
+            } else if (mag_mode) {
+              static_for<0, 16>([&](auto ic) {
+                constexpr int q = decltype(ic)::value;
+                add(ic, db[q]);
+                db[q] = fmaf(k10Log10_2, __builtin_amdgcn_logf(db[q]), cal_v);
+              });
+            } else {
+              static_for<0, 16>([&](auto ic) {
+                constexpr int q = decltype(ic)::value;
+                const float a = fmaf(db[q], ps_v, fl_v);
+                add(ic, a);
+                db[q] = fmaf(k10Log10_2, __builtin_amdgcn_logf(a), cal_v);
+              });
+            }
+          };
+          if ((st_maskc | st_partc) != 0u) {
+            if (st_partc == 0u) band_loops(st_band_add);
+            else band_loops(st_band_add_exact);
           } else {
           if (mag_mode && __builtin_amdgcn_ballot_w64(tiny) != 0) {   // near-silent frame: exact DB_MAG
             static_for<0, 16>([&](auto ic) {
