@@ -351,7 +351,7 @@ def test_top_peaks_random_traces(pkg, an, seed):
     rng = np.random.default_rng(9000 + seed)
     n = int(2 ** rng.integers(6, 15))
     if seed % 4 == 3:
-        n = int(rng.choice([70, 100, 1000, 5000, 12345, 16383]))     # ragged last block of 32 bins
+        n = int(rng.choice([3, 5, 33, 70, 100, 1000, 5000, 12345, 16383]))     # tiny rows, ragged last block of 32 bins
     rows = []
     for _ in range(12):
         k = np.arange(n)
