@@ -425,47 +425,83 @@ __device__ __forceinline__ double marker_prominence(const float* row, const Mark
 // `xp - v >= threshold` - the walk of a side stops at the first such sample (side passed), or at the first sample above
 // the peak / NaN / the end of the row (side failed: the peak is out).  A noise peak is settled in a handful of steps,
 // a carrier in two or three (the window's skirt); only ripple of less than the threshold walks far, in blocks.
+//
+// The test per sample is ONE float compare: `(double)xp - (double)v >= threshold` holds for exactly the floats v <= thr, thr =
+// the largest float that passes (the difference is monotone in v) - found once per peak next to float(xp - threshold).  And the
+// first kMarkNear steps of a side run as a fixed-length predicated loop (every lane the same trip count, no exec juggling):
+// the walks of the lanes of a wave ended within it in all but a few percent of the peaks, and the divergent loop with its
+// block skipping - some 40 instructions per step - was where the kernel's time went.
+constexpr int kMarkNear = 6;
 __device__ __forceinline__ bool marker_prominent(const float* row, const MarkerLds& L, int n, int p, double prominence) {
   if (0.0 >= prominence) return true;                        // the bases start at the peak itself: prominence >= 0
   const float xp = row[p];
   const double dxp = (double)xp;
-  bool ok = false;
-  int i = p - 1;
-  while (i >= 0) {
-    if ((i & 31) == 31) {
-      if ((i & 1023) == 1023 && L.bmax2[i >> 10] <= xp) {
-        if (dxp - (double)L.bmin2[i >> 10] >= prominence) { ok = true; break; }
-        i -= 1024; continue;
-      }
-      if (L.bmax1[i >> 5] <= xp) {
-        if (dxp - (double)L.bmin1[i >> 5] >= prominence) { ok = true; break; }
-        i -= 32; continue;
-      }
-    }
-    const float v = row[i];
-    if (!(v <= xp)) break;
-    if (dxp - (double)v >= prominence) { ok = true; break; }
+  auto passes = [&](float v) { return dxp - (double)v >= prominence; };
+  float thr = (float)(dxp - prominence);
+  if (!passes(thr)) thr = nextafterf(thr, -INFINITY);
+  if (!passes(thr)) thr = nextafterf(thr, -INFINITY);
+  if (!passes(thr)) return false;                            // (a NaN threshold, or none of the floats around it: nothing can pass)
+  for (int k = 0; k < 2; ++k) {
+    const float up = nextafterf(thr, INFINITY);
+    if (up != thr && passes(up)) thr = up;
+  }
+  // state of a side: 0 walking, 1 passed, 2 failed
+  int st = 0, i = p - 1;
+#pragma unroll
+  for (int k = 0; k < kMarkNear; ++k) {
+    const float v = row[i < 0 ? 0 : i];
+    const int now = (i < 0 || !(v <= xp)) ? 2 : (v <= thr ? 1 : 0);
+    st = st == 0 ? now : st;
     --i;
   }
-  if (!ok) return false;
-  i = p + 1;
-  while (i < n) {
-    if ((i & 31) == 0) {
-      if ((i & 1023) == 0 && L.bmax2[i >> 10] <= xp) {
-        if (dxp - (double)L.bmin2[i >> 10] >= prominence) return true;
-        i += 1024; continue;
+  if (st == 0) {
+    while (i >= 0) {
+      if ((i & 31) == 31) {
+        if ((i & 1023) == 1023 && L.bmax2[i >> 10] <= xp) {
+          if (L.bmin2[i >> 10] <= thr) { st = 1; break; }
+          i -= 1024; continue;
+        }
+        if (L.bmax1[i >> 5] <= xp) {
+          if (L.bmin1[i >> 5] <= thr) { st = 1; break; }
+          i -= 32; continue;
+        }
       }
-      if (L.bmax1[i >> 5] <= xp) {
-        if (dxp - (double)L.bmin1[i >> 5] >= prominence) return true;
-        i += 32; continue;
-      }
+      const float v = row[i];
+      if (!(v <= xp)) break;
+      if (v <= thr) { st = 1; break; }
+      --i;
     }
-    const float v = row[i];
-    if (!(v <= xp)) return false;
-    if (dxp - (double)v >= prominence) return true;
+  }
+  if (st != 1) return false;
+  st = 0;
+  i = p + 1;
+#pragma unroll
+  for (int k = 0; k < kMarkNear; ++k) {
+    const float v = row[i >= n ? n - 1 : i];
+    const int now = (i >= n || !(v <= xp)) ? 2 : (v <= thr ? 1 : 0);
+    st = st == 0 ? now : st;
     ++i;
   }
-  return false;
+  if (st == 0) {
+    while (i < n) {
+      if ((i & 31) == 0) {
+        if ((i & 1023) == 0 && L.bmax2[i >> 10] <= xp) {
+          if (L.bmin2[i >> 10] <= thr) return true;
+          i += 1024; continue;
+        }
+        if (L.bmax1[i >> 5] <= xp) {
+          if (L.bmin1[i >> 5] <= thr) return true;
+          i += 32; continue;
+        }
+      }
+      const float v = row[i];
+      if (!(v <= xp)) return false;
+      if (v <= thr) return true;
+      ++i;
+    }
+    return false;
+  }
+  return st == 1;
 }
 
 __global__ void __launch_bounds__(kMarkThreads) marker_peaks_kernel(const float* __restrict__ rows, int n, double height,
@@ -581,13 +617,16 @@ __global__ void __launch_bounds__(kMarkThreads) marker_peaks_kernel(const float*
           const float xp = row[p];
           bool removed = false, wait = false;
           const int q0 = p - reach < 0 ? 0 : p - reach, q1 = p + reach > n - 1 ? n - 1 : p + reach;
-          for (int q = q0; q <= q1; ++q) {
-            if (q == p || !((L.cand[q >> 5] >> (q & 31)) & 1u)) continue;
+          auto look = [&](int q) {
+            if (!((L.cand[q >> 5] >> (q & 31)) & 1u)) return;
             const float xq = row[q];
-            if (!(xq > xp || (xq == xp && q > p))) continue;            // lower priority: it waits for us
+            if (!(xq > xp || (xq == xp && q > p))) return;              // lower priority: it waits for us
             if ((L.kept[q >> 5] >> (q & 31)) & 1u) removed = true;
             else if (!((L.gone[q >> 5] >> (q & 31)) & 1u)) wait = true;
-          }
+          };
+          // (the bins next to a peak are never peaks: with scipy's default distance 3 one bin is looked at on each side)
+          for (int q = q0; q <= p - 2; ++q) look(q);
+          for (int q = p + 2; q <= q1; ++q) look(q);
           if (removed) g |= 1u << b;
           else if (!wait) k |= 1u << b;
           else open = 1;
