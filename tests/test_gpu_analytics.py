@@ -454,7 +454,7 @@ def test_marker_peaks_random_traces(pkg, an, seed):
     n = int(rng.choice([3, 5, 33, 64, 1000, 1024, 4096, 5000, 16384, int(rng.integers(3, 16385))]))
     rows = _marker_rows(rng, n, 10)
     thr = float(rng.choice([-200.0, -90.0, -75.0]))
-    exc = float(rng.choice([0.0, 3.0, 6.0, 10.0]))
+    exc = float(rng.choice([0.0, 3.0, 6.0, 10.0, 6.3, 0.7, 1e-3, 2.5000001, 250.0]))   # (exact and inexact against 0.5 dB steps)
     dist = int(rng.choice([1, 2, 3, 3, 3, 7, 40]))
     cur = int(rng.integers(-1, n + 1))
     with pkg.SpectrumEngine(64, max_frames=1) as e, DevRows(pkg, rows) as d:
