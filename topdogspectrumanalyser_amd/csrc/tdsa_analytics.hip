@@ -516,7 +516,6 @@ __global__ void __launch_bounds__(kMarkThreads) marker_peaks_kernel(const float*
   const int nw = (n + 31) >> 5, nw2 = (n + 1023) >> 10;
 
   // load + block extrema of 32: a half-wave holds one block
-  PeakPair amax{-INFINITY, 0x7fffffff};                     // np.argmax of the row (the fallback of snap_to_peak)
   if ((n & 3) == 0) {
     // four samples per lane, every load of the row in flight before the first is used; eight lanes hold a block of 32
     typedef float f4 __attribute__((ext_vector_type(4)));
@@ -540,17 +539,14 @@ __global__ void __launch_bounds__(kMarkThreads) marker_peaks_kernel(const float*
         const float e[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const PeakPair cnd{e[j], 4 * c + j};
-          if (better(cnd, amax)) amax = cnd;
           mx = fmaxf(mx, e[j] != e[j] ? INFINITY : e[j]);
           mn = fminf(mn, e[j]);
         }
       }
-#pragma unroll
-      for (int o = 4; o >= 1; o >>= 1) {
-        mx = fmaxf(mx, __shfl_xor(mx, o));
-        mn = fminf(mn, __shfl_xor(mn, o));
-      }
+      // eight lanes hold a block of 32 bins: two quad steps and the mirror of each half-row (DPP, no LDS round trips)
+      mx = fmaxf(mx, dpp_f<0xB1, 0xf>(mx)); mn = fminf(mn, dpp_f<0xB1, 0xf>(mn));
+      mx = fmaxf(mx, dpp_f<0x4E, 0xf>(mx)); mn = fminf(mn, dpp_f<0x4E, 0xf>(mn));
+      mx = fmaxf(mx, dpp_f<0x141, 0xf>(mx)); mn = fminf(mn, dpp_f<0x141, 0xf>(mn));
       if ((lane & 7) == 0 && (c >> 3) < nw) {
         L.bmax1[c >> 3] = mx;
         L.bmin1[c >> 3] = mn;
@@ -563,8 +559,6 @@ __global__ void __launch_bounds__(kMarkThreads) marker_peaks_kernel(const float*
     const float v = in ? src[i] : 0.0f;
     if (in) {
       row[i] = v;
-      const PeakPair c{v, i};
-      if (better(c, amax)) amax = c;
     }
     float mx = in ? (v != v ? INFINITY : v) : -INFINITY, mn = in ? v : INFINITY;
 #pragma unroll
@@ -675,15 +669,12 @@ __global__ void __launch_bounds__(kMarkThreads) marker_peaks_kernel(const float*
     first = f2 < first ? f2 : first;
     next = n2 < next ? n2 : next;
   }
-  amax = wave_best(amax);
   if (lane == 63) L.scan[wv] = incl;
   if (lane == 0) {
     L.red_i[wv][0] = top.i;
     L.red_i[wv][1] = first;
     L.red_i[wv][2] = next;
-    L.red_i[wv][3] = amax.i;
     L.red_f[wv] = top.v;
-    L.red_a[wv] = amax.v;
   }
   __syncthreads();
   int base = 0, total = 0;
@@ -693,15 +684,31 @@ __global__ void __launch_bounds__(kMarkThreads) marker_peaks_kernel(const float*
     base += k < wv ? c : 0;
     total += c;
   }
+  if (total == 0 && out_snap) {
+    // no peak at all: snap_to_peak falls back to np.argmax of the row (marker_manager.py:97) - formed only then
+    PeakPair amax{-INFINITY, 0x7fffffff};
+    for (int i = tid; i < n; i += kMarkThreads) {
+      const PeakPair c{row[i], i};
+      if (better(c, amax)) amax = c;
+    }
+    amax = wave_best(amax);
+    if (lane == 0) { L.red_i[wv][3] = amax.i; L.red_a[wv] = amax.v; }
+    __syncthreads();                                        // (total is the same in every thread)
+  }
   if (tid == 0) {
-    PeakPair am{L.red_a[0], L.red_i[0][3]};
+    PeakPair am{-INFINITY, 0x7fffffff};
+    if (total == 0 && out_snap) {
+      am = PeakPair{L.red_a[0], L.red_i[0][3]};
+      for (int k = 1; k < kMarkThreads / 64; ++k) {
+        const PeakPair a{L.red_a[k], L.red_i[k][3]};
+        if (better(a, am)) am = a;
+      }
+    }
     for (int k = 1; k < kMarkThreads / 64; ++k) {
       const PeakPair t{L.red_f[k], L.red_i[k][0]};
       if (t.v > top.v || (t.v == top.v && t.i < top.i)) top = t;
       first = L.red_i[k][1] < first ? L.red_i[k][1] : first;
       next = L.red_i[k][2] < next ? L.red_i[k][2] : next;
-      const PeakPair a{L.red_a[k], L.red_i[k][3]};
-      if (better(a, am)) am = a;
     }
     if (out_count) out_count[blockIdx.x] = total;
     if (out_snap) out_snap[blockIdx.x] = total > 0 ? top.i : am.i;                       // marker_manager.py:93-97
