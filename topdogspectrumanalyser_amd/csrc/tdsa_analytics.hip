@@ -582,20 +582,32 @@ __global__ void __launch_bounds__(kMarkThreads) marker_peaks_kernel(const float*
     L.bmax2[b] = mx;
     L.bmin2[b] = mn;
   }
-  // 1 + 2: the thread of a rising left edge walks its flat top (whole equal blocks at a time) and marks the middle
-  for (int i = tid; i < n; i += kMarkThreads) {
-    if (i < 1 || i > n - 2) continue;
-    const float v = row[i];
-    if (!(row[i - 1] < v)) continue;
-    int a = i + 1;
-    while (a < n - 1) {
-      if ((a & 31) == 0 && a + 32 < n - 1 && L.bmax1[a >> 5] == v && L.bmin1[a >> 5] == v) { a += 32; continue; }
-      if (row[a] != v) break;
-      ++a;
+  // 1 + 2: a bin above both neighbours is a peak (one ballot per 64 bins, a half-wave = one word of the bit set); the thread
+  // of the rising left edge of a FLAT top - rare - walks it (whole equal blocks at a time) and marks the middle
+  for (int i0 = 0; i0 < n; i0 += kMarkThreads) {
+    const int i = i0 + tid;
+    bool simple = false, flat = false;
+    float v = 0.0f;
+    if (i >= 1 && i <= n - 2) {
+      v = row[i];
+      const float l = row[i - 1], r = row[i + 1];
+      simple = l < v && r < v && (double)v >= height;
+      flat = l < v && r == v;
     }
-    if (row[a] < v && (double)v >= height) {
-      const int mid = (i + a - 1) >> 1;
-      atomicOr(&L.cand[mid >> 5], 1u << (mid & 31));
+    const unsigned long long hits = __builtin_amdgcn_ballot_w64(simple);
+    const unsigned half = unsigned(hits >> (lane & 32));
+    if ((lane & 31) == 0 && half != 0u) atomicOr(&L.cand[i >> 5], half);     // (bins beyond n never hit)
+    if (flat) {
+      int a = i + 1;
+      while (a < n - 1) {
+        if ((a & 31) == 0 && a + 32 < n - 1 && L.bmax1[a >> 5] == v && L.bmin1[a >> 5] == v) { a += 32; continue; }
+        if (row[a] != v) break;
+        ++a;
+      }
+      if (row[a] < v && (double)v >= height) {
+        const int mid = (i + a - 1) >> 1;
+        atomicOr(&L.cand[mid >> 5], 1u << (mid & 31));
+      }
     }
   }
   __syncthreads();
