@@ -614,6 +614,16 @@ __global__ void __launch_bounds__(kMarkThreads) marker_peaks_kernel(const float*
   // 3: distance rule (peaks are never adjacent: distance <= 2 removes nothing)
   if (distance > 2) {
     const int reach = distance - 1;
+    if (reach < 32) {
+      // a peak with no other peak within reach stays, whatever its height: settled by shifts of the bit set before the rounds
+      for (int w = tid; w < nw; w += kMarkThreads) {
+        const unsigned cw = L.cand[w], below = w > 0 ? L.cand[w - 1] : 0u, above = w + 1 < nw ? L.cand[w + 1] : 0u;
+        unsigned near = 0u;
+        for (int d = 2; d <= reach; ++d) near |= (cw << d) | (cw >> d) | (below >> (32 - d)) | (above << (32 - d));
+        L.kept[w] = cw & ~near;
+      }
+      __syncthreads();
+    }
     for (;;) {
       int open = 0;
       for (int w = tid; w < nw; w += kMarkThreads) {
