@@ -820,7 +820,7 @@ __global__ void __launch_bounds__(kDensWaves * 64) __attribute__((amdgpu_waves_p
   __syncthreads();                       // s_wh is zero
   int par = 0;
   for (int r0 = 0; r0 < n_rows; r0 += kDensRows, par ^= 1) {
-    auto cell = [&](float v, int r) {
+    auto cell = [&](float v, int r) -> unsigned {
       int idx = -1;
       if (r0 + r < n_rows && f_ok) {
         const float x = (v - kAmpMin) / kAmpRng * float(kAmpBins);
@@ -832,19 +832,30 @@ __global__ void __launch_bounds__(kDensWaves * 64) __attribute__((amdgpu_waves_p
       const int rel = idx - a_wg;
       const bool mine = idx >= 0 && rel >= 0 && rel < kDensWaves * kDensCells;
       s_idx[par][lane][r] = short(mine ? rel * (kDensOneStride * 4) : kDensNone);
-      if (mine) atomicOr(&s_wh[par][r], 1u << (rel / kDensCells));
+      return mine ? 1u << (rel / kDensCells) : 0u;        // the wave of this workgroup the sample hits
     };
-    cell(v0, lr);
-    cell(v1, lr + 16);
+    // which waves rows lr and lr + 16 hit: the 64 lanes of THIS wave are the rows' 64 frequency bins - an OR across the wave (DPP,
+    // both rows in one word) and plain stores by their only writer (sixty-four atomics on one LDS word took the LDS pipe as long
+    // as a hit wave's reads)
+    unsigned bits = cell(v0, lr) | (cell(v1, lr + 16) << 16);
+    bits |= unsigned(dpp_i<0xB1, 0xf>(int(bits)));
+    bits |= unsigned(dpp_i<0x4E, 0xf>(int(bits)));
+    bits |= unsigned(dpp_i<0x141, 0xf>(int(bits)));
+    bits |= unsigned(dpp_i<0x140, 0xf>(int(bits)));
+    bits |= unsigned(dpp_i<0x142, 0xa>(int(bits)));
+    bits |= unsigned(dpp_i<0x143, 0xc>(int(bits)));
+    if (lane == 63) {
+      s_wh[par][lr] = bits & 0xffffu;
+      s_wh[par][lr + 16] = bits >> 16;
+    }
     v0 = fetch(r0 + kDensRows + lr);      // the next chunk's values travel while this one is applied
     v1 = fetch(r0 + kDensRows + lr + 16);
     __syncthreads();
     const int lim = n_rows - r0 < kDensRows ? n_rows - r0 : kDensRows;
     const unsigned whv = lane < kDensRows ? s_wh[par][lane] : 0u;
     const unsigned hit_rows = unsigned(__builtin_amdgcn_ballot_w64(((whv >> w) & 1u) != 0u));
-    __syncthreads();                                    // every wave has its rows' masks: this parity can be cleared for the chunk after next
-    if (tid < kDensRows) s_wh[par][tid] = 0u;           // (wave 0 clears it before it reaches the next chunk's barrier; the marks of the
-                                                        //  chunk after next come behind that barrier)
+    // (one barrier per chunk: s_idx / s_wh of this parity are written again two chunks on, behind the next chunk's barrier, which
+    //  no wave passes before every wave has left this chunk)
     if (hit_rows != 0u && lim == kDensRows) {
       // a wave that is hit in a full chunk takes every row the same way - multiply, fetch the one-hot row (the row of zeros where
       // the sample belongs to other cells), add - as one block without branches: the reads of later rows are issued under the
@@ -873,8 +884,17 @@ __global__ void __launch_bounds__(kDensWaves * 64) __attribute__((amdgpu_waves_p
         }
       });
       wave_nz = true;
+    } else if (hit_rows == 0u && lim == kDensRows) {
+      // a wave whose cells only fade through a full chunk: 32 x 16 multiplies in a short loop, nothing else
+      if (wave_nz && do_decay) {
+#pragma unroll 2
+        for (int r = 0; r < kDensRows; ++r) {
+#pragma unroll
+          for (int k = 0; k < kDensCells; ++k) h[k] = __fmul_rn(h[k], decay_v);
+        }
+      }
     } else if (hit_rows != 0u || wave_nz) {
-      // a wave whose cells only fade (no hit in this chunk), or the ragged last chunk: row by row
+      // the ragged last chunk: row by row
       static_for<0, kDensRows>([&](auto rc) {
 #pragma clang fp contract(off)
         constexpr int r = decltype(rc)::value;
