@@ -169,15 +169,19 @@ __global__ void __launch_bounds__(256) frame_stats_finish_kernel(const uint4* __
 // maxima) are visited from the strongest down exactly like the reference's sorted loop: every round is a
 // block argmax over the live candidates plus one pass that forms the valley minimum against each peak
 // accepted so far.  Ends as soon as n_peaks are accepted or the candidates run out.
-constexpr int kPeakThreads = 1024;
+constexpr int kPeakThreads = 1024;                  // threads per row at the largest rows; smaller rows take fewer (below)
 constexpr int kMarkMaxNTop = 16384;                 // rows_top_peaks: n_bins <= 16384 (the row lives in LDS)
 constexpr int kMaxPeaks = 8;
 constexpr int kPeakVals = kMarkMaxNTop / kPeakThreads;   // bins per thread
-static_assert(kPeakThreads == 1024, "the pruning step shifts by 10");
 
-__global__ void __launch_bounds__(kPeakThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) top_peaks_kernel(const float* __restrict__ rows, int n, int n_peaks,
+// LOG2T: 2^LOG2T threads per row, 16 bins per thread at most - 64 threads for rows up to 1024 bins, ... 256 up to 4096 (eight rows per
+// CU), 512 up to 8192, 1024 above: the rounds are latency, and the rows in flight per CU are what hides it (a row of 1024 bins took as long as one
+// of 8192 while every row had 1024 threads)
+template <int LOG2T>
+__global__ void __launch_bounds__(1 << LOG2T) __attribute__((amdgpu_waves_per_eu(8, 8))) top_peaks_kernel(const float* __restrict__ rows, int n, int n_peaks,
                                                                  int min_sep, float excursion, int* out_bins,
                                                                  float* out_db) {
+  constexpr int T = 1 << LOG2T, W = T / 64;
   extern __shared__ float smem[];
   float* row = smem;             // [n]; the only large LDS array, so two rows are in flight per CU
   __shared__ PeakPair s_best[kPeakThreads / 64];
@@ -193,13 +197,13 @@ __global__ void __launch_bounds__(kPeakThreads) __attribute__((amdgpu_waves_per_
   float vals[kPeakVals];                              // the thread's own bins i = tid + 1024 k stay in registers
 #pragma unroll
   for (int k = 0; k < kPeakVals; ++k) {
-    const int i = tid + kPeakThreads * k;
+    const int i = tid + T * k;
     vals[k] = i < n ? src[i] : INFINITY;
   }
 #pragma unroll
   for (int k = 0; k < kPeakVals; ++k) {
-    const int i = tid + kPeakThreads * k;
-    if (kPeakThreads * k < n) {                       // (uniform)
+    const int i = tid + T * k;
+    if (T * k < n) {                       // (uniform)
       if (i < n) row[i] = vals[k];
       float mn = row_min(vals[k]);
       mn = fminf(mn, dpp_f<0x142, 0xa>(mn));          // row_bcast:15: lanes 31 and 63 hold the minimum of their 32 bins
@@ -212,7 +216,7 @@ __global__ void __launch_bounds__(kPeakThreads) __attribute__((amdgpu_waves_per_
   unsigned live = 0u;
 #pragma unroll
   for (int k = 0; k < kPeakVals; ++k) {
-    const int i = tid + kPeakThreads * k;
+    const int i = tid + T * k;
     const bool is_max = i > 0 && i < n - 1 && vals[k] > row[i - 1] && vals[k] > row[i + 1];
     live |= is_max ? (1u << k) : 0u;
   }
@@ -223,7 +227,7 @@ __global__ void __launch_bounds__(kPeakThreads) __attribute__((amdgpu_waves_per_
     mine = PeakPair{-INFINITY, -1};
 #pragma unroll
     for (int k = kPeakVals - 1; k >= 0; --k) {
-      if (((live >> k) & 1u) && vals[k] > mine.v) mine = PeakPair{vals[k], tid + kPeakThreads * k};
+      if (((live >> k) & 1u) && vals[k] > mine.v) mine = PeakPair{vals[k], tid + T * k};
     }
   };
   rescan();
@@ -233,11 +237,11 @@ __global__ void __launch_bounds__(kPeakThreads) __attribute__((amdgpu_waves_per_
     if (lane == 63) s_best[w] = best;
     __syncthreads();
     // every row of 16 lanes folds the 16 wave results itself (one LDS read per lane, four DPP steps): no serial section
-    const PeakPair gb = row_strongest(s_best[lane & (kPeakThreads / 64 - 1)]);
+    const PeakPair gb = row_strongest(s_best[lane & (W - 1)]);
     const int cur = __builtin_amdgcn_readfirstlane(gb.v == -INFINITY ? -1 : gb.i);   // (the same in every lane: scalar registers)
     if (cur < 0) break;
-    if (tid == (cur & (kPeakThreads - 1))) {      // the candidate leaves the list whatever happens to it
-      live &= ~(1u << (cur / kPeakThreads));
+    if (tid == (cur & (T - 1))) {      // the candidate leaves the list whatever happens to it
+      live &= ~(1u << (cur / T));
       rescan();
     }
     const float curv = gb.v;
@@ -271,7 +275,7 @@ __global__ void __launch_bounds__(kPeakThreads) __attribute__((amdgpu_waves_per_
     //  per wave; then one thread per block of 32 bins took the block's minimum where the block lay inside a range and walked
     //  it at a range's two ends - up to 62 dependent LDS reads by one thread, the longest chain of a round.  Now the threads
     //  take whole blocks strictly between the two peaks' blocks only; the two end blocks are wave 0's, below)
-    for (int b = tid; b < (n + 31) / 32; b += kPeakThreads) {
+    for (int b = tid; b < (n + 31) / 32; b += T) {
       const float bm = s_bmin[b];
 #pragma unroll
       for (int k = 0; k < kMaxPeaks; ++k) {
@@ -306,7 +310,7 @@ __global__ void __launch_bounds__(kPeakThreads) __attribute__((amdgpu_waves_per_
         const int kq = base + (lane >> 4);
         const bool valid = kq < nsel;
         const int k = valid ? kq : 0;
-        float valley = row_min(valid ? s_min[k][lane & 15] : INFINITY);
+        float valley = row_min(valid && (lane & 15) < W ? s_min[k][lane & 15] : INFINITY);
         const int sk = s_sel[k];
         valley = fminf(valley, cur < sk ? fminf(cur_from, s_sel_upto[k]) : fminf(cur_upto, s_sel_from[k]));
         const bool same = valid && (sk >> 5) == (cur >> 5);
@@ -342,13 +346,13 @@ __global__ void __launch_bounds__(kPeakThreads) __attribute__((amdgpu_waves_per_
       // accepted: every candidate closer than min_sep would be turned down when its turn came (the accepted set
       // only grows and a rejected candidate leaves no trace), so they go now instead of costing a round each
       const unsigned before = live;
-      if (2 * min_sep - 1 <= kPeakThreads) {
+      if (2 * min_sep - 1 <= T) {
         // the window (cur - min_sep, cur + min_sep) is no wider than the stride of a thread's bins: it holds at most one of them
-        const int last = cur + min_sep - 1, k = (last - tid) >> 10, i = tid + kPeakThreads * k;
+        const int last = cur + min_sep - 1, k = (last - tid) >> LOG2T, i = tid + T * k;
         if (last >= tid && k < kPeakVals && i > cur - min_sep) live &= ~(1u << k);
       } else {
         for (unsigned m = live; m != 0u; m &= m - 1u) {
-          const int k = __builtin_ctz(m), i = tid + kPeakThreads * k;
+          const int k = __builtin_ctz(m), i = tid + T * k;
           if (i > cur - min_sep && i < cur + min_sep) live &= ~(1u << k);
         }
       }
@@ -1030,10 +1034,20 @@ hipError_t launch_top_peaks(const float* rows, int n_rows, int n, int n_peaks, i
                             int* out_bins, float* out_db, hipStream_t s) {
   if (n_rows <= 0) return hipSuccess;
   const size_t lds = size_t(n) * sizeof(float);
-  static std::atomic<unsigned long long> attr_done{0};
-  const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(top_peaks_kernel), 72 * 1024, attr_done);
-  if (e != hipSuccess) return e;
-  top_peaks_kernel<<<n_rows, kPeakThreads, lds, s>>>(rows, n, n_peaks, min_sep, excursion, out_bins, out_db);
+  if (n <= 1024) {
+    top_peaks_kernel<6><<<n_rows, 64, lds, s>>>(rows, n, n_peaks, min_sep, excursion, out_bins, out_db);
+  } else if (n <= 2048) {
+    top_peaks_kernel<7><<<n_rows, 128, lds, s>>>(rows, n, n_peaks, min_sep, excursion, out_bins, out_db);
+  } else if (n <= 4096) {
+    top_peaks_kernel<8><<<n_rows, 256, lds, s>>>(rows, n, n_peaks, min_sep, excursion, out_bins, out_db);
+  } else if (n <= 8192) {
+    top_peaks_kernel<9><<<n_rows, 512, lds, s>>>(rows, n, n_peaks, min_sep, excursion, out_bins, out_db);
+  } else {
+    static std::atomic<unsigned long long> attr_done{0};
+    const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(top_peaks_kernel<10>), 72 * 1024, attr_done);
+    if (e != hipSuccess) return e;
+    top_peaks_kernel<10><<<n_rows, kPeakThreads, lds, s>>>(rows, n, n_peaks, min_sep, excursion, out_bins, out_db);
+  }
   return hipGetLastError();
 }
 
