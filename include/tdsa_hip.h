@@ -328,10 +328,11 @@ int tdsa_rows_marker_peaks(tdsa_plan p, const float* rows_dev, int n_rows, int n
  * range dropped), rows applied in order with float32 arithmetic.  _update_dev takes rows already on the
  * device (p = the plan that produced them, or NULL), _update one host row (the per-tick call),
  * _read copies the histogram or log1p(histogram) (what setImage receives).
- * tdsa_waterfall: Waterfall._buf (displays/waterfall.py:163-180): double-height circular row buffer
- * [2H][n_bins] initialised to min_db; a row that equals the previous pushed row (np.array_equal) is
- * skipped (:330-336), a new one is written at ptr = (ptr - 1) % H and ptr + H; _view returns
- * buf[ptr : ptr + H] (newest first).  These keep C4's 2 GiB of rows on the GPU: only the image leaves. */
+ * tdsa_waterfall: Waterfall._buf (displays/waterfall.py:163-180), a circular row buffer initialised to
+ * min_db; a row that equals the previous pushed row (np.array_equal) is skipped (:330-336), a new one
+ * is written at ptr = (ptr - 1) % H; _view returns what the reference's buf[ptr : ptr + H] holds (newest
+ * first).  The reference doubles the buffer ([2H][n_bins], every row at ptr and ptr + H) so that the view
+ * is one slice; the device ring keeps every line once and _view copies its two runs.  These keep C4's 2 GiB of rows on the GPU: only the image leaves. */
 typedef struct tdsa_density_s* tdsa_density;
 int tdsa_density_create(int device_id, int n_bins, float decay, tdsa_density* out);
 int tdsa_density_destroy(tdsa_density d);

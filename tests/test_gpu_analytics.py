@@ -259,6 +259,33 @@ def test_waterfall_ring_random(pkg, an, seed):
             assert np.array_equal(wf.view(), ref.view(), equal_nan=True), (seed, H, W)
 
 
+@pytest.mark.parametrize("H,W,k", [(50, 4096, 3000), (2000, 1001, 2500), (7, 2048, 1025), (600, 5000, 1500)])
+def test_waterfall_ring_long_batches(pkg, an, H, W, k):
+    """Batches of more than 1024 rows (the pointer walk is a scan with several rows per thread), shorter and longer than
+    the history, rows that differ from their predecessor only beyond the first 1024 bins or in the last bin, row lengths
+    that rule out 16-byte accesses: new-row count, pointer and view against the restatement, twice in a row."""
+    rng = np.random.default_rng(H * 7 + W)
+    pool = rng.normal(-90, 5, size=(9, W)).astype(np.float32)
+    pool[1] = pool[0]
+    pool[1, -1] += 1.0                                       # differs in the last bin only
+    pool[2] = pool[0]
+    pool[2, min(W - 1, 1500)] -= 2.0                         # differs beyond the first block of bins
+    pool[4, W // 2] = np.nan
+    ref = ao.WaterfallOracle(H, W, -120.0)
+    with an.WaterfallRing(H, W, -120.0) as wf:
+        for _call in range(2):
+            picks = rng.integers(0, len(pool), k)
+            picks = np.repeat(picks, rng.integers(1, 4, k))[:k]
+            rows = np.ascontiguousarray(pool[picks])
+            want = sum(ref.update(r) for r in rows)
+            with DevRows(pkg, rows) as d:
+                assert wf.push_rows(None, d, k) == want
+            assert wf.ptr == ref.ptr
+            assert np.array_equal(wf.view(), ref.view(), equal_nan=True)
+            lo, hi = -110.0, -70.0
+            assert np.array_equal(wf.view_u8(lo, hi), _levels_u8(ref.view(), lo, hi))
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("TDSA_STATS_CASES", "8"))))
 def test_rows_stats_random(pkg, an, seed):
     """Seeded random rows (ties at the maximum, NaNs, -inf, bands of every width incl. empty and out of range):

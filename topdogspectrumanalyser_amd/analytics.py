@@ -175,7 +175,8 @@ class DensityHistogram(_Handle):
 
 
 class WaterfallRing(_Handle):
-    """Waterfall._buf on the device: [2H, n_bins] float32 with the reference's pointer walk and dedup."""
+    """Waterfall._buf on the device ([H, n_bins] float32, every line once; the reference doubles it to make the view one
+    slice) with the reference's pointer walk and dedup."""
     _destroy = staticmethod(lambda h: nat.lib.tdsa_waterfall_destroy(h))
 
     def __init__(self, history_lines: int, n_bins: int, min_db: float, device: int = 0):

@@ -985,31 +985,111 @@ __global__ void __launch_bounds__(256) minmax_pos_kernel(const float* __restrict
 }
 
 // ---- waterfall ring -------------------------------------------------------------------------------------
-// differs[r] = !np.array_equal(rows[r], previous row)  (previous of row 0 = `last`, or "no previous")
+// The ring holds every line ONCE ([H][n]; the reference's doubled buffer exists to make its view one slice -
+// here the view is two copies and a pushed row crosses HBM twice instead of three times).  A push is three
+// launches and one host wait: new-row flags, the pointer walk as a scan over the flags, the scatter.
+// differs[r] = !np.array_equal(rows[r], previous row)  (previous of row 0 = `last`, or "no previous").
+// Rows that differ do so within their first bins as a rule: a block leaves at the first 1024 bins that differ.
 __global__ void __launch_bounds__(256) rows_differ_kernel(const float* __restrict__ rows, const float* __restrict__ last,
-                                                          int have_last, int n, int* differs) {
+                                                          int have_last, int n, int vec, int* differs) {
   const int r = blockIdx.x;
+  if (r == 0 && !have_last) {
+    if (threadIdx.x == 0) differs[0] = 1;
+    return;
+  }
   const float* cur = rows + (size_t)r * n;
   const float* prev = r > 0 ? cur - n : last;
-  int diff = (r == 0 && !have_last) ? 1 : 0;
-  if (!diff)
-    for (int i = threadIdx.x; i < n; i += 256) diff |= (cur[i] != prev[i]) ? 1 : 0;    // NaN != NaN, as in numpy
-  diff = __syncthreads_or(diff);
+  int diff = 0;
+  for (int base = 0; base < n; base += 1024) {                       // uniform trip count: the exit below is block-wide
+    const int i = base + threadIdx.x * 4;
+    if (vec) {
+      if (i < n) {
+        const float4 a = *reinterpret_cast<const float4*>(cur + i), b = *reinterpret_cast<const float4*>(prev + i);
+        diff = (a.x != b.x) | (a.y != b.y) | (a.z != b.z) | (a.w != b.w);      // NaN != NaN, as in numpy
+      }
+    } else {
+      for (int k = 0; k < 4; ++k)
+        if (i + k < n) diff |= (cur[i + k] != prev[i + k]) ? 1 : 0;
+    }
+    diff = __syncthreads_or(diff);
+    if (diff) break;
+  }
   if (threadIdx.x == 0) differs[r] = diff;
 }
-// copy row r to ring rows dst[r] and dst[r] + H (dst[r] < 0: duplicate, skipped)
+// Waterfall._add_row for a batch (displays/waterfall.py:171-175): ptr = (ptr - 1) % H for every new row, the row goes to
+// line ptr.  With c(r) = new rows among 0 ... r the line of a new row is (ptr0 - c(r)) mod H; when more than H rows are
+// new, later rows overwrite earlier ones - only the last H new rows are written (no write races in the scatter).
+// info = {new rows, index of the last new row or -1}, left in device memory for the scatter and in pinned host memory.
+__global__ void __launch_bounds__(1024) waterfall_plan_kernel(const int* __restrict__ differs, int n_rows, int ptr0,
+                                                              int history, int* __restrict__ dst, int* info_dev,
+                                                              int* info_host) {
+  __shared__ int s_cnt[16], s_last[16];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int per = (n_rows + 1023) / 1024;
+  const int r0 = min(t * per, n_rows), r1 = min(r0 + per, n_rows);
+  int c = 0, last = -1;
+  for (int r = r0; r < r1; ++r)
+    if (differs[r]) {
+      ++c;
+      last = r;
+    }
+  int inc = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(inc, o);
+    if (lane >= o) inc += v;
+    last = max(last, __shfl_xor(last, o));
+  }
+  if (lane == 63) s_cnt[wv] = inc;
+  if (lane == 0) s_last[wv] = last;
+  __syncthreads();
+  int before = 0, total = 0, last_all = -1;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int v = s_cnt[k];
+    before += k < wv ? v : 0;
+    total += v;
+    last_all = max(last_all, s_last[k]);
+  }
+  int run = before + inc - c;
+  for (int r = r0; r < r1; ++r) {
+    int d = -1;
+    if (differs[r]) {
+      ++run;
+      if (total - run < history) d = (ptr0 - run % history + history) % history;
+    }
+    dst[r] = d;
+  }
+  if (t == 0) {
+    info_dev[0] = total;
+    info_dev[1] = last_all;
+    info_host[0] = total;
+    info_host[1] = last_all;
+  }
+}
+// copy row r to ring line dst[r] (dst[r] < 0: duplicate or overwritten within the batch, skipped); the last new row is
+// also Waterfall._last_row of the next push
 __global__ void __launch_bounds__(256) waterfall_scatter_kernel(const float* __restrict__ rows, const int* __restrict__ dst,
-                                                                int n, int history, float* ring) {
+                                                                const int* __restrict__ info, int n, int vec,
+                                                                float* __restrict__ ring, float* __restrict__ last) {
   const int r = blockIdx.x;
   const int d = dst[r];
   if (d < 0) return;
+  const bool is_last = info[1] == r;
   const float* src = rows + (size_t)r * n;
   float* a = ring + (size_t)d * n;
-  float* b = ring + (size_t)(d + history) * n;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const float v = src[i];
-    a[i] = v;
-    b[i] = v;
+  if (vec) {
+    for (int i = threadIdx.x * 4; i < n; i += 1024) {
+      const float4 v = *reinterpret_cast<const float4*>(src + i);
+      *reinterpret_cast<float4*>(a + i) = v;
+      if (is_last) *reinterpret_cast<float4*>(last + i) = v;
+    }
+  } else {
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const float v = src[i];
+      a[i] = v;
+      if (is_last) last[i] = v;
+    }
   }
 }
 
@@ -1092,17 +1172,17 @@ hipError_t launch_minmax_pos(const float* in, size_t count, unsigned* mm_dev, hi
   return hipGetLastError();
 }
 
-hipError_t launch_rows_differ(const float* rows, const float* last, int have_last, int n_rows, int n, int* differs,
-                              hipStream_t s) {
-  if (n_rows <= 0) return hipSuccess;
-  rows_differ_kernel<<<n_rows, 256, 0, s>>>(rows, last, have_last, n, differs);
-  return hipGetLastError();
+static inline int rows_vec_ok(const void* p0, const void* p1, const void* p2, int n) {
+  return ((reinterpret_cast<uintptr_t>(p0) | reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2)) & 15) == 0 &&
+         (n & 3) == 0;
 }
-
-hipError_t launch_waterfall_scatter(const float* rows, const int* dst, int n_rows, int n, int history, float* ring,
-                                    hipStream_t s) {
+hipError_t launch_waterfall_push(const float* rows, int n_rows, int n, int have_last, int ptr0, int history, int* differs,
+                                 int* dst, int* info_dev, int* info_host, float* ring, float* last, hipStream_t s) {
   if (n_rows <= 0) return hipSuccess;
-  waterfall_scatter_kernel<<<n_rows, 256, 0, s>>>(rows, dst, n, history, ring);
+  const int vec = rows_vec_ok(rows, ring, last, n);
+  rows_differ_kernel<<<n_rows, 256, 0, s>>>(rows, last, have_last, n, vec, differs);
+  waterfall_plan_kernel<<<1, 1024, 0, s>>>(differs, n_rows, ptr0, history, dst, info_dev, info_host);
+  waterfall_scatter_kernel<<<n_rows, 256, 0, s>>>(rows, dst, info_dev, n, vec, ring, last);
   return hipGetLastError();
 }
 

@@ -2813,13 +2813,14 @@ struct tdsa_waterfall_s {
   int device = 0, n = 0, history = 0;
   int ptr = 0;
   bool have_last = false;
-  float* d_ring = nullptr;     // [2*history][n]
+  float* d_ring = nullptr;     // [history][n]: every line once, the view is two copies
   float* d_last = nullptr;     // [n] Waterfall._last_row
   unsigned char* d_u8 = nullptr;   // [history][n] the view as bytes (tdsa_waterfall_view_u8)
   float* d_row = nullptr;      // staging for host rows
-  int* d_flags = nullptr;      // [cap] differs / destination per pushed row
+  int* d_flags = nullptr;      // [2][cap] differs, destination line per pushed row
+  int* d_info = nullptr;       // {new rows, last new row} of the push in flight, for the scatter
+  int* h_info = nullptr;       // the same two words, pinned: what the host waits for
   int cap = 0;
-  std::vector<int> h_flags;
   hipStream_t stream = nullptr;
 };
 
@@ -2832,9 +2833,11 @@ int tdsa_waterfall_create(int device_id, int history_lines, int n_bins, float mi
   w->device = device_id;
   w->n = n_bins;
   w->history = history_lines;
-  const size_t cnt = size_t(2) * history_lines * n_bins;
+  const size_t cnt = size_t(history_lines) * n_bins;
   hipError_t e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMalloc(&w->d_ring, cnt * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&w->d_info, 2 * sizeof(int));
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&w->h_info), 2 * sizeof(int), hipHostMallocDefault);
   if (e == hipSuccess) e = hipMalloc(&w->d_last, size_t(n_bins) * sizeof(float));
   if (e == hipSuccess) e = hipMalloc(&w->d_row, size_t(n_bins) * sizeof(float));
   if (e == hipSuccess) e = launch_fill(w->d_ring, cnt, min_db, w->stream);    // np.full((2H, W), wf_min_db)
@@ -2856,6 +2859,8 @@ int tdsa_waterfall_destroy(tdsa_waterfall w) {
   if (w->d_u8) (void)hipFree(w->d_u8);
   if (w->d_row) (void)hipFree(w->d_row);
   if (w->d_flags) (void)hipFree(w->d_flags);
+  if (w->d_info) (void)hipFree(w->d_info);
+  if (w->h_info) (void)hipHostFree(w->h_info);
   if (w->stream) (void)hipStreamDestroy(w->stream);
   delete w;
   return TDSA_OK;
@@ -2866,43 +2871,19 @@ static int waterfall_push_rows(tdsa_waterfall w, const float* rows_dev, int n_ro
     if (w->d_flags) HIPCHK(hipFree(w->d_flags));
     w->d_flags = nullptr;
     w->cap = 0;
-    HIPCHK(hipMalloc(&w->d_flags, size_t(n_rows) * sizeof(int)));
+    HIPCHK(hipMalloc(&w->d_flags, size_t(2) * n_rows * sizeof(int)));
     w->cap = n_rows;
   }
-  w->h_flags.resize(size_t(n_rows));
-  HIPCHK(launch_rows_differ(rows_dev, w->d_last, w->have_last ? 1 : 0, n_rows, w->n, w->d_flags, w->stream));
-  HIPCHK(hipMemcpyAsync(w->h_flags.data(), w->d_flags, size_t(n_rows) * sizeof(int), hipMemcpyDeviceToHost, w->stream));
+  // new-row flags, the pointer walk of _add_row as a scan over them, the scatter: three launches, one wait
+  w->h_info[0] = 0;
+  w->h_info[1] = -1;
+  HIPCHK(launch_waterfall_push(rows_dev, n_rows, w->n, w->have_last ? 1 : 0, w->ptr, w->history, w->d_flags,
+                               w->d_flags + w->cap, w->d_info, w->h_info, w->d_ring, w->d_last, w->stream));
   HIPCHK(hipStreamSynchronize(w->stream));
-  // host walks the ring pointer exactly like _add_row: ptr = (ptr - 1) % H for every genuinely new row
-  int fresh = 0, last_new = -1;
-  for (int r = 0; r < n_rows; ++r) {
-    if (w->h_flags[size_t(r)]) {
-      w->ptr = (w->ptr - 1 + w->history) % w->history;
-      w->h_flags[size_t(r)] = w->ptr;
-      last_new = r;
-      ++fresh;
-    } else {
-      w->h_flags[size_t(r)] = -1;
-    }
-  }
-  // more new rows than history lines: later rows overwrite earlier ones, as they would one by one;
-  // keep only the last writer of every ring line so the scatter has no write races
-  if (fresh > w->history) {
-    std::vector<char> seen(size_t(w->history), 0);
-    for (int r = n_rows - 1; r >= 0; --r) {
-      const int dline = w->h_flags[size_t(r)];
-      if (dline < 0) continue;
-      if (seen[size_t(dline)]) w->h_flags[size_t(r)] = -1;
-      else seen[size_t(dline)] = 1;
-    }
-  }
+  const int fresh = w->h_info[0];
   if (fresh > 0) {
-    HIPCHK(hipMemcpyAsync(w->d_flags, w->h_flags.data(), size_t(n_rows) * sizeof(int), hipMemcpyHostToDevice, w->stream));
-    HIPCHK(launch_waterfall_scatter(rows_dev, w->d_flags, n_rows, w->n, w->history, w->d_ring, w->stream));
-    HIPCHK(hipMemcpyAsync(w->d_last, rows_dev + size_t(last_new) * w->n, size_t(w->n) * sizeof(float),
-                          hipMemcpyDeviceToDevice, w->stream));
+    w->ptr = ((w->ptr - fresh % w->history) % w->history + w->history) % w->history;
     w->have_last = true;
-    HIPCHK(hipStreamSynchronize(w->stream));
   }
   if (n_new) *n_new = fresh;
   return TDSA_OK;
@@ -2935,8 +2916,12 @@ int tdsa_waterfall_view(tdsa_waterfall w, float* view_host, int* ptr) {
   if (!w) return fail(TDSA_ERR_ARG, "null waterfall");
   HIPCHK(hipSetDevice(w->device));
   if (view_host) {   // _display_view: buf[ptr : ptr + H], newest row first
-    HIPCHK(hipMemcpyAsync(view_host, w->d_ring + size_t(w->ptr) * w->n, size_t(w->history) * w->n * sizeof(float),
-                          hipMemcpyDeviceToHost, w->stream));
+    const size_t head = size_t(w->history - w->ptr) * w->n;      // lines ptr ... H-1, then 0 ... ptr-1
+    HIPCHK(hipMemcpyAsync(view_host, w->d_ring + size_t(w->ptr) * w->n, head * sizeof(float), hipMemcpyDeviceToHost,
+                          w->stream));
+    if (w->ptr > 0)
+      HIPCHK(hipMemcpyAsync(view_host + head, w->d_ring, size_t(w->ptr) * w->n * sizeof(float), hipMemcpyDeviceToHost,
+                            w->stream));
     HIPCHK(hipStreamSynchronize(w->stream));
   }
   if (ptr) *ptr = w->ptr;
@@ -2949,7 +2934,9 @@ int tdsa_waterfall_view_u8(tdsa_waterfall w, float min_db, float max_db, uint8_t
   HIPCHK(hipSetDevice(w->device));
   const size_t cnt = size_t(w->history) * w->n;
   if (!w->d_u8) HIPCHK(hipMalloc(&w->d_u8, cnt));
-  HIPCHK(launch_quantize_u8(w->d_ring + size_t(w->ptr) * w->n, w->d_u8, cnt, min_db, max_db, w->stream));
+  const size_t head = size_t(w->history - w->ptr) * w->n;
+  HIPCHK(launch_quantize_u8(w->d_ring + size_t(w->ptr) * w->n, w->d_u8, head, min_db, max_db, w->stream));
+  HIPCHK(launch_quantize_u8(w->d_ring, w->d_u8 + head, cnt - head, min_db, max_db, w->stream));
   HIPCHK(hipMemcpyAsync(view_host, w->d_u8, cnt, hipMemcpyDeviceToHost, w->stream));
   HIPCHK(hipStreamSynchronize(w->stream));
   return TDSA_OK;

@@ -355,9 +355,7 @@ hipError_t launch_density(const float* rows, int n_rows, int n, float decay, flo
 hipError_t launch_log1p(const float* in, float* out, size_t count, hipStream_t s);
 hipError_t launch_quantize_u8(const float* in, unsigned char* out, size_t count, float lo, float hi, hipStream_t s);
 hipError_t launch_minmax_pos(const float* in, size_t count, unsigned* mm_dev, hipStream_t s);
-hipError_t launch_rows_differ(const float* rows, const float* last, int have_last, int n_rows, int n, int* differs,
-                              hipStream_t s);
-hipError_t launch_waterfall_scatter(const float* rows, const int* dst, int n_rows, int n, int history, float* ring,
-                                    hipStream_t s);
+hipError_t launch_waterfall_push(const float* rows, int n_rows, int n, int have_last, int ptr0, int history, int* differs,
+                                 int* dst, int* info_dev, int* info_host, float* ring, float* last, hipStream_t s);
 
 }  // namespace tdsa
