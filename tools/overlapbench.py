@@ -32,7 +32,11 @@ def main():
     for _ in range(3):
         e = SpectrumEngine(n, max_frames=F)
         e.set_window(np.hanning(n).astype(np.float32))
-        e.configure(db_mode="mag", log_floor=1e-12, dc_alpha=1.0, hold_max=bool(int(os.environ.get("HOLD", "1"))))
+        if os.environ.get("AVG"):             # AVG=exp,4: the batched TraceAverager path (frame kernel -> chain -> re-scan)
+            mode, cnt = os.environ["AVG"].split(",")
+            e.configure(db_mode="pow", power_scale=1.0, log_floor=1e-10, dc_alpha=1.0, avg=(mode, int(cnt)))
+        else:
+            e.configure(db_mode="mag", log_floor=1e-12, dc_alpha=1.0, hold_max=bool(int(os.environ.get("HOLD", "1"))))
         engs.append(e)
     def run_plans(k):
         use = engs[:k]
@@ -50,9 +54,12 @@ def main():
             e.process_device(nat.IN_I8, ins[i % ring], ns, hop, F, outs[i % ring])
         e.synchronize()
 
-    configs = [("1 plan, 1 stream", lambda: run_overlap(1)), ("1 plan, set_overlap(2)", lambda: run_overlap(2)),
-               ("1 plan, set_overlap(3)", lambda: run_overlap(3)), ("1 plan, set_overlap(4)", lambda: run_overlap(4)),
-               ("2 plans", lambda: run_plans(2)), ("3 plans", lambda: run_plans(3))]
+    if os.environ.get("AVG"):
+        configs = [("1 plan", lambda: run_plans(1)), ("2 plans", lambda: run_plans(2)), ("3 plans", lambda: run_plans(3))]
+    else:
+      configs = [("1 plan, 1 stream", lambda: run_overlap(1)), ("1 plan, set_overlap(2)", lambda: run_overlap(2)),
+                 ("1 plan, set_overlap(3)", lambda: run_overlap(3)), ("1 plan, set_overlap(4)", lambda: run_overlap(4)),
+                 ("2 plans", lambda: run_plans(2)), ("3 plans", lambda: run_plans(3))]
     for _ in range(5):                       # warm the clocks up
         run_overlap(1)
     acc = {name: [] for name, _ in configs}
