@@ -326,8 +326,9 @@ int tdsa_rows_marker_peaks(tdsa_plan p, const float* rows_dev, int n_rows, int n
  * amplitude histogram over -200..+100 dB; every row first multiplies the histogram by `decay` (when
  * decay < 1) and then adds 1 at int32((dB + 200) / 300 * 512) (truncation toward zero; NaN and out of
  * range dropped), rows applied in order with float32 arithmetic.  _update_dev takes rows already on the
- * device (p = the plan that produced them, or NULL), _update one host row (the per-tick call),
- * _read copies the histogram or log1p(histogram) (what setImage receives).
+ * device (p = the plan that produced them, or NULL), _update one host row (the per-tick call: returns
+ * when the row is staged in pinned memory and its update queued - every other entry point is ordered
+ * behind it and _read waits), _read copies the histogram or log1p(histogram) (what setImage receives).
  * tdsa_waterfall: Waterfall._buf (displays/waterfall.py:163-180), a circular row buffer initialised to
  * min_db; a row that equals the previous pushed row (np.array_equal) is skipped (:330-336), a new one
  * is written at ptr = (ptr - 1) % H; _view returns what the reference's buf[ptr : ptr + H] holds (newest

@@ -82,5 +82,33 @@ def main():
                     e.process_real2(st, chan)
                 print(f"N={n:6d} audio tick ({chan:6s}): {(time.perf_counter() - t0) / 2000 * 1e6:6.1f} us")
 
+    # the displays' share of a tick: one host row into the density histogram / the waterfall ring, the marker search and the
+    # peak list of one row on the device
+    from topdogspectrumanalyser_amd import analytics as an
+    for n in (1024, 4096, 16384):
+        row = np.random.default_rng(4).normal(-80, 5, n).astype(np.float32)
+        row[n // 3] = -20.0
+        with SpectrumEngine(n, max_frames=1) as e, an.DensityHistogram(n, 0.96) as dh, an.WaterfallRing(600, n, -120.0) as wf:
+            d_row = C.c_void_p()
+            nat.check(nat.lib.tdsa_dev_alloc(0, n * 4, C.byref(d_row)))
+            nat.check(nat.lib.tdsa_memcpy_h2d(0, d_row, row.ctypes.data_as(C.c_void_p), n * 4))
+            rows2 = [row, row + np.float32(0.5)]
+            calls = (("density update (host row)", lambda i: dh.update(rows2[i & 1])),
+                     ("waterfall push (host row)", lambda i: wf.push(rows2[i & 1])),
+                     ("waterfall view_u8 (600 lines back)", lambda i: wf.view_u8(-110.0, -20.0)),
+                     ("top-5 peaks of one device row", lambda i: an.rows_top_peaks(e, d_row.value, 1)),
+                     ("marker search of one device row", lambda i: an.rows_marker_peaks(e, d_row.value, 1, peak_threshold=-60.0,
+                                                                                        peak_excursion=6.0)),
+                     ("peak / argmax / band of one device row", lambda i: an.rows_stats(e, d_row.value, 1)))
+            for name, fn in calls:
+                reps = 200 if "view" in name else 2000
+                for i in range(50):
+                    fn(i)
+                t0 = time.perf_counter()
+                for i in range(reps):
+                    fn(i)
+                print(f"N={n:6d} {name:40s}: {(time.perf_counter() - t0) / reps * 1e6:7.1f} us")
+            nat.lib.tdsa_dev_free(0, d_row)
+
 if __name__ == "__main__":
     main()

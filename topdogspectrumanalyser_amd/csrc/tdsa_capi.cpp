@@ -2553,6 +2553,47 @@ int plan_scratch(tdsa_plan p, size_t need) {
   return TDSA_OK;
 }
 
+// Where the result arrays of a rows_* call are formed and how they reach the caller's (pageable) arrays: every copy
+// into pageable memory costs ~10 us in the runtime's own staging, so the arrays of a call sit back to back in ONE
+// region - the plan's pinned, device-visible buffer itself when they are a few KB (one displayed row per GUI tick:
+// the kernel stores over the bus, the host only waits), else device scratch and one DMA into the pinned buffer -
+// and leave it by memcpy.  Results too large for the bounce buffer go piece by piece as before.
+constexpr size_t kResultsDirectMax = 4096;
+struct RowsResults {
+  char* base = nullptr;      // where the kernel writes (device-visible)
+  const char* host = nullptr;   // where the host reads after fetch(): the pinned buffer, or null = piece by piece
+  size_t total = 0;
+};
+int rows_results_begin(tdsa_plan p, size_t total, RowsResults* r) {
+  r->total = total;
+  if (total <= kPinnedBounceMax) {
+    const int rc = ensure_pins(p, 0, total);
+    if (rc != TDSA_OK) return rc;
+    r->host = static_cast<const char*>(p->h_out_pin);
+  }
+  if (total <= kResultsDirectMax) {
+    r->base = static_cast<char*>(p->h_out_pin);
+    return TDSA_OK;
+  }
+  const int rc = plan_scratch(p, total);
+  if (rc != TDSA_OK) return rc;
+  r->base = static_cast<char*>(p->d_scratch);
+  return TDSA_OK;
+}
+// after the launch: wait; afterwards piece(off) is readable on the host (r.host != null)
+int rows_results_fetch(tdsa_plan p, const RowsResults& r) {
+  if (r.host && r.base != r.host)
+    HIPCHK(hipMemcpyAsync(p->h_out_pin, r.base, r.total, hipMemcpyDeviceToHost, p->stream));
+  if (r.host) HIPCHK(hipStreamSynchronize(p->stream));
+  return TDSA_OK;
+}
+int rows_results_piece(tdsa_plan p, const RowsResults& r, void* dst_host, size_t off, size_t bytes) {
+  if (!dst_host || bytes == 0) return TDSA_OK;
+  if (r.host) std::memcpy(dst_host, r.host + off, bytes);
+  else HIPCHK(hipMemcpyAsync(dst_host, r.base + off, bytes, hipMemcpyDeviceToHost, p->stream));
+  return TDSA_OK;
+}
+
 }  // namespace
 
 int tdsa_set_frame_stats(tdsa_plan p, int enable, int band_lo, int band_hi) {
@@ -2595,6 +2636,19 @@ int tdsa_get_frame_stats(tdsa_plan p, int calls_back, int capacity, int* n_frame
     sl.pending = false;
   }
   const size_t nf = size_t(sl.n_frames);
+  if (nf * 16 <= kPinnedBounceMax) {       // DMA into the pinned bounce buffer, one wait, memcpy out (pageable targets cost ~10 us each)
+    const int rc = ensure_pins(p, 0, nf * 16);
+    if (rc != TDSA_OK) return rc;
+    char* pin = static_cast<char*>(p->h_out_pin);
+    if (band_lin_host) HIPCHK(hipMemcpyAsync(pin, sl.d_band, nf * sizeof(double), hipMemcpyDeviceToHost, p->fs_stream));
+    if (peak_db_host) HIPCHK(hipMemcpyAsync(pin + nf * 8, sl.d_peak, nf * sizeof(float), hipMemcpyDeviceToHost, p->fs_stream));
+    if (peak_bin_host) HIPCHK(hipMemcpyAsync(pin + nf * 12, sl.d_bin, nf * sizeof(int), hipMemcpyDeviceToHost, p->fs_stream));
+    HIPCHK(hipStreamSynchronize(p->fs_stream));
+    if (band_lin_host) std::memcpy(band_lin_host, pin, nf * sizeof(double));
+    if (peak_db_host) std::memcpy(peak_db_host, pin + nf * 8, nf * sizeof(float));
+    if (peak_bin_host) std::memcpy(peak_bin_host, pin + nf * 12, nf * sizeof(int));
+    return TDSA_OK;
+  }
   if (peak_db_host) HIPCHK(hipMemcpyAsync(peak_db_host, sl.d_peak, nf * sizeof(float), hipMemcpyDeviceToHost, p->fs_stream));
   if (peak_bin_host) HIPCHK(hipMemcpyAsync(peak_bin_host, sl.d_bin, nf * sizeof(int), hipMemcpyDeviceToHost, p->fs_stream));
   if (band_lin_host) HIPCHK(hipMemcpyAsync(band_lin_host, sl.d_band, nf * sizeof(double), hipMemcpyDeviceToHost, p->fs_stream));
@@ -2611,18 +2665,20 @@ int tdsa_rows_stats(tdsa_plan p, const float* rows_dev, int n_rows, int n_bins, 
     return fail(TDSA_ERR_ARG, "band [%d, %d] outside [0, %d)", band_lo, band_hi, n_bins);
   HIPCHK(hipSetDevice(p->device));
   JOIN(p);
-  const size_t per = sizeof(float) + sizeof(int) + sizeof(double);
-  int rc = plan_scratch(p, size_t(n_rows) * per);
+  const size_t nr = size_t(n_rows), o_peak = nr * sizeof(double), o_bin = o_peak + nr * sizeof(float);
+  RowsResults res;
+  int rc = rows_results_begin(p, o_bin + nr * sizeof(int), &res);
   if (rc != TDSA_OK) return rc;
-  double* d_band = static_cast<double*>(p->d_scratch);
-  float* d_peak = reinterpret_cast<float*>(d_band + n_rows);
-  int* d_bin = reinterpret_cast<int*>(d_peak + n_rows);
+  double* d_band = reinterpret_cast<double*>(res.base);
+  float* d_peak = reinterpret_cast<float*>(res.base + o_peak);
+  int* d_bin = reinterpret_cast<int*>(res.base + o_bin);
   HIPCHK(launch_rows_stats(rows_dev, n_rows, n_bins, band_lo, band_hi, bin_width, d_peak, d_bin,
                            band_db_host ? d_band : nullptr, p->stream));
-  if (peak_db_host) HIPCHK(hipMemcpyAsync(peak_db_host, d_peak, size_t(n_rows) * sizeof(float), hipMemcpyDeviceToHost, p->stream));
-  if (peak_bin_host) HIPCHK(hipMemcpyAsync(peak_bin_host, d_bin, size_t(n_rows) * sizeof(int), hipMemcpyDeviceToHost, p->stream));
-  if (band_db_host) HIPCHK(hipMemcpyAsync(band_db_host, d_band, size_t(n_rows) * sizeof(double), hipMemcpyDeviceToHost, p->stream));
-  HIPCHK(hipStreamSynchronize(p->stream));
+  if ((rc = rows_results_fetch(p, res)) != TDSA_OK) return rc;
+  if ((rc = rows_results_piece(p, res, peak_db_host, o_peak, nr * sizeof(float))) != TDSA_OK) return rc;
+  if ((rc = rows_results_piece(p, res, peak_bin_host, o_bin, nr * sizeof(int))) != TDSA_OK) return rc;
+  if ((rc = rows_results_piece(p, res, band_db_host, 0, nr * sizeof(double))) != TDSA_OK) return rc;
+  if (!res.host) HIPCHK(hipStreamSynchronize(p->stream));
   return TDSA_OK;
 }
 
@@ -2636,14 +2692,16 @@ int tdsa_rows_top_peaks(tdsa_plan p, const float* rows_dev, int n_rows, int n_bi
   HIPCHK(hipSetDevice(p->device));
   JOIN(p);
   const size_t cnt = size_t(n_rows) * n_peaks;
-  int rc = plan_scratch(p, cnt * (sizeof(int) + sizeof(float)));
+  RowsResults res;
+  int rc = rows_results_begin(p, cnt * (sizeof(int) + sizeof(float)), &res);
   if (rc != TDSA_OK) return rc;
-  int* d_bins = static_cast<int*>(p->d_scratch);
-  float* d_db = reinterpret_cast<float*>(d_bins + cnt);
+  int* d_bins = reinterpret_cast<int*>(res.base);
+  float* d_db = reinterpret_cast<float*>(res.base + cnt * sizeof(int));
   HIPCHK(launch_top_peaks(rows_dev, n_rows, n_bins, n_peaks, min_sep_bins, min_excursion_db, d_bins, d_db, p->stream));
-  HIPCHK(hipMemcpyAsync(peak_bins_host, d_bins, cnt * sizeof(int), hipMemcpyDeviceToHost, p->stream));
-  if (peak_db_host) HIPCHK(hipMemcpyAsync(peak_db_host, d_db, cnt * sizeof(float), hipMemcpyDeviceToHost, p->stream));
-  HIPCHK(hipStreamSynchronize(p->stream));
+  if ((rc = rows_results_fetch(p, res)) != TDSA_OK) return rc;
+  if ((rc = rows_results_piece(p, res, peak_bins_host, 0, cnt * sizeof(int))) != TDSA_OK) return rc;
+  if ((rc = rows_results_piece(p, res, peak_db_host, cnt * sizeof(int), cnt * sizeof(float))) != TDSA_OK) return rc;
+  if (!res.host) HIPCHK(hipStreamSynchronize(p->stream));
   return TDSA_OK;
 }
 
@@ -2659,26 +2717,28 @@ int tdsa_rows_marker_peaks(tdsa_plan p, const float* rows_dev, int n_rows, int n
   if (height != height || prominence != prominence) return fail(TDSA_ERR_ARG, "NaN height / prominence");
   HIPCHK(hipSetDevice(p->device));
   JOIN(p);
-  const size_t cnt = size_t(n_rows) * max_list;
-  int rc = plan_scratch(p, cnt * (sizeof(double) + sizeof(int)) + size_t(n_rows) * 3 * sizeof(int));
+  const size_t cnt = size_t(n_rows) * max_list, rb = size_t(n_rows) * sizeof(int);
+  const size_t o_bins = cnt * sizeof(double), o_count = o_bins + cnt * sizeof(int), o_snap = o_count + rb, o_next = o_snap + rb;
+  RowsResults res;
+  int rc = rows_results_begin(p, o_next + rb, &res);
   if (rc != TDSA_OK) return rc;
-  double* d_prom = static_cast<double*>(p->d_scratch);
-  int* d_bins = reinterpret_cast<int*>(d_prom + cnt);
-  int* d_count = d_bins + cnt;
-  int* d_snap = d_count + n_rows;
-  int* d_next = d_snap + n_rows;
+  double* d_prom = reinterpret_cast<double*>(res.base);
+  int* d_bins = reinterpret_cast<int*>(res.base + o_bins);
+  int* d_count = reinterpret_cast<int*>(res.base + o_count);
+  int* d_snap = reinterpret_cast<int*>(res.base + o_snap);
+  int* d_next = reinterpret_cast<int*>(res.base + o_next);
   HIPCHK(launch_marker_peaks(rows_dev, n_rows, n_bins, height, prominence, distance, current_idx, max_list, d_count, d_snap,
                              d_next, max_list > 0 ? d_bins : nullptr, max_list > 0 && peak_prom_host ? d_prom : nullptr,
                              p->stream));
-  const size_t rb = size_t(n_rows) * sizeof(int);
-  if (n_peaks_host) HIPCHK(hipMemcpyAsync(n_peaks_host, d_count, rb, hipMemcpyDeviceToHost, p->stream));
-  if (snap_bin_host) HIPCHK(hipMemcpyAsync(snap_bin_host, d_snap, rb, hipMemcpyDeviceToHost, p->stream));
-  if (next_bin_host) HIPCHK(hipMemcpyAsync(next_bin_host, d_next, rb, hipMemcpyDeviceToHost, p->stream));
+  if ((rc = rows_results_fetch(p, res)) != TDSA_OK) return rc;
+  if ((rc = rows_results_piece(p, res, n_peaks_host, o_count, rb)) != TDSA_OK) return rc;
+  if ((rc = rows_results_piece(p, res, snap_bin_host, o_snap, rb)) != TDSA_OK) return rc;
+  if ((rc = rows_results_piece(p, res, next_bin_host, o_next, rb)) != TDSA_OK) return rc;
   if (max_list > 0) {
-    HIPCHK(hipMemcpyAsync(peak_bins_host, d_bins, cnt * sizeof(int), hipMemcpyDeviceToHost, p->stream));
-    if (peak_prom_host) HIPCHK(hipMemcpyAsync(peak_prom_host, d_prom, cnt * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    if ((rc = rows_results_piece(p, res, peak_bins_host, o_bins, cnt * sizeof(int))) != TDSA_OK) return rc;
+    if ((rc = rows_results_piece(p, res, peak_prom_host, 0, cnt * sizeof(double))) != TDSA_OK) return rc;
   }
-  HIPCHK(hipStreamSynchronize(p->stream));
+  if (!res.host) HIPCHK(hipStreamSynchronize(p->stream));
   return TDSA_OK;
 }
 
@@ -2689,7 +2749,9 @@ struct tdsa_density_s {
   float* d_hist = nullptr;     // [n][512]
   float* d_img = nullptr;      // log1p image scratch
   unsigned char* d_u8 = nullptr;   // the image as bytes (+ 8 bytes: its min / max)
-  float* d_row = nullptr;      // staging for host rows
+  float* h_row[2] = {nullptr, nullptr};   // pinned, device-visible staging of host rows (the kernel reads them in place)
+  hipEvent_t ev_row[2] = {nullptr, nullptr};   // ... free again when the update that read them has run
+  unsigned tick = 0;
   hipStream_t stream = nullptr;
 };
 
@@ -2705,7 +2767,12 @@ int tdsa_density_create(int device_id, int n_bins, float decay, tdsa_density* ou
   const size_t hb = size_t(n_bins) * 512 * sizeof(float);
   hipError_t e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMalloc(&d->d_hist, hb);
-  if (e == hipSuccess) e = hipMalloc(&d->d_row, size_t(n_bins) * sizeof(float));
+  for (int k = 0; k < 2; ++k) {
+    if (e == hipSuccess)
+      e = hipHostMalloc(reinterpret_cast<void**>(&d->h_row[k]), size_t(n_bins) * sizeof(float),
+                        hipHostMallocPortable | hipHostMallocMapped);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_row[k], hipEventDisableTiming);
+  }
   if (e == hipSuccess) e = hipMemsetAsync(d->d_hist, 0, hb, d->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
   if (e != hipSuccess) {
@@ -2723,7 +2790,10 @@ int tdsa_density_destroy(tdsa_density d) {
   if (d->d_hist) (void)hipFree(d->d_hist);
   if (d->d_img) (void)hipFree(d->d_img);
   if (d->d_u8) (void)hipFree(d->d_u8);
-  if (d->d_row) (void)hipFree(d->d_row);
+  for (int k = 0; k < 2; ++k) {
+    if (d->h_row[k]) (void)hipHostFree(d->h_row[k]);
+    if (d->ev_row[k]) (void)hipEventDestroy(d->ev_row[k]);
+  }
   if (d->stream) (void)hipStreamDestroy(d->stream);
   delete d;
   return TDSA_OK;
@@ -2764,9 +2834,14 @@ int tdsa_density_update(tdsa_density d, const float* row_host, int n) {
   if (!d || !row_host) return fail(TDSA_ERR_ARG, "null argument");
   if (n != d->n) return fail(TDSA_ERR_ARG, "row of %d bins, histogram has %d (re-create it: _ensure_hist)", n, d->n);
   HIPCHK(hipSetDevice(d->device));
-  HIPCHK(hipMemcpyAsync(d->d_row, row_host, size_t(n) * sizeof(float), hipMemcpyHostToDevice, d->stream));
-  HIPCHK(launch_density(d->d_row, 1, d->n, d->decay, d->d_hist, d->stream));
-  HIPCHK(hipStreamSynchronize(d->stream));
+  // the per-tick call returns when the row is staged and its update queued (every other entry point is ordered behind
+  // it on the histogram's stream; tdsa_density_read waits): two pinned rows the kernel reads in place, each free again
+  // once the update that read it has run
+  const unsigned k = d->tick++ & 1u;
+  HIPCHK(hipEventSynchronize(d->ev_row[k]));
+  std::memcpy(d->h_row[k], row_host, size_t(n) * sizeof(float));
+  HIPCHK(launch_density(d->h_row[k], 1, d->n, d->decay, d->d_hist, d->stream));
+  HIPCHK(hipEventRecord(d->ev_row[k], d->stream));
   return TDSA_OK;
 }
 
@@ -2816,7 +2891,8 @@ struct tdsa_waterfall_s {
   float* d_ring = nullptr;     // [history][n]: every line once, the view is two copies
   float* d_last = nullptr;     // [n] Waterfall._last_row
   unsigned char* d_u8 = nullptr;   // [history][n] the view as bytes (tdsa_waterfall_view_u8)
-  float* d_row = nullptr;      // staging for host rows
+  float* h_row = nullptr;      // pinned staging of a host row: small rows are read in place by the kernels,
+  float* d_row = nullptr;      // larger ones take one DMA into d_row first (the scatter reads every bin)
   int* d_flags = nullptr;      // [2][cap] differs, destination line per pushed row
   int* d_info = nullptr;       // {new rows, last new row} of the push in flight, for the scatter
   int* h_info = nullptr;       // the same two words, pinned: what the host waits for
@@ -2839,6 +2915,9 @@ int tdsa_waterfall_create(int device_id, int history_lines, int n_bins, float mi
   if (e == hipSuccess) e = hipMalloc(&w->d_info, 2 * sizeof(int));
   if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&w->h_info), 2 * sizeof(int), hipHostMallocDefault);
   if (e == hipSuccess) e = hipMalloc(&w->d_last, size_t(n_bins) * sizeof(float));
+  if (e == hipSuccess)
+    e = hipHostMalloc(reinterpret_cast<void**>(&w->h_row), size_t(n_bins) * sizeof(float),
+                      hipHostMallocPortable | hipHostMallocMapped);
   if (e == hipSuccess) e = hipMalloc(&w->d_row, size_t(n_bins) * sizeof(float));
   if (e == hipSuccess) e = launch_fill(w->d_ring, cnt, min_db, w->stream);    // np.full((2H, W), wf_min_db)
   if (e == hipSuccess) e = hipStreamSynchronize(w->stream);
@@ -2857,6 +2936,7 @@ int tdsa_waterfall_destroy(tdsa_waterfall w) {
   if (w->d_ring) (void)hipFree(w->d_ring);
   if (w->d_last) (void)hipFree(w->d_last);
   if (w->d_u8) (void)hipFree(w->d_u8);
+  if (w->h_row) (void)hipHostFree(w->h_row);
   if (w->d_row) (void)hipFree(w->d_row);
   if (w->d_flags) (void)hipFree(w->d_flags);
   if (w->d_info) (void)hipFree(w->d_info);
@@ -2908,7 +2988,9 @@ int tdsa_waterfall_push(tdsa_waterfall w, const float* row_host, int n, int* is_
   if (!w || !row_host) return fail(TDSA_ERR_ARG, "null argument");
   if (n != w->n) return fail(TDSA_ERR_ARG, "row of %d bins, ring has %d", n, w->n);
   HIPCHK(hipSetDevice(w->device));
-  HIPCHK(hipMemcpyAsync(w->d_row, row_host, size_t(n) * sizeof(float), hipMemcpyHostToDevice, w->stream));
+  std::memcpy(w->h_row, row_host, size_t(n) * sizeof(float));     // (every push ends with a wait: the row is free)
+  if (n <= 4096) return waterfall_push_rows(w, w->h_row, 1, is_new);
+  HIPCHK(hipMemcpyAsync(w->d_row, w->h_row, size_t(n) * sizeof(float), hipMemcpyHostToDevice, w->stream));
   return waterfall_push_rows(w, w->d_row, 1, is_new);
 }
 
