@@ -13,7 +13,7 @@ from topdogspectrumanalyser_amd import SpectrumEngine, _native as nat  # noqa: E
 
 
 def main():
-    for n in (1000, 1024, 4096, 16384, 1 << 15, 1 << 17, 1 << 20):
+    for n in (1000, 1024, 2048, 4096, 8192, 16384, 1 << 15, 1 << 17, 1 << 20):
         iq = np.random.default_rng(0).integers(-100, 100, size=2 * n, dtype=np.int8)
         x = (iq[0::2] + 1j * iq[1::2]).astype(np.complex64) / 128
         with SpectrumEngine(n, max_frames=1) as e:
