@@ -10,7 +10,7 @@
 //                         distance) (core/marker_manager.py:74-127)
 //   density_kernel        DensityDisplay._update_hist (displays/density_display.py:306-318)
 //   rows_differ_kernel /  Waterfall new-row test + _add_row (displays/waterfall.py:171-175, 330-336)
-//   waterfall_scatter_kernel
+//   waterfall_plan_kernel / waterfall_scatter_kernel
 #include "tdsa_fft.hpp"        // static_for
 #include "tdsa_kernels.hpp"
 
