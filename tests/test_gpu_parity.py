@@ -2608,13 +2608,16 @@ def test_call_sequences_that_crossed_the_old_allowance(pkg, trial, any_size):
     assert calls > 0 and rel <= REL_TOL and units <= bound, f"trial {trial} (N = {nfft}): {units:.2f} units, rel {rel:.2e}"
 
 
-@pytest.mark.parametrize("trial", range(int(os.environ.get("TDSA_SEQUENCE_TRIALS", "24"))))
+_TRIAL0 = int(os.environ.get("TDSA_TRIAL_OFFSET", "0"))      # soak runs: fresh seeds beyond those of earlier soaks
+
+
+@pytest.mark.parametrize("trial", range(_TRIAL0, _TRIAL0 + int(os.environ.get("TDSA_SEQUENCE_TRIALS", "24"))))
 def test_random_call_sequences(pkg, trial):
     units, rel, calls = call_sequence_trial(pkg, trial)
     assert calls > 0 and rel <= REL_TOL and units <= 2.0, f"trial {trial}: {units:.2f} units, rel {rel:.2e}"
 
 
-@pytest.mark.parametrize("trial", range(int(os.environ.get("TDSA_ANYSIZE_TRIALS", "12"))))
+@pytest.mark.parametrize("trial", range(_TRIAL0, _TRIAL0 + int(os.environ.get("TDSA_ANYSIZE_TRIALS", "12"))))
 def test_random_call_sequences_any_size(pkg, trial):
     bound, nfft = _sequence_bound(pkg, trial, True)
     units, rel, calls = call_sequence_trial(pkg, trial, any_size=True)
