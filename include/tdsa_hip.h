@@ -369,8 +369,13 @@ int tdsa_waterfall_view_u8(tdsa_waterfall w, float min_db, float max_db, uint8_t
  * tdsa_process_i8 had been called per slot.  want_rows: 0 keeps only the plan state (hold / Welch
  * traces); 1 reads the dB rows back into pinned host memory (tdsa_pipe_collect); 2 keeps them in the
  * slot's device buffer for the analytics / accumulators below (tdsa_pipe_collect_dev hands out the device
- * pointer, valid until that slot is acquired again) and skips the read-back leg.  One thread drives a
- * pipe; destroy it before its plan. */
+ * pointer, valid until that slot is acquired again) and skips the read-back leg; 3 reads them back as
+ * uint8 [n_frames][nfft] - what ImageItem.setImage(rows, levels=(min_db, max_db)) makes of them before the
+ * colour table (displays/waterfall.py:353-356: float32 (v - lo) / (hi - lo) * 255, clipped, truncated; NaN -> 0;
+ * levels from tdsa_pipe_set_levels, (-120, 0) until it is called, applied to slots submitted afterwards):
+ * a quarter of the bytes over PCIe, which is what bounds a pipe that returns rows (tdsa_pipe_collect_u8; the
+ * float32 rows of the slot stay on the device, tdsa_pipe_collect_dev hands them out as well).  One thread
+ * drives a pipe; destroy it before its plan. */
 typedef struct tdsa_pipe_s* tdsa_pipe;
 int tdsa_pipe_create(tdsa_plan p, int in_format, size_t slot_samples, int n_slots, int want_rows, tdsa_pipe* out);
 int tdsa_pipe_destroy(tdsa_pipe q);
@@ -378,6 +383,8 @@ int tdsa_pipe_acquire(tdsa_pipe q, void** host_slot);
 int tdsa_pipe_submit(tdsa_pipe q, size_t n_samples, int hop, int n_frames);
 int tdsa_pipe_collect(tdsa_pipe q, const float** rows_host, int* n_frames);
 int tdsa_pipe_collect_dev(tdsa_pipe q, const float** rows_dev, int* n_frames);
+int tdsa_pipe_collect_u8(tdsa_pipe q, const uint8_t** rows_host, int* n_frames);
+int tdsa_pipe_set_levels(tdsa_pipe q, float min_db, float max_db);
 int tdsa_pipe_pending(tdsa_pipe q, int* pending);
 
 /* A trace object owns the per-bin state the reference keeps in numpy arrays on MainWindow /

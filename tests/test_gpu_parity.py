@@ -2298,6 +2298,61 @@ def test_host_pipe_matches_synchronous_calls(pkg, rows, streams):
             assert np.array_equal(mx, ref_max)
 
 
+def test_host_pipe_rows_as_uint8_levels(pkg):
+    """rows="u8": the read-back leg carries what ImageItem.setImage(rows, levels=(min_db, max_db)) makes of the dB rows
+    (displays/waterfall.py:353-356) - byte for byte the numpy expression on the rows a synchronous call returns; levels
+    changed between submissions apply to the slots submitted afterwards; the slot's float32 rows stay on the device."""
+    import ctypes as C
+    nfft, hop, nf, chunks = 4096, 2048, 61, 7
+    ns = hop * (nf - 1) + nfft
+    batches = [so.synth_iq_int8(ns, nfft, seed=900 + i) for i in range(chunks)]
+    levels = [(-120.0, 0.0)] * 2 + [(-60.0, -10.0)] * 3 + [(-37.5, 12.25)] * 2
+
+    def as_u8(rows, lo, hi):
+        with np.errstate(invalid="ignore"):
+            t = np.clip((rows - lo) / (hi - lo) * 255, 0, 255)         # float32 rows against Python floats: float32
+        return np.where(np.isnan(t), 0, t).astype(np.uint8)
+
+    with _hackrf_engine(pkg, nfft, nf, hold_max=True) as e:
+        ref = [e.process(iq, hop=hop) for iq in batches]
+        ref_max, _ = e.hold()
+    with _hackrf_engine(pkg, nfft, nf, hold_max=True) as e:
+        e.set_overlap(2)
+        with e.pipe(ns, n_slots=3, rows="u8") as q:                     # (-120, 0) until set_levels is called
+            got = []
+            for i, iq in enumerate(batches):
+                if q.pending == 3:
+                    got.append(q.collect_u8().copy())
+                if i > 0 and levels[i] != levels[i - 1]:
+                    q.set_levels(*levels[i])
+                q.acquire()[: iq.size] = iq
+                q.submit(ns, hop, nf)
+            dev_ptr, dev_nf = None, None
+            while q.pending:
+                if q.pending == 1:                                       # the float32 rows of the slot are still there
+                    rows_dev, dev_nf = q.collect_device()
+                    last = np.empty((dev_nf, nfft), dtype=np.float32)
+                    nat = pkg._native
+                    nat.check(nat.lib.tdsa_memcpy_d2h(0, last.ctypes.data_as(C.c_void_p), C.c_void_p(rows_dev), last.nbytes))
+                    assert np.array_equal(last, ref[-1])
+                    break
+                got.append(q.collect_u8().copy())
+            with pytest.raises(Exception):
+                q.set_levels(0.0, 0.0)
+        for i, g in enumerate(got):
+            assert g.dtype == np.uint8 and g.shape == ref[i].shape
+            assert np.array_equal(g, as_u8(ref[i], *levels[i])), f"chunk {i}"
+        assert len(got) == chunks - 1
+        mx, _ = e.hold()
+        assert np.array_equal(mx, ref_max)
+        with e.pipe(ns, n_slots=2, rows=True) as q2:
+            q2.acquire()[: batches[0].size] = batches[0]
+            q2.submit(ns, hop, nf)
+            with pytest.raises(Exception):
+                q2.collect_u8()                                          # not a byte-row pipe
+            q2.collect()
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("TDSA_PIPE_CASES", "8"))))
 def test_host_pipe_random(pkg, seed):
     """Seeded random pipelines (size incl. a long frame, slots, frames per submit, overlap streams, averaging, tracked

@@ -25,7 +25,7 @@ def main():
     iq = synth_iq_int8(ns, n, seed=3)
     w = np.hanning(n).astype(np.float32)
     w /= np.sqrt(np.mean(w ** 2))
-    for rows in (True, False):
+    for rows in (True, "u8", False):
         with SpectrumEngine(n, max_frames=F) as e:
             e.set_window(w)
             e.configure(db_mode="mag", log_floor=1e-12, dc_alpha=1.0, hold_max=True)
@@ -35,21 +35,22 @@ def main():
                     for _ in range(a.slots):
                         q.acquire()[:] = iq
                         q.submit(ns, hop, F)
+                    collect = q.collect_u8 if rows == "u8" else q.collect
                     while q.pending:
-                        q.collect()
+                        collect()
                     t0 = time.perf_counter()
                     for i in range(a.steps):
                         if q.pending == a.slots:
-                            q.collect()
+                            collect()
                         s = q.acquire()
                         if fill:
                             s[:] = iq            # producer memcpy into the pinned slot (one host core)
                         q.submit(ns, hop, F)
                     while q.pending:
-                        q.collect()
+                        collect()
                     dt = (time.perf_counter() - t0) / a.steps
-                    gb = (2 * ns + (4 * F * n if rows else 0)) / 1e9
-                    print(f"rows={'yes' if rows else 'no (hold trace only)'}  producer memcpy={'yes' if fill else 'no '}: "
+                    gb = (2 * ns + ({True: 4, "u8": 1, False: 0}[rows] * F * n)) / 1e9
+                    print(f"rows={ {True: 'float32', 'u8': 'uint8 levels', False: 'no (hold trace only)'}[rows]:22s}  producer memcpy={'yes' if fill else 'no '}: "
                           f"{dt*1e3:7.3f} ms/step  {F/dt/1e6:6.3f} Mframes/s  {gb/dt:6.1f} GB/s over PCIe")
 
 

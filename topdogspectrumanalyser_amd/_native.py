@@ -99,6 +99,8 @@ _SIGNATURES = {
     "tdsa_pipe_submit": (C.c_int, [_P, C.c_size_t, C.c_int, C.c_int]),
     "tdsa_pipe_collect": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int)]),
     "tdsa_pipe_collect_dev": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int)]),
+    "tdsa_pipe_collect_u8": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_ubyte)), C.POINTER(C.c_int)]),
+    "tdsa_pipe_set_levels": (C.c_int, [_P, C.c_float, C.c_float]),
     "tdsa_pipe_pending": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "tdsa_trace_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(_P)]),
     "tdsa_trace_destroy": (C.c_int, [_P]),

@@ -2387,11 +2387,15 @@ struct tdsa_pipe_s {
   size_t slot_samples = 0;
   bool rows = false;        // dB rows are produced (kept per slot on the device)
   bool rows_host = false;   // ... and read back into pinned host memory
+  bool rows_u8 = false;     // ... as bytes under the display's levels (1 B per bin over PCIe instead of 4)
+  float lo_db = -120.0f, hi_db = 0.0f;
   struct Slot {
     void* h_in = nullptr;
     void* d_in = nullptr;
     float* h_out = nullptr;
     float* d_out = nullptr;
+    unsigned char* h_u8 = nullptr;
+    unsigned char* d_u8 = nullptr;
     hipEvent_t ev_h2d = nullptr, ev_done = nullptr, ev_d2h = nullptr;
     int n_frames = 0;
     bool acquired = false, in_flight = false;
@@ -2407,7 +2411,8 @@ int tdsa_pipe_create(tdsa_plan p, int in_format, size_t slot_samples, int n_slot
   if (in_format < TDSA_IN_I8 || in_format > TDSA_IN_C64) return fail(TDSA_ERR_ARG, "in_format %d", in_format);
   if (n_slots < 1 || n_slots > 16) return fail(TDSA_ERR_ARG, "n_slots=%d outside [1, 16]", n_slots);
   if (slot_samples < size_t(p->nfft)) return fail(TDSA_ERR_ARG, "slot_samples=%zu < nfft", slot_samples);
-  if (want_rows < 0 || want_rows > 2) return fail(TDSA_ERR_ARG, "want_rows=%d (0 none, 1 host, 2 device)", want_rows);
+  if (want_rows < 0 || want_rows > 3)
+    return fail(TDSA_ERR_ARG, "want_rows=%d (0 none, 1 host, 2 device, 3 host as uint8 levels)", want_rows);
   HIPCHK(hipSetDevice(p->device));
   tdsa_pipe q = new (std::nothrow) tdsa_pipe_s();
   if (!q) return fail(TDSA_ERR_NOMEM, "out of host memory");
@@ -2416,6 +2421,7 @@ int tdsa_pipe_create(tdsa_plan p, int in_format, size_t slot_samples, int n_slot
   q->slot_samples = slot_samples;
   q->rows = want_rows != 0;
   q->rows_host = want_rows == 1;
+  q->rows_u8 = want_rows == 3;
   q->slots.resize(size_t(n_slots));
   const size_t in_bytes = slot_samples * size_t(bytes_per_sample(in_format));
   const size_t out_rows = p->big ? 1 : size_t(p->max_frames);
@@ -2435,6 +2441,11 @@ int tdsa_pipe_create(tdsa_plan p, int in_format, size_t slot_samples, int n_slot
           (e = hipHostMalloc(reinterpret_cast<void**>(&sl.h_out), out_bytes, hipHostMallocDefault)) != hipSuccess)
         return bail(e, "pinned output slot");
       if ((e = hipMalloc(reinterpret_cast<void**>(&sl.d_out), out_bytes)) != hipSuccess) return bail(e, "device output slot");
+      if (q->rows_u8) {
+        if ((e = hipMalloc(reinterpret_cast<void**>(&sl.d_u8), out_bytes / 4)) != hipSuccess) return bail(e, "device byte rows");
+        if ((e = hipHostMalloc(reinterpret_cast<void**>(&sl.h_u8), out_bytes / 4, hipHostMallocDefault)) != hipSuccess)
+          return bail(e, "pinned byte rows");
+      }
     }
     if ((e = hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming)) != hipSuccess) return bail(e, "event");
     if ((e = hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming)) != hipSuccess) return bail(e, "event");
@@ -2455,6 +2466,8 @@ int tdsa_pipe_destroy(tdsa_pipe q) {
     if (sl.d_in) (void)hipFree(sl.d_in);
     if (sl.h_out) (void)hipHostFree(sl.h_out);
     if (sl.d_out) (void)hipFree(sl.d_out);
+    if (sl.h_u8) (void)hipHostFree(sl.h_u8);
+    if (sl.d_u8) (void)hipFree(sl.d_u8);
     if (sl.ev_h2d) (void)hipEventDestroy(sl.ev_h2d);
     if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
     if (sl.ev_d2h) (void)hipEventDestroy(sl.ev_d2h);
@@ -2499,6 +2512,13 @@ int tdsa_pipe_submit(tdsa_pipe q, size_t n_samples, int hop, int n_frames) {
                           q->s_out));
     HIPCHK(hipEventRecord(sl.ev_d2h, q->s_out));
   }
+  if (q->rows_u8) {   // the read-back leg carries what setImage(img, levels) makes of the rows: a quarter of the bytes
+    const size_t cnt = size_t(sl.n_frames) * p->nfft;
+    HIPCHK(hipStreamWaitEvent(q->s_out, sl.ev_done, 0));
+    HIPCHK(launch_quantize_u8(sl.d_out, sl.d_u8, cnt, q->lo_db, q->hi_db, q->s_out));
+    HIPCHK(hipMemcpyAsync(sl.h_u8, sl.d_u8, cnt, hipMemcpyDeviceToHost, q->s_out));
+    HIPCHK(hipEventRecord(sl.ev_d2h, q->s_out));
+  }
   sl.acquired = false;
   sl.in_flight = true;
   ++q->head;
@@ -2506,13 +2526,15 @@ int tdsa_pipe_submit(tdsa_pipe q, size_t n_samples, int hop, int n_frames) {
   return TDSA_OK;
 }
 
-static int pipe_collect(tdsa_pipe q, const float** rows_host, const float** rows_dev, int* n_frames) {
+static int pipe_collect(tdsa_pipe q, const float** rows_host, const float** rows_dev, int* n_frames,
+                        const uint8_t** rows_u8 = nullptr) {
   if (!q) return fail(TDSA_ERR_ARG, "null pipe");
   if (q->pending == 0) return fail(TDSA_ERR_STATE, "nothing submitted");
   auto& sl = q->slots[q->tail % q->slots.size()];
   HIPCHK(hipSetDevice(q->plan->device));
-  HIPCHK(hipEventSynchronize(q->rows_host ? sl.ev_d2h : sl.ev_done));
+  HIPCHK(hipEventSynchronize(q->rows_host || q->rows_u8 ? sl.ev_d2h : sl.ev_done));
   sl.in_flight = false;
+  if (rows_u8) *rows_u8 = sl.h_u8;
   if (rows_host) *rows_host = q->rows_host ? sl.h_out : nullptr;
   if (rows_dev) *rows_dev = q->rows ? sl.d_out : nullptr;
   if (n_frames) *n_frames = sl.n_frames;
@@ -2528,6 +2550,19 @@ int tdsa_pipe_collect(tdsa_pipe q, const float** rows_host, int* n_frames) {
 int tdsa_pipe_collect_dev(tdsa_pipe q, const float** rows_dev, int* n_frames) {
   if (q && !q->rows) return fail(TDSA_ERR_STATE, "this pipe keeps no dB rows (want_rows = 0)");
   return pipe_collect(q, nullptr, rows_dev, n_frames);
+}
+
+int tdsa_pipe_collect_u8(tdsa_pipe q, const uint8_t** rows_host, int* n_frames) {
+  if (q && !q->rows_u8) return fail(TDSA_ERR_STATE, "this pipe reads no byte rows back (want_rows != 3)");
+  return pipe_collect(q, nullptr, nullptr, n_frames, rows_host);
+}
+
+int tdsa_pipe_set_levels(tdsa_pipe q, float min_db, float max_db) {
+  if (!q) return fail(TDSA_ERR_ARG, "null pipe");
+  if (!(max_db > min_db)) return fail(TDSA_ERR_ARG, "levels (%g, %g): need max > min", double(min_db), double(max_db));
+  q->lo_db = min_db;      // slots submitted from now on
+  q->hi_db = max_db;
+  return TDSA_OK;
 }
 
 int tdsa_pipe_pending(tdsa_pipe q, int* pending) {

@@ -181,11 +181,17 @@ class SpectrumEngine:
     def synchronize(self) -> None:
         nat.check(nat.lib.tdsa_synchronize(self._h))
 
-    def pipe(self, slot_samples: int, n_slots: int = 3, rows=True, in_format: int = nat.IN_I8) -> "HostPipe":
+    def pipe(self, slot_samples: int, n_slots: int = 3, rows=True, in_format: int = nat.IN_I8,
+             levels: Optional[Tuple[float, float]] = None) -> "HostPipe":
         """Pinned host ring with asynchronous copy / compute / read-back legs (tdsa_pipe_*).
         rows: True / "host" = dB rows come back to pinned host memory, "device" = they stay on the GPU
-        (collect_device), False / None = plan state only."""
-        return HostPipe(self, slot_samples, n_slots, rows, in_format)
+        (collect_device), "u8" = they come back as bytes under `levels` = (min_db, max_db), what
+        ImageItem.setImage(rows, levels=...) feeds its colour table (collect_u8; a quarter of the bytes over PCIe),
+        False / None = plan state only."""
+        q = HostPipe(self, slot_samples, n_slots, rows, in_format)
+        if levels is not None:
+            q.set_levels(*levels)
+        return q
 
     def set_overlap(self, n_streams: int) -> None:
         """Let consecutive order-independent process_device() calls overlap on n_streams HIP streams
@@ -385,7 +391,7 @@ class HostPipe:
     def __init__(self, engine: SpectrumEngine, slot_samples: int, n_slots: int, rows: bool, in_format: int):
         self._eng = engine
         self.slot_samples = int(slot_samples)
-        self.rows_mode = {True: 1, "host": 1, "device": 2, False: 0, None: 0}[rows]
+        self.rows_mode = {True: 1, "host": 1, "device": 2, "u8": 3, False: 0, None: 0}[rows]
         self.rows = self.rows_mode == 1
         self.in_format = int(in_format)
         self._q = C.c_void_p()
@@ -432,6 +438,18 @@ class HostPipe:
         nat.check(nat.lib.tdsa_pipe_collect(self._q, C.byref(rows), C.byref(nf)))
         if not self.rows:
             return None
+        return np.ctypeslib.as_array(rows, shape=(nf.value, self._eng.nfft))
+
+    def set_levels(self, min_db: float, max_db: float) -> None:
+        """levels of a rows="u8" pipe (displays/waterfall.py:353-356), for the slots submitted from now on"""
+        nat.check(nat.lib.tdsa_pipe_set_levels(self._q, float(min_db), float(max_db)))
+
+    def collect_u8(self) -> np.ndarray:
+        """Wait for the oldest submitted slot of a rows="u8" pipe: its rows as uint8 [n_frames, N] (view of the
+        pinned slot, valid until that slot is acquired again)."""
+        rows = C.POINTER(C.c_ubyte)()
+        nf = C.c_int()
+        nat.check(nat.lib.tdsa_pipe_collect_u8(self._q, C.byref(rows), C.byref(nf)))
         return np.ctypeslib.as_array(rows, shape=(nf.value, self._eng.nfft))
 
     def collect_device(self) -> Tuple[int, int]:
