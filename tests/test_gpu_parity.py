@@ -2460,6 +2460,11 @@ def test_stream_spectra_helper(pkg):
     for g, r in zip(got, ref):
         assert g.shape == r.shape and np.array_equal(g, r)
     assert np.array_equal(mx, ref_max)
+    with _hackrf_engine(pkg, nfft, nf_max) as e:                               # the rows as the display's bytes
+        got8 = list(stream_spectra(e, chunks, hop=hop, rows="u8", levels=(-90.0, -5.0)))
+    for g, r in zip(got8, ref):
+        t = np.clip((r - (-90.0)) / (-5.0 - (-90.0)) * 255, 0, 255)
+        assert g.dtype == np.uint8 and np.array_equal(g, t.astype(np.uint8))
     with _hackrf_engine(pkg, nfft, nf_max) as e:
         assert list(stream_spectra(e, [])) == []
         with pytest.raises(ValueError):

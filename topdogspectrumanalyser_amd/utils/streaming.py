@@ -6,7 +6,7 @@ straight into a pinned slot, the copies of neighbouring chunks overlap the frame
 come back in submission order.  Framing is the deterministic batch framing of SURVEY.md 8(a) a2
 (frame k = iq[k*hop : k*hop + N]) applied per chunk.
 """
-from typing import Iterable, Iterator, Optional
+from typing import Iterable, Iterator, Optional, Tuple
 
 import numpy as np
 
@@ -14,9 +14,11 @@ from ..engine import SpectrumEngine
 
 
 def stream_spectra(engine: SpectrumEngine, chunks: Iterable[np.ndarray], hop: Optional[int] = None,
-                   n_slots: int = 3, rows: bool = True, copy: bool = True) -> Iterator[Optional[np.ndarray]]:
+                   n_slots: int = 3, rows=True, copy: bool = True,
+                   levels: Optional[Tuple[float, float]] = None) -> Iterator[Optional[np.ndarray]]:
     """Yield the dB rows [n_frames, N] of every chunk (None per chunk when rows=False: hold / averager
-    state only).  `chunks` are 1-D int8 arrays of interleaved I,Q; each must hold at least N samples and at
+    state only; rows="u8": uint8 rows under `levels` = (min_db, max_db), what ImageItem.setImage(rows, levels=...)
+    makes of them - a quarter of the read-back, which bounds the pipe).  `chunks` are 1-D int8 arrays of interleaved I,Q; each must hold at least N samples and at
     most the first chunk's length.  With copy=False the yielded array is a view of pinned memory that is
     valid until `n_slots - 1` further chunks have been submitted."""
     it = iter(chunks)
@@ -34,10 +36,10 @@ def stream_spectra(engine: SpectrumEngine, chunks: Iterable[np.ndarray], hop: Op
         raise ValueError(f"chunk holds {max_frames} frames, engine was created for {engine.max_frames}")
 
     def emit(q):
-        r = q.collect()
+        r = q.collect_u8() if rows == "u8" else q.collect()
         return None if r is None else (r.copy() if copy else r)
 
-    with engine.pipe(slot_samples, n_slots=n_slots, rows=rows) as q:
+    with engine.pipe(slot_samples, n_slots=n_slots, rows=rows, levels=levels) as q:
         chunk = first
         while chunk is not None:
             ns = chunk.size // 2
